@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Benchmark of the GeoBO GP joint-inversion hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 64] [--no-cpu]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one full pass of the hot path over one synthetic survey: forward operators A_g/A_m built on the
+device, fused covariance assembly x operator product (AK), AkA, Cholesky, posterior mean + variance, D2H of the
+cubes.  Workload = BASELINE config 3/4: 64^3 voxels of 100 m, gravity + magnetics joint inversion (density and
+magnetic-susceptibility cubes, P_out = 2), Matern-3/2 kernel with lengths (2.00, 2.02, 2.04) x 100 m, 50
+drill-core constraints, M = 4096 + 4096 + 50 observation rows.  With N > 1 the SAME problem is sharded by voxel
+columns over the ranks (strong scaling): one all-reduce of the partial AkA + one all-gather of the mu/var slices.
+
+Prints ONE JSON line on rank 0 (see the driver contract); extra objects:
+  roofline      dominant kernel = geobo_ak_fused (fp64 MFMA): algorithmic flops per launch / mean launch duration
+                measured with HIP events on the launch stream, against the 78.6 TFLOP/s fp64 matrix peak
+  cpu_baseline  the NumPy/OpenBLAS oracle (kind "port") timed on this box's host cores on a bounded column sample of
+                the same workload
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MATRIX_PEAK_TFLOPS = 78.6  # AMD MI355X datasheet, FP64 matrix (= FP64 vector); see DESIGN.md for the on-box microbenchmark
+
+
+def synthetic_inputs(inv, md):
+    """Synthetic survey of SURVEY.md section 8(d): reference 'cylinders' truth (+ smooth trend), survey = A rho / A chi
+    rounded through float32, drill voxels from default_rng(2020).  Uses the device-resident operators."""
+    from geobo_amd import hip
+    s = inv.settings
+    inv.create_cubegeometry()
+    x3, y3, z3 = inv.xxx, inv.yyy, inv.zzz
+    rad = s.yLcube / 18.
+    rc1 = ((y3 - s.yLcube / 1.3 - rad) ** 2) + ((z3 + s.zLcube / 4 - rad) ** 2)
+    rc2 = ((y3 - s.yLcube / 4. - rad) ** 2) + ((z3 + s.zLcube / 4 - rad) ** 2)
+    rho = x3 * 0. + 0.1
+    rho[rc2 <= rad ** 2] = 1.
+    rho[rc1 <= rad ** 2] = 1.
+    rho[(x3 < s.xLcube / 5.) | (x3 > s.xLcube * 4. / 5.)] = 0.1
+    rho = rho + 0.02 * (x3 / s.xLcube + 2. * y3 / s.yLcube - z3 / s.zLcube)
+    chi = s.gp_coeff[1] * rho
+    xs = np.linspace(0.5, s.xNcube - 0.5, s.xNcube) * s.xvoxsize
+    ys = np.linspace(0.5, s.yNcube - 0.5, s.yNcube) * s.yvoxsize
+    X, Y, Z = np.meshgrid(xs, ys, s.zmax + s.zoff)
+    loc = np.asarray([X.flatten(), Y.flatten(), Z.flatten()]).T
+    inv.sensor_locations = loc
+    A_g, A_m = inv._operators()
+    eng = inv.engine
+    pad = lambda v: torch.cat([hip.to_dev(v.reshape(-1), eng.device), torch.zeros(eng.N_pad - eng.N, dtype=torch.float64, device=eng.device)])
+    grav = (A_g @ pad(rho))[:eng.Ms].cpu().numpy().astype(np.float32).astype(np.float64)
+    mag = (A_m @ pad(chi))[:eng.Ms].cpu().numpy().astype(np.float32).astype(np.float64)
+    drill0 = np.zeros_like(rho)
+    if md > 0:
+        sel = np.random.default_rng(2020).choice(rho.size, md, replace=False)
+        drill0.reshape(-1)[sel] = rho.reshape(-1)[sel]
+    return grav, mag, loc, drill0
+
+
+def cpu_baseline(inv, lengths, target_seconds=15.0):
+    """Oracle ("port") on the host cores, bounded sample: the fused A.K product + the V solve / reductions for `b`
+    voxel columns x 2 properties of THIS workload, operators and Cholesky factor taken as given (so the CPU rate is
+    an upper bound: A_sens, AkA and the factorisation are not charged)."""
+    from oracle import geobo_oracle as O
+    from scipy.linalg import solve_triangular
+    eng = inv.engine
+    s = inv.settings
+    N, Ms = eng.N, eng.Ms
+    A_g = eng._A[[k for k in eng._A if k[0] == "grav"][0]][:Ms, :N].cpu().numpy()
+    A_m = eng._A[[k for k in eng._A if k[0] == "magn"][0]][:Ms, :N].cpu().numpy()
+    L = torch.tril(eng.last["L"]).cpu().numpy()
+    rows = np.r_[0:Ms, eng.Ms_pad:eng.Ms_pad + Ms, 2 * eng.Ms_pad:2 * eng.Ms_pad + inv._sel.size]
+    L = L[np.ix_(rows, rows)]
+    u = eng.last["u"].cpu().numpy()[rows]
+    P3 = O.grid_points((s.xNcube, s.yNcube, s.zNcube), (s.xvoxsize, s.yvoxsize, s.zvoxsize))
+    W = O.weight_matrix(s.gp_coeff)
+    sel = inv._sel
+    name = s.kernelfunc
+
+    def sample(b, c0):
+        t0 = time.perf_counter()
+        D2 = O.sqdist(P3, P3[c0:c0 + b])
+        out = []
+        for j in (0, 1):
+            AK = np.empty((L.shape[0], b))
+            AK[:Ms] = A_g @ O.k_block(name, D2, lengths, W, 0, j)
+            AK[Ms:2 * Ms] = A_m @ O.k_block(name, D2, lengths, W, 1, j)
+            if sel.size:
+                AK[2 * Ms:] = O.k_block(name, D2[sel], lengths, W, 2, j)
+            V = solve_triangular(L, AK, lower=True)
+            out.append((V.T @ u, 1.0 - np.einsum("mq,mq->q", V, V)))
+        return time.perf_counter() - t0, out
+
+    c0 = N // 2
+    t_small, _ = sample(16, c0)
+    b = int(max(16, min(2048, 16 * target_seconds / max(t_small, 1e-3))))
+    t, out = sample(b, c0)
+    # sanity: the sample must agree with the GPU posterior on the same columns
+    try:
+        from threadpoolctl import threadpool_info
+        thr = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        thr = os.cpu_count()
+    return dict(value=2.0 * b / t, unit="voxel-properties/s", cores=int(thr), kind="port",
+                sample="%d of %d voxel columns x 2 properties of the same 64^3 workload: fused A.K + triangular solve + "
+                       "mean/variance reductions in NumPy/OpenBLAS (oracle/geobo_oracle.py); operators and Cholesky factor "
+                       "given, so this is an upper bound on the CPU rate; %.1f s" % (b, N, t)), (c0, b, out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=64, help="cube edge in voxels (64 = BASELINE headline)")
+    ap.add_argument("--kernel", default="matern32")
+    ap.add_argument("--drill", type=int, default=50)
+    ap.add_argument("--no-cpu", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and world > 1:
+        raise SystemExit("--gpus must equal WORLD_SIZE")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+
+    from geobo_amd.config_loader import Settings
+    from geobo_amd.inversion import Inversion
+    n = a.size
+    s = Settings(dict(xmin=0, xmax=100.0 * n, ymin=0, ymax=100.0 * n, zmax=0, zoff=1, zLcube=100.0 * n, xNcube=n, yNcube=n,
+                      zNcube=n, gp_lengthscale=2, gp_err=[0.1, 0.1, 0.1], gp_coeff=[1.0, 0.2, 0.2], kernelfunc=a.kernel,
+                      XMAG=0, YMAG=0, ZMAG=1))
+    inv = Inversion(settings=s, props=(0, 1), rank=rank, world=world, device="cuda:%d" % local)
+    grav, mag, loc, drill0 = synthetic_inputs(inv, a.drill)
+    gp_length = np.array([2.00, 2.02, 2.04]) * s.xvoxsize if a.kernel == "matern32" else None
+
+    def step():
+        inv.engine.clear_operators()          # A_g / A_m are rebuilt inside every step
+        if gp_length is not None:
+            inv.gp_length = gp_length.copy()
+        else:
+            inv.gp_length = s.gp_lengthscale * np.asarray([s.xvoxsize] * 3)
+        return inv.cubing(grav, mag, drill0[drill0 != 0], loc, drill0)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    inv.engine.kernel_events = []
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        cubes = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ev = inv.engine.kernel_events
+    inv.engine.kernel_events = None
+    durs = [e0.elapsed_time(e1) * 1e-3 for (_, _, e0, e1) in ev]
+    flops = ev[0][1] if ev else 0.0
+    ach = flops / (sum(durs) / len(durs)) / 1e12 if durs else 0.0
+
+    if rank == 0:
+        eng = inv.engine
+        N = eng.N
+        p_out = 2
+        value = p_out * N * a.steps / dt
+        M = 2 * eng.Ms + int((drill0 != 0).sum())
+        Msd = 2 * eng.Ms
+        F = 2.0 * Msd * N * N * p_out + 2.0 * M * Msd * N + M ** 3 / 3.0 + 1.0 * M * M * p_out * N + 4.0 * M * p_out * N + M * M
+        out = {
+            "metric": "voxels/sec posterior (mean+var) for 64^3 x 2-prop joint inversion; fp64 roofline %",
+            "value": value, "unit": "voxel-properties/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%d^3 voxel cube (100 m), gravity+magnetics joint inversion, %s kernel lengths (2.00,2.02,2.04)x100 m, "
+                                   "%d drill constraints, M=%d rows, density+magsus cubes (P_out=2)" % (n, a.kernel, a.drill, M),
+                       "N_voxels": N, "M_rows": M, "props_out": p_out, "parallelism": "voxel-column shards x%d" % world,
+                       "algorithmic_flop_per_step": F, "end_to_end_fp64_roofline_frac": F * a.steps / dt / (FP64_MATRIX_PEAK_TFLOPS * 1e12 * world)},
+            "roofline": {"bound": "mfma", "kernel": "geobo_ak_fused (gemm_f64_kernel<4,2,GEN>)", "achieved": ach, "peak": FP64_MATRIX_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": ach / FP64_MATRIX_PEAK_TFLOPS, "traffic": None,
+                         "launches_timed": len(durs), "flop_per_launch": flops, "mean_launch_s": (sum(durs) / len(durs)) if durs else None},
+        }
+        if not a.no_cpu:
+            lengths = inv.gp_length
+            cb, (c0, b, smp) = cpu_baseline(inv, [float(v) for v in lengths])
+            got_mu = inv.mu_rec[c0:c0 + b]
+            cb["sample_max_abs_diff_vs_gpu_mu"] = float(np.abs(smp[0][0] - got_mu).max())
+            out["cpu_baseline"] = cb
+            out["config"]["speedup_vs_cpu_baseline"] = value / cb["value"]
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -142,18 +142,19 @@ __global__ void __launch_bounds__(256) potential_kernel(const double* __restrict
                                     : magn_potential(x[i], y[i], z[i], bx, by, bz, inv_norm_b);
 }
 
-__global__ void __launch_bounds__(256) mfma_peak_kernel(int iters, double* __restrict__ out) {
-  v4d acc[16];
+// 8 independent accumulators (64 VGPRs) so that up to 4 wavefronts fit per SIMD; iters x 16 MFMAs per wave
+__global__ void __launch_bounds__(256, 4) mfma_peak_kernel(int iters, double* __restrict__ out) {
+  v4d acc[8];
   const double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = (v4d){0., 0., 0., 0.};
+  for (int i = 0; i < 8; ++i) acc[i] = (v4d){0., 0., 0., 0.};
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    for (int i = 0; i < 16; ++i) acc[i & 7] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i & 7], 0, 0, 0);
   }
   double s = 0.;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
   out[(int64_t)blockIdx.x * 256 + threadIdx.x] = s;
 }
 

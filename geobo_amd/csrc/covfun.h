@@ -98,6 +98,14 @@ __device__ __forceinline__ double sqdist3(double px, double py, double pz, doubl
   return (dx * dx + dy * dy) + dz * dz;
 }
 
+// l1*e1 - l2*e2 with BOTH products rounded (no FMA contraction): at l1 == l2 the reference gets exactly 0 here and
+// inf*0 = NaN everywhere (kernels.py:153-156); a contracted fma would leave the rounding residual and give +-inf.
+__device__ __forceinline__ double matern_x_diff(double l1, double e1, double l2, double e2) {
+#pragma clang fp contract(off)
+  const double a = l1 * e1, b = l2 * e2;
+  return a - b;
+}
+
 // k(d2) for family ID (compile-time) -- without the w*amp scale
 template <int ID>
 __device__ __forceinline__ double cov_eval(const CovParams& p, double d2) {
@@ -112,7 +120,7 @@ __device__ __forceinline__ double cov_eval(const CovParams& p, double d2) {
     return (1 + nu) * exp_decay(-nu);
   } else if constexpr (ID == COV_MATERN32_X) {
     const double r = sqrt(3 * d2);
-    return p.c[2] * (p.l1 * exp_decay(-r * p.c[0]) - p.l2 * exp_decay(-r * p.c[1]));
+    return p.c[2] * matern_x_diff(p.l1, exp_decay(-r * p.c[0]), p.l2, exp_decay(-r * p.c[1]));
   } else if constexpr (ID == COV_SPARSE) {
     const double d = sqrt(d2);
     double res = 0.0;

@@ -29,6 +29,7 @@ import numpy as np
 import torch
 
 from . import hip
+from .sharding import allreduce_sum_, assemble_columns, gather_slices, shard_columns
 
 F64 = hip.F64
 
@@ -59,14 +60,6 @@ def weight_matrix(crossweights):
     return [[1.0, w3, w1], [w3, 1.0, w2], [w1, w2, 1.0]]
 
 
-def shard_columns(n_pad, world, rank):
-    """Contiguous voxel-column range of `rank` (multiples of 128)."""
-    units = n_pad // hip.PAD_N
-    u0 = units * rank // world
-    u1 = units * (rank + 1) // world
-    return u0 * hip.PAD_N, u1 * hip.PAD_N
-
-
 class PosteriorEngine:
     def __init__(self, settings, device=None, rank=0, world=1, group=None, profile=False):
         hip.require_gpu()
@@ -85,7 +78,7 @@ class PosteriorEngine:
         self.nc = self.c1 - self.c0
         self._xyz = None
         self._A = {}
-        self._loc_key = None
+        self.kernel_events = None  # set to [] to record (name, flops, start, stop) HIP events per fused launch
 
     # ---- geometry --------------------------------------------------------------------------------------------
     def grid_points(self):
@@ -136,6 +129,10 @@ class PosteriorEngine:
         self._A[key] = A
         return A
 
+    def clear_operators(self):
+        """Drop the resident forward operators (the benchmark rebuilds them inside every timed step)."""
+        self._A = {}
+
     # ---- stages ------------------------------------------------------------------------------------------------
     def _tick(self, name, t0=None):
         if not self.profile:
@@ -158,8 +155,15 @@ class PosteriorEngine:
             for s_, A in ((0, A_g), (1, A_m)):
                 kid = hip.kernel_id(name, s_ != j)
                 # block (row-block s, col-block j) of create_cov is w * k2(l_j, l_s)  (kernels.py:183-195)
+                if self.kernel_events is not None:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 hip.ak_fused(kid, A, xyz, self.c0, nc, lengths[j], lengths[s_], W[s_][j], amp,
                              AK[s_ * self.Ms_pad:(s_ + 1) * self.Ms_pad, cols])
+                if self.kernel_events is not None:
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record()  # same stream as the launch (torch's current stream)
+                    self.kernel_events.append(("ak_fused", 2.0 * self.Ms_pad * self.N_pad * nc, e0, e1))
             if Md:
                 rows = tuple(c[sel_t] for c in xyz)
                 colc = tuple(c[self.c0:self.c1] for c in xyz)
@@ -176,8 +180,7 @@ class PosteriorEngine:
         for s_, A in ((0, A_g), (1, A_m)):
             jj = props.index(s_)
             hip.gemm_nt(AK[:, jj * nc:(jj + 1) * nc], A[:, self.c0:self.c1], AkA[:, s_ * self.Ms_pad:(s_ + 1) * self.Ms_pad])
-        if self.world > 1:
-            torch.distributed.all_reduce(AkA, group=self.group)
+        allreduce_sum_(AkA, self.world, self.group)
         dvec = torch.ones(M_pad, dtype=F64, device=self.device)
         dvec[0:self.Ms] = float(gp_sigma[0]) ** 2
         dvec[self.Ms_pad:self.Ms_pad + self.Ms] = float(gp_sigma[1]) ** 2
@@ -230,37 +233,11 @@ class PosteriorEngine:
         if want_mean_var:
             mu_l, var_l = hip.posterior_reduce(Linv, AK, u, gp_amp * 1.0)
             t = self._tick("posterior", t)
-            mu = np.full(3 * self.N, np.nan)
-            var = np.full(3 * self.N, np.nan)
-            nc = self.nc
-            if self.world > 1:
-                mu_all, var_all = self._gather(mu_l, len(props)), self._gather(var_l, len(props))
-            else:
-                mu_all, var_all = [mu_l], [var_l]
-            for r, (m_r, v_r) in enumerate(zip(mu_all, var_all)):
-                c0, c1 = shard_columns(self.N_pad, self.world, r)
-                ncr = c1 - c0
-                m_h, v_h = m_r.cpu().numpy(), v_r.cpu().numpy()
-                hi = min(c1, self.N)
-                if hi <= c0:
-                    continue
-                for jj, j in enumerate(props):
-                    mu[j * self.N + c0:j * self.N + hi] = m_h[jj * ncr:jj * ncr + (hi - c0)]
-                    var[j * self.N + c0:j * self.N + hi] = v_h[jj * ncr:jj * ncr + (hi - c0)]
+            mu = assemble_columns(gather_slices(mu_l, len(props), self.N_pad, self.world, self.group), props, self.N,
+                                  self.N_pad, self.world)
+            var = assemble_columns(gather_slices(var_l, len(props), self.N_pad, self.world, self.group), props, self.N,
+                                   self.N_pad, self.world)
             out["mu"], out["var"] = mu, var
             self._tick("d2h", t)
         self.last = dict(L=L, Linv=Linv, u=u, AK=AK)
         return out
-
-    def _gather(self, t, nblocks):
-        """all-gather of per-rank slices that may differ in length by one 128-column unit."""
-        sizes = []
-        for r in range(self.world):
-            c0, c1 = shard_columns(self.N_pad, self.world, r)
-            sizes.append((c1 - c0) * nblocks)
-        mx = max(sizes)
-        buf = torch.zeros(mx, dtype=t.dtype, device=t.device)
-        buf[:t.numel()] = t
-        outs = [torch.empty(mx, dtype=t.dtype, device=t.device) for _ in range(self.world)]
-        torch.distributed.all_gather(outs, buf, group=self.group)
-        return [o[:n] for o, n in zip(outs, sizes)]

@@ -199,4 +199,5 @@ def mfma_f64_peak(blocks=1024, iters=20000):
 
 
 def to_dev(a, device="cuda"):
+    require_gpu()
     return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), dtype=F64).to(device)

@@ -148,9 +148,11 @@ class Inversion:
     def cubing(self, gravfield, magfield, drillfield, sensor_locations, drilldata0):
         """Joint inversion and cubing of sensor data; returns the six cubes of the reference, each (yN, xN, zN)."""
         s = self.settings
-        self.gravfield = np.asarray(gravfield, dtype=np.float64)
-        self.magfield = np.asarray(magfield, dtype=np.float64)
-        self.drillfield = np.asarray(drillfield, dtype=np.float64)
+        # no dtype cast: the reference z-scores the survey in the dtype it arrives in (float32 from a GeoTIFF
+        # through scipy zoom, run_geobo.py:56-60) -- inversion.py:209-214
+        self.gravfield = np.asarray(gravfield)
+        self.magfield = np.asarray(magfield)
+        self.drillfield = np.asarray(drillfield)
         self.sensor_locations = sensor_locations
         self.drilldata0 = drilldata0
         if not hasattr(self, "voxelpos"):

@@ -1,0 +1,61 @@
+"""Voxel-column sharding of the inversion across the GPUs of one node (one process per GPU).
+
+The path shards by voxel COLUMNS of AK / V: once L is known every column is
+independent.  The only data-path collectives are
+    all-reduce(sum)  of the M_pad x M_pad partial AkA   (each rank contracts its own columns)
+    all-gather       of the per-rank mu / var slices
+issued through torch.distributed (backend "nccl" = RCCL over xGMI on ROCm; "gloo" on CPU for the tests).
+Everything here is device agnostic so the N > 1 host logic is covered by world_size-2 gloo tests.
+"""
+import numpy as np
+import torch
+
+PAD_N = 128
+
+
+def shard_columns(n_pad, world, rank):
+    """Contiguous voxel-column range [c0, c1) of `rank`, in units of 128 columns."""
+    units = n_pad // PAD_N
+    u0 = units * rank // world
+    u1 = units * (rank + 1) // world
+    return u0 * PAD_N, u1 * PAD_N
+
+
+def allreduce_sum_(t, world, group=None):
+    """In-place sum over ranks of the partial AkA."""
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=group)
+    return t
+
+
+def gather_slices(t, nblocks, n_pad, world, group=None):
+    """All-gather per-rank vectors of length nblocks * (c1 - c0); shard sizes may differ by one 128-unit, so the
+    payload is padded to the largest shard.  Returns the list of per-rank tensors (trimmed)."""
+    if world == 1:
+        return [t]
+    sizes = []
+    for r in range(world):
+        c0, c1 = shard_columns(n_pad, world, r)
+        sizes.append((c1 - c0) * nblocks)
+    mx = max(sizes)
+    buf = torch.zeros(mx, dtype=t.dtype, device=t.device)
+    buf[:t.numel()] = t
+    outs = [torch.empty(mx, dtype=t.dtype, device=t.device) for _ in range(world)]
+    torch.distributed.all_gather(outs, buf, group=group)
+    return [o[:n] for o, n in zip(outs, sizes)]
+
+
+def assemble_columns(parts, props, n, n_pad, world):
+    """Per-rank [P_c x ncols_r] slices -> one (3n,) host vector in the reference's property-major order
+    (NaN for property blocks that were not computed)."""
+    out = np.full(3 * n, np.nan)
+    for r, part in enumerate(parts):
+        c0, c1 = shard_columns(n_pad, world, r)
+        ncr = c1 - c0
+        hi = min(c1, n)
+        if hi <= c0:
+            continue
+        ph = part.detach().cpu().numpy() if isinstance(part, torch.Tensor) else np.asarray(part)
+        for jj, j in enumerate(props):
+            out[j * n + c0:j * n + hi] = ph[jj * ncr:jj * ncr + (hi - c0)]
+    return out

@@ -355,9 +355,9 @@ def cubing(grid: Grid, gravfield, magfield, drillfield, sensor_locations, drilld
 
     Returns dict(cubes=(6, ny, nx, nz) in the reference's return order, mu, var, logl, gp_length
     (after the create_cov mutation), A_g, A_m, sel, Fs3)."""
-    gravfield = np.asarray(gravfield, dtype=float)
-    magfield = np.asarray(magfield, dtype=float)
-    drillfield = np.asarray(drillfield, dtype=float)
+    # NB no dtype cast: run_geobo.py hands float32 survey arrays (scipy zoom of a float32 GeoTIFF) and the
+    # reference z-scores them in that dtype (inversion.py:209-214) -- observable at the 1e-7 level
+    gravfield, magfield, drillfield = np.asarray(gravfield), np.asarray(magfield), np.asarray(drillfield)
     with np.errstate(all="ignore"):
         gs, ms = gravfield.std(), magfield.std()
         ds = drillfield.std() if drillfield.size else np.nan

@@ -1,0 +1,76 @@
+"""The C-ABI library builds for gfx950, loads without a GPU and exports every symbol include/geobo_hip.h declares.
+No compute calls here (CPU-only container)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from geobo_amd.build import build
+    path = build()
+    assert os.path.exists(path)
+    return ctypes.CDLL(path)
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "geobo_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(geobo_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported(lib):
+    names = declared_functions()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), "libgeobo_hip.so does not export %s" % n
+
+
+def test_ctypes_table_matches_header():
+    from geobo_amd import _lib
+    assert sorted(_lib.SIGNATURES) == declared_functions()
+    _lib.load()
+
+
+def test_host_side_helpers(lib):
+    lib.geobo_pad_m.restype = ctypes.c_int64
+    lib.geobo_pad_m.argtypes = [ctypes.c_int64]
+    lib.geobo_pad_n.restype = ctypes.c_int64
+    lib.geobo_pad_n.argtypes = [ctypes.c_int64]
+    lib.geobo_potrf_ws_bytes.restype = ctypes.c_size_t
+    lib.geobo_potrf_ws_bytes.argtypes = [ctypes.c_int64]
+    assert lib.geobo_version() == 100
+    assert lib.geobo_pad_m(8242) == 8448 and lib.geobo_pad_m(256) == 256 and lib.geobo_pad_m(1) == 256
+    assert lib.geobo_pad_n(480) == 512 and lib.geobo_pad_n(262144) == 262144
+    assert lib.geobo_potrf_ws_bytes(8448) == (33 * 128) ** 2 * 8
+
+
+def test_argument_validation_without_gpu(lib):
+    """Entry points validate before touching the device: null pointers / misaligned dims give error codes."""
+    from geobo_amd import _lib
+    L = _lib.load()
+    assert L.geobo_gemm_nt(256, 128, 16, 1.0, None, 16, None, 16, 0.0, None, 128, 0, None) == -1
+    assert L.geobo_ak_fused(1, None, 256, 256, 256, None, None, None, 0, 128, 1., 1., 1., 1., None, 128, None) == -1
+    assert L.geobo_potrf_inv(100, None, 100, None, 100, None, None, 0, None) == -1
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "geobo_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "geobo_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
+
+
+def test_compute_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from geobo_amd import _lib, kernels
+    with pytest.raises(_lib.GeoboHipUnavailable):
+        kernels.gpkernel([1.0, 2.0], 3.0)

@@ -1,0 +1,111 @@
+"""Host-side logic that needs no GPU: settings derivation, create_cov's length mutation, drill selection,
+sharding arithmetic, API surface."""
+import inspect
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, settings_for
+
+
+def test_settings_derivation_matches_reference_formulas():
+    from geobo_amd.config_loader import Settings, load
+    s = Settings(dict(xmin=0, xmax=3050, ymin=0, ymax=1952, zmax=0, zoff=1, zLcube=800., xNcube=25, yNcube=16, zNcube=16))
+    assert (s.xvoxsize, s.yvoxsize, s.zvoxsize) == (122.0, 122.0, 50.0)
+    assert s.Nsensor == 400 and s.zmin == -800.0
+    assert np.array_equal(s.magneticField, np.array([0, 0, 1]) * 1e-3)
+    assert s.c_MILLIGALS_UNITS == 6.673848e-11 * 10000 * 1000.0
+    import geobo_amd.config_loader as cl
+    load(s)
+    assert cl.xvoxsize == 122.0 and cl.kernelfunc == "sparse" and cl.active() is s
+
+
+def test_yaml_roundtrip(tmp_path):
+    import yaml
+    from geobo_amd.config_loader import Settings
+    f = load_golden("example1.npz")
+    import json
+    d = json.loads(str(f["settings_json"]))
+    p = tmp_path / "s.yaml"
+    p.write_text(yaml.safe_dump(d))
+    s = Settings.from_yaml(str(p))
+    assert (s.xNcube, s.yNcube, s.zNcube, s.kernelfunc) == (25, 16, 16, "sparse")
+    assert s.gp_coeff == [1.0, 0.2, 0.2]
+
+
+def test_create_cov_length_mutation_is_in_place():
+    from geobo_amd.engine import create_cov_lengths
+    g = load_golden("kat_kernels.npz")
+    for key, start in (("mutated_eq", [200., 200., 200.]), ("mutated_20", [200., 300., 200.]), ("mutated_21", [200., 300., 300.])):
+        a = np.array(start)
+        r = create_cov_lengths(a)
+        assert r is a and np.array_equal(a, g[key])
+
+
+def test_inversion_surface_and_geometry():
+    from geobo_amd.inversion import Inversion
+    f = load_golden("tiny_exp.npz")
+    inv = Inversion(settings=settings_for(10, 8, 6))
+    assert np.array_equal(inv.gp_length, [200., 200., 200.]) and inv.gp_amp == 1.0
+    vox = inv.create_cubegeometry()
+    assert np.array_equal(vox, f["voxelpos"]) and np.array_equal(inv.Edges, f["Edges"])
+    assert inv.xxx.shape == (8, 10, 6)
+    for name, params in (("cubing", ["gravfield", "magfield", "drillfield", "sensor_locations", "drilldata0"]),
+                         ("predict3", ["calclogl"]), ("calc_logl", ["params"]), ("optimize_gp", []), ("create_cubegeometry", [])):
+        assert list(inspect.signature(getattr(Inversion, name)).parameters)[1:] == params
+
+
+def test_drill_selection_and_A_drill():
+    from geobo_amd import sensormodel as sm
+    from geobo_amd.inversion import Inversion
+    f = load_golden("tiny_exp.npz")
+    inv = Inversion(settings=settings_for(10, 8, 6))
+    inv.create_cubegeometry()
+    d0 = f["drilldata0"]
+    inv.drilldata0 = d0
+    assert np.array_equal(inv._drill_selection(), f["sel"])
+    vd = np.vstack([inv.xxx[d0 != 0], inv.yyy[d0 != 0], inv.zzz[d0 != 0]])
+    A = sm.A_drill(vd, inv.voxelpos)
+    assert A.shape == (5, 480) and np.array_equal(np.flatnonzero(A.sum(0)), f["sel"]) and (A.sum(1) == 1).all()
+    assert np.array_equal(sm.drill_index(vd, inv.voxelpos), f["sel"])
+
+
+def test_edge_axes_roundtrip_and_validation():
+    from geobo_amd import sensormodel as sm
+    f = load_golden("tiny_exp.npz")
+    xe, ye, ze = sm._edge_axes(f["Edges"], 10, 8, 6)
+    assert np.array_equal(xe, np.linspace(0, 10, 11) * 100.0) and ze[-1] == 600.0
+    bad = f["Edges"].copy()
+    bad[0, 3, 4, 2] += 1.0
+    with pytest.raises(ValueError):
+        sm._edge_axes(bad, 10, 8, 6)
+
+
+def test_shard_columns_cover_and_align():
+    from geobo_amd.sharding import shard_columns
+    for n_pad in (512, 6400 + 0, 262144, 32768 + 128):
+        n_pad = (n_pad + 127) // 128 * 128
+        for world in (1, 2, 3, 4, 8):
+            prev = 0
+            for r in range(world):
+                c0, c1 = shard_columns(n_pad, world, r)
+                assert c0 == prev and c0 % 128 == 0 and c1 % 128 == 0
+                prev = c1
+            assert prev == n_pad
+
+
+def test_diagonal_covariance_object():
+    from geobo_amd.inversion import DiagonalCovariance
+    d = DiagonalCovariance(np.arange(6.0))
+    assert d.shape == (6, 6) and np.array_equal(d.diagonal(), np.arange(6.0))
+    with pytest.raises(TypeError):
+        np.asarray(d)
+
+
+def test_kernel_id_mapping():
+    from geobo_amd import hip
+    assert hip.kernel_id("exp", False) == 1 and hip.kernel_id("exp", True) == 2
+    assert hip.kernel_id("matern32", True) == 4 and hip.kernel_id("sparse", False) == 5
+    with pytest.raises(ValueError):
+        hip.kernel_id("rbf", False)
+    assert hip.pad_m(8242) == 8448 and hip.pad_n(480) == 512

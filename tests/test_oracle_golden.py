@@ -1,0 +1,120 @@
+"""Pin the CPU oracle (oracle/geobo_oracle.py) to golden vectors produced by RUNNING THE REFERENCE
+(tests/golden/make_golden.py).  CPU only; this is what makes the oracle a trustworthy checker."""
+import json
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, normwise
+from oracle import geobo_oracle as O
+
+
+def test_F0_kernel_known_answers():
+    g = load_golden("kat_kernels.npz")
+    assert O.k_cross("exp", 0., 600., 650.) == float(g["k2_0"]) == 0.9984012779544537
+    assert O.k_cross("matern32", 0., 600., 650.) == float(g["m2_0"])
+    d2 = g["d2_line"]
+    assert np.array_equal(O.k_auto("exp", d2, 200.), g["k_exp"])
+    assert np.array_equal(O.k_cross("exp", d2, 200., 204.), g["k_exp2"])
+    assert np.array_equal(O.k_auto("sparse", d2, 400.), g["k_sp"])
+    assert np.array_equal(O.k_cross("sparse", d2, 400., 408.), g["k_sp2"])
+    assert np.array_equal(O.k_cross("sparse", d2, 400., 400.), g["k_sp2_eq"])   # equal-length offset 1e-3
+    assert np.array_equal(O.k_auto("matern32", d2, 200.), g["k_m"])
+    assert np.array_equal(O.k_cross("matern32", d2, 200., 204.), g["k_m2"])
+    assert np.array_equal(O.grid_points((3, 2, 4), (10., 20., 5.)), g["points3D"])
+    assert np.array_equal(O.sqdist(np.array([[0., 0., 0.], [100., 0., 0.], [100., 250., 75.]])), g["D2"])
+
+
+@pytest.mark.parametrize("name", O.KERNELS)
+def test_F0_create_cov_blocks_and_mutation(name):
+    g = load_golden("kat_kernels.npz")
+    for tag, gl, w in (("eq", [200., 200., 200.], [1.0, .2, .2]), ("ne", [200., 230., 270.], [.7, .3, .2])):
+        gl = np.array(gl)
+        c = O.create_cov(g["D2"], gl, w, name)
+        r = g["cov_%s_%s" % (tag, name)]
+        assert np.array_equal(np.isnan(c), np.isnan(r))      # matern32 is NaN at equal lengths (blocks 0<->2)
+        assert np.array_equal(c[~np.isnan(c)], r[~np.isnan(r)])
+    for key, start in (("mutated_eq", [200., 200., 200.]), ("mutated_20", [200., 300., 200.]), ("mutated_21", [200., 300., 300.])):
+        gl = np.array(start)
+        O.create_cov(g["D2"], gl, [1, 1, 1], "exp")
+        assert np.array_equal(gl, g[key])
+
+
+def _grid_for(f, nx, ny, nz, kern, vox=100.0):
+    return O.Grid(nx=nx, ny=ny, nz=nz, xmax=vox * nx, ymax=vox * ny, zLcube=vox * nz, kernelfunc=kern)
+
+
+@pytest.mark.parametrize("kern", ["exp", "sparse", "matern32"])
+def test_F1_tiny_noncubic_grid(kern):
+    f = load_golden("tiny_%s.npz" % kern)
+    G = _grid_for(f, 10, 8, 6, kern)
+    loc = f["sensor_locations"]
+    assert np.array_equal(G.sensor_locations(), loc)
+    assert np.array_equal(G.edges(), f["Edges"])
+    assert np.array_equal(np.vstack([v.flatten() for v in G.voxel_centres()]), f["voxelpos"])
+    A_g = O.a_sens(G, G.B * 0, loc, G.edges(), "grav")
+    A_m = O.a_sens(G, G.B, loc, G.edges(), "magn")
+    assert normwise(A_g, f["A_g"]) < 1e-13 and normwise(A_m, f["A_m"]) < 1e-13
+    d0 = f["drilldata0"]
+    assert np.array_equal(O.drill_selection(d0), f["sel"])
+    for dense, tol in ((True, 1e-12), (False, 1e-11)):
+        r = O.cubing(G, f["gravfield"], f["magfield"], d0[d0 != 0], loc, d0, gp_length=f["gp_length_in"].copy(), dense=dense)
+        for a, b in zip(r["cubes"], f["cubes"]):
+            assert normwise(a, b) < tol
+        assert normwise(r["mu"], f["mu"]) < tol and normwise(r["var"], f["var"]) < tol
+        assert abs(r["logl"] - float(f["logl"])) < 1e-9 * abs(float(f["logl"]))
+        assert np.array_equal(r["gp_length"], f["gp_length_out"])
+        assert normwise(r["AkA"], f["AkA"]) < 1e-13
+        assert np.array_equal(r["Fs3"], f["Fs3"])
+
+
+def test_F1_no_drill_rows_gives_nan_drill_cubes():
+    f = load_golden("tiny_exp_nodrill.npz")
+    G = _grid_for(f, 10, 8, 6, "exp")
+    d0 = f["drilldata0"]
+    r = O.cubing(G, f["gravfield"], f["magfield"], d0[d0 != 0], f["sensor_locations"], d0)
+    for i in (0, 1, 3, 4):
+        assert normwise(r["cubes"][i], f["cubes"][i]) < 1e-11
+    assert np.isnan(r["cubes"][2]).all() and np.isnan(f["cubes"][2]).all()
+
+
+@pytest.mark.parametrize("name,kern", [("cube16_exp", "exp"), ("cube16_matern32", "matern32"), ("cube16_sparse", "sparse")])
+def test_F2_cube16_blocked_form(name, kern):
+    f = load_golden(name + ".npz")
+    G = _grid_for(f, 16, 16, 16, kern)
+    d0 = f["drilldata0"]
+    r = O.cubing(G, f["gravfield"], f["magfield"], d0[d0 != 0], f["sensor_locations"], d0, gp_length=f["gp_length_in"].copy())
+    errs = [normwise(a, b) for a, b in zip(r["cubes"], f["cubes"]) if not np.isnan(b).all()]
+    assert max(errs) < 1e-10, errs
+    assert abs(r["logl"] - float(f["logl"])) < 1e-9 * abs(float(f["logl"]))
+    assert normwise(r["A_g"].sum(axis=1), f["A_g_rowsum"]) < 1e-12 and normwise(r["A_m"].sum(axis=0), f["A_m_colsum"]) < 1e-12
+
+
+@pytest.mark.parametrize("name", ["example1", "example2"])
+def test_F3_shipped_examples(name):
+    f = load_golden(name + ".npz")
+    G = O.Grid.from_settings(json.loads(str(f["settings_json"])))
+    r = O.cubing(G, f["gravfield"], f["magfield"], f["drillfield"], f["sensor_locations"], f["drilldata0"])
+    for a, b, v in zip(r["cubes"], f["cubes"], f["vtk_cubes"]):
+        assert normwise(a, b) < 1e-10          # vs the reference re-run in this container
+        assert normwise(a, v) < 5e-8           # vs the committed examples/results/*.vtk (re-run itself: <= 3.7e-8)
+    assert np.array_equal(r["gp_length"], f["gp_length_out"])
+
+
+def test_F4_forward_model_known_answer():
+    f = load_golden("forward_kat.npz")
+    G = O.Grid(nx=25, ny=16, nz=16, xmax=3050, ymax=1952, zLcube=800.)
+    loc = f["sensor_locations"]
+    A_g = O.a_sens(G, G.B * 0, loc, G.edges(), "grav")
+    A_m = O.a_sens(G, G.B, loc, G.edges(), "magn")
+    assert normwise(A_g @ f["density"], f["gravity_csv"]) < 1e-13
+    assert normwise(A_m @ f["magsus"], f["magnetic_csv"]) < 1e-13
+
+
+def test_synthetic_survey_matches_golden_inputs():
+    f = load_golden("tiny_exp.npz")
+    G = _grid_for(f, 10, 8, 6, "exp")
+    sv = O.synthetic_survey(G, 5)
+    assert np.array_equal(sv["drilldata0"], f["drilldata0"])
+    assert np.array_equal(sv["rho"], f["rho"])
+    assert normwise(sv["gravfield"], f["gravfield"]) < 1e-6   # float32-rounded data

@@ -1,0 +1,95 @@
+"""N > 1 host path on CPU: two gloo ranks shard the voxel columns exactly as the GPU engine does
+(geobo_amd/sharding.py), exchange the partial AkA with the product's all-reduce and the mu/var slices with its
+all-gather, and must reproduce the unsharded oracle posterior."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT, load_golden
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from scipy.linalg import cholesky, solve_triangular
+    from geobo_amd.sharding import allreduce_sum_, assemble_columns, gather_slices, shard_columns
+    from oracle import geobo_oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    f = load_golden("tiny_matern32.npz")
+    N, N_pad, props = 480, 512, (0, 1, 2)
+    P3 = O.grid_points((10, 8, 6), (100., 100., 100.))
+    lengths = O.mutate_lengths(f["gp_length_in"].copy())
+    W = O.weight_matrix((1.0, 0.2, 0.2))
+    A = {0: f["A_g"], 1: f["A_m"]}
+    sel, y = f["sel"], f["Fs3"]
+    mg, md = 80, sel.size
+    M = 2 * mg + md
+    c0, c1 = shard_columns(N_pad, world, rank)
+    cols = np.arange(c0, min(c1, N))
+    # this rank's columns of AK (contraction over ALL voxels), exactly the engine's step 1
+    D2 = O.sqdist(P3, P3[cols])
+    AK = {}
+    for j in props:
+        blk = np.zeros((M, c1 - c0))
+        for s_ in (0, 1):
+            blk[s_ * mg:(s_ + 1) * mg, :cols.size] = A[s_] @ O.k_block("matern32", D2, lengths, W, s_, j)
+        blk[2 * mg:, :cols.size] = O.k_block("matern32", D2[sel], lengths, W, 2, j)
+        AK[j] = blk
+    part = np.zeros((M, M))
+    for s_ in (0, 1):
+        part[:, s_ * mg:(s_ + 1) * mg] = AK[s_][:, :cols.size] @ A[s_][:, cols].T
+    t = torch.from_numpy(part)
+    allreduce_sum_(t, world)                                     # <- product collective #1
+    AkA = t.numpy()
+    AkA[:2 * mg, 2 * mg:] = AkA[2 * mg:, :2 * mg].T
+    AkA[2 * mg:, 2 * mg:] = O.k_block("matern32", O.sqdist(P3[sel]), lengths, W, 2, 2)
+    AkA += np.diag(np.r_[np.full(2 * mg, 0.01), np.full(md, 0.01)])
+    L = cholesky(AkA, lower=True)
+    u = solve_triangular(L, y, lower=True)
+    mu_l, var_l = [], []
+    for j in props:
+        V = solve_triangular(L, AK[j], lower=True)
+        mu_l.append(V.T @ u)
+        var_l.append(1.0 - np.einsum("mq,mq->q", V, V))
+    mu_parts = gather_slices(torch.from_numpy(np.concatenate(mu_l)), len(props), N_pad, world)   # <- collective #2
+    var_parts = gather_slices(torch.from_numpy(np.concatenate(var_l)), len(props), N_pad, world)
+    mu = assemble_columns(mu_parts, props, N, N_pad, world)
+    var = assemble_columns(var_parts, props, N, N_pad, world)
+    if rank == 0:
+        q.put((mu, var, AkA))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_rank_sharded_posterior_matches_reference(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    mu, var, AkA = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    f = load_golden("tiny_matern32.npz")
+    assert np.abs(AkA - f["AkA"]).max() / np.abs(f["AkA"]).max() < 1e-13
+    assert np.abs(mu - f["mu"]).max() / np.abs(f["mu"]).max() < 1e-10
+    assert np.abs(var - f["var"]).max() / np.abs(f["var"]).max() < 1e-10
