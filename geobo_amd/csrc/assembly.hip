@@ -51,6 +51,22 @@ __global__ void __launch_bounds__(256) k_block_kernel(const double* __restrict__
   }
 }
 
+// covariance sampled on the difference lattice of a regular grid: table[(diy*nx + dix)*nz + diz] = scale*k(|P(0,0,0) - P(diy,dix,diz)|^2)
+// with P = (i+1)*voxel size exactly as calcGridPoints3D builds it (kernels.py:36-38) -- i.e. the value the coordinate
+// path produces for the voxel pair (0, d).
+template <int ID>
+__global__ void __launch_bounds__(256) cov_table_kernel(int nx, int ny, int nz, double sx, double sy, double sz,
+                                                        const CovParams p, double* __restrict__ table) {
+  const int64_t n = (int64_t)nx * ny * nz;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int dz = (int)(i % nz);
+    const int64_t t = i / nz;
+    const int dx = (int)(t % nx), dy = (int)(t / nx);
+    const double d2 = sqdist3(1.0 * sx, 1.0 * sy, 1.0 * sz, (double)(dx + 1) * sx, (double)(dy + 1) * sy, (double)(dz + 1) * sz);
+    table[i] = p.scale * cov_eval<ID>(p, d2);
+  }
+}
+
 template <int ID>
 __global__ void __launch_bounds__(256) k_eval_kernel(const double* __restrict__ d2, int64_t n, const CovParams p,
                                                      double* __restrict__ out) {
@@ -158,7 +174,46 @@ __global__ void __launch_bounds__(256, 4) mfma_peak_kernel(int iters, double* __
   out[(int64_t)blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// co-issue probe: NV independent VALU ops of a given flavour after every MFMA (same wave)
+template <int MODE, int NV>
+__global__ void __launch_bounds__(256, 4) mfma_mix_kernel(int iters, double* __restrict__ out) {
+  v4d acc[8];
+  const double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
+  double xd[8];
+  float xf[8];
+  unsigned xi[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { acc[i] = (v4d){0., 0., 0., 0.}; xd[i] = a + i; xf[i] = (float)(a + i); xi[i] = threadIdx.x + i; }
+  const double cd = 0.999999, dd = 1e-7;
+  const float cf = 0.999999f, df = 1e-7f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      acc[i & 7] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i & 7], 0, 0, 0);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        if constexpr (MODE == 1) xd[v & 7] = __builtin_fma(xd[v & 7], cd, dd);
+        if constexpr (MODE == 2) xf[v & 7] = __builtin_fmaf(xf[v & 7], cf, df);
+        if constexpr (MODE == 3) xi[v & 7] = xi[v & 7] * 1664525u + 1013904223u;
+      }
+    }
+  }
+  double s = 0.;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3] + xd[i] + xf[i] + xi[i];
+  out[(int64_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 }  // namespace
+
+extern "C" int geobo_mfma_mix(int mode, int nv, int blocks, int iters, double* out, void* stream) {
+  if (!out || blocks <= 0 || iters <= 0) return GEOBO_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+#define MIX(M, N) if (mode == M && nv == N) { hipLaunchKernelGGL((mfma_mix_kernel<M, N>), dim3(blocks), dim3(256), 0, st, iters, out); return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH; }
+  MIX(0, 0) MIX(1, 2) MIX(1, 4) MIX(1, 8) MIX(1, 16) MIX(2, 4) MIX(2, 8) MIX(2, 16) MIX(2, 32) MIX(3, 8) MIX(3, 16) MIX(3, 32)
+#undef MIX
+  return GEOBO_E_UNSUPPORTED;
+}
 
 extern "C" int geobo_version(void) { return GEOBO_VERSION; }
 extern "C" int64_t geobo_pad_m(int64_t m) { return (m + GEOBO_PAD_M - 1) / GEOBO_PAD_M * GEOBO_PAD_M; }
@@ -176,6 +231,20 @@ extern "C" int geobo_k_block(int kernel_id, const double* rx, const double* ry, 
 #define GEOBO_KB(ID) hipLaunchKernelGGL(k_block_kernel<ID>, grid, dim3(256), 0, st, rx, ry, rz, nr, cx, cy, cz, nc, p, out, ld)
   COV_DISPATCH(kernel_id, GEOBO_KB);
 #undef GEOBO_KB
+  return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
+}
+
+extern "C" int geobo_cov_table(int kernel_id, int nx, int ny, int nz, double sx, double sy, double sz, double l1, double l2,
+                               double w, double amp, double* table, void* stream) {
+  if (!table || nx <= 0 || ny <= 0 || nz <= 0) return GEOBO_E_ARG;
+  const CovParams p = make_cov(kernel_id, l1, l2, w, amp);
+  const int64_t n = (int64_t)nx * ny * nz;
+  int64_t nb = (n + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipStream_t st = (hipStream_t)stream;
+#define GEOBO_CT(ID) hipLaunchKernelGGL(cov_table_kernel<ID>, dim3((unsigned)nb), dim3(256), 0, st, nx, ny, nz, sx, sy, sz, p, table)
+  COV_DISPATCH(kernel_id, GEOBO_CT);
+#undef GEOBO_CT
   return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
 }
 

@@ -35,7 +35,7 @@ namespace {
 constexpr int BK = 16;  // contraction chunk
 constexpr int XS = 18;  // LDS row stride in doubles for [rows][16] tiles (144 B: 16-B aligned, de-phased banks)
 
-enum { Y_GEN = 0, Y_NT = 1, Y_NN = 2 };
+enum { Y_GEN = 0, Y_NT = 1, Y_NN = 2, Y_TAB = 3 };
 enum { EPI_STORE = 0, EPI_REDUCE = 1 };
 enum { TRI_LOWER_ONLY = 1, TRI_X_LOWER = 2, TRI_Y_LOWER = 4 };
 
@@ -49,6 +49,8 @@ struct GemmArgs {
   // generator
   const double *px, *py, *pz; int64_t gcol0;
   CovParams cov;
+  // lattice-table generator (Y_TAB): table[(|diy|*gnx + |dix|)*gnz + |diz|] = w*amp*k on the grid's difference lattice
+  const double* table; int gnx, gny, gnz; int64_t gN;
   // reduce epilogue
   const double* u; double* part_mu; double* part_ss; int64_t ncols;
 };
@@ -108,7 +110,7 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_f64_kernel(const GemmArgs a
 
   // ---- staging helpers ---------------------------------------------------------------------------------
   v2d xr[XU];
-  v2d yr[(YMODE == Y_GEN) ? EPT / 2 : YU];
+  v2d yr[(YMODE == Y_GEN || YMODE == Y_TAB) ? EPT / 2 : YU];
   const double* const Xg = a.X + row0 * a.ldx;
 
   // generator state: this thread's output column q and its (wave-uniform) slice of the chunk
@@ -118,6 +120,24 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_f64_kernel(const GemmArgs a
   if constexpr (YMODE == Y_GEN) {
     const int64_t q = a.gcol0 + col0 + gq;
     qx = a.px[q]; qy = a.py[q]; qz = a.pz[q];
+  }
+  // lattice generator state: this thread's voxel (qiy,qix,qiz) and the wave-uniform voxel (piy,pix,piz) of the first
+  // contraction index of the chunk being staged; all integer arithmetic (it co-issues with the fp64 MFMA pipe,
+  // FP VALU does not -- DESIGN.md "what shares the fp64 pipe")
+  int qiy = 0, qix = 0, qiz = 0, piy = 0, pix = 0, piz = 0;
+  int64_t pk = kb;
+  if constexpr (YMODE == Y_TAB) {
+    int64_t q = a.gcol0 + col0 + gq;
+    if (q >= a.gN) q = a.gN - 1;
+    qiz = (int)(q % a.gnz);
+    const int64_t t = q / a.gnz;
+    qix = (int)(t % a.gnx);
+    qiy = (int)(t / a.gnx);
+    const int64_t p = kb + gsub * EPT;
+    piz = (int)(p % a.gnz);
+    const int64_t tp = p / a.gnz;
+    pix = (int)(tp % a.gnx);
+    piy = (int)(tp / a.gnx);
   }
 
   auto load_x = [&](int64_t k0) {
@@ -149,6 +169,30 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_f64_kernel(const GemmArgs a
         const int kr = u / (TN / 2), c2 = u % (TN / 2);
         yr[i] = *reinterpret_cast<const v2d*>(a.Y + (k0 + kr) * a.ldy + col0 + 2 * c2);
       }
+    } else if constexpr (YMODE == Y_TAB) {
+      // advance the uniform voxel position by (k0 - pk) in {0, 16}; at most one carry per axis because gnz >= 16
+      const int adv = (int)(k0 - pk);
+      pk = k0;
+      piz += adv;
+      int c = piz >= a.gnz ? 1 : 0;
+      piz -= c ? a.gnz : 0;
+      pix += c;
+      c = pix >= a.gnx ? 1 : 0;
+      pix -= c ? a.gnx : 0;
+      piy += c;
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        int ez = piz + e;
+        int c1 = ez >= a.gnz ? 1 : 0;
+        ez -= c1 ? a.gnz : 0;
+        int ex = pix + c1;
+        int c2 = ex >= a.gnx ? 1 : 0;
+        ex -= c2 ? a.gnx : 0;
+        int ey = piy + c2;
+        if (ey >= a.gny) { ey = a.gny - 1; ex = a.gnx - 1; ez = a.gnz - 1; }  // padded contraction index (A column is 0)
+        const int dy = __builtin_abs(qiy - ey), dx = __builtin_abs(qix - ex), dz = __builtin_abs(qiz - ez);
+        yr[e >> 1][e & 1] = a.table[((int64_t)dy * a.gnx + dx) * a.gnz + dz];
+      }
     } else {
       const int64_t p0 = k0 + gsub * EPT;  // wave-uniform -> scalar loads of the p coordinates
 #pragma unroll
@@ -179,6 +223,10 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_f64_kernel(const GemmArgs a
   };
 
   // ---- main loop ---------------------------------------------------------------------------------------
+  // One basic block per chunk (no branches): the staging target of the last chunk is clamped to the chunk itself.
+  // In generator mode the covariances of the NEXT chunk are computed between the MFMAs of the CURRENT one
+  // (EPT/4 values after each 16-MFMA k-step) and the scheduler is pinned to a 1 MFMA : GEN_VALU VALU pattern, so
+  // the VALU work rides under the 64-cycle matrix-pipe occupancy of each v_mfma_f64_16x16x4_f64.
   if (kb < ke) {
     load_x(kb);
     load_y(kb);
@@ -187,46 +235,56 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_f64_kernel(const GemmArgs a
     __syncthreads();
     int cur = 0;
     for (int64_t k0 = kb; k0 < ke; k0 += BK) {
-      const bool more = (k0 + BK) < ke;
-      if (more) {
-        load_x(k0 + BK);
-        load_y(k0 + BK);
-      }
+      int64_t kn = k0 + BK;
+      if (kn >= ke) kn = ke - BK;
+      load_x(kn);
+      if constexpr (YMODE != Y_GEN) load_y(kn);
       const double* xb = Xs + cur * XBUF + (wm * 64 + lr) * XS + 4 * lg;
       v2d av[4][2], bv[4][2];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        av[m][0] = *reinterpret_cast<const v2d*>(xb + m * 16 * XS);
-        av[m][1] = *reinterpret_cast<const v2d*>(xb + m * 16 * XS + 2);
-      }
-      if constexpr (YMODE == Y_NN) {
-        const double* yb = Ys + cur * YBUF + (4 * lg) * YS_NN + wn * 64 + lr;
+      for (int h = 0; h < 2; ++h) {
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-          bv[n][0][0] = yb[0 * YS_NN + n * 16];
-          bv[n][0][1] = yb[1 * YS_NN + n * 16];
-          bv[n][1][0] = yb[2 * YS_NN + n * 16];
-          bv[n][1][1] = yb[3 * YS_NN + n * 16];
-        }
-      } else {
-        const double* yb = Ys + cur * YBUF + (wn * 64 + lr) * XS + 4 * lg;
+        for (int m = 0; m < 4; ++m) av[m][h] = *reinterpret_cast<const v2d*>(xb + m * 16 * XS + 2 * h);
+        if constexpr (YMODE == Y_NN) {
+          const double* yb = Ys + cur * YBUF + (4 * lg + 2 * h) * YS_NN + wn * 64 + lr;
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-          bv[n][0] = *reinterpret_cast<const v2d*>(yb + n * 16 * XS);
-          bv[n][1] = *reinterpret_cast<const v2d*>(yb + n * 16 * XS + 2);
+          for (int n = 0; n < 4; ++n) {
+            bv[n][h][0] = yb[n * 16];
+            bv[n][h][1] = yb[YS_NN + n * 16];
+          }
+        } else {
+          const double* yb = Ys + cur * YBUF + (wn * 64 + lr) * XS + 4 * lg + 2 * h;
+#pragma unroll
+          for (int n = 0; n < 4; ++n) bv[n][h] = *reinterpret_cast<const v2d*>(yb + n * 16 * XS);
         }
       }
+      const int64_t p0 = kn + gsub * EPT;  // generator: wave-uniform -> scalar loads of the p coordinates
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < 4; ++t) {
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
           for (int n = 0; n < 4; ++n)
             acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m][t >> 1][t & 1], bv[n][t >> 1][t & 1], acc[m][n], 0, 0, 0);
-      if (more) {
-        store_x(Xs + (cur ^ 1) * XBUF);
-        store_y(Ys + (cur ^ 1) * YBUF);
+        if constexpr (YMODE == Y_GEN) {
+#pragma unroll
+          for (int e = t * (EPT / 4); e < (t + 1) * (EPT / 4); ++e) {
+            const double d2 = sqdist3(a.px[p0 + e], a.py[p0 + e], a.pz[p0 + e], qx, qy, qz);
+            yr[e >> 1][e & 1] = a.cov.scale * cov_eval<KID>(a.cov, d2);
+          }
+        }
       }
+      if constexpr (YMODE == Y_GEN && (KID <= COV_MATERN32_X)) {
+        // 64 x { 1 MFMA, up to GEN_VALU VALU }: interleave the generator into the matrix-pipe shadow
+        constexpr int GEN_VALU = (KID == COV_MATERN32_X) ? 7 : ((KID == COV_D2) ? 1 : 5);
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, GEN_VALU * (EPT / 4), 0);
+        }
+      }
+      store_x(Xs + (cur ^ 1) * XBUF);
+      store_y(Ys + (cur ^ 1) * YBUF);
       __syncthreads();
       cur ^= 1;
     }
@@ -343,6 +401,20 @@ extern "C" int geobo_ak_fused(int kernel_id, const double* A, int64_t Ms_pad, in
   COV_DISPATCH(kernel_id, GEOBO_FUSED);
 #undef GEOBO_FUSED
   return GEOBO_E_ARG;
+}
+
+extern "C" int geobo_ak_fused_grid(const double* A, int64_t Ms_pad, int64_t N_pad, int64_t lda, int nx, int ny, int nz,
+                                   const double* table, int64_t col0, int64_t ncols, double* AK, int64_t ldak,
+                                   void* stream) {
+  if (!A || !table || !AK) return GEOBO_E_ARG;
+  if (nx <= 0 || ny <= 0 || nz < BK) return GEOBO_E_UNSUPPORTED;  // one carry per chunk needs nz >= 16
+  const int64_t N = (int64_t)nx * ny * nz;
+  if (Ms_pad % 128 || N_pad % BK || ncols % 128 || (lda & 1) || col0 < 0 || col0 + ncols > N_pad || N_pad < N) return GEOBO_E_ALIGN;
+  GemmArgs a{};
+  a.X = A; a.ldx = lda; a.Y = nullptr; a.ldy = 0; a.C = AK; a.ldc = ldak; a.k = N_pad;
+  a.alpha = 1.0; a.beta = 0.0; a.tri = 0;
+  a.gcol0 = col0; a.table = table; a.gnx = nx; a.gny = ny; a.gnz = nz; a.gN = N;
+  return launch_by_rows<Y_TAB, EPI_STORE, COV_D2>(a, Ms_pad, ncols, (hipStream_t)stream);
 }
 
 extern "C" int geobo_gemm_nt(int64_t m, int64_t n, int64_t k, double alpha, const double* X, int64_t ldx,

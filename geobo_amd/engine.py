@@ -78,6 +78,7 @@ class PosteriorEngine:
         self.nc = self.c1 - self.c0
         self._xyz = None
         self._A = {}
+        self.use_grid = self.nz >= 16  # lattice-table generator (geobo_ak_fused_grid); coordinates otherwise
         self.kernel_events = None  # set to [] to record (name, flops, start, stop) HIP events per fused launch
 
     # ---- geometry --------------------------------------------------------------------------------------------
@@ -155,11 +156,19 @@ class PosteriorEngine:
             for s_, A in ((0, A_g), (1, A_m)):
                 kid = hip.kernel_id(name, s_ != j)
                 # block (row-block s, col-block j) of create_cov is w * k2(l_j, l_s)  (kernels.py:183-195)
+                out = AK[s_ * self.Ms_pad:(s_ + 1) * self.Ms_pad, cols]
+                if self.use_grid:
+                    # regular grid: covariance = table on the index-difference lattice (built once per block, N doubles)
+                    sset = self.s
+                    tab = hip.cov_table(kid, self.nx, self.ny, self.nz, sset.xvoxsize, sset.yvoxsize, sset.zvoxsize,
+                                        lengths[j], lengths[s_], W[s_][j], amp, self.device)
                 if self.kernel_events is not None:
                     e0 = torch.cuda.Event(enable_timing=True)
                     e0.record()
-                hip.ak_fused(kid, A, xyz, self.c0, nc, lengths[j], lengths[s_], W[s_][j], amp,
-                             AK[s_ * self.Ms_pad:(s_ + 1) * self.Ms_pad, cols])
+                if self.use_grid:
+                    hip.ak_fused_grid(A, self.nx, self.ny, self.nz, tab, self.c0, nc, out)
+                else:
+                    hip.ak_fused(kid, A, xyz, self.c0, nc, lengths[j], lengths[s_], W[s_][j], amp, out)
                 if self.kernel_events is not None:
                     e1 = torch.cuda.Event(enable_timing=True)
                     e1.record()  # same stream as the launch (torch's current stream)

@@ -91,6 +91,17 @@ int geobo_ak_fused(int kernel_id, const double* A, int64_t Ms_pad, int64_t N_pad
                    const double* x, const double* y, const double* z, int64_t col0, int64_t ncols,
                    double l1, double l2, double w, double amp, double* AK, int64_t ldak, void* stream);
 
+/* Regular-grid form of the same product.  On the grid of calcGridPoints3D (kernels.py:27-42) every covariance is a
+ * function of the index difference (|diy|,|dix|,|diz|), so the generator stage becomes an integer-indexed gather from
+ * a lattice table (nx*ny*nz doubles, L2 resident) instead of exp/sqrt on the FP pipe that the fp64 MFMA also needs:
+ *   geobo_cov_table:     table[(diy*nx + dix)*nz + diz] = w*amp*k(|P(0,0,0) - P(diy,dix,diz)|^2; l1, l2),  P = (i+1)*voxel
+ *   geobo_ak_fused_grid: AK[r, c] = sum_p A[r, p] * table[|iy_p-iy_q|, |ix_p-ix_q|, |iz_p-iz_q|],  q = col0 + c
+ * Same padding contract as geobo_ak_fused; requires nz >= 16. */
+int geobo_cov_table(int kernel_id, int nx, int ny, int nz, double sx, double sy, double sz, double l1, double l2,
+                    double w, double amp, double* table, void* stream);
+int geobo_ak_fused_grid(const double* A, int64_t Ms_pad, int64_t N_pad, int64_t lda, int nx, int ny, int nz,
+                        const double* table, int64_t col0, int64_t ncols, double* AK, int64_t ldak, void* stream);
+
 /* C = alpha * X * Y^T + beta * C   (X: m x k, Y: n x k, both k-contiguous).  inversion.py:96 (AkA = (A K) A^T),
  * Cholesky panel/trailing updates.  m % 256 == 0, n % 128 == 0, k % 16 == 0.
  * lower_only != 0: tiles strictly above the diagonal are skipped (SYRK-style). */
@@ -129,6 +140,10 @@ int geobo_trmv_stats(int64_t m, const double* Linv, int64_t ldi, const double* y
 /* micro-benchmark used by bench.py to pin the fp64 MFMA ceiling on the box: each of `blocks` workgroups
  * (256 threads) issues iters x 16 independent v_mfma_f64_16x16x4_f64; out receives a checksum. */
 int geobo_mfma_f64_peak(int blocks, int iters, double* out, void* stream);
+
+/* co-issue probe: `nv` VALU ops (mode 1 fp64 fma, 2 fp32 fma, 3 int mad; 0 none) after every fp64 MFMA of the same
+ * wave; used to decide what the generator stage may cost (DESIGN.md "what shares the fp64 pipe"). */
+int geobo_mfma_mix(int mode, int nv, int blocks, int iters, double* out, void* stream);
 
 #ifdef __cplusplus
 }

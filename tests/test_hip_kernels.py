@@ -166,6 +166,39 @@ def test_ak_fused_matches_oracle(hip, name, cross):
     assert np.array_equal(out2.cpu().numpy(), got[:, 128:256])
 
 
+@pytest.mark.parametrize("name,cross", [("exp", True), ("matern32", False), ("matern32", True), ("sparse", True)])
+@pytest.mark.parametrize("dims", [(6, 5, 16), (3, 7, 24)])
+def test_ak_fused_grid_matches_coordinate_path(hip, name, cross, dims):
+    """Lattice-table generator == coordinate generator on a regular (anisotropic, non-cubic) grid, incl. column shards."""
+    from oracle import geobo_oracle as O
+    nx, ny, nz = dims
+    vox = (122.0, 97.5, 50.0)
+    P = O.grid_points((nx, ny, nz), vox)
+    N = P.shape[0]
+    Np, Msp, Ms = hip.pad_n(N), 256, 40
+    A = np.zeros((Msp, Np))
+    A[:Ms, :N] = np.random.default_rng(7).standard_normal((Ms, N))
+    l1, l2 = (260.0, 291.0) if cross else (260.0, 260.0)
+    kid = hip.kernel_id(name, cross)
+    pad = lambda v: np.concatenate([v, np.full(Np - N, v[-1])])
+    xyz = tuple(hip.to_dev(pad(P[:, d])) for d in range(3))
+    Ad = hip.to_dev(A)
+    ref = torch.zeros((Msp, Np), dtype=torch.float64, device="cuda")
+    hip.ak_fused(kid, Ad, xyz, 0, Np, l1, l2, 0.3, 1.2, ref)
+    tab = hip.cov_table(kid, nx, ny, nz, *vox, l1, l2, 0.3, 1.2)
+    Kfull = 0.3 * 1.2 * (O.k_cross(name, O.sqdist(P[:1], P), l1, l2) if cross else O.k_auto(name, O.sqdist(P[:1], P), l1))
+    # table entry (diy,dix,diz) = covariance between voxel 0 and voxel (diy,dix,diz): the first row of K
+    assert np.abs(tab.cpu().numpy() - Kfull[0]).max() <= 2e-12 * max(1.0, np.abs(Kfull).max())
+    got = torch.full((Msp, Np), float("nan"), dtype=torch.float64, device="cuda")
+    hip.ak_fused_grid(Ad, nx, ny, nz, tab, 0, Np, got)
+    r, g = ref.cpu().numpy()[:Ms, :N], got.cpu().numpy()[:Ms, :N]
+    assert np.isfinite(got.cpu().numpy()).all()
+    assert np.abs(g - r).max() <= 1e-12 * np.abs(r).max()
+    sh = torch.zeros((Msp, 128), dtype=torch.float64, device="cuda")
+    hip.ak_fused_grid(Ad, nx, ny, nz, tab, Np - 128, 128, sh)
+    assert np.array_equal(sh.cpu().numpy(), got.cpu().numpy()[:, Np - 128:])
+
+
 @pytest.mark.parametrize("m", [256, 512, 1280])
 def test_potrf_inv_matches_torch(hip, m):
     B = _rand((m, m), 20)

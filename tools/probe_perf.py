@@ -31,6 +31,10 @@ if "fused" in what:
             kid = hip.KERNEL_IDS["d2"] if cross is None else hip.kernel_id(name, cross)
             t = timed(lambda: hip.ak_fused(kid, A, xyz, 0, N, 200.0, 204.0, 0.2, 1.0, out), reps=2)
             print("ak_fused N=%d Ms=%d %s cross=%s: %.3f s  %.1f TF/s" % (N, Ms, name, cross, t, 2.0 * Ms * N * N / t / 1e12), flush=True)
+        if n_ >= 16:
+            tab = hip.cov_table(hip.kernel_id("matern32", True), n_, n_, n_, 100., 100., 100., 200.0, 204.0, 0.2, 1.0)
+            t = timed(lambda: hip.ak_fused_grid(A, n_, n_, n_, tab, 0, N, out), reps=2)
+            print("ak_fused_grid N=%d Ms=%d: %.3f s  %.1f TF/s" % (N, Ms, t, 2.0 * Ms * N * N / t / 1e12), flush=True)
         del A, out
 if "nt" in what:
     for (m, n2, k) in ((2304, 1024, 32768), (8448, 4096, 65536)):
