@@ -24,6 +24,7 @@
 // row tile (they stream the same A rows through that XCD's L2) and different column tiles.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "covfun.h"
 #include "geobo_hip.h"
 
@@ -63,7 +64,7 @@ constexpr int lds_doubles() {
 }
 
 template <int WM, int WN, int YMODE, int EPI, int KID>
-__global__ void __launch_bounds__(64 * WM * WN) gemm_f64_kernel(const GemmArgs a) {
+__global__ void __launch_bounds__(64 * WM * WN, 2) gemm_f64_kernel(const GemmArgs a) {
   constexpr int TM = 64 * WM, TN = 64 * WN, NT = 64 * WM * WN;
   constexpr int YS_NN = TN + 4;
   constexpr int XBUF = TM * XS;
@@ -180,18 +181,24 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_f64_kernel(const GemmArgs a
       c = pix >= a.gnx ? 1 : 0;
       pix -= c ? a.gnx : 0;
       piy += c;
+      // the EPT consecutive contraction indices of this wave span at most two z-columns: A = (piy,pix), B = its successor
+      int bx = pix + 1, by = piy;
+      if (bx >= a.gnx) { bx = 0; by += 1; }
+      const int ay = piy < a.gny ? piy : a.gny - 1;   // padded contraction indices: any in-range entry (A column is 0)
+      by = by < a.gny ? by : a.gny - 1;
+      // row offsets into the table: (|dy|*nx + |dx|)*nz, 32-bit integer VALU only (v_sad_u32 / v_mul_u32_u24)
+      const unsigned rowA = __umul24(__usad((unsigned)qix, (unsigned)pix,
+                                __umul24(__usad((unsigned)qiy, (unsigned)ay, 0u), (unsigned)a.gnx)), (unsigned)a.gnz);
+      const unsigned rowB = __umul24(__usad((unsigned)qix, (unsigned)bx,
+                                __umul24(__usad((unsigned)qiy, (unsigned)by, 0u), (unsigned)a.gnx)), (unsigned)a.gnz);
+      const char* const tb = reinterpret_cast<const char*>(a.table);
 #pragma unroll
       for (int e = 0; e < EPT; ++e) {
         int ez = piz + e;
-        int c1 = ez >= a.gnz ? 1 : 0;
-        ez -= c1 ? a.gnz : 0;
-        int ex = pix + c1;
-        int c2 = ex >= a.gnx ? 1 : 0;
-        ex -= c2 ? a.gnx : 0;
-        int ey = piy + c2;
-        if (ey >= a.gny) { ey = a.gny - 1; ex = a.gnx - 1; ez = a.gnz - 1; }  // padded contraction index (A column is 0)
-        const int dy = __builtin_abs(qiy - ey), dx = __builtin_abs(qix - ex), dz = __builtin_abs(qiz - ez);
-        yr[e >> 1][e & 1] = a.table[((int64_t)dy * a.gnx + dx) * a.gnz + dz];
+        const bool carry = ez >= a.gnz;   // uniform
+        ez -= carry ? a.gnz : 0;
+        const unsigned idx = __usad((unsigned)qiz, (unsigned)ez, carry ? rowB : rowA);
+        yr[e >> 1][e & 1] = *reinterpret_cast<const double*>(tb + (idx << 3));
       }
     } else {
       const int64_t p0 = k0 + gsub * EPT;  // wave-uniform -> scalar loads of the p coordinates
@@ -272,6 +279,16 @@ __global__ void __launch_bounds__(64 * WM * WN) gemm_f64_kernel(const GemmArgs a
             const double d2 = sqdist3(a.px[p0 + e], a.py[p0 + e], a.pz[p0 + e], qx, qy, qz);
             yr[e >> 1][e & 1] = a.cov.scale * cov_eval<KID>(a.cov, d2);
           }
+        }
+      }
+      if constexpr (YMODE != Y_GEN) {
+        // spread the staging work (LDS fragment reads, address arithmetic, global loads / table gathers) under the
+        // matrix pipe: after every MFMA up to 3 non-FP instructions; integer VALU, SALU, VMEM and DS issue do not
+        // compete with v_mfma_f64 for the FP pipe (FP VALU does).
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x126, 3, 0);
         }
       }
       if constexpr (YMODE == Y_GEN && (KID <= COV_MATERN32_X)) {
@@ -379,7 +396,8 @@ template <int YMODE, int EPI, int KID>
 int launch_by_rows(GemmArgs& a, int64_t m, int64_t n, hipStream_t st) {
   if (n % 128) return GEOBO_E_ALIGN;
   a.nbj = (int)(n / 128);
-  if (m % 256 == 0) { a.nbi = (int)(m / 256); return launch<4, 2, YMODE, EPI, KID>(a, st); }
+  static const bool force128 = getenv("GEOBO_TILE128") != nullptr;  // experiment switch: 2 independent 4-wave WGs per CU
+  if (m % 256 == 0 && !force128) { a.nbi = (int)(m / 256); return launch<4, 2, YMODE, EPI, KID>(a, st); }
   if (m % 128 == 0) { a.nbi = (int)(m / 128); return launch<2, 2, YMODE, EPI, KID>(a, st); }
   return GEOBO_E_ALIGN;
 }
