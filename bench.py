@@ -66,6 +66,18 @@ def synthetic_inputs(inv, md):
     return grav, mag, loc, drill0
 
 
+def pmc_traffic(flops_per_launch):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (separate --pmc runs of
+    tools/run_fused_once.py: FETCH_SIZE x2 (gfx950 half-count of wide loads, MI355X_MICROARCH.md) + WRITE_SIZE, KiB),
+    scaled from the profiled 1/8-size launch to this launch by its flop count.  None if no PMC summary is committed."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_ak_fused_grid_v0.json")))["counters"]
+        sample_flops = 2.0 * 4096 * 262144 * 32768
+        return (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0 * flops_per_launch / sample_flops
+    except Exception:
+        return None
+
+
 def cpu_baseline(inv, lengths, target_seconds=15.0):
     """Oracle ("port") on the host cores, bounded sample: the fused A.K product + the V solve / reductions for `b`
     voxel columns x 2 properties of THIS workload, operators and Cholesky factor taken as given (so the CPU rate is
@@ -198,8 +210,8 @@ def main():
                                    "%d drill constraints, M=%d rows, density+magsus cubes (P_out=2)" % (n, a.kernel, a.drill, M),
                        "N_voxels": N, "M_rows": M, "props_out": p_out, "parallelism": "voxel-column shards x%d" % world,
                        "algorithmic_flop_per_step": F, "end_to_end_fp64_roofline_frac": F * a.steps / dt / (FP64_MATRIX_PEAK_TFLOPS * 1e12 * world)},
-            "roofline": {"bound": "mfma", "kernel": "geobo_ak_fused (gemm_f64_kernel<4,2,GEN>)", "achieved": ach, "peak": FP64_MATRIX_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach / FP64_MATRIX_PEAK_TFLOPS, "traffic": None,
+            "roofline": {"bound": "mfma", "kernel": "geobo_ak_fused_grid (gemm_f64_kernel<4,2,TAB>)" if inv.engine.use_grid else "geobo_ak_fused (gemm_f64_kernel<4,2,GEN>)", "achieved": ach, "peak": FP64_MATRIX_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": ach / FP64_MATRIX_PEAK_TFLOPS, "traffic": pmc_traffic(flops),
                          "launches_timed": len(durs), "flop_per_launch": flops, "mean_launch_s": (sum(durs) / len(durs)) if durs else None},
         }
         if not a.no_cpu:
