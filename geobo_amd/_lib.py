@@ -6,7 +6,7 @@ resolved, importing a compute function raises `GeoboHipUnavailable` with the bui
 import ctypes as C
 import os
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libgeobo_hip.so")
+LIB_PATH = os.environ.get("GEOBO_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libgeobo_hip.so")
 
 _dp = C.c_void_p      # device pointers travel as integers
 _i64 = C.c_int64

@@ -51,17 +51,22 @@ __global__ void __launch_bounds__(256) k_block_kernel(const double* __restrict__
   }
 }
 
-// covariance sampled on the difference lattice of a regular grid: table[(diy*nx + dix)*nz + diz] = scale*k(|P(0,0,0) - P(diy,dix,diz)|^2)
-// with P = (i+1)*voxel size exactly as calcGridPoints3D builds it (kernels.py:36-38) -- i.e. the value the coordinate
-// path produces for the voxel pair (0, d).
+// covariance sampled on the difference lattice of a regular grid, z axis MIRRORED so that ascending contraction index
+// means ascending table index: table[(diy*nx + dix)*2nz + (dz + nz - 1)] = scale*k(|P(0,0,0) - P(diy,dix,|dz|)|^2),
+// dz in [-(nz-1), nz-1] (entry 2nz-1 of each row is padding), P = (i+1)*voxel size exactly as calcGridPoints3D builds
+// it (kernels.py:36-38) -- i.e. the value the coordinate path produces for the voxel pair (0, d).
 template <int ID>
 __global__ void __launch_bounds__(256) cov_table_kernel(int nx, int ny, int nz, double sx, double sy, double sz,
                                                         const CovParams p, double* __restrict__ table) {
-  const int64_t n = (int64_t)nx * ny * nz;
+  const int nz2 = 2 * nz;
+  const int64_t n = (int64_t)nx * ny * nz2;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const int dz = (int)(i % nz);
-    const int64_t t = i / nz;
+    const int zi = (int)(i % nz2);
+    const int64_t t = i / nz2;
     const int dx = (int)(t % nx), dy = (int)(t / nx);
+    int dz = zi - (nz - 1);
+    dz = dz < 0 ? -dz : dz;
+    if (dz > nz - 1) dz = nz - 1;  // padding entry
     const double d2 = sqdist3(1.0 * sx, 1.0 * sy, 1.0 * sz, (double)(dx + 1) * sx, (double)(dy + 1) * sy, (double)(dz + 1) * sz);
     table[i] = p.scale * cov_eval<ID>(p, d2);
   }
@@ -238,7 +243,7 @@ extern "C" int geobo_cov_table(int kernel_id, int nx, int ny, int nz, double sx,
                                double w, double amp, double* table, void* stream) {
   if (!table || nx <= 0 || ny <= 0 || nz <= 0) return GEOBO_E_ARG;
   const CovParams p = make_cov(kernel_id, l1, l2, w, amp);
-  const int64_t n = (int64_t)nx * ny * nz;
+  const int64_t n = (int64_t)nx * ny * nz * 2;
   int64_t nb = (n + 255) / 256;
   if (nb > 4096) nb = 4096;
   hipStream_t st = (hipStream_t)stream;

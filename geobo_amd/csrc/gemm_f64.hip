@@ -33,8 +33,17 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 
 namespace {
 
-constexpr int BK = 16;  // contraction chunk
-constexpr int XS = 18;  // LDS row stride in doubles for [rows][16] tiles (144 B: 16-B aligned, de-phased banks)
+constexpr int BK = 16;   // contraction chunk
+constexpr int XS = 16;   // LDS row stride in doubles for [rows][16] tiles: 128-byte rows, XOR-swizzled 16-byte slots
+constexpr int NST = 3;   // LDS ring depth (stages)
+
+// 16-byte slot swizzle of a [rows][8 slots] tile: slot' = slot ^ swz(row).  With 128-byte rows a wave's ds_read_b128
+// (lane = (row r = lane&15, k-group g = lane>>4), slot 2g+h) then touches 16 distinct 16-byte positions of the 256-byte
+// bank row in every hardware lane group {0-3,12-15,20-27},{4-11,16-19,28-31},... -> conflict free without padding.
+__device__ __forceinline__ int swz(int row) {
+  const int p = (row >> 1) & 7;
+  return (p & 1) | (((p >> 2) & 1) * 6);
+}
 
 enum { Y_GEN = 0, Y_NT = 1, Y_NN = 2, Y_TAB = 3 };
 enum { EPI_STORE = 0, EPI_REDUCE = 1 };
@@ -60,23 +69,23 @@ template <int WM, int WN, int YMODE>
 constexpr int lds_doubles() {
   constexpr int TM = 64 * WM, TN = 64 * WN;
   constexpr int ybuf = (YMODE == Y_NN) ? BK * (TN + 4) : TN * XS;
-  return 2 * (TM * XS + ybuf);
+  return NST * (TM * XS + ybuf);
 }
 
 template <int WM, int WN, int YMODE, int EPI, int KID>
-__global__ void __launch_bounds__(64 * WM * WN, 2) gemm_f64_kernel(const GemmArgs a) {
+__global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 1) gemm_f64_kernel(const GemmArgs a) {
   constexpr int TM = 64 * WM, TN = 64 * WN, NT = 64 * WM * WN;
   constexpr int YS_NN = TN + 4;
   constexpr int XBUF = TM * XS;
   constexpr int YBUF = (YMODE == Y_NN) ? BK * YS_NN : TN * XS;
   constexpr int XU = TM * 8 / NT;                                    // 16-byte units of X per thread per chunk
-  constexpr int YU = (YMODE == Y_NN) ? (8 * TN / NT) : (TN * 8 / NT);  // same for Y (memory modes)
+  constexpr int YU = (YMODE == Y_NN) ? (8 * TN / NT) : (TN * 8 / NT);  // same for Y (memory / lattice modes)
   constexpr int EPT = BK * TN / NT;                                  // generated covariances per thread per chunk
   static_assert(NT % TN == 0 && EPT >= 2 && EPT % 2 == 0, "generator mapping");
 
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* const Xs = smem;
-  double* const Ys = smem + 2 * XBUF;
+  double* const Ys = smem + NST * XBUF;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -109,66 +118,84 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_f64_kernel(const GemmArg
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[m][n] = (v4d){0., 0., 0., 0.};
 
-  // ---- staging helpers ---------------------------------------------------------------------------------
-  v2d xr[XU];
-  v2d yr[(YMODE == Y_GEN || YMODE == Y_TAB) ? EPT / 2 : YU];
-  const double* const Xg = a.X + row0 * a.ldx;
+  // ---- staging: global -> LDS by LDS-DMA (global_load_lds_dwordx4) -------------------------------------------
+  // No VGPR round trip and no ds_write: a wave instruction moves 64 x 16 B = 8 tile rows; the LDS image is lane-linear
+  // (uniform base + lane*16), so the XOR slot swizzle is applied to the per-lane SOURCE address and again by the
+  // fragment reads (same involution).  Measured on MI355X: the register path's ds_write_b128 traffic cost ~8 % of the
+  // matrix-pipe time, the DMA path costs nothing but issue slots.
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+  auto dma16 = [&](const void* src, double* dst_wave_uniform) {
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)dst_wave_uniform, 16, 0, 0);
+  };
+  constexpr int RPI = NT / 8;  // tile rows covered by one pass of the whole workgroup (8 lanes per 128-byte row)
+  const int srow = tid >> 3;   // this thread's row within a pass
+  const char* const Xgb = reinterpret_cast<const char*>(a.X + row0 * a.ldx);
+  int64_t xsrc[XU];
+#pragma unroll
+  for (int i = 0; i < XU; ++i) {
+    const int row = i * RPI + srow;
+    xsrc[i] = ((int64_t)row * a.ldx + 2 * ((tid & 7) ^ swz(row))) * 8;
+  }
+  auto stage_x = [&](int64_t k0, int st) {
+#pragma unroll
+    for (int i = 0; i < XU; ++i) dma16(Xgb + xsrc[i] + k0 * 8, Xs + st * XBUF + (i * RPI + wave * 8) * XS);
+  };
 
-  // generator state: this thread's output column q and its (wave-uniform) slice of the chunk
+  // Y operand, memory modes
+  int64_t ysrc[(YMODE == Y_NT) ? YU : 1];
+  const char* const Ygb = (YMODE == Y_NT) ? reinterpret_cast<const char*>(a.Y + col0 * a.ldy) : nullptr;
+  if constexpr (YMODE == Y_NT) {
+#pragma unroll
+    for (int i = 0; i < YU; ++i) {
+      const int row = i * RPI + srow;
+      ysrc[i] = ((int64_t)row * a.ldy + 2 * ((tid & 7) ^ swz(row))) * 8;
+    }
+  }
+
+  // generator state (coordinate mode): this thread's output column q and its wave-uniform slice of the chunk
   double qx = 0., qy = 0., qz = 0.;
   const int gq = tid % TN;
   const int gsub = __builtin_amdgcn_readfirstlane(tid / TN);
+  v2d yr[EPT / 2];
   if constexpr (YMODE == Y_GEN) {
     const int64_t q = a.gcol0 + col0 + gq;
     qx = a.px[q]; qy = a.py[q]; qz = a.pz[q];
   }
-  // lattice generator state: this thread's voxel (qiy,qix,qiz) and the wave-uniform voxel (piy,pix,piz) of the first
-  // contraction index of the chunk being staged; all integer arithmetic (it co-issues with the fp64 MFMA pipe,
-  // FP VALU does not -- DESIGN.md "what shares the fp64 pipe")
-  int qiy = 0, qix = 0, qiz = 0, piy = 0, pix = 0, piz = 0;
+
+  // lattice-table mode: per staged 16-byte slot this thread serves (q-row, k-pair); all index arithmetic is 32-bit
+  // integer VALU (v_sad_u32 / v_mul_u32_u24 / v_cndmask), which co-issues with the fp64 MFMA pipe (FP VALU does not).
+  int tqy[YU], tqx[YU], tqz[YU], tsl[YU];
+  int piy = 0, pix = 0, piz = 0;   // wave-uniform voxel of the staged chunk's first contraction index
   int64_t pk = kb;
   if constexpr (YMODE == Y_TAB) {
-    int64_t q = a.gcol0 + col0 + gq;
-    if (q >= a.gN) q = a.gN - 1;
-    qiz = (int)(q % a.gnz);
-    const int64_t t = q / a.gnz;
-    qix = (int)(t % a.gnx);
-    qiy = (int)(t / a.gnx);
-    const int64_t p = kb + gsub * EPT;
-    piz = (int)(p % a.gnz);
-    const int64_t tp = p / a.gnz;
+#pragma unroll
+    for (int i = 0; i < YU; ++i) {
+      const int row = i * RPI + srow;
+      int64_t q = a.gcol0 + col0 + row;
+      if (q >= a.gN) q = a.gN - 1;
+      tqz[i] = (int)(q % a.gnz);
+      const int64_t t = q / a.gnz;
+      tqx[i] = (int)(t % a.gnx);
+      tqy[i] = (int)(t / a.gnx);
+      tsl[i] = (tid & 7) ^ swz(row);
+    }
+    piz = (int)(kb % a.gnz);
+    const int64_t tp = kb / a.gnz;
     pix = (int)(tp % a.gnx);
     piy = (int)(tp / a.gnx);
   }
 
-  auto load_x = [&](int64_t k0) {
-#pragma unroll
-    for (int i = 0; i < XU; ++i) {
-      const int u = tid + i * NT;
-      xr[i] = *reinterpret_cast<const v2d*>(Xg + (int64_t)(u >> 3) * a.ldx + k0 + 2 * (u & 7));
-    }
-  };
-  auto store_x = [&](double* buf) {
-#pragma unroll
-    for (int i = 0; i < XU; ++i) {
-      const int u = tid + i * NT;
-      *reinterpret_cast<v2d*>(buf + (u >> 3) * XS + 2 * (u & 7)) = xr[i];
-    }
-  };
-  auto load_y = [&](int64_t k0) {
+  auto stage_y = [&](int64_t k0, int st) {
     if constexpr (YMODE == Y_NT) {
-      const double* const Yg = a.Y + col0 * a.ldy;
 #pragma unroll
-      for (int i = 0; i < YU; ++i) {
-        const int u = tid + i * NT;
-        yr[i] = *reinterpret_cast<const v2d*>(Yg + (int64_t)(u >> 3) * a.ldy + k0 + 2 * (u & 7));
-      }
+      for (int i = 0; i < YU; ++i) dma16(Ygb + ysrc[i] + k0 * 8, Ys + st * YBUF + (i * RPI + wave * 8) * XS);
     } else if constexpr (YMODE == Y_NN) {
+      // [16 k-rows][TN] tile: one wave instruction = one 1-KiB k-row (TN = 128 columns), padded row stride in LDS
 #pragma unroll
       for (int i = 0; i < YU; ++i) {
-        const int u = tid + i * NT;
-        const int kr = u / (TN / 2), c2 = u % (TN / 2);
-        yr[i] = *reinterpret_cast<const v2d*>(a.Y + (k0 + kr) * a.ldy + col0 + 2 * c2);
+        const int kr = i * (NT / 64) + wave;
+        dma16(a.Y + (k0 + kr) * a.ldy + col0 + 2 * lane, Ys + st * YBUF + kr * YS_NN);
       }
     } else if constexpr (YMODE == Y_TAB) {
       // advance the uniform voxel position by (k0 - pk) in {0, 16}; at most one carry per axis because gnz >= 16
@@ -181,98 +208,106 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_f64_kernel(const GemmArg
       c = pix >= a.gnx ? 1 : 0;
       pix -= c ? a.gnx : 0;
       piy += c;
-      // the EPT consecutive contraction indices of this wave span at most two z-columns: A = (piy,pix), B = its successor
+      // the 16 contraction indices of the chunk span at most two z-columns: A = (piy,pix) and its successor B
       int bx = pix + 1, by = piy;
       if (bx >= a.gnx) { bx = 0; by += 1; }
       const int ay = piy < a.gny ? piy : a.gny - 1;   // padded contraction indices: any in-range entry (A column is 0)
       by = by < a.gny ? by : a.gny - 1;
-      // row offsets into the table: (|dy|*nx + |dx|)*nz, 32-bit integer VALU only (v_sad_u32 / v_mul_u32_u24)
-      const unsigned rowA = __umul24(__usad((unsigned)qix, (unsigned)pix,
-                                __umul24(__usad((unsigned)qiy, (unsigned)ay, 0u), (unsigned)a.gnx)), (unsigned)a.gnz);
-      const unsigned rowB = __umul24(__usad((unsigned)qix, (unsigned)bx,
-                                __umul24(__usad((unsigned)qiy, (unsigned)by, 0u), (unsigned)a.gnx)), (unsigned)a.gnz);
       const char* const tb = reinterpret_cast<const char*>(a.table);
+      const unsigned nz2 = 2u * (unsigned)a.gnz;
 #pragma unroll
-      for (int e = 0; e < EPT; ++e) {
-        int ez = piz + e;
-        const bool carry = ez >= a.gnz;   // uniform
-        ez -= carry ? a.gnz : 0;
-        const unsigned idx = __usad((unsigned)qiz, (unsigned)ez, carry ? rowB : rowA);
-        yr[e >> 1][e & 1] = *reinterpret_cast<const double*>(tb + (idx << 3));
-      }
-    } else {
-      const int64_t p0 = k0 + gsub * EPT;  // wave-uniform -> scalar loads of the p coordinates
-#pragma unroll
-      for (int e = 0; e < EPT; ++e) {
-        const double d2 = sqdist3(a.px[p0 + e], a.py[p0 + e], a.pz[p0 + e], qx, qy, qz);
-        yr[e >> 1][e & 1] = a.cov.scale * cov_eval<KID>(a.cov, d2);
+      for (int i = 0; i < YU; ++i) {
+        int pz = piz + 2 * tsl[i];
+        const bool carry = pz >= a.gnz;
+        pz -= carry ? a.gnz : 0;
+        const unsigned cy = carry ? by : ay, cx = carry ? bx : pix;
+        const unsigned rowb = __umul24(__usad((unsigned)tqx[i], cx, __umul24(__usad((unsigned)tqy[i], cy, 0u), (unsigned)a.gnx)), nz2);
+        // mirrored z axis: entry (dz + nz - 1), dz = z_p - z_q; the pair (p, p+1) is contiguous and ascending
+        const unsigned idx = rowb + (unsigned)(pz - tqz[i] + a.gnz - 1);
+        dma16(tb + (idx << 3), Ys + st * YBUF + (i * RPI + wave * 8) * XS);
       }
     }
   };
-  auto store_y = [&](double* buf) {
-    if constexpr (YMODE == Y_NT) {
+  auto gen_y = [&](int64_t k0) {  // coordinate generator (prologue form; the main loop interleaves it with the MFMAs)
+    const int64_t p0 = k0 + gsub * EPT;
 #pragma unroll
-      for (int i = 0; i < YU; ++i) {
-        const int u = tid + i * NT;
-        *reinterpret_cast<v2d*>(buf + (u >> 3) * XS + 2 * (u & 7)) = yr[i];
-      }
-    } else if constexpr (YMODE == Y_NN) {
-#pragma unroll
-      for (int i = 0; i < YU; ++i) {
-        const int u = tid + i * NT;
-        const int kr = u / (TN / 2), c2 = u % (TN / 2);
-        *reinterpret_cast<v2d*>(buf + kr * YS_NN + 2 * c2) = yr[i];
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < EPT / 2; ++e) *reinterpret_cast<v2d*>(buf + gq * XS + gsub * EPT + 2 * e) = yr[e];
+    for (int e = 0; e < EPT; ++e) {
+      const double d2 = sqdist3(a.px[p0 + e], a.py[p0 + e], a.pz[p0 + e], qx, qy, qz);
+      yr[e >> 1][e & 1] = a.cov.scale * cov_eval<KID>(a.cov, d2);
     }
+  };
+  auto store_gen = [&](int st) {
+    double* buf = Ys + st * YBUF;
+#pragma unroll
+    for (int e = 0; e < EPT / 2; ++e)
+      *reinterpret_cast<v2d*>(buf + gq * XS + 2 * ((gsub * (EPT / 2) + e) ^ swz(gq))) = yr[e];
   };
 
   // ---- main loop ---------------------------------------------------------------------------------------
-  // One basic block per chunk (no branches): the staging target of the last chunk is clamped to the chunk itself.
-  // In generator mode the covariances of the NEXT chunk are computed between the MFMAs of the CURRENT one
-  // (EPT/4 values after each 16-MFMA k-step) and the scheduler is pinned to a 1 MFMA : GEN_VALU VALU pattern, so
-  // the VALU work rides under the 64-cycle matrix-pipe occupancy of each v_mfma_f64_16x16x4_f64.
+  // Three-stage LDS ring, one barrier per 16-deep chunk, fragments in two rotating half sets:
+  //   iteration c:  LDS-DMA of chunk c+2 issued (lands before this iteration's barrier)
+  //                 set1 <- LDS(chunk c,   k-half 1)      | 32 MFMAs on set0 (chunk c, k-half 0)
+  //                 set0 <- LDS(chunk c+1, k-half 0)      | 32 MFMAs on set1
+  //                 barrier
+  // Chunk c+1 became visible at the barrier of iteration c-1, so its first fragments are already in registers when
+  // the barrier of iteration c releases: the matrix pipe restarts without waiting for LDS.  The body is one basic
+  // block (the tail re-stages the last chunk instead of branching).  In coordinate-generator mode (Y_GEN) the
+  // covariances of chunk c+2 are computed between the MFMA k-steps and written with ds_write; FP VALU competes with
+  // the fp64 MFMA pipe, which is why the lattice-table mode is the production path on regular grids.
   if (kb < ke) {
-    load_x(kb);
-    load_y(kb);
-    store_x(Xs);
-    store_y(Ys);
-    __syncthreads();
-    int cur = 0;
-    for (int64_t k0 = kb; k0 < ke; k0 += BK) {
-      int64_t kn = k0 + BK;
-      if (kn >= ke) kn = ke - BK;
-      load_x(kn);
-      if constexpr (YMODE != Y_GEN) load_y(kn);
-      const double* xb = Xs + cur * XBUF + (wm * 64 + lr) * XS + 4 * lg;
-      v2d av[4][2], bv[4][2];
+    const int xoff0 = 2 * ((2 * lg + 0) ^ swz(lr)), xoff1 = 2 * ((2 * lg + 1) ^ swz(lr));
+    const double* const xfrag = Xs + (wm * 64 + lr) * XS;
+    const double* const yfrag = (YMODE == Y_NN) ? (Ys + wn * 64 + lr) : (Ys + (wn * 64 + lr) * XS);
+    auto read_half = [&](int stage, int h, v2d (&av)[4], v2d (&bv)[4]) {
+      const double* xb = xfrag + stage * XBUF + (h ? xoff1 : xoff0);
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+      for (int m = 0; m < 4; ++m) av[m] = *reinterpret_cast<const v2d*>(xb + m * 16 * XS);
+      if constexpr (YMODE == Y_NN) {
+        const double* yb = yfrag + stage * YBUF + (4 * lg + 2 * h) * YS_NN;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) av[m][h] = *reinterpret_cast<const v2d*>(xb + m * 16 * XS + 2 * h);
-        if constexpr (YMODE == Y_NN) {
-          const double* yb = Ys + cur * YBUF + (4 * lg + 2 * h) * YS_NN + wn * 64 + lr;
+        for (int n = 0; n < 4; ++n) { bv[n][0] = yb[n * 16]; bv[n][1] = yb[YS_NN + n * 16]; }
+      } else {
+        const double* yb = yfrag + stage * YBUF + (h ? xoff1 : xoff0);
 #pragma unroll
-          for (int n = 0; n < 4; ++n) {
-            bv[n][h][0] = yb[n * 16];
-            bv[n][h][1] = yb[YS_NN + n * 16];
-          }
-        } else {
-          const double* yb = Ys + cur * YBUF + (wn * 64 + lr) * XS + 4 * lg + 2 * h;
-#pragma unroll
-          for (int n = 0; n < 4; ++n) bv[n][h] = *reinterpret_cast<const v2d*>(yb + n * 16 * XS);
-        }
+        for (int n = 0; n < 4; ++n) bv[n] = *reinterpret_cast<const v2d*>(yb + n * 16 * XS);
       }
+    };
+    {
+      const int64_t k1 = (kb + BK < ke) ? kb + BK : kb;
+      stage_x(kb, 0);
+      stage_x(k1, 1);
+      if constexpr (YMODE == Y_GEN) {
+        gen_y(kb); store_gen(0);
+        gen_y(k1); store_gen(1);
+      } else {
+        stage_y(kb, 0);
+        stage_y(k1, 1);
+      }
+    }
+    __syncthreads();
+    v2d a0[4], b0[4], a1[4], b1[4];
+    read_half(0, 0, a0, b0);
+    int s0 = 0, s1 = 1, s2 = 2;  // ring stages of chunk c, c+1, c+2
+    for (int64_t k0 = kb; k0 < ke; k0 += BK) {
+      int64_t kn = k0 + 2 * BK;
+      if (kn >= ke) kn = ke - BK;
+#ifndef GEOBO_ABL_NO_XLOAD
+      stage_x(kn, s2);
+#endif
+#ifndef GEOBO_ABL_NO_YLOAD
+      if constexpr (YMODE != Y_GEN) stage_y(kn, s2);
+#endif
       const int64_t p0 = kn + gsub * EPT;  // generator: wave-uniform -> scalar loads of the p coordinates
+      read_half(s0, 1, a1, b1);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
+        if (t == 2) read_half(s1, 0, a0, b0);   // next chunk's first half (after the MFMAs that still read a0/b0)
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
           for (int n = 0; n < 4; ++n)
-            acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m][t >> 1][t & 1], bv[n][t >> 1][t & 1], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(t < 2 ? a0[m][t & 1] : a1[m][t & 1],
+                                                             t < 2 ? b0[n][t & 1] : b1[n][t & 1], acc[m][n], 0, 0, 0);
         if constexpr (YMODE == Y_GEN) {
 #pragma unroll
           for (int e = t * (EPT / 4); e < (t + 1) * (EPT / 4); ++e) {
@@ -282,9 +317,9 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_f64_kernel(const GemmArg
         }
       }
       if constexpr (YMODE != Y_GEN) {
-        // spread the staging work (LDS fragment reads, address arithmetic, global loads / table gathers) under the
-        // matrix pipe: after every MFMA up to 3 non-FP instructions; integer VALU, SALU, VMEM and DS issue do not
-        // compete with v_mfma_f64 for the FP pipe (FP VALU does).
+        // spread the staging work (LDS fragment reads, address arithmetic, DMA issue) under the matrix pipe: after
+        // every MFMA up to 3 non-FP instructions (integer VALU, SALU, VMEM and DS issue do not compete with
+        // v_mfma_f64 for the FP pipe)
 #pragma unroll
         for (int i = 0; i < 64; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -300,10 +335,11 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_f64_kernel(const GemmArg
           __builtin_amdgcn_sched_group_barrier(0x002, GEN_VALU * (EPT / 4), 0);
         }
       }
-      store_x(Xs + (cur ^ 1) * XBUF);
-      store_y(Ys + (cur ^ 1) * YBUF);
+      if constexpr (YMODE == Y_GEN) store_gen(s2);
+#ifndef GEOBO_ABL_NO_BARRIER
       __syncthreads();
-      cur ^= 1;
+#endif
+      const int ts = s0; s0 = s1; s1 = s2; s2 = ts;
     }
   }
 
@@ -425,7 +461,8 @@ extern "C" int geobo_ak_fused_grid(const double* A, int64_t Ms_pad, int64_t N_pa
                                    const double* table, int64_t col0, int64_t ncols, double* AK, int64_t ldak,
                                    void* stream) {
   if (!A || !table || !AK) return GEOBO_E_ARG;
-  if (nx <= 0 || ny <= 0 || nz < BK) return GEOBO_E_UNSUPPORTED;  // one carry per chunk needs nz >= 16
+  if (nx <= 0 || ny <= 0 || nz < BK || (nz & 1)) return GEOBO_E_UNSUPPORTED;  // one carry per chunk: nz >= 16; k-pairs: nz even
+  if ((int64_t)nx * ny * nz * 16 >= (int64_t)1 << 32) return GEOBO_E_UNSUPPORTED;  // 32-bit byte offsets into the table
   const int64_t N = (int64_t)nx * ny * nz;
   if (Ms_pad % 128 || N_pad % BK || ncols % 128 || (lda & 1) || col0 < 0 || col0 + ncols > N_pad || N_pad < N) return GEOBO_E_ALIGN;
   GemmArgs a{};

@@ -78,7 +78,7 @@ class PosteriorEngine:
         self.nc = self.c1 - self.c0
         self._xyz = None
         self._A = {}
-        self.use_grid = self.nz >= 16  # lattice-table generator (geobo_ak_fused_grid); coordinates otherwise
+        self.use_grid = self.nz >= 16 and self.nz % 2 == 0  # lattice-table generator (geobo_ak_fused_grid); coordinates otherwise
         self.kernel_events = None  # set to [] to record (name, flops, start, stop) HIP events per fused launch
 
     # ---- geometry --------------------------------------------------------------------------------------------

@@ -121,9 +121,9 @@ def ak_fused(kid, A, xyz, col0, ncols, l1, l2, w, amp, out):
 
 
 def cov_table(kid, nx, ny, nz, sx, sy, sz, l1, l2, w, amp, device="cuda"):
-    """Covariance on the grid's difference lattice: (ny*nx*nz,) tensor, index (diy*nx + dix)*nz + diz."""
+    """Covariance on the grid's difference lattice, z mirrored: (ny*nx*2nz,) tensor, index (diy*nx + dix)*2nz + (dz + nz-1)."""
     lib = require_gpu()
-    tab = torch.empty(int(nx) * int(ny) * int(nz), dtype=F64, device=device)
+    tab = torch.empty(2 * int(nx) * int(ny) * int(nz), dtype=F64, device=device)
     _lib.check(lib.geobo_cov_table(kid, int(nx), int(ny), int(nz), float(sx), float(sy), float(sz), float(l1), float(l2),
                                    float(w), float(amp), _p(tab), _stream()), "geobo_cov_table")
     return tab
@@ -135,7 +135,7 @@ def ak_fused_grid(A, nx, ny, nz, table, col0, ncols, out):
     lda = _rowmajor(A, "A")
     ldo = _rowmajor(out, "AK")
     Ms_pad, N_pad = A.shape
-    assert out.shape[0] >= Ms_pad and out.shape[1] >= ncols and _chk(table, "table").numel() >= nx * ny * nz
+    assert out.shape[0] >= Ms_pad and out.shape[1] >= ncols and _chk(table, "table").numel() >= 2 * nx * ny * nz
     _lib.check(lib.geobo_ak_fused_grid(_p(A), Ms_pad, N_pad, lda, int(nx), int(ny), int(nz), _p(table), int(col0), int(ncols),
                                        _p(out), ldo, _stream()), "geobo_ak_fused_grid")
     return out

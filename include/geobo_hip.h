@@ -94,9 +94,10 @@ int geobo_ak_fused(int kernel_id, const double* A, int64_t Ms_pad, int64_t N_pad
 /* Regular-grid form of the same product.  On the grid of calcGridPoints3D (kernels.py:27-42) every covariance is a
  * function of the index difference (|diy|,|dix|,|diz|), so the generator stage becomes an integer-indexed gather from
  * a lattice table (nx*ny*nz doubles, L2 resident) instead of exp/sqrt on the FP pipe that the fp64 MFMA also needs:
- *   geobo_cov_table:     table[(diy*nx + dix)*nz + diz] = w*amp*k(|P(0,0,0) - P(diy,dix,diz)|^2; l1, l2),  P = (i+1)*voxel
- *   geobo_ak_fused_grid: AK[r, c] = sum_p A[r, p] * table[|iy_p-iy_q|, |ix_p-ix_q|, |iz_p-iz_q|],  q = col0 + c
- * Same padding contract as geobo_ak_fused; requires nz >= 16. */
+ *   geobo_cov_table:     table[(diy*nx + dix)*2nz + (dz + nz-1)] = w*amp*k(|P(0,0,0) - P(diy,dix,|dz|)|^2; l1, l2),
+ *                        dz = -(nz-1)..nz-1 (z axis mirrored, 2*nx*ny*nz doubles), P = (i+1)*voxel
+ *   geobo_ak_fused_grid: AK[r, c] = sum_p A[r, p] * table[|iy_p-iy_q|, |ix_p-ix_q|, iz_p-iz_q],  q = col0 + c
+ * Same padding contract as geobo_ak_fused; requires nz >= 16 and even. */
 int geobo_cov_table(int kernel_id, int nx, int ny, int nz, double sx, double sy, double sz, double l1, double l2,
                     double w, double amp, double* table, void* stream);
 int geobo_ak_fused_grid(const double* A, int64_t Ms_pad, int64_t N_pad, int64_t lda, int nx, int ny, int nz,

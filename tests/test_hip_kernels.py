@@ -187,8 +187,11 @@ def test_ak_fused_grid_matches_coordinate_path(hip, name, cross, dims):
     hip.ak_fused(kid, Ad, xyz, 0, Np, l1, l2, 0.3, 1.2, ref)
     tab = hip.cov_table(kid, nx, ny, nz, *vox, l1, l2, 0.3, 1.2)
     Kfull = 0.3 * 1.2 * (O.k_cross(name, O.sqdist(P[:1], P), l1, l2) if cross else O.k_auto(name, O.sqdist(P[:1], P), l1))
-    # table entry (diy,dix,diz) = covariance between voxel 0 and voxel (diy,dix,diz): the first row of K
-    assert np.abs(tab.cpu().numpy() - Kfull[0]).max() <= 2e-12 * max(1.0, np.abs(Kfull).max())
+    # table entry (diy,dix,dz) = covariance between voxel 0 and voxel (diy,dix,|dz|): the first row of K, z mirrored
+    tabh = tab.cpu().numpy().reshape(ny, nx, 2 * nz)
+    K0 = Kfull[0].reshape(ny, nx, nz)
+    assert np.abs(tabh[:, :, nz - 1:2 * nz - 1] - K0).max() <= 2e-12 * max(1.0, np.abs(Kfull).max())
+    assert np.array_equal(tabh[:, :, :nz - 1], tabh[:, :, nz:2 * nz - 1][:, :, ::-1])
     got = torch.full((Msp, Np), float("nan"), dtype=torch.float64, device="cuda")
     hip.ak_fused_grid(Ad, nx, ny, nz, tab, 0, Np, got)
     r, g = ref.cpu().numpy()[:Ms, :N], got.cpu().numpy()[:Ms, :N]
