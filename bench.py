@@ -123,7 +123,7 @@ def cpu_baseline(inv, lengths, target_seconds=15.0):
     except Exception:
         thr = os.cpu_count()
     return dict(value=2.0 * b / t, unit="voxel-properties/s", cores=int(thr), kind="port",
-                sample="%d of %d voxel columns x 2 properties of the same 64^3 workload: fused A.K + triangular solve + "
+                sample="%d of %d voxel columns x 2 properties of the same workload: fused A.K + triangular solve + "
                        "mean/variance reductions in NumPy/OpenBLAS (oracle/geobo_oracle.py); operators and Cholesky factor "
                        "given, so this is an upper bound on the CPU rate; %.1f s" % (b, N, t)), (c0, b, out)
 
@@ -137,6 +137,7 @@ def main():
     ap.add_argument("--kernel", default="matern32")
     ap.add_argument("--drill", type=int, default=50)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU dry runs)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -144,12 +145,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world and world > 1:
         raise SystemExit("--gpus must equal WORLD_SIZE")
+    local = local % max(torch.cuda.device_count(), 1)   # (dry runs may put several ranks on one device)
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend=a.backend, rank=rank, world_size=world)
 
     from geobo_amd.config_loader import Settings
     from geobo_amd.inversion import Inversion
@@ -214,7 +216,7 @@ def main():
                          "unit": "TFLOP/s", "frac": ach / FP64_MATRIX_PEAK_TFLOPS, "traffic": pmc_traffic(flops),
                          "launches_timed": len(durs), "flop_per_launch": flops, "mean_launch_s": (sum(durs) / len(durs)) if durs else None},
         }
-        if not a.no_cpu:
+        if not a.no_cpu and world == 1:   # CPU baseline: rank 0 at N = 1 only
             lengths = inv.gp_length
             cb, (c0, b, smp) = cpu_baseline(inv, [float(v) for v in lengths])
             got_mu = inv.mu_rec[c0:c0 + b]

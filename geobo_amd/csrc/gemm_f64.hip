@@ -317,14 +317,51 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 1) gemm_f64
         }
       }
       if constexpr (YMODE != Y_GEN) {
-        // spread the staging work (LDS fragment reads, address arithmetic, DMA issue) under the matrix pipe: after
-        // every MFMA up to 3 non-FP instructions (integer VALU, SALU, VMEM and DS issue do not compete with
-        // v_mfma_f64 for the FP pipe)
+        // Issue-order hints under the matrix pipe (integer VALU, SALU, VMEM and DS issue do not compete with v_mfma_f64
+        // for the FP pipe).  GEOBO_SCHED selects the pattern (tuned on MI355X):
+#ifndef GEOBO_SCHED
+#define GEOBO_SCHED 5
+#endif
+#if GEOBO_SCHED == 1   // 64 x {MFMA, <=3 of (VALU|SALU|VMEM read|DS read)}
 #pragma unroll
         for (int i = 0; i < 64; ++i) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x126, 3, 0);
         }
+#elif GEOBO_SCHED == 2  // 2 x { 8 x {MFMA, DS read}, 24 x {MFMA, <=3 others} }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, (YMODE == Y_NN) ? 3 : 1, 0);
+          }
+#pragma unroll
+          for (int i = 0; i < 24; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x026, 3, 0);
+          }
+        }
+#elif GEOBO_SCHED == 3  // 64 x {MFMA, <=2 others}
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x126, 2, 0);
+        }
+#elif GEOBO_SCHED == 4  // 64 x {MFMA, <=1 DS read, <=2 others}
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x026, 2, 0);
+        }
+#elif GEOBO_SCHED == 5  // 64 x {MFMA, <=4 others}
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x126, 4, 0);
+        }
+#endif
       }
       if constexpr (YMODE == Y_GEN && (KID <= COV_MATERN32_X)) {
         // 64 x { 1 MFMA, up to GEN_VALU VALU }: interleave the generator into the matrix-pipe shadow
