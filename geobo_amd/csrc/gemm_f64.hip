@@ -106,6 +106,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 1) gemm_f64
     }
   }
   if (bi >= a.nbi) return;
+  if (a.tri & TRI_X_LOWER) bi = a.nbi - 1 - bi;  // triangular X: the longest contraction ranges are dispatched first
   const int64_t row0 = (int64_t)bi * TM, col0 = (int64_t)bj * TN;
   if ((a.tri & TRI_LOWER_ONLY) && col0 >= row0 + TM) return;
   int64_t kb = (a.tri & TRI_Y_LOWER) ? col0 : 0;

@@ -73,7 +73,7 @@ def test_tiny_grid_solver_parity_with_reference_operators(kern):
     print("T1 %s mu %.2e var %.2e logl %.3e cond %.2e" % (kern, e_mu, e_var, r["logl"] - float(f["logl"]), float(f["cond_AkA"])))
     assert e_mu <= TOL_T1 and e_var <= TOL_T1
     assert abs(r["logl"] - float(f["logl"])) <= 1e-10 * abs(float(f["logl"]))
-    # AkA itself (sensor/drill blocks at their padded offsets) against the reference's matrix
+    # AkA (lower triangle is what the engine computes) against the reference matrix via L L^T
     L = eng.last["L"]
     Md = f["sel"].size
     rows = np.r_[0:ng, eng.Ms_pad:eng.Ms_pad + ng, 2 * eng.Ms_pad:2 * eng.Ms_pad + Md]
