@@ -154,6 +154,16 @@ __global__ void __launch_bounds__(512) a_sens_kernel(const SensArgs a) {
   }
 }
 
+__global__ void __launch_bounds__(256) scale_broadcast_kernel(const double* __restrict__ a, const double* __restrict__ b,
+                                                              int64_t n2, int64_t nb2, double* __restrict__ out) {
+  // 16-byte accesses; nb (the broadcast period) is even, so a pair never straddles the period
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (int64_t)gridDim.x * 256) {
+    const v2d x = reinterpret_cast<const v2d*>(a)[i];
+    const v2d y = reinterpret_cast<const v2d*>(b)[i % nb2];
+    reinterpret_cast<v2d*>(out)[i] = x * y;
+  }
+}
+
 template <int FUNC>
 __global__ void __launch_bounds__(256) potential_kernel(const double* __restrict__ x, const double* __restrict__ y,
                                                         const double* __restrict__ z, int64_t n, double bx, double by,
@@ -313,6 +323,16 @@ extern "C" int geobo_potential(int func_id, const double* B3_host, const double*
     hipLaunchKernelGGL(potential_kernel<GEOBO_F_MAGN>, dim3((unsigned)nb), dim3(256), 0, st, x, y, z, n, bx, by, bz, inb, out);
   else
     return GEOBO_E_UNSUPPORTED;
+  return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
+}
+
+extern "C" int geobo_scale_broadcast(const double* a, const double* b, int64_t n, int64_t nb, double* out, void* stream) {
+  if (!a || !b || !out) return GEOBO_E_ARG;
+  if (n <= 0) return GEOBO_OK;
+  if ((n & 1) || (nb & 1) || nb <= 0 || n % nb) return GEOBO_E_ALIGN;
+  int64_t nblk = (n / 2 + 255) / 256;
+  if (nblk > 256 * 32) nblk = 256 * 32;
+  hipLaunchKernelGGL(scale_broadcast_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, a, b, n / 2, nb / 2, out);
   return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
 }
 

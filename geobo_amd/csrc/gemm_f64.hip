@@ -56,6 +56,8 @@ struct GemmArgs {
   int64_t k;
   double alpha, beta;
   int nbi, nbj, tri, xcd_map;
+  // batching (blockIdx.y) and store predicates (the compute tile grid may overhang the valid m x n region)
+  int64_t sXb, sYb, sCb, m_valid, n_valid; int batch;
   // generator
   const double *px, *py, *pz; int64_t gcol0;
   CovParams cov;
@@ -87,6 +89,9 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 1) gemm_f64
   double* const Xs = smem;
   double* const Ys = smem + NST * XBUF;
 
+  const double* const Xp = a.X + (int64_t)blockIdx.y * a.sXb;
+  const double* const Yp = a.Y + (int64_t)blockIdx.y * a.sYb;
+  double* const Cp = a.C + (int64_t)blockIdx.y * a.sCb;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
@@ -131,7 +136,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 1) gemm_f64
   };
   constexpr int RPI = NT / 8;  // tile rows covered by one pass of the whole workgroup (8 lanes per 128-byte row)
   const int srow = tid >> 3;   // this thread's row within a pass
-  const char* const Xgb = reinterpret_cast<const char*>(a.X + row0 * a.ldx);
+  const char* const Xgb = reinterpret_cast<const char*>(Xp + row0 * a.ldx);
   int64_t xsrc[XU];
 #pragma unroll
   for (int i = 0; i < XU; ++i) {
@@ -145,7 +150,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 1) gemm_f64
 
   // Y operand, memory modes
   int64_t ysrc[(YMODE == Y_NT) ? YU : 1];
-  const char* const Ygb = (YMODE == Y_NT) ? reinterpret_cast<const char*>(a.Y + col0 * a.ldy) : nullptr;
+  const char* const Ygb = (YMODE == Y_NT) ? reinterpret_cast<const char*>(Yp + col0 * a.ldy) : nullptr;
   if constexpr (YMODE == Y_NT) {
 #pragma unroll
     for (int i = 0; i < YU; ++i) {
@@ -196,7 +201,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 1) gemm_f64
 #pragma unroll
       for (int i = 0; i < YU; ++i) {
         const int kr = i * (NT / 64) + wave;
-        dma16(a.Y + (k0 + kr) * a.ldy + col0 + 2 * lane, Ys + st * YBUF + kr * YS_NN);
+        dma16(Yp + (k0 + kr) * a.ldy + col0 + 2 * lane, Ys + st * YBUF + kr * YS_NN);
       }
     } else if constexpr (YMODE == Y_TAB) {
       // advance the uniform voxel position by (k0 - pk) in {0, 16}; at most one carry per axis because gnz >= 16
@@ -391,10 +396,12 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 1) gemm_f64
         for (int r = 0; r < 4; ++r) {
           const int64_t row = row0 + wm * 64 + m * 16 + lg + 4 * r;
           const int64_t col = col0 + wn * 64 + n * 16 + lr;
-          double v = a.alpha * acc[m][n][r];
-          double* dst = a.C + row * a.ldc + col;
-          if (a.beta != 0.0) v += a.beta * (*dst);
-          *dst = v;
+          if (row < a.m_valid && col < a.n_valid) {
+            double v = a.alpha * acc[m][n][r];
+            double* dst = Cp + row * a.ldc + col;
+            if (a.beta != 0.0) v += a.beta * (*dst);
+            *dst = v;
+          }
         }
   } else {
     // column reductions over this tile's rows: mu-part = sum_r V[r,c] u[r],  ss-part = sum_r V[r,c]^2
@@ -460,9 +467,11 @@ int launch(GemmArgs& a, hipStream_t st) {
       return GEOBO_E_LAUNCH;
     attr_set = true;
   }
+  if (a.m_valid <= 0) a.m_valid = (int64_t)1 << 62;
+  if (a.n_valid <= 0) a.n_valid = (int64_t)1 << 62;
   a.xcd_map = (a.nbi >= 8) ? 1 : 0;
   const int nblocks = a.xcd_map ? 8 * ((a.nbi + 7) / 8) * a.nbj : a.nbi * a.nbj;
-  hipLaunchKernelGGL(kern, dim3(nblocks), dim3(NT), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(nblocks, a.batch > 0 ? a.batch : 1), dim3(NT), lds, st, a);
   return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
 }
 
@@ -530,6 +539,19 @@ extern "C" int geobo_gemm_nn(int64_t m, int64_t n, int64_t k, double alpha, cons
   a.X = X; a.ldx = ldx; a.Y = Y; a.ldy = ldy; a.C = C; a.ldc = ldc; a.k = k;
   a.alpha = alpha; a.beta = beta; a.tri = (x_lower ? TRI_X_LOWER : 0) | (y_lower ? TRI_Y_LOWER : 0);
   return launch_by_rows<Y_NN, EPI_STORE, COV_D2>(a, m, n, (hipStream_t)stream);
+}
+
+extern "C" int geobo_gemm_batched(int y_is_kn, int64_t m, int64_t n, int64_t k, double alpha, const double* X, int64_t ldx,
+                                  int64_t strideX, const double* Y, int64_t ldy, int64_t strideY, double beta, double* C,
+                                  int64_t ldc, int64_t strideC, int64_t m_valid, int64_t n_valid, int batch, void* stream) {
+  if (!X || !Y || !C || batch <= 0 || batch > 65535) return GEOBO_E_ARG;
+  if (k % BK || (ldx & 1) || (ldy & 1) || (strideX & 1) || (strideY & 1)) return GEOBO_E_ALIGN;
+  GemmArgs a{};
+  a.X = X; a.ldx = ldx; a.Y = Y; a.ldy = ldy; a.C = C; a.ldc = ldc; a.k = k;
+  a.alpha = alpha; a.beta = beta; a.tri = 0;
+  a.sXb = strideX; a.sYb = strideY; a.sCb = strideC; a.m_valid = m_valid; a.n_valid = n_valid; a.batch = batch;
+  if (y_is_kn) return launch_by_rows<Y_NN, EPI_STORE, COV_D2>(a, m, n, (hipStream_t)stream);
+  return launch_by_rows<Y_NT, EPI_STORE, COV_D2>(a, m, n, (hipStream_t)stream);
 }
 
 extern "C" size_t geobo_posterior_ws_bytes(int64_t m, int64_t ncols) {

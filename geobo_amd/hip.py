@@ -165,6 +165,30 @@ def gemm_nn(X, Y, C_, alpha=1.0, beta=0.0, x_lower=False, y_lower=False):
     return C_
 
 
+def gemm_batched(y_is_kn, m, n, k, X, ldx, strideX, Y, ldy, strideY, C_, ldc, strideC, m_valid, n_valid, batch, alpha=1.0,
+                 beta=0.0):
+    """Raw batched GEMM (see include/geobo_hip.h); X/Y/C are tensors whose data_ptr is the batch-0 origin."""
+    lib = require_gpu()
+    done = 0
+    esz = 8
+    while done < batch:                      # gridDim.y limit
+        nb = min(batch - done, 65535)
+        _lib.check(lib.geobo_gemm_batched(1 if y_is_kn else 0, int(m), int(n), int(k), float(alpha),
+                                          C.c_void_p(X.data_ptr() + done * strideX * esz), int(ldx), int(strideX),
+                                          C.c_void_p(Y.data_ptr() + done * strideY * esz), int(ldy), int(strideY), float(beta),
+                                          C.c_void_p(C_.data_ptr() + done * strideC * esz), int(ldc), int(strideC),
+                                          int(m_valid), int(n_valid), int(nb), _stream()), "geobo_gemm_batched")
+        done += nb
+    return C_
+
+
+def scale_broadcast(a, b, out):
+    lib = require_gpu()
+    _lib.check(lib.geobo_scale_broadcast(_p(_chk(a, "a")), _p(_chk(b, "b")), a.numel(), b.numel(), _p(out), _stream()),
+               "geobo_scale_broadcast")
+    return out
+
+
 def potrf_inv(A):
     """In-place lower Cholesky of A (m x m, m % 128 == 0); returns (Linv, info_tensor)."""
     lib = require_gpu()

@@ -39,7 +39,8 @@ class DiagonalCovariance:
 class Inversion:
     """Class for inversion and reconstruction of 3D cubes from 2D sensor data (inversion.py:23-248)."""
 
-    def __init__(self, settings=None, props=(0, 1, 2), rank=0, world=1, group=None, device=None, profile=False):
+    def __init__(self, settings=None, props=(0, 1, 2), rank=0, world=1, group=None, device=None, profile=False,
+                 method="dense"):
         self.settings = s = settings or config_loader.active()
         # inversion.py:46-51 -- NB x voxel size for all three length scales
         self.gp_length = s.gp_lengthscale * np.asarray([s.xvoxsize, s.xvoxsize, s.xvoxsize])
@@ -47,7 +48,7 @@ class Inversion:
         self.coeffm = np.asarray(s.gp_coeff)
         self.gp_amp = 1.
         self.props = tuple(props)
-        self._engine_args = dict(rank=rank, world=world, group=group, device=device, profile=profile)
+        self._engine_args = dict(rank=rank, world=world, group=group, device=device, profile=profile, method=method)
         self._engine = None
 
     # ---- geometry (host, inversion.py:54-74) -------------------------------------------------------------------

@@ -1,0 +1,148 @@
+"""Spectral (real-DFT) form of the covariance x forward-operator product  AK = A_s K_sj  on a regular grid.
+
+SURVEY.md section 8(f) row f2 ("structure-exploiting assembly: same results, fewer flops").  On the grid of
+`calcGridPoints3D` (kernels.py:27-42) every block K_sj of `create_cov` (kernels.py:158-195) is a symmetric
+three-level Toeplitz matrix: K(p,q) = k(|dy|,|dx|,|dz|).  Embedded in a symmetric three-level circulant of size
+(2ny, 2nx, 2nz) it is diagonalised by the Kronecker product of the REAL transforms
+
+    G_a  (P x n, P = 2n):   rows  sqrt(w_o) cos(2 pi o z / P), o = 0..P/2   and   sqrt(2) sin(2 pi o z / P), o = 1..P/2-1
+
+(w_o = 1 for o in {0, P/2}, else 2):   K = crop[ (Gy x Gx x Gz)^T diag(Lambda / PyPxPz) (Gy x Gx x Gz) ],
+Lambda(oy,ox,oz) = sum_d k(d) prod_a c_a(d_a) cos(2 pi o_a d_a / P_a)  (c = 1 for d = 0, 2 otherwise) -- all real, because
+k is even in every coordinate.  One row of A_s (a ny x nx x nz volume) therefore costs three small-k GEMM passes forward
+and three per property block backward (cropping on the way back) instead of an N x N contraction:
+2.25e15 -> ~1.2e13 flop at 64^3.  Every pass is a batch of MFMA GEMMs against a fixed cosine/sine matrix
+(`geobo_gemm_batched`); no FFT library, no complex arithmetic.
+
+Numerics: the transform matrices are orthogonal up to scaling, so the result differs from the dense path by a few
+1e-16 of max|A| max|K| per entry (normwise); the posterior cubes stay far inside the 1e-8 contract (tests).
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import hip
+
+F64 = hip.F64
+SLACK = 4096  # doubles of slack behind every buffer: compute tiles may overhang the valid region (reads only)
+
+
+def _omega(P):
+    rho = np.arange(P)
+    return np.where(rho <= P // 2, rho, rho - P // 2)
+
+
+def forward_matrix(n):
+    """G (P x n): real eigenvector basis of symmetric circulants of size P = 2n, restricted to the first n inputs."""
+    P = 2 * n
+    z = np.arange(n)
+    G = np.empty((P, n))
+    for rho in range(P):
+        m = (rho if rho <= P // 2 else rho - P // 2) * z % P          # exact integer phase index
+        ang = 2.0 * np.pi * m / P
+        if rho <= P // 2:
+            G[rho] = (1.0 if rho in (0, P // 2) else math.sqrt(2.0)) * np.cos(ang)
+        else:
+            G[rho] = math.sqrt(2.0) * np.sin(ang)
+    return G
+
+
+def eigen_matrix(n):
+    """E (P x n): Lambda' = E k for a half table k(d), d = 0..n-1, laid out on the same row index as G."""
+    P = 2 * n
+    d = np.arange(n)
+    om = _omega(P)
+    E = np.cos(2.0 * np.pi * ((om[:, None] * d[None, :]) % P) / P)
+    E[:, 1:] *= 2.0
+    return E
+
+
+def _pad_rows(M, mult=128):
+    r = (M.shape[0] + mult - 1) // mult * mult + mult      # one extra tile of zero rows: row-offset views may overhang
+    out = np.zeros((r, M.shape[1]))
+    out[:M.shape[0]] = M
+    return out
+
+
+def _buf(n, device):
+    return torch.empty(int(n) + SLACK, dtype=F64, device=device)
+
+
+class SpectralProduct:
+    """AK rows by the real-DFT route for one grid; holds the transform matrices and the work buffers."""
+
+    def __init__(self, nx, ny, nz, device, rows_per_batch=None):
+        if nx % 16 or ny % 16 or nz % 16:
+            raise ValueError("spectral path needs grid extents that are multiples of 16")
+        self.nx, self.ny, self.nz = nx, ny, nz
+        self.Px, self.Py, self.Pz = 2 * nx, 2 * ny, 2 * nz
+        self.N = nx * ny * nz
+        self.P3 = self.Px * self.Py * self.Pz
+        self.device = device
+        dev = lambda a: hip.to_dev(a, device)
+        self.G = {a: dev(_pad_rows(forward_matrix(n))) for a, n in (("x", nx), ("y", ny), ("z", nz))}
+        self.GT = {a: dev(_pad_rows(forward_matrix(n).T.copy())) for a, n in (("x", nx), ("y", ny), ("z", nz))}
+        self.E = {a: dev(_pad_rows(eigen_matrix(n))) for a, n in (("x", nx), ("y", ny), ("z", nz))}
+        if rows_per_batch is None:
+            rows_per_batch = max(1, min(128, (3 << 30) // (self.P3 * 8)))  # ~3 GB per full-spectrum buffer
+        g = 128 // math.gcd(nx * ny, 128)
+        self.R = max(g, rows_per_batch // g * g)
+        self._bufs = {}
+
+    def buf(self, name, n):
+        b = self._bufs.get(name)
+        if b is None or b.numel() < n + SLACK:
+            b = self._bufs[name] = _buf(n, self.device)
+        return b
+
+    # ---- three axis passes, z (contiguous) then x then y: [R][ny][nx][nz] -> [R][Py][Px][Pz] --------------------------------
+    def forward(self, src, R, M, out_name="T3"):
+        nx, ny, nz, Px, Py, Pz = self.nx, self.ny, self.nz, self.Px, self.Py, self.Pz
+        rows = R * ny * nx
+        t1 = self.buf("T1", rows * Pz)
+        hip.gemm_batched(False, hip.pad_n(rows), hip.pad_n(Pz), nz, src, nz, 0, M["z"], nz, 0, t1, Pz, 0, rows, Pz, 1)
+        t2 = self.buf("T2", R * ny * Px * Pz)
+        hip.gemm_batched(True, hip.pad_n(Px), hip.pad_n(Pz), nx, M["x"], nx, 0, t1, Pz, nx * Pz, t2, Pz, Px * Pz, Px, Pz, R * ny)
+        t3 = self.buf(out_name, R * self.P3)
+        hip.gemm_batched(True, hip.pad_n(Py), hip.pad_n(Px * Pz), ny, M["y"], ny, 0, t2, Px * Pz, ny * Px * Pz, t3, Px * Pz,
+                         self.P3, Py, Px * Pz, R)
+        return t3
+
+    # ---- back: y (crop to the slab [y0,y1)), x, z; writes rows of `out` (leading dimension ldo) -----------------------------
+    def backward(self, spec, R, y0, y1, out, ldo):
+        nx, nz, Px, Py, Pz = self.nx, self.nz, self.Px, self.Py, self.Pz
+        slab = y1 - y0
+        gyt = self.GT["y"][y0:]                                  # rows y0.. of G_y^T (padded rows behind are zero / slack)
+        u2 = self.buf("U2", R * slab * Px * Pz)
+        hip.gemm_batched(True, hip.pad_n(slab), hip.pad_n(Px * Pz), Py, gyt, Py, 0, spec, Px * Pz, self.P3, u2, Px * Pz,
+                         slab * Px * Pz, slab, Px * Pz, R)
+        u1 = self.buf("U1", R * slab * nx * Pz)
+        hip.gemm_batched(True, hip.pad_n(nx), hip.pad_n(Pz), Px, self.GT["x"], Px, 0, u2, Pz, Px * Pz, u1, Pz, nx * Pz, nx, Pz,
+                         R * slab)
+        hip.gemm_batched(False, hip.pad_n(slab * nx), hip.pad_n(nz), Pz, u1, Pz, slab * nx * Pz, self.GT["z"], Pz, 0, out, nz, ldo,
+                         slab * nx, nz, R)
+
+    def eigenvalues(self, table_mirrored):
+        """Lambda'/(Py Px Pz) on the G row index, from the (z-mirrored) lattice table of geobo_cov_table."""
+        nx, ny, nz = self.nx, self.ny, self.nz
+        T = table_mirrored[:ny * nx * 2 * nz].view(ny, nx, 2 * nz)[:, :, nz - 1:2 * nz - 1].contiguous()
+        src = self.buf("Tsrc", self.N)
+        src[:self.N] = T.reshape(-1)
+        lam = self.forward(src, 1, self.E, out_name="Lam")[:self.P3].clone()
+        lam.mul_(1.0 / float(self.P3))
+        return lam
+
+    def product(self, A, Ms, lam_list, outs, y0=0, y1=None):
+        """outs[j][r, :] = (A[r, :N] convolved with block j) restricted to y-slab [y0,y1), r < Ms.
+        A: (>=Ms x N) row-major with leading dimension N; outs[j]: 2-D views (rows x (y1-y0)*nx*nz)."""
+        y1 = self.ny if y1 is None else y1
+        N = self.N
+        assert A.stride(0) == N and A.stride(1) == 1, "spectral path needs unpadded voxel columns (N % 128 == 0)"
+        for r0 in range(0, Ms, self.R):
+            R = min(self.R, Ms - r0)
+            spec = self.forward(A[r0:], R, self.G)
+            for lam, out in zip(lam_list, outs):
+                s = self.buf("S", R * self.P3)
+                hip.scale_broadcast(spec[:R * self.P3], lam, s[:R * self.P3])
+                self.backward(s, R, y0, y1, out[r0:], out.stride(0))

@@ -116,6 +116,19 @@ int geobo_gemm_nn(int64_t m, int64_t n, int64_t k, double alpha, const double* X
                   const double* Y, int64_t ldy, double beta, double* C, int64_t ldc,
                   int x_lower, int y_lower, void* stream);
 
+/* Batched form of the two products above with store predicates: for b < batch
+ *     C_b[:m_valid, :n_valid] = alpha * X_b * op(Y_b) + beta * C_b,   X_b = X + b*strideX etc. (stride 0 = shared operand)
+ * y_is_kn = 0: Y_b is n x k (k-contiguous, "NT");  y_is_kn = 1: Y_b is k x n (n-contiguous, "NN").
+ * m, n are the COMPUTE extents (multiples of 128; operands must be readable over them), m_valid <= m and n_valid <= n
+ * the stored extents.  Used by the spectral (real-DFT) form of the covariance product: every axis pass of the 3-D
+ * transform is a batch of small-k MFMA GEMMs against a fixed cosine/sine matrix. */
+int geobo_gemm_batched(int y_is_kn, int64_t m, int64_t n, int64_t k, double alpha, const double* X, int64_t ldx,
+                       int64_t strideX, const double* Y, int64_t ldy, int64_t strideY, double beta, double* C, int64_t ldc,
+                       int64_t strideC, int64_t m_valid, int64_t n_valid, int batch, void* stream);
+
+/* out[i] = a[i] * b[i % nb]   (spectrum x eigenvalue table, broadcast over the batch) */
+int geobo_scale_broadcast(const double* a, const double* b, int64_t n, int64_t nb, double* out, void* stream);
+
 /* In-place lower Cholesky of the (m x m, ld) matrix A, m % 256 == 0 (padding rows/cols = identity);
  * scipy.linalg.cholesky(AkA, lower=True), inversion.py:100.  Also writes Linv = L^-1 (m x m, ldi; lower,
  * upper part zeroed), used instead of the two solve_triangular calls (inversion.py:105,114).
