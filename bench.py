@@ -136,6 +136,8 @@ def main():
     ap.add_argument("--size", type=int, default=64, help="cube edge in voxels (64 = BASELINE headline)")
     ap.add_argument("--kernel", default="matern32")
     ap.add_argument("--drill", type=int, default=50)
+    ap.add_argument("--method", default="auto", choices=["auto", "dense", "spectral"],
+                    help="A.K route: dense = fused in-kernel covariance generation; spectral = real-DFT on batched MFMA GEMMs")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU dry runs)")
     a = ap.parse_args()
@@ -159,7 +161,7 @@ def main():
     s = Settings(dict(xmin=0, xmax=100.0 * n, ymin=0, ymax=100.0 * n, zmax=0, zoff=1, zLcube=100.0 * n, xNcube=n, yNcube=n,
                       zNcube=n, gp_lengthscale=2, gp_err=[0.1, 0.1, 0.1], gp_coeff=[1.0, 0.2, 0.2], kernelfunc=a.kernel,
                       XMAG=0, YMAG=0, ZMAG=1))
-    inv = Inversion(settings=s, props=(0, 1), rank=rank, world=world, device="cuda:%d" % local)
+    inv = Inversion(settings=s, props=(0, 1), rank=rank, world=world, device="cuda:%d" % local, method=a.method)
     grav, mag, loc, drill0 = synthetic_inputs(inv, a.drill)
     gp_length = np.array([2.00, 2.02, 2.04]) * s.xvoxsize if a.kernel == "matern32" else None
 
@@ -191,9 +193,21 @@ def main():
         dt = float(t.item())
     ev = inv.engine.kernel_events
     inv.engine.kernel_events = None
-    durs = [e0.elapsed_time(e1) * 1e-3 for (_, _, e0, e1) in ev]
-    flops = ev[0][1] if ev else 0.0
-    ach = flops / (sum(durs) / len(durs)) / 1e12 if durs else 0.0
+    # per-stage / per-kernel device time from HIP events recorded on the launch stream (torch's current stream)
+    stages = {}
+    for name, fl, e0, e1 in ev:
+        d = stages.setdefault(name, dict(calls=0, seconds=0.0, flop=0.0))
+        d["calls"] += 1
+        d["seconds"] += e0.elapsed_time(e1) * 1e-3
+        d["flop"] += fl
+    single = [k for k in stages if k in ("ak_fused_grid", "ak_fused", "posterior_reduce", "aka_gemm_nt")]
+    dom = max(single, key=lambda k: stages[k]["seconds"]) if single else None
+    ach = stages[dom]["flop"] / stages[dom]["seconds"] / 1e12 if dom else 0.0
+    flops = stages[dom]["flop"] / stages[dom]["calls"] if dom else 0.0
+    durs = [stages[dom]["seconds"] / stages[dom]["calls"]] * stages[dom]["calls"] if dom else []
+    kernel_names = {"ak_fused_grid": "geobo_ak_fused_grid (gemm_f64_kernel<4,2,TAB>)", "ak_fused": "geobo_ak_fused (gemm_f64_kernel<4,2,GEN>)",
+                    "posterior_reduce": "geobo_posterior_reduce (gemm_f64_kernel<4,2,NN,REDUCE>)",
+                    "aka_gemm_nt": "geobo_gemm_nt (gemm_f64_kernel<4,2,NT>)"}
 
     if rank == 0:
         eng = inv.engine
@@ -203,6 +217,7 @@ def main():
         M = 2 * eng.Ms + int((drill0 != 0).sum())
         Msd = 2 * eng.Ms
         F = 2.0 * Msd * N * N * p_out + 2.0 * M * Msd * N + M ** 3 / 3.0 + 1.0 * M * M * p_out * N + 4.0 * M * p_out * N + M * M
+        F_exec = sum(d["flop"] for d in stages.values()) / a.steps   # flop actually executed by the MFMA kernels of this route
         out = {
             "metric": "voxels/sec posterior (mean+var) for 64^3 x 2-prop joint inversion; fp64 roofline %",
             "value": value, "unit": "voxel-properties/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -211,9 +226,12 @@ def main():
             "config": {"workload": "%d^3 voxel cube (100 m), gravity+magnetics joint inversion, %s kernel lengths (2.00,2.02,2.04)x100 m, "
                                    "%d drill constraints, M=%d rows, density+magsus cubes (P_out=2)" % (n, a.kernel, a.drill, M),
                        "N_voxels": N, "M_rows": M, "props_out": p_out, "parallelism": "voxel-column shards x%d" % world,
-                       "algorithmic_flop_per_step": F, "end_to_end_fp64_roofline_frac": F * a.steps / dt / (FP64_MATRIX_PEAK_TFLOPS * 1e12 * world)},
-            "roofline": {"bound": "mfma", "kernel": "geobo_ak_fused_grid (gemm_f64_kernel<4,2,TAB>)" if inv.engine.use_grid else "geobo_ak_fused (gemm_f64_kernel<4,2,GEN>)", "achieved": ach, "peak": FP64_MATRIX_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach / FP64_MATRIX_PEAK_TFLOPS, "traffic": pmc_traffic(flops),
+                       "method": "spectral" if inv.engine.use_spectral else "dense",
+                       "dense_algorithmic_flop_per_step": F, "executed_mfma_flop_per_step_rank0": F_exec,
+                       "end_to_end_fp64_roofline_frac_of_executed_flop": F_exec * a.steps / dt / (FP64_MATRIX_PEAK_TFLOPS * 1e12),
+                       "stage_ms_per_step_rank0": {k: round(1e3 * v["seconds"] / a.steps, 3) for k, v in stages.items()}},
+            "roofline": {"bound": "mfma", "kernel": kernel_names.get(dom), "achieved": ach, "peak": FP64_MATRIX_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": ach / FP64_MATRIX_PEAK_TFLOPS, "traffic": pmc_traffic(flops) if dom == "ak_fused_grid" else None,
                          "launches_timed": len(durs), "flop_per_launch": flops, "mean_launch_s": (sum(durs) / len(durs)) if durs else None},
         }
         if not a.no_cpu and world == 1:   # CPU baseline: rank 0 at N = 1 only

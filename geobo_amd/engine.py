@@ -61,7 +61,7 @@ def weight_matrix(crossweights):
 
 
 class PosteriorEngine:
-    def __init__(self, settings, device=None, rank=0, world=1, group=None, profile=False, method="dense"):
+    def __init__(self, settings, device=None, rank=0, world=1, group=None, profile=False, method="auto"):
         hip.require_gpu()
         self.s = settings
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
@@ -81,8 +81,10 @@ class PosteriorEngine:
         self.use_grid = self.nz >= 16 and self.nz % 2 == 0  # lattice-table generator (geobo_ak_fused_grid); coordinates otherwise
         # spectral (real-DFT) product: regular grid with extents % 16 == 0, unpadded voxel columns, shards on y-slab boundaries
         plane = self.nx * self.nz
+        if method not in ("auto", "dense", "spectral"):
+            raise ValueError("method must be 'auto', 'dense' or 'spectral'")
         self.method = method
-        self.use_spectral = (method == "spectral" and self.nx % 16 == 0 and self.ny % 16 == 0 and self.nz % 16 == 0
+        self.use_spectral = (method in ("auto", "spectral") and self.nx % 16 == 0 and self.ny % 16 == 0 and self.nz % 16 == 0
                              and self.N == self.N_pad and self.c0 % plane == 0 and self.c1 % plane == 0 and self.nc > 0)
         if method == "spectral" and not self.use_spectral:
             raise ValueError("spectral method needs grid extents % 16 == 0 and column shards on y-slab boundaries")
@@ -132,11 +134,22 @@ class PosteriorEngine:
         else:
             Bv = s.magneticField if B is None else np.asarray(B, dtype=float)
             mul, div = 1.0, s.fcor_mag
-        hip.a_sens(func, Bv, hip.to_dev(loc, self.device), self.nx, self.ny, self.nz, hip.to_dev(xe, self.device),
-                   hip.to_dev(ye, self.device), hip.to_dev(ze, self.device), mul, div, A)
+        locd, xed, yed, zed = (hip.to_dev(v, self.device) for v in (loc, xe, ye, ze))
+        self._timed("a_sens_" + func, 0.0, lambda: hip.a_sens(func, Bv, locd, self.nx, self.ny, self.nz, xed, yed, zed, mul, div, A))
         self._A = {k: v for k, v in self._A.items() if k[0] != func}  # one operator per type stays resident
         self._A[key] = A
         return A
+
+    def _timed(self, name, flops, fn):
+        """Run fn(); when kernel_events is a list, bracket it with HIP events on the launch stream (torch's current one)."""
+        if self.kernel_events is None:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn()
+        e1.record()
+        self.kernel_events.append((name, float(flops), e0, e1))
+        return r
 
     def clear_operators(self):
         """Drop the resident forward operators (the benchmark rebuilds them inside every timed step)."""
@@ -174,17 +187,12 @@ class PosteriorEngine:
                     sset = self.s
                     tab = hip.cov_table(kid, self.nx, self.ny, self.nz, sset.xvoxsize, sset.yvoxsize, sset.zvoxsize,
                                         lengths[j], lengths[s_], W[s_][j], amp, self.device)
-                if self.kernel_events is not None:
-                    e0 = torch.cuda.Event(enable_timing=True)
-                    e0.record()
                 if self.use_grid:
-                    hip.ak_fused_grid(A, self.nx, self.ny, self.nz, tab, self.c0, nc, out)
+                    self._timed("ak_fused_grid", 2.0 * self.Ms_pad * self.N_pad * nc,
+                                lambda: hip.ak_fused_grid(A, self.nx, self.ny, self.nz, tab, self.c0, nc, out))
                 else:
-                    hip.ak_fused(kid, A, xyz, self.c0, nc, lengths[j], lengths[s_], W[s_][j], amp, out)
-                if self.kernel_events is not None:
-                    e1 = torch.cuda.Event(enable_timing=True)
-                    e1.record()  # same stream as the launch (torch's current stream)
-                    self.kernel_events.append(("ak_fused", 2.0 * self.Ms_pad * self.N_pad * nc, e0, e1))
+                    self._timed("ak_fused", 2.0 * self.Ms_pad * self.N_pad * nc,
+                                lambda: hip.ak_fused(kid, A, xyz, self.c0, nc, lengths[j], lengths[s_], W[s_][j], amp, out))
             if Md:
                 rows = tuple(c[sel_t] for c in xyz)
                 colc = tuple(c[self.c0:self.c1] for c in xyz)
@@ -207,14 +215,7 @@ class PosteriorEngine:
                                     sset.zvoxsize, lengths[j], lengths[s_], W[s_][j], amp, self.device)
                 lams.append(sp.eigenvalues(tab))
                 outs.append(AK[s_ * self.Ms_pad:s_ * self.Ms_pad + self.Ms, jj * nc:(jj + 1) * nc])
-            if self.kernel_events is not None:
-                e0 = torch.cuda.Event(enable_timing=True)
-                e0.record()
-            sp.product(A, self.Ms, lams, outs, y0, y1)
-            if self.kernel_events is not None:
-                e1 = torch.cuda.Event(enable_timing=True)
-                e1.record()
-                self.kernel_events.append(("spectral_product", 0.0, e0, e1))
+            self._timed("spectral_product", sp.flops(self.Ms, len(props), y1 - y0), lambda: sp.product(A, self.Ms, lams, outs, y0, y1))
 
     def _assemble_AkA(self, AK, M_pad, A_g, A_m, sel_t, lengths, name, amp, gp_sigma, props):
         xyz = self.grid_points()
@@ -227,7 +228,11 @@ class PosteriorEngine:
         for s_, A in ((0, A_g), (1, A_m)):
             jj = props.index(s_)
             r0 = s_ * self.Ms_pad
-            hip.gemm_nt(AK[r0:, jj * nc:(jj + 1) * nc], A[:, self.c0:self.c1], AkA[r0:, r0:r0 + self.Ms_pad], lower_only=True)
+            rows = M_pad - r0
+            tiles = sum(min(2 * (bi + 1), self.Ms_pad // 128) for bi in range(rows // 256))  # lower-only 256x128 tiles
+            self._timed("aka_gemm_nt", 2.0 * 256 * 128 * nc * tiles,
+                        lambda: hip.gemm_nt(AK[r0:, jj * nc:(jj + 1) * nc], A[:, self.c0:self.c1], AkA[r0:, r0:r0 + self.Ms_pad],
+                                            lower_only=True))
         allreduce_sum_(AkA, self.world, self.group)
         dvec = torch.ones(M_pad, dtype=F64, device=self.device)
         dvec[0:self.Ms] = float(gp_sigma[0]) ** 2
@@ -263,7 +268,7 @@ class PosteriorEngine:
         t = self._tick("ak_fused", t)
         AkA = self._assemble_AkA(AK, M_pad, A_g, A_m, sel_t, lengths, kernelfunc, gp_amp, gp_sigma, props)
         t = self._tick("aka", t)
-        Linv, info = hip.potrf_inv(AkA)  # AkA now holds L
+        Linv, info = self._timed("potrf_inv", 2.0 * M_pad ** 3 / 3.0, lambda: hip.potrf_inv(AkA))  # AkA now holds L
         L = AkA
         y = self._pad_y(y_g, y_m, y_d, M_pad)
         u, stats = hip.trmv_stats(Linv, y, L)
@@ -279,7 +284,9 @@ class PosteriorEngine:
         else:
             out["logl"] = 0.0
         if want_mean_var:
-            mu_l, var_l = hip.posterior_reduce(Linv, AK, u, gp_amp * 1.0)
+            # executed flop: lower-triangular Linv, 256-row tiles -> sum_bi 2*256*(256*(bi+1))*ncols
+            fl = 2.0 * 256 * 256 * AK.shape[1] * sum(bi + 1 for bi in range(M_pad // 256))
+            mu_l, var_l = self._timed("posterior_reduce", fl, lambda: hip.posterior_reduce(Linv, AK, u, gp_amp * 1.0))
             t = self._tick("posterior", t)
             mu = assemble_columns(gather_slices(mu_l, len(props), self.N_pad, self.world, self.group), props, self.N,
                                   self.N_pad, self.world)

@@ -123,6 +123,14 @@ class SpectralProduct:
         hip.gemm_batched(False, hip.pad_n(slab * nx), hip.pad_n(nz), Pz, u1, Pz, slab * nx * Pz, self.GT["z"], Pz, 0, out, nz, ldo,
                          slab * nx, nz, R)
 
+    def flops(self, rows, nblocks, slab):
+        """Executed flop of product(): forward passes once, backward passes per property block (compute extents)."""
+        nx, ny, nz, Px, Py, Pz = self.nx, self.ny, self.nz, self.Px, self.Py, self.Pz
+        pn = hip.pad_n
+        fwd = 2.0 * (ny * nx * pn(Pz) * nz + ny * pn(Px) * pn(Pz) * nx + pn(Py) * Px * Pz * ny)
+        bwd = 2.0 * (pn(slab) * Px * Pz * Py + slab * pn(nx) * pn(Pz) * Px + pn(slab * nx) * pn(nz) * Pz)
+        return rows * (fwd + nblocks * bwd)
+
     def eigenvalues(self, table_mirrored):
         """Lambda'/(Py Px Pz) on the G row index, from the (z-mirrored) lattice table of geobo_cov_table."""
         nx, ny, nz = self.nx, self.ny, self.nz

@@ -81,11 +81,13 @@ def test_tiny_grid_solver_parity_with_reference_operators(kern):
     assert normwise(Lh @ Lh.T, f["AkA"]) <= 1e-12
 
 
+@pytest.mark.parametrize("method", ["dense", "spectral"])
 @pytest.mark.parametrize("name,kern", [("cube16_exp", "exp"), ("cube16_matern32", "matern32"), ("cube16_sparse", "sparse")])
-def test_cube16_end_to_end(name, kern):
+def test_cube16_end_to_end(name, kern, method):
     f = load_golden(name + ".npz")
     s = settings_for(16, 16, 16, kernelfunc=kern)
-    inv = _inv(s)
+    inv = _inv(s, method=method)
+    assert inv.engine.use_spectral == (method == "spectral")
     inv.gp_length = f["gp_length_in"].copy()
     d0 = f["drilldata0"]
     cubes = inv.cubing(f["gravfield"], f["magfield"], d0[d0 != 0], f["sensor_locations"], d0)
@@ -128,11 +130,12 @@ def test_props_subset_and_errors():
 
 
 # ---- BASELINE config 2 and the 32^3 Matern case: oracle-generated vectors (the reference cannot run 32^3) -----------
+@pytest.mark.parametrize("method", ["dense", "spectral"])
 @pytest.mark.parametrize("name,kern", [("oracle32_exp", "exp"), ("oracle32_matern32", "matern32")])
-def test_cube32_against_oracle_vectors(name, kern):
+def test_cube32_against_oracle_vectors(name, kern, method):
     f = load_golden(name + ".npz")
     s = settings_for(32, 32, 32, kernelfunc=kern)
-    inv = _inv(s)
+    inv = _inv(s, method=method)
     inv.gp_length = f["gp_length_in"].copy()
     d0 = np.zeros(32 ** 3)
     d0[f["sel"]] = f["drillvalues"]
@@ -164,11 +167,11 @@ def test_column_shards_reproduce_the_unsharded_posterior():
     from geobo_amd.sharding import assemble_columns, shard_columns
     f = load_golden("oracle32_matern32.npz")
     s = settings_for(32, 32, 32, kernelfunc="matern32")
-    full = E.PosteriorEngine(s)
+    full = E.PosteriorEngine(s, method="dense")
     ref = _engine_posterior(full, f, "matern32")
     L_ref = torch.tril(full.last["L"]).clone()
     world = 3
-    engs = [E.PosteriorEngine(s, rank=r, world=1) for r in range(world)]
+    engs = [E.PosteriorEngine(s, rank=r, world=1, method="dense") for r in range(world)]
     parts, AKs = [], []
     W = E.weight_matrix(s.gp_coeff)
     lengths = [float(v) for v in E.create_cov_lengths(f["gp_length_in"].copy())]
@@ -244,7 +247,8 @@ def test_full_size_64cube_properties():
     from geobo_amd.inversion import Inversion
     n = 64
     s = Settings(dict(xmax=100.0 * n, ymax=100.0 * n, zLcube=100.0 * n, xNcube=n, yNcube=n, zNcube=n, kernelfunc="matern32"))
-    inv = Inversion(settings=s, props=(0, 1))
+    inv = Inversion(settings=s, props=(0, 1))          # method="auto" -> spectral route at 64^3
+    assert inv.engine.use_spectral
     grav, mag, loc, drill0 = bench.synthetic_inputs(inv, 50)
     inv.gp_length = np.array([200.0, 202.0, 204.0])
     cubes = inv.cubing(grav, mag, drill0[drill0 != 0], loc, drill0)
@@ -265,3 +269,34 @@ def test_full_size_64cube_properties():
     assert np.abs(smp[0][1] - var[c0:c0 + b]).max() <= 1e-10
     assert np.abs(smp[1][0] - inv.mu_rec[N + c0:N + c0 + b]).max() <= 1e-10 * np.abs(inv.mu_rec[N:2 * N]).max()
     assert all(c.shape == (n, n, n) for c in cubes)
+
+
+def test_spectral_y_slab_shards_match_dense():
+    """Column shards of the spectral route (y-slab cropping in the backward pass) against the dense AK, rank by rank."""
+    import geobo_amd.engine as E
+    f = load_golden("oracle32_matern32.npz")
+    s = settings_for(32, 32, 32, kernelfunc="matern32")
+    W = E.weight_matrix(s.gp_coeff)
+    lengths = [float(v) for v in E.create_cov_lengths(f["gp_length_in"].copy())]
+    sel_t = torch.as_tensor(f["sel"], device="cuda")
+    world = 4
+    for r in (0, 3):
+        out = {}
+        for method in ("dense", "spectral"):
+            eng = E.PosteriorEngine(s, rank=r, world=world, method=method)
+            assert eng.use_spectral == (method == "spectral")
+            A_g, A_m = eng.operator("grav", f["sensor_locations"]), eng.operator("magn", f["sensor_locations"])
+            out[method], _ = eng._assemble_AK(A_g, A_m, sel_t, lengths, W, "matern32", 1.0, (0, 1, 2))
+        d = (out["dense"] - out["spectral"]).abs().max().item()
+        assert d <= 1e-12 * out["dense"].abs().max().item(), (r, d)
+
+
+def test_spectral_transform_matrices_diagonalise_toeplitz():
+    """CPU-side identity behind the spectral route: crop[G^T diag(E k / P) G] equals the symmetric Toeplitz matrix of k."""
+    from geobo_amd.spectral import eigen_matrix, forward_matrix
+    n = 16
+    k = np.exp(-0.3 * np.arange(n)) * (1 + 0.1 * np.arange(n))
+    G, Em = forward_matrix(n), eigen_matrix(n)
+    T = G.T @ np.diag(Em @ k / (2 * n)) @ G
+    ref = k[np.abs(np.arange(n)[:, None] - np.arange(n)[None, :])]
+    assert np.abs(T - ref).max() < 1e-13
