@@ -78,6 +78,7 @@ class PosteriorEngine:
         self.nc = self.c1 - self.c0
         self._xyz = None
         self._A = {}
+        self._ws = {}   # persistent device workspaces keyed by name (re-used across calls: no per-step allocation)
         self.use_grid = self.nz >= 16 and self.nz % 2 == 0  # lattice-table generator (geobo_ak_fused_grid); coordinates otherwise
         # spectral (real-DFT) product: regular grid with extents % 16 == 0, unpadded voxel columns, shards on y-slab boundaries
         plane = self.nx * self.nz
@@ -127,7 +128,11 @@ class PosteriorEngine:
         if key in self._A:
             return self._A[key]
         xe, ye, ze = self.node_axes() if axes is None else axes
-        A = torch.zeros((self.Ms_pad, self.N_pad), dtype=F64, device=self.device)
+        A = self._workspace("A_" + func, (self.Ms_pad, self.N_pad))
+        if self.Ms_pad > self.Ms:
+            A[self.Ms:].zero_()
+        if self.N_pad > self.N:
+            A[:, self.N:].zero_()
         if func == "grav":
             Bv = np.zeros(3) if B is None else np.asarray(B, dtype=float)
             mul, div = s.c_MILLIGALS_UNITS, s.fcor_grav
@@ -151,6 +156,14 @@ class PosteriorEngine:
         self.kernel_events.append((name, float(flops), e0, e1))
         return r
 
+    def _workspace(self, name, shape):
+        """Persistent uninitialised device tensor; reallocated only when the shape changes (large hipMallocs are slow)."""
+        t = self._ws.get(name)
+        if t is None or tuple(t.shape) != tuple(shape):
+            self._ws.pop(name, None)
+            t = self._ws[name] = torch.empty(shape, dtype=F64, device=self.device)
+        return t
+
     def clear_operators(self):
         """Drop the resident forward operators (the benchmark rebuilds them inside every timed step)."""
         self._A = {}
@@ -171,7 +184,15 @@ class PosteriorEngine:
         off_d = 2 * self.Ms_pad
         M_pad = hip.pad_m(off_d + Md)
         nc = self.nc
-        AK = torch.zeros((M_pad, len(props) * nc), dtype=F64, device=self.device)
+        AK = self._workspace("AK", (M_pad, len(props) * nc))
+        # every sensor/drill row is overwritten below; only the padding must be defined: rows behind each row block
+        # (zero, so that AkA / V get zero rows) and voxel columns >= N of the last shard (finite: they meet zero A columns)
+        for r0, r1 in ((self.Ms, self.Ms_pad), (self.Ms_pad + self.Ms, off_d), (off_d + Md, M_pad)):
+            if r1 > r0:
+                AK[r0:r1].zero_()
+        if self.c1 > self.N:
+            for jj in range(len(props)):
+                AK[:, jj * nc + max(self.N - self.c0, 0):(jj + 1) * nc].zero_()
         if self.use_spectral:
             self._assemble_AK_spectral(AK, A_g, A_m, lengths, W, name, amp, props)
         for jj, j in enumerate(props):
@@ -222,7 +243,8 @@ class PosteriorEngine:
         nc = self.nc
         Md = 0 if sel_t is None else sel_t.numel()
         off_d = 2 * self.Ms_pad
-        AkA = torch.zeros((M_pad, M_pad), dtype=F64, device=self.device)
+        AkA = self._workspace("AkA", (M_pad, M_pad))
+        AkA.zero_()
         # only the LOWER triangle of AkA is consumed (Cholesky, lower=True): block column s needs rows >= s*Ms_pad, and
         # tiles strictly above the diagonal are skipped inside the GEMM (47 % fewer tiles at 64^3)
         for s_, A in ((0, A_g), (1, A_m)):
@@ -268,7 +290,8 @@ class PosteriorEngine:
         t = self._tick("ak_fused", t)
         AkA = self._assemble_AkA(AK, M_pad, A_g, A_m, sel_t, lengths, kernelfunc, gp_amp, gp_sigma, props)
         t = self._tick("aka", t)
-        Linv, info = self._timed("potrf_inv", 2.0 * M_pad ** 3 / 3.0, lambda: hip.potrf_inv(AkA))  # AkA now holds L
+        Linv, info = self._timed("potrf_inv", 2.0 * M_pad ** 3 / 3.0, lambda: hip.potrf_inv(
+            AkA, self._workspace("Linv", (M_pad, M_pad)), self._workspace("potrf_ws", (hip.potrf_ws_doubles(M_pad),))))  # AkA now holds L
         L = AkA
         y = self._pad_y(y_g, y_m, y_d, M_pad)
         u, stats = hip.trmv_stats(Linv, y, L)
@@ -286,7 +309,8 @@ class PosteriorEngine:
         if want_mean_var:
             # executed flop: lower-triangular Linv, 256-row tiles -> sum_bi 2*256*(256*(bi+1))*ncols
             fl = 2.0 * 256 * 256 * AK.shape[1] * sum(bi + 1 for bi in range(M_pad // 256))
-            mu_l, var_l = self._timed("posterior_reduce", fl, lambda: hip.posterior_reduce(Linv, AK, u, gp_amp * 1.0))
+            mu_l, var_l = self._timed("posterior_reduce", fl, lambda: hip.posterior_reduce(
+                Linv, AK, u, gp_amp * 1.0, self._workspace("post_ws", (hip.posterior_ws_doubles(M_pad, AK.shape[1]),))))
             t = self._tick("posterior", t)
             mu = assemble_columns(gather_slices(mu_l, len(props), self.N_pad, self.world, self.group), props, self.N,
                                   self.N_pad, self.world)

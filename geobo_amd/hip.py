@@ -189,15 +189,17 @@ def scale_broadcast(a, b, out):
     return out
 
 
-def potrf_inv(A):
-    """In-place lower Cholesky of A (m x m, m % 128 == 0); returns (Linv, info_tensor)."""
+def potrf_inv(A, Linv=None, ws=None):
+    """In-place lower Cholesky of A (m x m, m % 128 == 0); returns (Linv, info_tensor).  Linv / ws may be caller-owned."""
     lib = require_gpu()
     ld = _rowmajor(A, "A")
     m = A.shape[0]
-    Linv = torch.empty((m, m), dtype=F64, device=A.device)
+    if Linv is None:
+        Linv = torch.empty((m, m), dtype=F64, device=A.device)
     info = torch.zeros(1, dtype=torch.int32, device=A.device)
     nbytes = lib.geobo_potrf_ws_bytes(m)
-    ws = torch.empty(max(nbytes // 8, 1), dtype=F64, device=A.device)
+    if ws is None or ws.numel() * 8 < nbytes:
+        ws = torch.empty(max(nbytes // 8, 1), dtype=F64, device=A.device)
     _lib.check(lib.geobo_potrf_inv(m, _p(A), ld, _p(Linv), Linv.stride(0), _p(info), _p(ws), nbytes, _stream()),
                "geobo_potrf_inv")
     return Linv, info
@@ -214,14 +216,23 @@ def trmv_stats(Linv, y, L):
     return u, stats
 
 
-def posterior_reduce(Linv, AK, u, prior_var):
+def potrf_ws_doubles(m):
+    return max(_lib.load().geobo_potrf_ws_bytes(int(m)) // 8, 1)
+
+
+def posterior_ws_doubles(m, ncols):
+    return max(_lib.load().geobo_posterior_ws_bytes(int(m), int(ncols)) // 8, 1)
+
+
+def posterior_reduce(Linv, AK, u, prior_var, ws=None):
     """mu[c] = sum_m (Linv AK)[m,c] u[m],  var[c] = prior_var - sum_m (Linv AK)[m,c]^2 (V never stored)."""
     lib = require_gpu()
     m, ncols = AK.shape
     mu = torch.empty(ncols, dtype=F64, device=AK.device)
     var = torch.empty(ncols, dtype=F64, device=AK.device)
     nbytes = lib.geobo_posterior_ws_bytes(m, ncols)
-    ws = torch.empty(max(nbytes // 8, 1), dtype=F64, device=AK.device)
+    if ws is None or ws.numel() * 8 < nbytes:
+        ws = torch.empty(max(nbytes // 8, 1), dtype=F64, device=AK.device)
     _lib.check(lib.geobo_posterior_reduce(m, ncols, _p(Linv), _rowmajor(Linv, "Linv"), _p(AK), _rowmajor(AK, "AK"),
                                           _p(_chk(u, "u")), float(prior_var), _p(mu), _p(var), _p(ws), nbytes, _stream()),
                "geobo_posterior_reduce")
