@@ -101,10 +101,17 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 1) gemm_f64
   int bi, bj;
   {
     const int b = blockIdx.x;
-    if (a.xcd_map) {
+    if (a.xcd_map == 1) {          // one row tile per XCD at a time (generator modes: only the X operand is streamed)
       const int xcd = b & 7, s = b >> 3;
       bj = s % a.nbj;
       bi = xcd + 8 * (s / a.nbj);
+    } else if (a.xcd_map == 2) {   // memory modes: every XCD works on a 4 x 8 supertile (32 workgroups share 4 X and 8 Y panels in its L2)
+      const int xcd = b & 7, s = b >> 3;
+      const int within = s & 31, g = (s >> 5) * 8 + xcd;
+      const int nsi = (a.nbi + 3) >> 2;
+      bi = 4 * (g % nsi) + (within & 3);
+      bj = 8 * (g / nsi) + (within >> 2);
+      if (bj >= a.nbj) return;
     } else {
       bi = b % a.nbi;
       bj = b / a.nbi;
@@ -469,8 +476,18 @@ int launch(GemmArgs& a, hipStream_t st) {
   }
   if (a.m_valid <= 0) a.m_valid = (int64_t)1 << 62;
   if (a.n_valid <= 0) a.n_valid = (int64_t)1 << 62;
+  static const int force_map = getenv("GEOBO_TILE_MAP") ? atoi(getenv("GEOBO_TILE_MAP")) : -1;  // experiment switch
   a.xcd_map = (a.nbi >= 8) ? 1 : 0;
-  const int nblocks = a.xcd_map ? 8 * ((a.nbi + 7) / 8) * a.nbj : a.nbi * a.nbj;
+  // supertiles help when both operands stream (measured: posterior_reduce 59 -> 66 TF/s); with lower_only skipping they
+  // unbalance the tail (AkA 420 -> 499 ms), so triangular-output launches keep the row-per-XCD map
+  if ((YMODE == Y_NT || YMODE == Y_NN) && !(a.tri & TRI_LOWER_ONLY) && a.nbi >= 4 && a.nbj >= 8) a.xcd_map = 2;
+  if (force_map >= 0 && !(force_map == 1 && a.nbi < 8)) a.xcd_map = force_map;
+  int nblocks = a.nbi * a.nbj;
+  if (a.xcd_map == 1) nblocks = 8 * ((a.nbi + 7) / 8) * a.nbj;
+  if (a.xcd_map == 2) {
+    const int nst = ((a.nbi + 3) / 4) * ((a.nbj + 7) / 8);
+    nblocks = 8 * 32 * ((nst + 7) / 8);
+  }
   hipLaunchKernelGGL(kern, dim3(nblocks, a.batch > 0 ? a.batch : 1), dim3(NT), lds, st, a);
   return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
 }
