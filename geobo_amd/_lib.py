@@ -27,6 +27,7 @@ SIGNATURES = {
     "geobo_cov_table": (_int, [_int, _int, _int, _int, _f64, _f64, _f64, _f64, _f64, _f64, _f64, _dp, _dp]),
     "geobo_ak_fused_grid": (_int, [_dp, _i64, _i64, _i64, _int, _int, _int, _dp, _i64, _i64, _dp, _i64, _dp]),
     "geobo_gemm_nt": (_int, [_i64, _i64, _i64, _f64, _dp, _i64, _dp, _i64, _f64, _dp, _i64, _int, _dp]),
+    "geobo_gemm_nt_splitk": (_int, [_i64, _i64, _i64, _int, _dp, _i64, _dp, _i64, _dp, _i64, _int, _dp, _sz, _dp]),
     "geobo_gemm_nn": (_int, [_i64, _i64, _i64, _f64, _dp, _i64, _dp, _i64, _f64, _dp, _i64, _int, _int, _dp]),
     "geobo_gemm_batched": (_int, [_int, _i64, _i64, _i64, _f64, _dp, _i64, _i64, _dp, _i64, _i64, _f64, _dp, _i64, _i64, _i64, _i64, _int, _dp]),
     "geobo_scale_broadcast": (_int, [_dp, _dp, _i64, _i64, _dp, _dp]),

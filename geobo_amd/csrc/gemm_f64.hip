@@ -452,6 +452,18 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 1) gemm_f64
   }
 }
 
+// out[r, c] = sum_s part[s][r][c]  (fixed order -> deterministic), 16-byte accesses
+__global__ void __launch_bounds__(256) sum_slices_kernel(const double* __restrict__ part, int splits, int64_t m, int64_t n,
+                                                         double* __restrict__ out, int64_t ldo) {
+  const int64_t n2 = n >> 1, total = m * n2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / n2, c = (i - r * n2) * 2;
+    v2d acc = *reinterpret_cast<const v2d*>(part + r * n + c);
+    for (int s = 1; s < splits; ++s) acc += *reinterpret_cast<const v2d*>(part + (int64_t)s * m * n + r * n + c);
+    *reinterpret_cast<v2d*>(out + r * ldo + c) = acc;
+  }
+}
+
 // deterministic final pass of the posterior reduction
 __global__ void posterior_finish_kernel(const double* part_mu, const double* part_ss, int nbi, int64_t ncols,
                                         double prior_var, double* mu, double* var) {
@@ -545,6 +557,26 @@ extern "C" int geobo_gemm_nt(int64_t m, int64_t n, int64_t k, double alpha, cons
   a.X = X; a.ldx = ldx; a.Y = Y; a.ldy = ldy; a.C = C; a.ldc = ldc; a.k = k;
   a.alpha = alpha; a.beta = beta; a.tri = lower_only ? TRI_LOWER_ONLY : 0;
   return launch_by_rows<Y_NT, EPI_STORE, COV_D2>(a, m, n, (hipStream_t)stream);
+}
+
+extern "C" int geobo_gemm_nt_splitk(int64_t m, int64_t n, int64_t k, int splits, const double* X, int64_t ldx, const double* Y,
+                                    int64_t ldy, double* C, int64_t ldc, int lower_only, void* ws, size_t ws_bytes,
+                                    void* stream) {
+  if (!X || !Y || !C || !ws || splits < 1 || splits > 64) return GEOBO_E_ARG;
+  if (k % (BK * splits) || (ldx & 1) || (ldy & 1) || (ldc & 1) || (n & 1)) return GEOBO_E_ALIGN;
+  if (ws_bytes < (size_t)splits * m * n * sizeof(double)) return GEOBO_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(ws, 0, (size_t)splits * m * n * sizeof(double), st) != hipSuccess) return GEOBO_E_LAUNCH;
+  GemmArgs a{};
+  a.X = X; a.ldx = ldx; a.Y = Y; a.ldy = ldy; a.C = (double*)ws; a.ldc = n; a.k = k / splits;
+  a.alpha = 1.0; a.beta = 0.0; a.tri = lower_only ? TRI_LOWER_ONLY : 0;
+  a.sXb = k / splits; a.sYb = k / splits; a.sCb = m * n; a.batch = splits;
+  int rc = launch_by_rows<Y_NT, EPI_STORE, COV_D2>(a, m, n, st);
+  if (rc) return rc;
+  int64_t nblk = (m * (n / 2) + 255) / 256;
+  if (nblk > 256 * 16) nblk = 256 * 16;
+  hipLaunchKernelGGL(sum_slices_kernel, dim3((unsigned)nblk), dim3(256), 0, st, (const double*)ws, splits, m, n, C, ldc);
+  return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
 }
 
 extern "C" int geobo_gemm_nn(int64_t m, int64_t n, int64_t k, double alpha, const double* X, int64_t ldx,

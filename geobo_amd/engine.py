@@ -252,9 +252,18 @@ class PosteriorEngine:
             r0 = s_ * self.Ms_pad
             rows = M_pad - r0
             tiles = sum(min(2 * (bi + 1), self.Ms_pad // 128) for bi in range(rows // 256))  # lower-only 256x128 tiles
-            self._timed("aka_gemm_nt", 2.0 * 256 * 128 * nc * tiles,
-                        lambda: hip.gemm_nt(AK[r0:, jj * nc:(jj + 1) * nc], A[:, self.c0:self.c1], AkA[r0:, r0:r0 + self.Ms_pad],
-                                            lower_only=True))
+            # a few hundred long tiles do not fill 256 CUs evenly: split the contraction into concurrent slices
+            splits = 1
+            for cand in (4, 2):
+                if nc % (16 * cand) == 0 and nc // cand >= 2048 and tiles < 4096:
+                    splits = cand
+                    break
+            Xv, Yv, Cv = AK[r0:, jj * nc:(jj + 1) * nc], A[:, self.c0:self.c1], AkA[r0:, r0:r0 + self.Ms_pad]
+            if splits > 1:
+                ws = self._workspace("aka_ws", (splits * rows * self.Ms_pad,))
+                self._timed("aka_gemm_nt", 2.0 * 256 * 128 * nc * tiles, lambda: hip.gemm_nt_splitk(Xv, Yv, Cv, splits, ws, lower_only=True))
+            else:
+                self._timed("aka_gemm_nt", 2.0 * 256 * 128 * nc * tiles, lambda: hip.gemm_nt(Xv, Yv, Cv, lower_only=True))
         allreduce_sum_(AkA, self.world, self.group)
         dvec = torch.ones(M_pad, dtype=F64, device=self.device)
         dvec[0:self.Ms] = float(gp_sigma[0]) ** 2

@@ -153,6 +153,18 @@ def gemm_nt(X, Y, C_, alpha=1.0, beta=0.0, lower_only=False):
     return C_
 
 
+def gemm_nt_splitk(X, Y, C_, splits, ws, lower_only=False):
+    """C = X Y^T with the contraction split into `splits` concurrent slices (ws: >= splits*m*n doubles)."""
+    lib = require_gpu()
+    ldx, ldy, ldc = _rowmajor(X, "X"), _rowmajor(Y, "Y"), _rowmajor(C_, "C")
+    m, k = X.shape
+    n = Y.shape[0]
+    assert Y.shape[1] == k and C_.shape[0] >= m and C_.shape[1] >= n and ws.numel() >= splits * m * n
+    _lib.check(lib.geobo_gemm_nt_splitk(m, n, k, int(splits), _p(X), ldx, _p(Y), ldy, _p(C_), ldc, 1 if lower_only else 0,
+                                        _p(ws), ws.numel() * 8, _stream()), "geobo_gemm_nt_splitk")
+    return C_
+
+
 def gemm_nn(X, Y, C_, alpha=1.0, beta=0.0, x_lower=False, y_lower=False):
     """C = alpha X Y + beta C."""
     lib = require_gpu()

@@ -109,6 +109,12 @@ int geobo_ak_fused_grid(const double* A, int64_t Ms_pad, int64_t N_pad, int64_t 
 int geobo_gemm_nt(int64_t m, int64_t n, int64_t k, double alpha, const double* X, int64_t ldx,
                   const double* Y, int64_t ldy, double beta, double* C, int64_t ldc, int lower_only, void* stream);
 
+/* C = X * Y^T with the contraction split into `splits` slices that run concurrently (more, shorter workgroups: fills the
+ * chip when m/256 * n/128 is only a few hundred tiles, as in AkA) and are summed in fixed order afterwards (deterministic).
+ * ws: splits * m * n doubles.  k % (16 * splits) == 0. */
+int geobo_gemm_nt_splitk(int64_t m, int64_t n, int64_t k, int splits, const double* X, int64_t ldx, const double* Y,
+                         int64_t ldy, double* C, int64_t ldc, int lower_only, void* ws, size_t ws_bytes, void* stream);
+
 /* C = alpha * X * Y + beta * C      (X: m x k k-contiguous, Y: k x n n-contiguous).
  * x_lower != 0: X is lower triangular (k range clipped to k < row_end of each tile);
  * y_lower != 0: Y is lower triangular (k range starts at the tile's first column). */
