@@ -35,7 +35,7 @@ namespace {
 
 constexpr int BK = 16;   // contraction chunk
 constexpr int XS = 16;   // LDS row stride in doubles for [rows][16] tiles: 128-byte rows, XOR-swizzled 16-byte slots
-constexpr int NST = 3;   // LDS ring depth (stages)
+constexpr int NST = 3;   // LDS ring depth of the 8-wave configuration; 4-wave workgroups use 2 stages (two fit one CU)
 
 // 16-byte slot swizzle of a [rows][8 slots] tile: slot' = slot ^ swz(row).  With 128-byte rows a wave's ds_read_b128
 // (lane = (row r = lane&15, k-group g = lane>>4), slot 2g+h) then touches 16 distinct 16-byte positions of the 256-byte
@@ -67,15 +67,18 @@ struct GemmArgs {
   const double* u; double* part_mu; double* part_ss; int64_t ncols;
 };
 
+template <int WM, int WN>
+constexpr int ring_depth() { return (WM * WN >= 8) ? NST : 2; }
+
 template <int WM, int WN, int YMODE>
 constexpr int lds_doubles() {
   constexpr int TM = 64 * WM, TN = 64 * WN;
   constexpr int ybuf = (YMODE == Y_NN) ? BK * (TN + 4) : TN * XS;
-  return NST * (TM * XS + ybuf);
+  return ring_depth<WM, WN>() * (TM * XS + ybuf);
 }
 
 template <int WM, int WN, int YMODE, int EPI, int KID>
-__global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 1) gemm_f64_kernel(const GemmArgs a) {
+__global__ void __launch_bounds__(64 * WM * WN, 2) gemm_f64_kernel(const GemmArgs a) {
   constexpr int TM = 64 * WM, TN = 64 * WN, NT = 64 * WM * WN;
   constexpr int YS_NN = TN + 4;
   constexpr int XBUF = TM * XS;
@@ -87,7 +90,8 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 1) gemm_f64
 
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* const Xs = smem;
-  double* const Ys = smem + NST * XBUF;
+  constexpr int NSTG = ring_depth<WM, WN>();
+  double* const Ys = smem + NSTG * XBUF;
 
   const double* const Xp = a.X + (int64_t)blockIdx.y * a.sXb;
   const double* const Yp = a.Y + (int64_t)blockIdx.y * a.sYb;
@@ -285,111 +289,142 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN >= 8) ? 2 : 1) gemm_f64
         for (int n = 0; n < 4; ++n) bv[n] = *reinterpret_cast<const v2d*>(yb + n * 16 * XS);
       }
     };
-    {
-      const int64_t k1 = (kb + BK < ke) ? kb + BK : kb;
+    if constexpr (NSTG == 2) {
+      // 4-wave workgroups (128-row tiles: Cholesky / L^-1 pieces and the small-k axis passes of the spectral route):
+      // plain double buffer, all fragments of chunk c read after the barrier; two such workgroups share a CU and
+      // cover each other's barrier / LDS latency.
       stage_x(kb, 0);
-      stage_x(k1, 1);
-      if constexpr (YMODE == Y_GEN) {
-        gen_y(kb); store_gen(0);
-        gen_y(k1); store_gen(1);
-      } else {
-        stage_y(kb, 0);
-        stage_y(k1, 1);
-      }
-    }
-    __syncthreads();
-    v2d a0[4], b0[4], a1[4], b1[4];
-    read_half(0, 0, a0, b0);
-    int s0 = 0, s1 = 1, s2 = 2;  // ring stages of chunk c, c+1, c+2
-    for (int64_t k0 = kb; k0 < ke; k0 += BK) {
-      int64_t kn = k0 + 2 * BK;
-      if (kn >= ke) kn = ke - BK;
-#ifndef GEOBO_ABL_NO_XLOAD
-      stage_x(kn, s2);
-#endif
-#ifndef GEOBO_ABL_NO_YLOAD
-      if constexpr (YMODE != Y_GEN) stage_y(kn, s2);
-#endif
-      const int64_t p0 = kn + gsub * EPT;  // generator: wave-uniform -> scalar loads of the p coordinates
-      read_half(s0, 1, a1, b1);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        if (t == 2) read_half(s1, 0, a0, b0);   // next chunk's first half (after the MFMAs that still read a0/b0)
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-          for (int n = 0; n < 4; ++n)
-            acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(t < 2 ? a0[m][t & 1] : a1[m][t & 1],
-                                                             t < 2 ? b0[n][t & 1] : b1[n][t & 1], acc[m][n], 0, 0, 0);
-        if constexpr (YMODE == Y_GEN) {
-#pragma unroll
-          for (int e = t * (EPT / 4); e < (t + 1) * (EPT / 4); ++e) {
-            const double d2 = sqdist3(a.px[p0 + e], a.py[p0 + e], a.pz[p0 + e], qx, qy, qz);
-            yr[e >> 1][e & 1] = a.cov.scale * cov_eval<KID>(a.cov, d2);
-          }
-        }
-      }
-      if constexpr (YMODE != Y_GEN) {
-        // Issue-order hints under the matrix pipe (integer VALU, SALU, VMEM and DS issue do not compete with v_mfma_f64
-        // for the FP pipe).  GEOBO_SCHED selects the pattern (tuned on MI355X):
-#ifndef GEOBO_SCHED
-#define GEOBO_SCHED 5
-#endif
-#if GEOBO_SCHED == 1   // 64 x {MFMA, <=3 of (VALU|SALU|VMEM read|DS read)}
-#pragma unroll
-        for (int i = 0; i < 64; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x126, 3, 0);
-        }
-#elif GEOBO_SCHED == 2  // 2 x { 8 x {MFMA, DS read}, 24 x {MFMA, <=3 others} }
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, (YMODE == Y_NN) ? 3 : 1, 0);
-          }
-#pragma unroll
-          for (int i = 0; i < 24; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x026, 3, 0);
-          }
-        }
-#elif GEOBO_SCHED == 3  // 64 x {MFMA, <=2 others}
-#pragma unroll
-        for (int i = 0; i < 64; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x126, 2, 0);
-        }
-#elif GEOBO_SCHED == 4  // 64 x {MFMA, <=1 DS read, <=2 others}
-#pragma unroll
-        for (int i = 0; i < 64; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x026, 2, 0);
-        }
-#elif GEOBO_SCHED == 5  // 64 x {MFMA, <=4 others}
-#pragma unroll
-        for (int i = 0; i < 64; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x126, 4, 0);
-        }
-#endif
-      }
-      if constexpr (YMODE == Y_GEN && (KID <= COV_MATERN32_X)) {
-        // 64 x { 1 MFMA, up to GEN_VALU VALU }: interleave the generator into the matrix-pipe shadow
-        constexpr int GEN_VALU = (KID == COV_MATERN32_X) ? 7 : ((KID == COV_D2) ? 1 : 5);
-#pragma unroll
-        for (int i = 0; i < 64; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, GEN_VALU * (EPT / 4), 0);
-        }
-      }
-      if constexpr (YMODE == Y_GEN) store_gen(s2);
-#ifndef GEOBO_ABL_NO_BARRIER
+      if constexpr (YMODE == Y_GEN) { gen_y(kb); store_gen(0); } else { stage_y(kb, 0); }
       __syncthreads();
-#endif
-      const int ts = s0; s0 = s1; s1 = s2; s2 = ts;
+      int cur = 0;
+      for (int64_t k0 = kb; k0 < ke; k0 += BK) {
+        int64_t kn = k0 + BK;
+        if (kn >= ke) kn = ke - BK;
+        stage_x(kn, cur ^ 1);
+        if constexpr (YMODE != Y_GEN) stage_y(kn, cur ^ 1);
+        v2d a0[4], b0[4], a1[4], b1[4];
+        read_half(cur, 0, a0, b0);
+        read_half(cur, 1, a1, b1);
+        if constexpr (YMODE == Y_GEN) gen_y(kn);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+              acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(t < 2 ? a0[m][t & 1] : a1[m][t & 1],
+                                                               t < 2 ? b0[n][t & 1] : b1[n][t & 1], acc[m][n], 0, 0, 0);
+        if constexpr (YMODE == Y_GEN) store_gen(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+      }
+    } else {
+    {
+        const int64_t k1 = (kb + BK < ke) ? kb + BK : kb;
+        stage_x(kb, 0);
+        stage_x(k1, 1);
+        if constexpr (YMODE == Y_GEN) {
+          gen_y(kb); store_gen(0);
+          gen_y(k1); store_gen(1);
+        } else {
+          stage_y(kb, 0);
+          stage_y(k1, 1);
+        }
+      }
+      __syncthreads();
+      v2d a0[4], b0[4], a1[4], b1[4];
+      read_half(0, 0, a0, b0);
+      int s0 = 0, s1 = 1, s2 = 2;  // ring stages of chunk c, c+1, c+2
+      for (int64_t k0 = kb; k0 < ke; k0 += BK) {
+        int64_t kn = k0 + 2 * BK;
+        if (kn >= ke) kn = ke - BK;
+  #ifndef GEOBO_ABL_NO_XLOAD
+        stage_x(kn, s2);
+  #endif
+  #ifndef GEOBO_ABL_NO_YLOAD
+        if constexpr (YMODE != Y_GEN) stage_y(kn, s2);
+  #endif
+        const int64_t p0 = kn + gsub * EPT;  // generator: wave-uniform -> scalar loads of the p coordinates
+        read_half(s0, 1, a1, b1);
+  #pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (t == 2) read_half(s1, 0, a0, b0);   // next chunk's first half (after the MFMAs that still read a0/b0)
+  #pragma unroll
+          for (int m = 0; m < 4; ++m)
+  #pragma unroll
+            for (int n = 0; n < 4; ++n)
+              acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(t < 2 ? a0[m][t & 1] : a1[m][t & 1],
+                                                               t < 2 ? b0[n][t & 1] : b1[n][t & 1], acc[m][n], 0, 0, 0);
+          if constexpr (YMODE == Y_GEN) {
+  #pragma unroll
+            for (int e = t * (EPT / 4); e < (t + 1) * (EPT / 4); ++e) {
+              const double d2 = sqdist3(a.px[p0 + e], a.py[p0 + e], a.pz[p0 + e], qx, qy, qz);
+              yr[e >> 1][e & 1] = a.cov.scale * cov_eval<KID>(a.cov, d2);
+            }
+          }
+        }
+        if constexpr (YMODE != Y_GEN) {
+          // Issue-order hints under the matrix pipe (integer VALU, SALU, VMEM and DS issue do not compete with v_mfma_f64
+          // for the FP pipe).  GEOBO_SCHED selects the pattern (tuned on MI355X):
+  #ifndef GEOBO_SCHED
+  #define GEOBO_SCHED 5
+  #endif
+  #if GEOBO_SCHED == 1   // 64 x {MFMA, <=3 of (VALU|SALU|VMEM read|DS read)}
+  #pragma unroll
+          for (int i = 0; i < 64; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x126, 3, 0);
+          }
+  #elif GEOBO_SCHED == 2  // 2 x { 8 x {MFMA, DS read}, 24 x {MFMA, <=3 others} }
+  #pragma unroll
+          for (int half = 0; half < 2; ++half) {
+  #pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x100, (YMODE == Y_NN) ? 3 : 1, 0);
+            }
+  #pragma unroll
+            for (int i = 0; i < 24; ++i) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x026, 3, 0);
+            }
+          }
+  #elif GEOBO_SCHED == 3  // 64 x {MFMA, <=2 others}
+  #pragma unroll
+          for (int i = 0; i < 64; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x126, 2, 0);
+          }
+  #elif GEOBO_SCHED == 4  // 64 x {MFMA, <=1 DS read, <=2 others}
+  #pragma unroll
+          for (int i = 0; i < 64; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x026, 2, 0);
+          }
+  #elif GEOBO_SCHED == 5  // 64 x {MFMA, <=4 others}
+  #pragma unroll
+          for (int i = 0; i < 64; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x126, 4, 0);
+          }
+  #endif
+        }
+        if constexpr (YMODE == Y_GEN && (KID <= COV_MATERN32_X)) {
+          // 64 x { 1 MFMA, up to GEN_VALU VALU }: interleave the generator into the matrix-pipe shadow
+          constexpr int GEN_VALU = (KID == COV_MATERN32_X) ? 7 : ((KID == COV_D2) ? 1 : 5);
+  #pragma unroll
+          for (int i = 0; i < 64; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, GEN_VALU * (EPT / 4), 0);
+          }
+        }
+        if constexpr (YMODE == Y_GEN) store_gen(s2);
+  #ifndef GEOBO_ABL_NO_BARRIER
+        __syncthreads();
+  #endif
+        const int ts = s0; s0 = s1; s1 = s2; s2 = ts;
+      }
     }
   }
 
