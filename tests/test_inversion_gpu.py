@@ -300,3 +300,27 @@ def test_spectral_transform_matrices_diagonalise_toeplitz():
     T = G.T @ np.diag(Em @ k / (2 * n)) @ G
     ref = k[np.abs(np.arange(n)[:, None] - np.arange(n)[None, :])]
     assert np.abs(T - ref).max() < 1e-13
+
+
+@pytest.mark.parametrize("name,sub", [("example1", "synthetic"), ("example2", "sample")])
+def test_yaml_workflow_from_raw_files(name, sub, tmp_path):
+    """f3 row end to end: YAML + the reference's raw GeoTIFF / CSV inputs -> ingestion -> GPU inversion -> VTK cubes,
+    compared with the cubes the reference produced from the same files."""
+    import os
+    import yaml
+    from conftest import GOLDEN
+    from geobo_amd import dataio, run_geobo
+    f = load_golden(name + ".npz")
+    d = json.loads(str(f["settings_json"]))
+    d.update(inpath=os.path.join(GOLDEN, "data", sub) + "/", outpath=str(tmp_path) + "/", bayesopt_vertical=True,
+             bayesopt_nonvertical=False)
+    y = tmp_path / "settings.yaml"
+    y.write_text(yaml.safe_dump(d))
+    out = run_geobo.run(str(y))
+    names = ["cube_density", "cube_magsus", "cube_drill", "cube_density_variance", "cube_magsus_variance", "cube_drill_variance"]
+    _check_cubes([out[n] for n in names], f["cubes"], TOL_T3, name + " workflow")
+    for n, ref in zip(names, f["cubes"]):
+        cube, _, _ = dataio.read_vtkcube(os.path.join(str(tmp_path), n + ".vtk"))
+        assert normwise(cube, ref) <= TOL_T3
+    assert os.path.exists(os.path.join(str(tmp_path), "newdrill_proposals_vertical.csv"))
+    assert len(out["proposals_vertical"]) >= 1 and np.isfinite(out["proposals_vertical"]["BO_GAIN"]).all()
