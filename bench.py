@@ -66,14 +66,17 @@ def synthetic_inputs(inv, md):
     return grav, mag, loc, drill0
 
 
-def pmc_traffic(flops_per_launch):
+PMC_FILES = {"ak_fused_grid": "r01_pmc_ak_fused_grid_v2.json", "posterior_reduce": "r01_pmc_posterior_reduce.json"}
+
+
+def pmc_traffic(kernel, flops_per_launch):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (separate --pmc runs of
-    tools/run_fused_once.py: FETCH_SIZE x2 (gfx950 half-count of wide loads, MI355X_MICROARCH.md) + WRITE_SIZE, KiB),
-    scaled from the profiled 1/8-size launch to this launch by its flop count.  None if no PMC summary is committed."""
+    tools/run_fused_once.py / tools/run_posterior_once.py: FETCH_SIZE x2 (gfx950 half-count of wide loads,
+    MI355X_MICROARCH.md) + WRITE_SIZE, KiB), scaled from the profiled launch to this launch by its flop count.
+    None if no PMC summary is committed for that kernel."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_ak_fused_grid_v0.json")))["counters"]
-        sample_flops = 2.0 * 4096 * 262144 * 32768
-        return (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0 * flops_per_launch / sample_flops
+        d = json.load(open(os.path.join(ROOT, "profiles", PMC_FILES[kernel])))
+        return d["derived"]["hbm_bytes_per_launch_corrected"] * flops_per_launch / d["flop"]
     except Exception:
         return None
 
@@ -131,7 +134,7 @@ def cpu_baseline(inv, lengths, target_seconds=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=64, help="cube edge in voxels (64 = BASELINE headline)")
     ap.add_argument("--kernel", default="matern32")
@@ -231,7 +234,7 @@ def main():
                        "end_to_end_fp64_roofline_frac_of_executed_flop": F_exec * a.steps / dt / (FP64_MATRIX_PEAK_TFLOPS * 1e12),
                        "stage_ms_per_step_rank0": {k: round(1e3 * v["seconds"] / a.steps, 3) for k, v in stages.items()}},
             "roofline": {"bound": "mfma", "kernel": kernel_names.get(dom), "achieved": ach, "peak": FP64_MATRIX_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach / FP64_MATRIX_PEAK_TFLOPS, "traffic": pmc_traffic(flops) if dom == "ak_fused_grid" else None,
+                         "unit": "TFLOP/s", "frac": ach / FP64_MATRIX_PEAK_TFLOPS, "traffic": pmc_traffic(dom, flops),
                          "launches_timed": len(durs), "flop_per_launch": flops, "mean_launch_s": (sum(durs) / len(durs)) if durs else None},
         }
         if not a.no_cpu and world == 1:   # CPU baseline: rank 0 at N = 1 only
