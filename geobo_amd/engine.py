@@ -128,7 +128,7 @@ class PosteriorEngine:
         if key in self._A:
             return self._A[key]
         xe, ye, ze = self.node_axes() if axes is None else axes
-        A = self._workspace("A_" + func, (self.Ms_pad, self.N_pad))
+        A = self._workspace2d("A_" + func, self.Ms_pad, self.N_pad)
         if self.Ms_pad > self.Ms:
             A[self.Ms:].zero_()
         if self.N_pad > self.N:
@@ -164,6 +164,12 @@ class PosteriorEngine:
             t = self._ws[name] = torch.empty(shape, dtype=F64, device=self.device)
         return t
 
+    def _workspace2d(self, name, rows, cols, pad=16):
+        """(rows x cols) view of a persistent buffer whose leading dimension is cols + pad.  Power-of-two row strides
+        (4 MiB for AK at 64^3) alias rows onto the same cache sets / channels and cost the GEMMs ~12 %; 128 bytes of
+        padding per row remove it (profiles/r01_row_stride.txt)."""
+        return self._workspace(name, (rows, cols + pad))[:, :cols]
+
     def clear_operators(self):
         """Drop the resident forward operators (the benchmark rebuilds them inside every timed step)."""
         self._A = {}
@@ -184,7 +190,7 @@ class PosteriorEngine:
         off_d = 2 * self.Ms_pad
         M_pad = hip.pad_m(off_d + Md)
         nc = self.nc
-        AK = self._workspace("AK", (M_pad, len(props) * nc))
+        AK = self._workspace2d("AK", M_pad, len(props) * nc)
         # every sensor/drill row is overwritten below; only the padding must be defined: rows behind each row block
         # (zero, so that AkA / V get zero rows) and voxel columns >= N of the last shard (finite: they meet zero A columns)
         for r0, r1 in ((self.Ms, self.Ms_pad), (self.Ms_pad + self.Ms, off_d), (off_d + Md, M_pad)):

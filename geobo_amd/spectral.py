@@ -97,11 +97,13 @@ class SpectralProduct:
         return b
 
     # ---- three axis passes, z (contiguous) then x then y: [R][ny][nx][nz] -> [R][Py][Px][Pz] --------------------------------
-    def forward(self, src, R, M, out_name="T3"):
+    def forward(self, src, R, M, out_name="T3", src_row_stride=None):
+        """src: R volumes of ny*nx*nz doubles, `src_row_stride` doubles apart (default: contiguous)."""
         nx, ny, nz, Px, Py, Pz = self.nx, self.ny, self.nz, self.Px, self.Py, self.Pz
         rows = R * ny * nx
         t1 = self.buf("T1", rows * Pz)
-        hip.gemm_batched(False, hip.pad_n(rows), hip.pad_n(Pz), nz, src, nz, 0, M["z"], nz, 0, t1, Pz, 0, rows, Pz, 1)
+        lds = self.N if src_row_stride is None else int(src_row_stride)
+        hip.gemm_batched(False, hip.pad_n(ny * nx), hip.pad_n(Pz), nz, src, nz, lds, M["z"], nz, 0, t1, Pz, ny * nx * Pz, ny * nx, Pz, R)
         t2 = self.buf("T2", R * ny * Px * Pz)
         hip.gemm_batched(True, hip.pad_n(Px), hip.pad_n(Pz), nx, M["x"], nx, 0, t1, Pz, nx * Pz, t2, Pz, Px * Pz, Px, Pz, R * ny)
         t3 = self.buf(out_name, R * self.P3)
@@ -146,10 +148,10 @@ class SpectralProduct:
         A: (>=Ms x N) row-major with leading dimension N; outs[j]: 2-D views (rows x (y1-y0)*nx*nz)."""
         y1 = self.ny if y1 is None else y1
         N = self.N
-        assert A.stride(0) == N and A.stride(1) == 1, "spectral path needs unpadded voxel columns (N % 128 == 0)"
+        assert A.stride(1) == 1 and A.stride(0) >= N and A.stride(0) % 2 == 0
         for r0 in range(0, Ms, self.R):
             R = min(self.R, Ms - r0)
-            spec = self.forward(A[r0:], R, self.G)
+            spec = self.forward(A[r0:], R, self.G, src_row_stride=A.stride(0))
             for lam, out in zip(lam_list, outs):
                 s = self.buf("S", R * self.P3)
                 hip.scale_broadcast(spec[:R * self.P3], lam, s[:R * self.P3])
