@@ -164,6 +164,18 @@ __global__ void __launch_bounds__(256) scale_broadcast_kernel(const double* __re
   }
 }
 
+__global__ void __launch_bounds__(256) scale_broadcast2_kernel(const double* __restrict__ a, const double* __restrict__ b0,
+                                                               const double* __restrict__ b1, int64_t n2, int64_t nb2,
+                                                               double* __restrict__ out0, double* __restrict__ out1) {
+  // one read of the spectrum, two eigenvalue tables, two outputs (both property blocks of one operator)
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (int64_t)gridDim.x * 256) {
+    const v2d x = reinterpret_cast<const v2d*>(a)[i];
+    const int64_t j = i % nb2;
+    reinterpret_cast<v2d*>(out0)[i] = x * reinterpret_cast<const v2d*>(b0)[j];
+    reinterpret_cast<v2d*>(out1)[i] = x * reinterpret_cast<const v2d*>(b1)[j];
+  }
+}
+
 template <int FUNC>
 __global__ void __launch_bounds__(256) potential_kernel(const double* __restrict__ x, const double* __restrict__ y,
                                                         const double* __restrict__ z, int64_t n, double bx, double by,
@@ -333,6 +345,18 @@ extern "C" int geobo_scale_broadcast(const double* a, const double* b, int64_t n
   int64_t nblk = (n / 2 + 255) / 256;
   if (nblk > 256 * 32) nblk = 256 * 32;
   hipLaunchKernelGGL(scale_broadcast_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, a, b, n / 2, nb / 2, out);
+  return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
+}
+
+extern "C" int geobo_scale_broadcast2(const double* a, const double* b0, const double* b1, int64_t n, int64_t nb, double* out0,
+                                      double* out1, void* stream) {
+  if (!a || !b0 || !b1 || !out0 || !out1) return GEOBO_E_ARG;
+  if (n <= 0) return GEOBO_OK;
+  if ((n & 1) || (nb & 1) || nb <= 0 || n % nb) return GEOBO_E_ALIGN;
+  int64_t nblk = (n / 2 + 255) / 256;
+  if (nblk > 256 * 32) nblk = 256 * 32;
+  hipLaunchKernelGGL(scale_broadcast2_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, a, b0, b1, n / 2, nb / 2,
+                     out0, out1);
   return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
 }
 

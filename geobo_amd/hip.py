@@ -201,6 +201,12 @@ def scale_broadcast(a, b, out):
     return out
 
 
+def scale_broadcast2(a, b0, b1, out0, out1):
+    lib = require_gpu()
+    _lib.check(lib.geobo_scale_broadcast2(_p(_chk(a, "a")), _p(_chk(b0, "b0")), _p(_chk(b1, "b1")), a.numel(), b0.numel(),
+                                          _p(out0), _p(out1), _stream()), "geobo_scale_broadcast2")
+
+
 def potrf_inv(A, Linv=None, ws=None):
     """In-place lower Cholesky of A (m x m, m % 128 == 0); returns (Linv, info_tensor).  Linv / ws may be caller-owned."""
     lib = require_gpu()

@@ -152,7 +152,17 @@ class SpectralProduct:
         for r0 in range(0, Ms, self.R):
             R = min(self.R, Ms - r0)
             spec = self.forward(A[r0:], R, self.G, src_row_stride=A.stride(0))
-            for lam, out in zip(lam_list, outs):
-                s = self.buf("S", R * self.P3)
-                hip.scale_broadcast(spec[:R * self.P3], lam, s[:R * self.P3])
-                self.backward(s, R, y0, y1, out[r0:], out.stride(0))
+            n = R * self.P3
+            j = 0
+            while j < len(lam_list):
+                if j + 1 < len(lam_list):      # two property blocks per read of the spectrum
+                    s0, s1 = self.buf("S", n), self.buf("S1", n)
+                    hip.scale_broadcast2(spec[:n], lam_list[j], lam_list[j + 1], s0[:n], s1[:n])
+                    self.backward(s0, R, y0, y1, outs[j][r0:], outs[j].stride(0))
+                    self.backward(s1, R, y0, y1, outs[j + 1][r0:], outs[j + 1].stride(0))
+                    j += 2
+                else:
+                    s0 = self.buf("S", n)
+                    hip.scale_broadcast(spec[:n], lam_list[j], s0[:n])
+                    self.backward(s0, R, y0, y1, outs[j][r0:], outs[j].stride(0))
+                    j += 1

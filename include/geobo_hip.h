@@ -134,6 +134,9 @@ int geobo_gemm_batched(int y_is_kn, int64_t m, int64_t n, int64_t k, double alph
 
 /* out[i] = a[i] * b[i % nb]   (spectrum x eigenvalue table, broadcast over the batch) */
 int geobo_scale_broadcast(const double* a, const double* b, int64_t n, int64_t nb, double* out, void* stream);
+/* the same for two tables at once: out0 = a .* b0, out1 = a .* b1 (one read of the spectrum for both property blocks) */
+int geobo_scale_broadcast2(const double* a, const double* b0, const double* b1, int64_t n, int64_t nb, double* out0,
+                           double* out1, void* stream);
 
 /* In-place lower Cholesky of the (m x m, ld) matrix A, m % 256 == 0 (padding rows/cols = identity);
  * scipy.linalg.cholesky(AkA, lower=True), inversion.py:100.  Also writes Linv = L^-1 (m x m, ldi; lower,
