@@ -232,7 +232,8 @@ def main():
                        "method": "spectral" if inv.engine.use_spectral else "dense",
                        "dense_algorithmic_flop_per_step": F, "executed_mfma_flop_per_step_rank0": F_exec,
                        "end_to_end_fp64_roofline_frac_of_executed_flop": F_exec * a.steps / dt / (FP64_MATRIX_PEAK_TFLOPS * 1e12),
-                       "stage_ms_per_step_rank0": {k: round(1e3 * v["seconds"] / a.steps, 3) for k, v in stages.items()}},
+                       "stage_ms_per_step_rank0": {k: round(1e3 * v["seconds"] / a.steps, 3) for k, v in stages.items()},
+                       "mfma_kernels_tflops_rank0": {k: round(v["flop"] / v["seconds"] / 1e12, 2) for k, v in stages.items() if v["flop"] > 0}},
             "roofline": {"bound": "mfma", "kernel": kernel_names.get(dom), "achieved": ach, "peak": FP64_MATRIX_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": ach / FP64_MATRIX_PEAK_TFLOPS, "traffic": pmc_traffic(dom, flops),
                          "launches_timed": len(durs), "flop_per_launch": flops, "mean_launch_s": (sum(durs) / len(durs)) if durs else None},
