@@ -54,8 +54,10 @@ def synthetic_inputs(inv, md):
     X, Y, Z = np.meshgrid(xs, ys, s.zmax + s.zoff)
     loc = np.asarray([X.flatten(), Y.flatten(), Z.flatten()]).T
     inv.sensor_locations = loc
-    A_g, A_m = inv._operators()
     eng = inv.engine
+    # full operators on every rank for the synthetic data (the timed steps build only what each rank needs)
+    A_g = eng.operator("grav", loc, B=s.magneticField * 0., full=True)
+    A_m = eng.operator("magn", loc, B=s.magneticField, full=True)
     pad = lambda v: torch.cat([hip.to_dev(v.reshape(-1), eng.device), torch.zeros(eng.N_pad - eng.N, dtype=torch.float64, device=eng.device)])
     grav = (A_g @ pad(rho))[:eng.Ms].cpu().numpy().astype(np.float32).astype(np.float64)
     mag = (A_m @ pad(chi))[:eng.Ms].cpu().numpy().astype(np.float32).astype(np.float64)
@@ -230,6 +232,8 @@ def main():
                                    "%d drill constraints, M=%d rows, density+magsus cubes (P_out=2)" % (n, a.kernel, a.drill, M),
                        "N_voxels": N, "M_rows": M, "props_out": p_out, "parallelism": "voxel-column shards x%d" % world,
                        "method": "spectral" if inv.engine.use_spectral else "dense",
+                       "row_exchange": bool(inv.engine.exchange),
+                       "cube_checksums": [float(np.abs(c).sum()) for c in (cubes[0], cubes[1], cubes[3], cubes[4])],
                        "dense_algorithmic_flop_per_step": F, "executed_mfma_flop_per_step_rank0": F_exec,
                        "end_to_end_fp64_roofline_frac_of_executed_flop": F_exec * a.steps / dt / (FP64_MATRIX_PEAK_TFLOPS * 1e12),
                        "stage_ms_per_step_rank0": {k: round(1e3 * v["seconds"] / a.steps, 3) for k, v in stages.items()},

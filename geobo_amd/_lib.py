@@ -22,6 +22,7 @@ SIGNATURES = {
     "geobo_k_block": (_int, [_int, _dp, _dp, _dp, _i64, _dp, _dp, _dp, _i64, _f64, _f64, _f64, _f64, _dp, _i64, _dp]),
     "geobo_k_eval": (_int, [_int, _dp, _i64, _f64, _f64, _f64, _f64, _dp, _dp]),
     "geobo_a_sens": (_int, [_int, C.POINTER(_f64), _dp, _i64, _int, _int, _int, _dp, _dp, _dp, _f64, _f64, _dp, _i64, _dp]),
+    "geobo_a_sens_slab": (_int, [_int, C.POINTER(_f64), _dp, _i64, _int, _int, _int, _dp, _dp, _dp, _f64, _f64, _int, _int, _dp, _i64, _dp]),
     "geobo_potential": (_int, [_int, C.POINTER(_f64), _dp, _dp, _dp, _i64, _dp, _dp]),
     "geobo_ak_fused": (_int, [_int, _dp, _i64, _i64, _i64, _dp, _dp, _dp, _i64, _i64, _f64, _f64, _f64, _f64, _dp, _i64, _dp]),
     "geobo_cov_table": (_int, [_int, _int, _int, _int, _f64, _f64, _f64, _f64, _f64, _f64, _f64, _dp, _dp]),

@@ -103,7 +103,7 @@ __device__ __forceinline__ double magn_potential(double x, double y, double z, d
 }
 
 struct SensArgs {
-  const double* loc; int64_t Ms; int nx, ny, nz, wx;
+  const double* loc; int64_t Ms; int nx, ny, nz, wx, iy0, iy1;
   const double *xe, *ye, *ze;
   double bx, by, bz, inv_norm_b, scale_mul, scale_div;
   double* A; int64_t ld;
@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(512) a_sens_kernel(const SensArgs a) {
   const double sx = a.loc[3 * (int64_t)n + 0], sy = a.loc[3 * (int64_t)n + 1], sz = a.loc[3 * (int64_t)n + 2];
   const double far = 1e6;
   double* row_out = a.A + (int64_t)n * a.ld;
-  for (int i = 0; i <= a.ny; ++i) {
+  for (int i = a.iy0; i <= a.iy1; ++i) {   // node planes iy0..iy1 -> voxel slabs iy0..iy1-1
     double* cur = planes + (i & 1) * pn;
     const double* prev = planes + ((i & 1) ^ 1) * pn;
     double y0 = a.ye[i] - sy;
@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(512) a_sens_kernel(const SensArgs a) {
                                       : magn_potential(x0, y0, z0, a.bx, a.by, a.bz, a.inv_norm_b);
     }
     __syncthreads();
-    if (i > 0) {
+    if (i > a.iy0) {
       const int iy = i - 1;
       const int nv = wx * a.nz;
       for (int t = threadIdx.x; t < nv; t += blockDim.x) {
@@ -289,10 +289,21 @@ extern "C" int geobo_k_eval(int kernel_id, const double* d2, int64_t n, double l
   return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
 }
 
+extern "C" int geobo_a_sens_slab(int func_id, const double* B3_host, const double* loc, int64_t Ms, int nx, int ny, int nz,
+                                 const double* xe, const double* ye, const double* ze, double scale_mul, double scale_div,
+                                 int iy0, int iy1, double* A, int64_t ld, void* stream);
+
 extern "C" int geobo_a_sens(int func_id, const double* B3_host, const double* loc, int64_t Ms, int nx, int ny, int nz,
                             const double* xe, const double* ye, const double* ze, double scale_mul, double scale_div,
                             double* A, int64_t ld, void* stream) {
+  return geobo_a_sens_slab(func_id, B3_host, loc, Ms, nx, ny, nz, xe, ye, ze, scale_mul, scale_div, 0, ny, A, ld, stream);
+}
+
+extern "C" int geobo_a_sens_slab(int func_id, const double* B3_host, const double* loc, int64_t Ms, int nx, int ny, int nz,
+                                 const double* xe, const double* ye, const double* ze, double scale_mul, double scale_div,
+                                 int iy0, int iy1, double* A, int64_t ld, void* stream) {
   if (!B3_host || !loc || !xe || !ye || !ze || !A) return GEOBO_E_ARG;
+  if (iy0 < 0 || iy1 > ny || iy0 >= iy1) return GEOBO_E_ARG;
   if (Ms <= 0 || nx <= 0 || ny <= 0 || nz <= 0 || ld < (int64_t)nx * ny * nz) return GEOBO_E_ARG;
   if (func_id != GEOBO_F_GRAV && func_id != GEOBO_F_MAGN) return GEOBO_E_UNSUPPORTED;
   SensArgs a;
@@ -300,7 +311,7 @@ extern "C" int geobo_a_sens(int func_id, const double* B3_host, const double* lo
   a.xe = xe; a.ye = ye; a.ze = ze;
   a.bx = B3_host[0]; a.by = B3_host[1]; a.bz = B3_host[2];
   a.inv_norm_b = 1. / sqrt(a.bx * a.bx + a.by * a.by + a.bz * a.bz);  // sensormodel.py:129 (inf for B = 0: grav ignores it)
-  a.scale_mul = scale_mul; a.scale_div = scale_div; a.A = A; a.ld = ld;
+  a.scale_mul = scale_mul; a.scale_div = scale_div; a.A = A; a.ld = ld; a.iy0 = iy0; a.iy1 = iy1;
   // two node planes of (wx+1)*(nz+1) doubles must fit the LDS budget
   const int budget = 128 * 1024;
   int wx = budget / (16 * (nz + 1)) - 1;

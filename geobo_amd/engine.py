@@ -23,13 +23,14 @@ Multi-GPU (one process per GPU, torch.distributed/RCCL): voxel COLUMNS are shard
 all-reduce of the M_pad x M_pad partial AkA and one all-gather of the mu/var slices.
 """
 import math
+import os
 import time
 
 import numpy as np
 import torch
 
 from . import hip
-from .sharding import allreduce_sum_, assemble_columns, gather_slices, shard_columns
+from .sharding import allreduce_sum_, assemble_columns, exchange_blocks, gather_slices, shard_columns
 
 F64 = hip.F64
 
@@ -90,6 +91,12 @@ class PosteriorEngine:
         if method == "spectral" and not self.use_spectral:
             raise ValueError("spectral method needs grid extents % 16 == 0 and column shards on y-slab boundaries")
         self._spectral = None
+        # row-sharded spectral product (N > 1): every rank transforms Ms/world sensor rows of each operator for ALL voxels
+        # and one all-to-all hands each peer the block-columns it owns; needs equal shards
+        ncs = {shard_columns(self.N_pad, world, r)[1] - shard_columns(self.N_pad, world, r)[0] for r in range(world)}
+        self.exchange = (self.use_spectral and world > 1 and self.Ms % world == 0 and len(ncs) == 1
+                         and os.environ.get("GEOBO_SPECTRAL_EXCHANGE", "1") != "0")
+        self._Arows = {}
         self.kernel_events = None  # set to [] to record (name, flops, start, stop) HIP events per fused launch
 
     # ---- geometry --------------------------------------------------------------------------------------------
@@ -119,12 +126,15 @@ class PosteriorEngine:
         return xe, ye, -ze
 
     # ---- forward operators -----------------------------------------------------------------------------------
-    def operator(self, func, sensor_locations, B=None, axes=None):
-        """A_sens on the device: (Ms_pad x N_pad) zero padded tensor (sensormodel.py:29-93)."""
+    def operator(self, func, sensor_locations, B=None, axes=None, full=False):
+        """A_sens on the device: (Ms_pad x N_pad) zero padded tensor (sensormodel.py:29-93).
+        In the row-sharded multi-GPU form (self.exchange) only what this rank needs is built unless `full`: the voxel
+        columns of its y-slab for every sensor (AkA operand) and all voxels for its own sensor rows (transform input)."""
         s = self.s
         loc = np.ascontiguousarray(sensor_locations, dtype=np.float64)
         assert loc.shape == (self.Ms, 3), "A_sens handles exactly xNcube*yNcube sensors (sensormodel.py:54,58)"
-        key = (func, loc.tobytes(), None if B is None else tuple(np.asarray(B, dtype=float)))
+        partial = self.exchange and not full
+        key = (func, loc.tobytes(), None if B is None else tuple(np.asarray(B, dtype=float)), partial)
         if key in self._A:
             return self._A[key]
         xe, ye, ze = self.node_axes() if axes is None else axes
@@ -140,7 +150,19 @@ class PosteriorEngine:
             Bv = s.magneticField if B is None else np.asarray(B, dtype=float)
             mul, div = 1.0, s.fcor_mag
         locd, xed, yed, zed = (hip.to_dev(v, self.device) for v in (loc, xe, ye, ze))
-        self._timed("a_sens_" + func, 0.0, lambda: hip.a_sens(func, Bv, locd, self.nx, self.ny, self.nz, xed, yed, zed, mul, div, A))
+        if partial:
+            plane = self.nx * self.nz
+            rows_r = self.Ms // self.world
+            Ar = self._workspace2d("Arows_" + func, rows_r, self.N_pad)
+            loc_r = locd[self.rank * rows_r:(self.rank + 1) * rows_r].contiguous()
+
+            def build():
+                hip.a_sens(func, Bv, locd, self.nx, self.ny, self.nz, xed, yed, zed, mul, div, A, self.c0 // plane, self.c1 // plane)
+                hip.a_sens(func, Bv, loc_r, self.nx, self.ny, self.nz, xed, yed, zed, mul, div, Ar)
+            self._timed("a_sens_" + func, 0.0, build)
+            self._Arows[func] = Ar
+        else:
+            self._timed("a_sens_" + func, 0.0, lambda: hip.a_sens(func, Bv, locd, self.nx, self.ny, self.nz, xed, yed, zed, mul, div, A))
         self._A = {k: v for k, v in self._A.items() if k[0] != func}  # one operator per type stays resident
         self._A[key] = A
         return A
@@ -235,6 +257,8 @@ class PosteriorEngine:
         sp, sset, nc = self._spectral, self.s, self.nc
         plane = self.nx * self.nz
         y0, y1 = self.c0 // plane, self.c1 // plane
+        if self.exchange:
+            return self._assemble_AK_spectral_exchange(AK, lengths, W, name, amp, props)
         for s_, A in ((0, A_g), (1, A_m)):
             lams, outs = [], []
             for jj, j in enumerate(props):
@@ -243,6 +267,44 @@ class PosteriorEngine:
                 lams.append(sp.eigenvalues(tab))
                 outs.append(AK[s_ * self.Ms_pad:s_ * self.Ms_pad + self.Ms, jj * nc:(jj + 1) * nc])
             self._timed("spectral_product", sp.flops(self.Ms, len(props), y1 - y0), lambda: sp.product(A, self.Ms, lams, outs, y0, y1))
+
+    def _assemble_AK_spectral_exchange(self, AK, lengths, W, name, amp, props):
+        """Row-sharded spectral product + all-to-all (multi-GPU): rank r transforms sensor rows [r*Ms/G, (r+1)*Ms/G) of both
+        operators for every voxel, cropping the backward passes once per destination y-slab straight into the send buffer
+        [dest][operator][block][row][col]; one all_to_all_single over xGMI; the received blocks are this rank's columns of
+        every sensor row."""
+        send = self._exchange_send(lengths, W, name, amp, props)
+        recv = self._timed("xgmi_all_to_all", 0.0, lambda: exchange_blocks(send, self.world, self.group))
+        self._exchange_place(AK, recv, props)
+
+    def _exchange_send(self, lengths, W, name, amp, props):
+        sp, sset, nc, G = self._spectral, self.s, self.nc, self.world
+        plane = self.nx * self.nz
+        rows_r, P_c = self.Ms // G, len(props)
+        blk = 2 * P_c * rows_r * nc
+        send = self._workspace("xchg_send", (G, blk))
+        slabs_of = [tuple(c // plane for c in shard_columns(self.N_pad, G, d)) for d in range(G)]
+        for s_, func in ((0, "grav"), (1, "magn")):
+            lams = []
+            for j in props:
+                tab = hip.cov_table(hip.kernel_id(name, s_ != j), self.nx, self.ny, self.nz, sset.xvoxsize, sset.yvoxsize,
+                                    sset.zvoxsize, lengths[j], lengths[s_], W[s_][j], amp, self.device)
+                lams.append(sp.eigenvalues(tab))
+            slabs = [(slabs_of[d][0], slabs_of[d][1], [send[d].view(2, P_c, rows_r, nc)[s_, jj] for jj in range(P_c)])
+                     for d in range(G)]
+            Ar = self._Arows[func]
+            self._timed("spectral_product", sp.flops(rows_r, P_c, self.ny), lambda: sp.product(Ar, rows_r, lams, None, slabs=slabs))
+        return send
+
+    def _exchange_place(self, AK, recv, props):
+        G, nc = self.world, self.nc
+        rows_r, P_c = self.Ms // G, len(props)
+        for src in range(G):
+            blocks = recv[src].view(2, P_c, rows_r, nc)
+            for s_ in (0, 1):
+                r0 = s_ * self.Ms_pad + src * rows_r
+                for jj in range(P_c):
+                    AK[r0:r0 + rows_r, jj * nc:(jj + 1) * nc].copy_(blocks[s_, jj])
 
     def _assemble_AkA(self, AK, M_pad, A_g, A_m, sel_t, lengths, name, amp, gp_sigma, props):
         xyz = self.grid_points()

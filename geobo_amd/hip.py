@@ -87,14 +87,15 @@ def k_eval(kid, d2, l1, l2, w=1.0, amp=1.0):
     return out
 
 
-def a_sens(func, B, loc, nx, ny, nz, xe, ye, ze, scale_mul, scale_div, out):
+def a_sens(func, B, loc, nx, ny, nz, xe, ye, ze, scale_mul, scale_div, out, iy0=0, iy1=None):
+    """Forward operator rows for the sensors in `loc`; optionally only the voxel slab iy0 <= iy < iy1."""
     lib = require_gpu()
     ld = _rowmajor(out, "A")
     loc = _chk(loc, "loc").contiguous()
     Bh = (C.c_double * 3)(*[float(b) for b in B])
-    _lib.check(lib.geobo_a_sens(FUNC_IDS[func], Bh, _p(loc), loc.shape[0], int(nx), int(ny), int(nz), _p(_chk(xe, "xe")),
-                                _p(_chk(ye, "ye")), _p(_chk(ze, "ze")), float(scale_mul), float(scale_div), _p(out), ld,
-                                _stream()), "geobo_a_sens")
+    _lib.check(lib.geobo_a_sens_slab(FUNC_IDS[func], Bh, _p(loc), loc.shape[0], int(nx), int(ny), int(nz), _p(_chk(xe, "xe")),
+                                     _p(_chk(ye, "ye")), _p(_chk(ze, "ze")), float(scale_mul), float(scale_div), int(iy0),
+                                     int(ny if iy1 is None else iy1), _p(out), ld, _stream()), "geobo_a_sens_slab")
     return out
 
 

@@ -59,3 +59,24 @@ def assemble_columns(parts, props, n, n_pad, world):
         for jj, j in enumerate(props):
             out[j * n + c0:j * n + hi] = ph[jj * ncr:jj * ncr + (hi - c0)]
     return out
+
+
+def exchange_blocks(send, world, group=None):
+    """All-to-all of equal blocks: `send` is (world, blk) contiguous, row d goes to rank d; returns (world, blk) whose row s
+    came from rank s.  RCCL: one all_to_all_single over xGMI (the exchange step of the row-sharded spectral product: every
+    rank transforms its own sensor rows and hands each peer the block-columns that peer owns).  Backends without
+    all-to-all (gloo: CPU tests, single-GPU dry runs) fall back to an all-gather + selection."""
+    if world == 1:
+        return send
+    import torch.distributed as dist
+    assert send.dim() == 2 and send.shape[0] == world and send.is_contiguous()
+    recv = torch.empty_like(send)
+    if dist.get_backend(group) == "nccl":
+        dist.all_to_all_single(recv, send, group=group)
+    else:
+        parts = [torch.empty_like(send) for _ in range(world)]
+        dist.all_gather(parts, send, group=group)
+        me = dist.get_rank(group)
+        for src in range(world):
+            recv[src].copy_(parts[src][me])
+    return recv

@@ -143,10 +143,14 @@ class SpectralProduct:
         lam.mul_(1.0 / float(self.P3))
         return lam
 
-    def product(self, A, Ms, lam_list, outs, y0=0, y1=None):
+    def product(self, A, Ms, lam_list, outs, y0=0, y1=None, slabs=None):
         """outs[j][r, :] = (A[r, :N] convolved with block j) restricted to y-slab [y0,y1), r < Ms.
-        A: (>=Ms x N) row-major with leading dimension N; outs[j]: 2-D views (rows x (y1-y0)*nx*nz)."""
+        A: (>=Ms x N) row-major; outs[j]: 2-D views (rows x (y1-y0)*nx*nz).
+        `slabs` = [(y0, y1, outs), ...] crops the SAME scaled spectrum to several y-slabs (one per destination rank of the
+        row-sharded multi-GPU form); the forward passes and the scaling are done once."""
         y1 = self.ny if y1 is None else y1
+        if slabs is None:
+            slabs = [(y0, y1, outs)]
         N = self.N
         assert A.stride(1) == 1 and A.stride(0) >= N and A.stride(0) % 2 == 0
         for r0 in range(0, Ms, self.R):
@@ -158,11 +162,13 @@ class SpectralProduct:
                 if j + 1 < len(lam_list):      # two property blocks per read of the spectrum
                     s0, s1 = self.buf("S", n), self.buf("S1", n)
                     hip.scale_broadcast2(spec[:n], lam_list[j], lam_list[j + 1], s0[:n], s1[:n])
-                    self.backward(s0, R, y0, y1, outs[j][r0:], outs[j].stride(0))
-                    self.backward(s1, R, y0, y1, outs[j + 1][r0:], outs[j + 1].stride(0))
+                    for ya, yb, o in slabs:
+                        self.backward(s0, R, ya, yb, o[j][r0:], o[j].stride(0))
+                        self.backward(s1, R, ya, yb, o[j + 1][r0:], o[j + 1].stride(0))
                     j += 2
                 else:
                     s0 = self.buf("S", n)
                     hip.scale_broadcast(spec[:n], lam_list[j], s0[:n])
-                    self.backward(s0, R, y0, y1, outs[j][r0:], outs[j].stride(0))
+                    for ya, yb, o in slabs:
+                        self.backward(s0, R, ya, yb, o[j][r0:], o[j].stride(0))
                     j += 1

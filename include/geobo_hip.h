@@ -77,6 +77,12 @@ int geobo_a_sens(int func_id, const double* B3_host, const double* loc, int64_t 
                  const double* xe, const double* ye, const double* ze, double scale_mul, double scale_div,
                  double* A, int64_t ld, void* stream);
 
+/* The same operator restricted to the voxel slab iy0 <= iy < iy1 (columns p = (iy*nx+ix)*nz+iz of that slab only; the rest of
+ * A is not touched): a rank of a column-sharded run only needs its own y-slab of every sensor row. */
+int geobo_a_sens_slab(int func_id, const double* B3_host, const double* loc, int64_t Ms, int nx, int ny, int nz,
+                      const double* xe, const double* ye, const double* ze, double scale_mul, double scale_div,
+                      int iy0, int iy1, double* A, int64_t ld, void* stream);
+
 /* Node potential itself, elementwise: out[i] = grav_func(x,y,z) (sensormodel.py:96-110) or
  * magn_func(x,y,z,B) (sensormodel.py:113-133); same arithmetic as inside geobo_a_sens. */
 int geobo_potential(int func_id, const double* B3_host, const double* x, const double* y, const double* z, int64_t n,

@@ -271,9 +271,11 @@ def test_full_size_64cube_properties():
     assert all(c.shape == (n, n, n) for c in cubes)
 
 
-def test_spectral_y_slab_shards_match_dense():
-    """Column shards of the spectral route (y-slab cropping in the backward pass) against the dense AK, rank by rank."""
+def test_spectral_y_slab_shards_match_dense(monkeypatch):
+    """Column shards of the spectral route without the row exchange (replicated forward passes, y-slab cropping in the
+    backward pass: GEOBO_SPECTRAL_EXCHANGE=0, also the fallback for uneven shards) against the dense AK, rank by rank."""
     import geobo_amd.engine as E
+    monkeypatch.setenv("GEOBO_SPECTRAL_EXCHANGE", "0")
     f = load_golden("oracle32_matern32.npz")
     s = settings_for(32, 32, 32, kernelfunc="matern32")
     W = E.weight_matrix(s.gp_coeff)
@@ -324,3 +326,41 @@ def test_yaml_workflow_from_raw_files(name, sub, tmp_path):
         assert normwise(cube, ref) <= TOL_T3
     assert os.path.exists(os.path.join(str(tmp_path), "newdrill_proposals_vertical.csv"))
     assert len(out["proposals_vertical"]) >= 1 and np.isfinite(out["proposals_vertical"]["BO_GAIN"]).all()
+
+
+def test_row_sharded_exchange_matches_dense_columns():
+    """Multi-GPU row-sharded spectral product, simulated on one device: each of 4 'ranks' transforms its sensor rows and fills
+    its send buffer; the all-to-all is done by hand (recv_r[src] = send_src[r]); the assembled AK of every rank must equal the
+    dense route's AK for that rank's columns.  Also checks the slab-restricted forward operator against the full one."""
+    import geobo_amd.engine as E
+    f = load_golden("oracle32_matern32.npz")
+    s = settings_for(32, 32, 32, kernelfunc="matern32")
+    W = E.weight_matrix(s.gp_coeff)
+    lengths = [float(v) for v in E.create_cov_lengths(f["gp_length_in"].copy())]
+    sel_t = torch.as_tensor(f["sel"], device="cuda")
+    world, props = 4, (0, 1, 2)
+    full = E.PosteriorEngine(s, method="dense")
+    Af = {k: full.operator(k, f["sensor_locations"]).clone() for k in ("grav", "magn")}
+    engs = [E.PosteriorEngine(s, rank=r, world=world) for r in range(world)]
+    assert all(e.exchange for e in engs)
+    sends = []
+    for e in engs:
+        A_g, A_m = e.operator("grav", f["sensor_locations"]), e.operator("magn", f["sensor_locations"])
+        # this rank's slab of every sensor row, and all voxels of its own sensor rows, are bit-identical to the full operator
+        rows_r = e.Ms // world
+        for k, A in (("grav", A_g), ("magn", A_m)):
+            assert torch.equal(A[:e.Ms, e.c0:e.c1], Af[k][:e.Ms, e.c0:e.c1])
+            assert torch.equal(e._Arows[k][:, :e.N], Af[k][e.rank * rows_r:(e.rank + 1) * rows_r, :e.N])
+        from geobo_amd.spectral import SpectralProduct
+        e._spectral = SpectralProduct(e.nx, e.ny, e.nz, e.device)
+        sends.append(e._exchange_send(lengths, W, "matern32", 1.0, props).clone())
+    for r, e in enumerate(engs):
+        recv = torch.stack([sends[src][r] for src in range(world)])
+        M_pad = E.hip.pad_m(2 * e.Ms_pad + f["sel"].size)
+        AK = torch.zeros((M_pad, len(props) * e.nc), dtype=torch.float64, device="cuda")
+        e._exchange_place(AK, recv, props)
+        d = E.PosteriorEngine(s, rank=r, world=world, method="dense")
+        ref, _ = d._assemble_AK(Af["grav"], Af["magn"], sel_t, lengths, W, "matern32", 1.0, props)
+        rows = np.r_[0:e.Ms, e.Ms_pad:e.Ms_pad + e.Ms]
+        diff = (AK[rows] - ref[rows]).abs().max().item()
+        assert diff <= 1e-12 * ref.abs().max().item(), (r, diff)

@@ -93,3 +93,38 @@ def test_two_rank_sharded_posterior_matches_reference(world):
     assert np.abs(AkA - f["AkA"]).max() / np.abs(f["AkA"]).max() < 1e-13
     assert np.abs(mu - f["mu"]).max() / np.abs(f["mu"]).max() < 1e-10
     assert np.abs(var - f["var"]).max() / np.abs(f["var"]).max() < 1e-10
+
+
+def _xchg_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from geobo_amd.sharding import exchange_blocks
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    blk = 6
+    send = torch.arange(world * blk, dtype=torch.float64).reshape(world, blk) + 1000.0 * rank   # row d -> rank d
+    recv = exchange_blocks(send, world)
+    q.put((rank, recv.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_blocks_is_an_all_to_all():
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_xchg_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    blk = 6
+    for r in range(world):
+        for src in range(world):   # row src of rank r's result = row r of rank src's send buffer
+            want = np.arange(r * blk, (r + 1) * blk, dtype=np.float64) + 1000.0 * src
+            assert np.array_equal(got[r][src], want)
