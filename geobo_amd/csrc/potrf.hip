@@ -3,9 +3,9 @@
 // (inversion.py:105-110).
 //
 // Right-looking, block size 128:
-//   potf2_inv_kernel  one workgroup factors the 128x128 diagonal block inside LDS (132 KiB of the CU's
-//                     160 KiB), writes L_kk, then inverts it in place in LDS (dtrti2 order) and writes
-//                     L_kk^-1 straight into the diagonal block of Linv;
+//   potf2_inv_kernel  one workgroup factors the 128x128 diagonal block in registers (2-D cyclic over 256 threads),
+//                     carrying the inverse along by forward substitution, and writes L_kk and L_kk^-1 (the latter
+//                     straight into the diagonal block of Linv);
 //   panel solve       P = A[k+1:,k] * (L_kk^-1)^T           -> geobo_gemm_nt on the fp64 MFMA core (in place)
 //   trailing update   A[k+1:,k+1:] -= P P^T (lower tiles)   -> geobo_gemm_nt, lower_only
 // L^-1 is then assembled by recursive halving, two MFMA GEMMs per merge:
@@ -17,64 +17,97 @@
 namespace {
 
 constexpr int NB = 128;
-constexpr int LS = NB + 1;  // LDS row stride (doubles): conflict-free column walks
 
-__global__ void __launch_bounds__(256) potf2_inv_kernel(double* __restrict__ A, int64_t ld, double* __restrict__ Linv,
-                                                        int64_t ldi, int kb_global, int* __restrict__ info) {
-  extern __shared__ __attribute__((aligned(16))) double S[];  // [NB][LS]
-  const int tid = threadIdx.x;
-  // load the block (rows are 1 KiB contiguous)
-  for (int idx = tid; idx < NB * NB; idx += 256) {
-    const int i = idx >> 7, c = idx & (NB - 1);
-    S[i * LS + c] = A[(int64_t)i * ld + c];
-  }
-  const int ti = tid >> 4, tj = tid & 15;
-  bool bad_seen = false;
-  for (int j = 0; j < NB; ++j) {
+// The 128x128 diagonal block AND the running inverse live in registers: thread (ti, tj) of a 16 x 16 grid owns the
+// 2-D cyclic elements (ti + 16 p, tj + 16 q), p, q < 8.  Column step j broadcasts column j of the block and row j of
+// the inverse through a double-buffered 2 KiB LDS line (ONE barrier per column), then every thread applies the
+// rank-1 updates   A[i][c] -= l_i l_c  (i, c > j)   and   X[i][c] -= l_i X[j][c]  (i > j >= c)   on its registers.
+// X starts as the identity, so after the last column X = L_kk^-1 (forward substitution fused into the
+// factorisation).  The outer loop over 16-column groups is unrolled, so all register indices are static and the
+// update ranges shrink with the group index.  (A version with the block in LDS spent ~90 % of its 0.35 ms in
+// ~640 barriers and LDS round trips.)
+template <int JB>
+__device__ __forceinline__ void potf2_group(double (&a)[8][8], double (&x)[8][8], double (&colbuf)[2][NB],
+                                            double (&rowbuf)[2][NB], int tid, int ti, int tj, int kb_global,
+                                            int* __restrict__ info, bool& bad_seen) {
+#pragma unroll 1
+  for (int jj = 0; jj < 16; ++jj) {
+    const int j = JB * 16 + jj, buf = jj & 1;
+    if (tj == jj) {
+#pragma unroll
+      for (int p = JB; p < 8; ++p) colbuf[buf][ti + 16 * p] = a[p][JB];
+    }
+    if (ti == jj) {
+#pragma unroll
+      for (int q = 0; q <= JB; ++q) rowbuf[buf][tj + 16 * q] = x[JB][q];
+    }
     __syncthreads();
-    const double d = S[j * LS + j];
+    const double d = colbuf[buf][j];
     if (!(d > 0.0) && !bad_seen) {  // non-positive or NaN pivot: LAPACK dpotrf's info = j (1-based)
       bad_seen = true;
       if (tid == 0 && *info == 0) *info = kb_global + j + 1;
     }
     const double r = sqrt(d);
     const double rinv = 1.0 / r;
-    __syncthreads();
-    if (tid < NB) {
-      if (tid > j) S[tid * LS + j] *= rinv;
-      else if (tid == j) S[j * LS + j] = r;
+    double li[8], lc[8], xj[8];
+#pragma unroll
+    for (int p = JB; p < 8; ++p) li[p] = (ti + 16 * p > j) ? colbuf[buf][ti + 16 * p] * rinv : 0.0;
+#pragma unroll
+    for (int q = JB; q < 8; ++q) lc[q] = (tj + 16 * q > j) ? colbuf[buf][tj + 16 * q] * rinv : 0.0;
+#pragma unroll
+    for (int q = 0; q <= JB; ++q) xj[q] = (tj + 16 * q <= j) ? rowbuf[buf][tj + 16 * q] * rinv : 0.0;
+    if (tj == jj) {  // column j of L: scaled sub-diagonal, sqrt on the diagonal
+#pragma unroll
+      for (int p = JB; p < 8; ++p) {
+        const int i = ti + 16 * p;
+        a[p][JB] = (i > j) ? li[p] : (i == j ? r : a[p][JB]);
+      }
     }
-    __syncthreads();
-    for (int i = j + 1 + ti; i < NB; i += 16) {
-      const double lij = S[i * LS + j];
-      for (int c = j + 1 + tj; c <= i; c += 16) S[i * LS + c] -= lij * S[c * LS + j];
+    if (ti == jj) {  // row j of the inverse is final
+#pragma unroll
+      for (int q = 0; q <= JB; ++q) x[JB][q] = xj[q];
     }
-  }
-  __syncthreads();
-  // write L_kk (upper part zeroed, like scipy's lower=True result)
-  for (int idx = tid; idx < NB * NB; idx += 256) {
-    const int i = idx >> 7, c = idx & (NB - 1);
-    A[(int64_t)i * ld + c] = (c <= i) ? S[i * LS + c] : 0.0;
-  }
-  // in-place inverse of the lower triangle, last column first
-  for (int j = NB - 1; j >= 0; --j) {
-    __syncthreads();
-    const double ajj = 1.0 / S[j * LS + j];
-    double acc = 0.0;
-    if (tid < NB && tid > j) {
-      for (int k = j + 1; k <= tid; ++k) acc = __builtin_fma(S[tid * LS + k], S[k * LS + j], acc);
-    }
-    __syncthreads();
-    if (tid < NB) {
-      if (tid > j) S[tid * LS + j] = -ajj * acc;
-      else if (tid == j) S[j * LS + j] = ajj;
+#pragma unroll
+    for (int p = JB; p < 8; ++p) {
+#pragma unroll
+      for (int q = JB; q < 8; ++q) a[p][q] = __builtin_fma(-li[p], lc[q], a[p][q]);
+#pragma unroll
+      for (int q = 0; q <= JB; ++q) x[p][q] = __builtin_fma(-li[p], xj[q], x[p][q]);
     }
   }
-  __syncthreads();
-  for (int idx = tid; idx < NB * NB; idx += 256) {
-    const int i = idx >> 7, c = idx & (NB - 1);
-    Linv[(int64_t)i * ldi + c] = (c <= i) ? S[i * LS + c] : 0.0;
-  }
+}
+
+__global__ void __launch_bounds__(256) potf2_inv_kernel(double* __restrict__ A, int64_t ld, double* __restrict__ Linv,
+                                                        int64_t ldi, int kb_global, int* __restrict__ info) {
+  __shared__ double colbuf[2][NB], rowbuf[2][NB];
+  const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+  double a[8][8], x[8][8];
+#pragma unroll
+  for (int p = 0; p < 8; ++p)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = ti + 16 * p, c = tj + 16 * q;
+      a[p][q] = (c <= i) ? A[(int64_t)i * ld + c] : 0.0;
+      x[p][q] = (c == i) ? 1.0 : 0.0;
+    }
+  bool bad_seen = false;
+  potf2_group<0>(a, x, colbuf, rowbuf, tid, ti, tj, kb_global, info, bad_seen);
+  potf2_group<1>(a, x, colbuf, rowbuf, tid, ti, tj, kb_global, info, bad_seen);
+  potf2_group<2>(a, x, colbuf, rowbuf, tid, ti, tj, kb_global, info, bad_seen);
+  potf2_group<3>(a, x, colbuf, rowbuf, tid, ti, tj, kb_global, info, bad_seen);
+  potf2_group<4>(a, x, colbuf, rowbuf, tid, ti, tj, kb_global, info, bad_seen);
+  potf2_group<5>(a, x, colbuf, rowbuf, tid, ti, tj, kb_global, info, bad_seen);
+  potf2_group<6>(a, x, colbuf, rowbuf, tid, ti, tj, kb_global, info, bad_seen);
+  potf2_group<7>(a, x, colbuf, rowbuf, tid, ti, tj, kb_global, info, bad_seen);
+  // L_kk with the upper part zeroed (like scipy's lower=True result) and L_kk^-1
+#pragma unroll
+  for (int p = 0; p < 8; ++p)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = ti + 16 * p, c = tj + 16 * q;
+      A[(int64_t)i * ld + c] = (c <= i) ? a[p][q] : 0.0;
+      Linv[(int64_t)i * ldi + c] = (c <= i) ? x[p][q] : 0.0;
+    }
 }
 
 // u[i] = sum_{k<=i} Linv[i,k] y[k]: one wavefront per row, shuffle-tree reduction
@@ -142,18 +175,11 @@ extern "C" int geobo_potrf_inv(int64_t m, double* A, int64_t ld, double* Linv, i
   if (m <= 0 || m % NB || (ld & 1) || (ldi & 1) || ld < m || ldi < m) return GEOBO_E_ALIGN;
   if (ws_bytes < geobo_potrf_ws_bytes(m)) return GEOBO_E_ARG;
   hipStream_t st = (hipStream_t)stream;
-  static bool attr_set = false;
-  constexpr size_t lds = sizeof(double) * NB * LS;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_inv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return GEOBO_E_LAUNCH;
-    attr_set = true;
-  }
   if (hipMemsetAsync(info, 0, sizeof(int), st) != hipSuccess) return GEOBO_E_LAUNCH;
   if (hipMemset2DAsync(Linv, (size_t)ldi * sizeof(double), 0, (size_t)m * sizeof(double), (size_t)m, st) != hipSuccess)
     return GEOBO_E_LAUNCH;
   for (int64_t kb = 0; kb < m; kb += NB) {
-    hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(256), lds, st, A + kb * ld + kb, ld, Linv + kb * ldi + kb, ldi,
+    hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(256), 0, st, A + kb * ld + kb, ld, Linv + kb * ldi + kb, ldi,
                        (int)kb, info);
     if (hipGetLastError() != hipSuccess) return GEOBO_E_LAUNCH;
     const int64_t rem = m - kb - NB;
