@@ -208,6 +208,18 @@ def scale_broadcast2(a, b0, b1, out0, out1):
                                           _p(out0), _p(out1), _stream()), "geobo_scale_broadcast2")
 
 
+def toeplitz_y(ny, C, R, src, tabs, outs, y0=0, y1=None):
+    """outs[j][r, y - y0, c] = sum_y' tabs[j][|y - y'|, c] * src[r, y', c]  (geobo_toeplitz_y); 1 or 2 property blocks."""
+    lib = require_gpu()
+    y1 = ny if y1 is None else y1
+    n = len(tabs)
+    assert n in (1, 2) and len(outs) == n
+    t1 = tabs[1] if n == 2 else tabs[0]
+    o1 = outs[1] if n == 2 else outs[0]
+    _lib.check(lib.geobo_toeplitz_y(int(ny), int(C), int(R), n, _p(_chk(src, "src")), _p(_chk(tabs[0], "tab0")), _p(_chk(t1, "tab1")),
+                                    _p(outs[0]), _p(o1), int(y0), int(y1), _stream()), "geobo_toeplitz_y")
+
+
 def potrf_inv(A, Linv=None, ws=None):
     """In-place lower Cholesky of A (m x m, m % 128 == 0); returns (Linv, info_tensor).  Linv / ws may be caller-owned."""
     lib = require_gpu()

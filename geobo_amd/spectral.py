@@ -18,6 +18,7 @@ Numerics: the transform matrices are orthogonal up to scaling, so the result dif
 1e-16 of max|A| max|K| per entry (normwise); the posterior cubes stay far inside the 1e-8 contract (tests).
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -84,8 +85,12 @@ class SpectralProduct:
         self.G = {a: dev(_pad_rows(forward_matrix(n))) for a, n in (("x", nx), ("y", ny), ("z", nz))}
         self.GT = {a: dev(_pad_rows(forward_matrix(n).T.copy())) for a, n in (("x", nx), ("y", ny), ("z", nz))}
         self.E = {a: dev(_pad_rows(eigen_matrix(n))) for a, n in (("x", nx), ("y", ny), ("z", nz))}
+        # y axis: applied as Toeplitz blocks per (x, z) mode (geobo_toeplitz_y) when the kernel has the extent, else carried
+        # through the spectrum like x and z
+        self.dense_y = ny in (16, 32, 48, 64) and os.environ.get("GEOBO_SPECTRAL_DENSE_Y", "1") != "0"
         if rows_per_batch is None:
-            rows_per_batch = max(1, min(128, (3 << 30) // (self.P3 * 8)))  # ~3 GB per full-spectrum buffer
+            per_row = (ny * self.Px * self.Pz if self.dense_y else self.P3) * 8
+            rows_per_batch = max(1, min(256 if self.dense_y else 128, (3 << 30) // per_row))  # ~3 GB per work buffer
         g = 128 // math.gcd(nx * ny, 128)
         self.R = max(g, rows_per_batch // g * g)
         self._bufs = {}
@@ -96,16 +101,21 @@ class SpectralProduct:
             b = self._bufs[name] = _buf(n, self.device)
         return b
 
-    # ---- three axis passes, z (contiguous) then x then y: [R][ny][nx][nz] -> [R][Py][Px][Pz] --------------------------------
-    def forward(self, src, R, M, out_name="T3", src_row_stride=None):
+    # ---- axis passes, z (contiguous) then x [then y]: [R][ny][nx][nz] -> [R][ny][Px][Pz] [-> [R][Py][Px][Pz]] -----------------
+    def forward_zx(self, src, R, M, src_row_stride=None, out_name="T2"):
         """src: R volumes of ny*nx*nz doubles, `src_row_stride` doubles apart (default: contiguous)."""
-        nx, ny, nz, Px, Py, Pz = self.nx, self.ny, self.nz, self.Px, self.Py, self.Pz
+        nx, ny, nz, Px, Pz = self.nx, self.ny, self.nz, self.Px, self.Pz
         rows = R * ny * nx
         t1 = self.buf("T1", rows * Pz)
         lds = self.N if src_row_stride is None else int(src_row_stride)
         hip.gemm_batched(False, hip.pad_n(ny * nx), hip.pad_n(Pz), nz, src, nz, lds, M["z"], nz, 0, t1, Pz, ny * nx * Pz, ny * nx, Pz, R)
-        t2 = self.buf("T2", R * ny * Px * Pz)
+        t2 = self.buf(out_name, R * ny * Px * Pz)
         hip.gemm_batched(True, hip.pad_n(Px), hip.pad_n(Pz), nx, M["x"], nx, 0, t1, Pz, nx * Pz, t2, Pz, Px * Pz, Px, Pz, R * ny)
+        return t2
+
+    def forward(self, src, R, M, out_name="T3", src_row_stride=None):
+        ny, Px, Py, Pz = self.ny, self.Px, self.Py, self.Pz
+        t2 = self.forward_zx(src, R, M, src_row_stride)
         t3 = self.buf(out_name, R * self.P3)
         hip.gemm_batched(True, hip.pad_n(Py), hip.pad_n(Px * Pz), ny, M["y"], ny, 0, t2, Px * Pz, ny * Px * Pz, t3, Px * Pz,
                          self.P3, Py, Px * Pz, R)
@@ -113,32 +123,53 @@ class SpectralProduct:
 
     # ---- back: y (crop to the slab [y0,y1)), x, z; writes rows of `out` (leading dimension ldo) -----------------------------
     def backward(self, spec, R, y0, y1, out, ldo):
-        nx, nz, Px, Py, Pz = self.nx, self.nz, self.Px, self.Py, self.Pz
+        Px, Py, Pz = self.Px, self.Py, self.Pz
         slab = y1 - y0
         gyt = self.GT["y"][y0:]                                  # rows y0.. of G_y^T (padded rows behind are zero / slack)
         u2 = self.buf("U2", R * slab * Px * Pz)
         hip.gemm_batched(True, hip.pad_n(slab), hip.pad_n(Px * Pz), Py, gyt, Py, 0, spec, Px * Pz, self.P3, u2, Px * Pz,
                          slab * Px * Pz, slab, Px * Pz, R)
-        u1 = self.buf("U1", R * slab * nx * Pz)
+        self.backward_xz(u2, R, y0, y1, [(y0, y1, out, ldo)])
+
+    def backward_xz(self, u2, R, ylo, yhi, targets):
+        """u2: [R][yhi-ylo][Px][Pz] (y already in the space domain).  x pass over every (row, y), then one z pass per target
+        (ya, yb, out, ldo): rows of `out` receive the y-slab [ya, yb) of every row."""
+        nx, nz, Px, Pz = self.nx, self.nz, self.Px, self.Pz
+        Ly = yhi - ylo
+        u1 = self.buf("U1", R * Ly * nx * Pz)
         hip.gemm_batched(True, hip.pad_n(nx), hip.pad_n(Pz), Px, self.GT["x"], Px, 0, u2, Pz, Px * Pz, u1, Pz, nx * Pz, nx, Pz,
-                         R * slab)
-        hip.gemm_batched(False, hip.pad_n(slab * nx), hip.pad_n(nz), Pz, u1, Pz, slab * nx * Pz, self.GT["z"], Pz, 0, out, nz, ldo,
-                         slab * nx, nz, R)
+                         R * Ly)
+        for ya, yb, out, ldo in targets:
+            slab = yb - ya
+            hip.gemm_batched(False, hip.pad_n(slab * nx), hip.pad_n(nz), Pz, u1[(ya - ylo) * nx * Pz:], Pz, Ly * nx * Pz,
+                             self.GT["z"], Pz, 0, out, nz, ldo, slab * nx, nz, R)
 
     def flops(self, rows, nblocks, slab):
-        """Executed flop of product(): forward passes once, backward passes per property block (compute extents)."""
+        """Executed flop of product(): forward passes once, the rest per property block (compute extents)."""
         nx, ny, nz, Px, Py, Pz = self.nx, self.ny, self.nz, self.Px, self.Py, self.Pz
         pn = hip.pad_n
-        fwd = 2.0 * (ny * nx * pn(Pz) * nz + ny * pn(Px) * pn(Pz) * nx + pn(Py) * Px * Pz * ny)
-        bwd = 2.0 * (pn(slab) * Px * Pz * Py + slab * pn(nx) * pn(Pz) * Px + pn(slab * nx) * pn(nz) * Pz)
+        fwd = 2.0 * (ny * nx * pn(Pz) * nz + ny * pn(Px) * pn(Pz) * nx)
+        bwd = 2.0 * (slab * pn(nx) * pn(Pz) * Px + pn(slab * nx) * pn(nz) * Pz)
+        if self.dense_y:
+            bwd += 2.0 * ny * ny * Px * Pz          # the kernel computes every output y and stores the slab
+        else:
+            fwd += 2.0 * pn(Py) * Px * Pz * ny
+            bwd += 2.0 * pn(slab) * Px * Pz * Py
         return rows * (fwd + nblocks * bwd)
 
     def eigenvalues(self, table_mirrored):
-        """Lambda'/(Py Px Pz) on the G row index, from the (z-mirrored) lattice table of geobo_cov_table."""
+        """What product() needs of one covariance block, from the (z-mirrored) lattice table of geobo_cov_table:
+        dense-y route: the Toeplitz generators t[d][ox][oz] = (E_x E_z k)(d, ox, oz) / (Px Pz)   ([ny][Px*Pz]);
+        otherwise the full eigenvalue cube Lambda'/(Py Px Pz) on the G row index."""
         nx, ny, nz = self.nx, self.ny, self.nz
         T = table_mirrored[:ny * nx * 2 * nz].view(ny, nx, 2 * nz)[:, :, nz - 1:2 * nz - 1].contiguous()
         src = self.buf("Tsrc", self.N)
         src[:self.N] = T.reshape(-1)
+        if self.dense_y:
+            n = ny * self.Px * self.Pz
+            gen = self.forward_zx(src, 1, self.E, out_name="Lam")[:n].clone()
+            gen.mul_(1.0 / float(self.Px * self.Pz))
+            return gen
         lam = self.forward(src, 1, self.E, out_name="Lam")[:self.P3].clone()
         lam.mul_(1.0 / float(self.P3))
         return lam
@@ -153,6 +184,8 @@ class SpectralProduct:
             slabs = [(y0, y1, outs)]
         N = self.N
         assert A.stride(1) == 1 and A.stride(0) >= N and A.stride(0) % 2 == 0
+        if self.dense_y:
+            return self._product_dense_y(A, Ms, lam_list, slabs)
         for r0 in range(0, Ms, self.R):
             R = min(self.R, Ms - r0)
             spec = self.forward(A[r0:], R, self.G, src_row_stride=A.stride(0))
@@ -172,3 +205,18 @@ class SpectralProduct:
                     for ya, yb, o in slabs:
                         self.backward(s0, R, ya, yb, o[j][r0:], o[j].stride(0))
                     j += 1
+
+    def _product_dense_y(self, A, Ms, gens, slabs):
+        """z and x through the spectrum, y as Toeplitz blocks: one read of the (x, z)-spectrum per pair of property blocks."""
+        ny, C = self.ny, self.Px * self.Pz
+        ylo, yhi = min(s[0] for s in slabs), max(s[1] for s in slabs)
+        n_out = (yhi - ylo) * C
+        for r0 in range(0, Ms, self.R):
+            R = min(self.R, Ms - r0)
+            t2 = self.forward_zx(A[r0:], R, self.G, src_row_stride=A.stride(0))
+            for j in range(0, len(gens), 2):
+                js = list(range(j, min(j + 2, len(gens))))
+                u2 = [self.buf(("S", "S1")[i], R * n_out) for i in range(len(js))]
+                hip.toeplitz_y(ny, C, R, t2, [gens[jj] for jj in js], u2, ylo, yhi)
+                for i, jj in enumerate(js):
+                    self.backward_xz(u2[i], R, ylo, yhi, [(ya, yb, o[jj][r0:], o[jj].stride(0)) for ya, yb, o in slabs])

@@ -144,6 +144,14 @@ int geobo_scale_broadcast(const double* a, const double* b, int64_t n, int64_t n
 int geobo_scale_broadcast2(const double* a, const double* b0, const double* b1, int64_t n, int64_t nb, double* out0,
                            double* out1, void* stream);
 
+/* y-axis stage of the structured product on a regular grid: for every mode c < C (the (x, z)
+ * spectral index, contiguous) and row r < R,   out_j[r][y - y0][c] = sum_{y'} tab_j[|y - y'|][c] * in[r][y'][c]
+ * for y in [y0, y1) -- the symmetric Toeplitz blocks of create_cov's K_sj (kernels.py:158-195) applied directly.
+ * in: [R][ny][C]; tab_j: [ny][C]; out_j: [R][y1-y0][C]; nprop = 1 or 2 property blocks per sweep (tab1/out1 unused
+ * for 1).  ny in {16, 32, 48, 64} (GEOBO_E_UNSUPPORTED otherwise), C % 64 == 0, ny*C*8 < 2^31. */
+int geobo_toeplitz_y(int ny, int64_t C, int64_t R, int nprop, const double* in, const double* tab0, const double* tab1,
+                     double* out0, double* out1, int y0, int y1, void* stream);
+
 /* In-place lower Cholesky of the (m x m, ld) matrix A, m % 256 == 0 (padding rows/cols = identity);
  * scipy.linalg.cholesky(AkA, lower=True), inversion.py:100.  Also writes Linv = L^-1 (m x m, ldi; lower,
  * upper part zeroed), used instead of the two solve_triangular calls (inversion.py:105,114).

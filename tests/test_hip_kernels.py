@@ -268,3 +268,19 @@ def test_gemm_nt_splitk_matches_torch(hip):
             assert (C - ref)[keep].abs().max().item() < 1e-11 and C[~keep].abs().max().item() == 0.0 if (~keep).any() else True
         else:
             assert (C - ref).abs().max().item() < 1e-11
+
+
+@pytest.mark.parametrize("ny,C,R,nprop,y0,y1", [(16, 64, 3, 1, 0, 16), (32, 128, 5, 2, 0, 32), (48, 64, 4, 2, 16, 32),
+                                                 (64, 256, 9, 2, 0, 64), (64, 128, 2, 1, 32, 64)])
+def test_toeplitz_y_matches_torch(hip, ny, C, R, nprop, y0, y1):
+    # out_j[r, y - y0, c] = sum_y' tab_j[|y - y'|, c] in[r, y', c]: the per-mode symmetric Toeplitz blocks of K_sj
+    src = _rand((R, ny, C), 11)
+    tabs = [_rand((ny, C), 12 + j) for j in range(nprop)]
+    outs = [torch.full((R, y1 - y0, C), float("nan"), dtype=torch.float64, device="cuda") for _ in range(nprop)]
+    hip.toeplitz_y(ny, C, R, src.reshape(-1), [t.reshape(-1) for t in tabs], [o.reshape(-1) for o in outs], y0, y1)
+    torch.cuda.synchronize()
+    idx = (torch.arange(ny)[:, None] - torch.arange(ny)[None, :]).abs().cuda()      # |y - y'|
+    for j in range(nprop):
+        T = tabs[j][idx]                                                            # [y][y'][c]
+        ref = torch.einsum("ypc,rpc->ryc", T, src)[:, y0:y1]
+        assert normwise(outs[j].cpu().numpy(), ref.cpu().numpy()) < 1e-14
