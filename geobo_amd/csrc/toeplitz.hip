@@ -15,7 +15,6 @@
 // outputs with every index static.  8 flop per byte of traffic; VALU-bound at ~NY^2 * 4 cycles per wave-row.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 #include "geobo_hip.h"
 
 namespace {
@@ -25,7 +24,7 @@ struct ToeplitzArgs {
   const double* tab[2];   // [NY][C] per property block
   double* out[2];         // [R][y1-y0][C] per property block
   int64_t C, R;
-  int nprop, y0, y1, row_step;
+  int nprop, y0, y1;
 };
 
 // Buffer addressing: wave-uniform resource (row base, 4 SGPRs) + scalar byte offset (y * C * 8) + one per-lane
@@ -42,54 +41,36 @@ __device__ __forceinline__ void st_lane(rsrc_t rs, unsigned lane8, int soff, dou
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rs, lane8, soff, 0);
 }
 
-// One group of GS = 8 inputs of the row sweep: q-th of NQ = (NY/OC) * (NY/8) groups (chunk h = q / NG of OC outputs,
-// input group gq = q % NG).  A template (not a loop) so that every table index is a compile-time constant.
-template <int NY, int OC, int Q>
-__device__ __forceinline__ void toeplitz_group(const ToeplitzArgs& g, const double (&t)[NY], double (&acc)[OC],
-                                               double (&xb)[2][8], rsrc_t src, rsrc_t nxt, rsrc_t dst, int C8,
-                                               unsigned lane8, int y0, int y1) {
-  constexpr int GS = 8, NG = NY / GS, NQ = (NY / OC) * NG;
-  constexpr int h = Q / NG, gq = Q % NG;
-  // launder the row pitch: the byte offsets y * C8 are recomputed where they are used (a handful of scalar ops)
-  // instead of being hoisted out of the row loop into >128 live SGPRs (same for the 64 store predicates)
-  asm volatile("" : "+s"(C8), "+s"(y0), "+s"(y1));
-  {  // prefetch the next group: of this chunk, of the next chunk (re-reads the row: L1/L2 hits), or of the next row
-    const rsrc_t rs = (Q + 1 == NQ) ? nxt : src;
-    constexpr int y_first = ((Q + 1) % NG) * GS;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+// NY x (NY/2) multiply-adds of one wave-row, all table indices compile-time constants.  The wave computes outputs
+// o = 0..OC-1 of the row as stored in LDS; the second half of the outputs uses the SAME code on the reversed row
+// (T is persymmetric: out[NY-1-o] = sum_y'' t(|o - y''|) in[NY-1-y'']), selected by the sign of `xstep`.
+template <int NY, int OC, int YP>
+__device__ __forceinline__ void toeplitz_fma(const double (&t)[NY], double (&acc)[OC], const char* xp, int xstep) {
+  // compiler barrier every 8 inputs: the scheduler may run LDS reads ahead, but not all NY of them (spills)
+  if constexpr (YP % 8 == 0) asm volatile("" ::: "memory");
+  const double x = *reinterpret_cast<const double*>(xp);
 #pragma unroll
-    for (int i = 0; i < GS; ++i) xb[(Q + 1) & 1][i] = ld_lane(rs, lane8, (y_first + i) * C8);
+  for (int o = 0; o < OC; ++o) {
+    const int d = o - YP;
+    acc[o] = (YP == 0) ? t[d < 0 ? -d : d] * x : __builtin_fma(t[d < 0 ? -d : d], x, acc[o]);
   }
-  // compiler barrier: keeps the scheduler from hoisting every load of the row (which would spill the table)
-  asm volatile("" ::: "memory");
-  if (gq == 0) {
-#pragma unroll
-    for (int o = 0; o < OC; ++o) acc[o] = 0.0;
-  }
-#pragma unroll
-  for (int i = 0; i < GS; ++i) {
-    const int yp = gq * GS + i;
-    const double x = xb[Q & 1][i];
-#pragma unroll
-    for (int o = 0; o < OC; ++o) {
-      const int d = h * OC + o - yp;
-      acc[o] = __builtin_fma(t[d < 0 ? -d : d], x, acc[o]);
-    }
-  }
-  if (gq == NG - 1) {
-#pragma unroll
-    for (int o = 0; o < OC; ++o) {
-      const int y = h * OC + o;
-      if (y >= y0 && y < y1) st_lane(dst, lane8, (y - y0) * C8, acc[o]);
-    }
-  }
-  if constexpr (Q + 1 < NQ) toeplitz_group<NY, OC, Q + 1>(g, t, acc, xb, src, nxt, dst, C8, lane8, y0, y1);
+  if constexpr (YP + 1 < NY) toeplitz_fma<NY, OC, YP + 1>(t, acc, xp + xstep, xstep);
 }
 
-template <int NY, int OC>
+// Workgroup = 2 * nprop waves sharing ONE row at a time: wave (prop, half).  The next row streams into the other half
+// of a 2 x NY x 512 B LDS ring by LDS-DMA (no registers, issued a whole row -- ~7 us of arithmetic -- ahead), so the
+// VALU never waits on HBM and each input is fetched once per workgroup for both property blocks.
+template <int NY>
 __global__ void __launch_bounds__(256, 2) toeplitz_y_kernel(ToeplitzArgs g) {
+  constexpr int OC = NY / 2;
+  __shared__ __attribute__((aligned(16))) double xs[2][NY][64];
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nw = 2 * g.nprop;
   const unsigned lane8 = (unsigned)lane * 8u;
-  const int prop = w % g.nprop, rlane = w / g.nprop;
+  const int prop = w >> 1, half = w & 1;
   const int64_t C = g.C, c0 = (int64_t)blockIdx.x * 64;
   const int C8 = (int)(C * 8), in_bytes = NY * C8, out_bytes = (g.y1 - g.y0) * C8;
   double t[NY];
@@ -98,37 +79,54 @@ __global__ void __launch_bounds__(256, 2) toeplitz_y_kernel(ToeplitzArgs g) {
 #pragma unroll
     for (int d = 0; d < NY; ++d) t[d] = ld_lane(tr, lane8, d * C8);
   }
-  const int64_t rstep = (int64_t)gridDim.y * g.row_step;
-  int64_t r = (int64_t)blockIdx.y * g.row_step + rlane;
+  int64_t r = blockIdx.y;
   if (r >= g.R) return;
+  const int64_t rstep = gridDim.y;
   const int64_t ostep = (int64_t)(g.y1 - g.y0) * C;  // output rows hold the slab [y0, y1) only
   double* po = g.out[prop] + c0 + r * ostep;
   const double* ps = g.in + r * NY * C + c0;
-  rsrc_t src = make_rsrc(ps, in_bytes);
-  double xb[2][8];  // inputs stream through a two-deep ring of 8-value groups
-#pragma unroll
-  for (int i = 0; i < 8; ++i) xb[0][i] = ld_lane(src, lane8, i * C8);
+  // one DMA instruction moves two y-planes (2 x 64 modes x 8 B): lanes 0-31 plane 2i, lanes 32-63 plane 2i+1
+  const int64_t dma_lane = (int64_t)(lane >> 5) * C + (lane & 31) * 2;
+  auto stage = [&](const double* row, int b) {
+    for (int i = w; i < NY / 2; i += nw)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(row + (int64_t)(2 * i) * C + dma_lane), (lds_ptr_t)&xs[b][2 * i][0], 16, 0, 0);
+  };
+  stage(ps, 0);
+  __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): this wave's planes have landed
+  __syncthreads();
+  const int xstep = half ? -512 : 512;
+  const int ysgn = half ? -1 : 1, ybase = half ? NY - 1 : 0;
+  int b = 0;
   for (; r < g.R; r += rstep) {
-    if (r + rstep < g.R) ps += rstep * NY * C;
-    const rsrc_t nxt = make_rsrc(ps, in_bytes);
-    const rsrc_t dst = make_rsrc(po, out_bytes);
+    const bool more = r + rstep < g.R;
+    if (more) {
+      ps += rstep * NY * C;
+      stage(ps, b ^ 1);
+    }
     double acc[OC];
-    toeplitz_group<NY, OC, 0>(g, t, acc, xb, src, nxt, dst, C8, lane8, g.y0, g.y1);
-    src = nxt;
+    const char* xp = reinterpret_cast<const char*>(&xs[b][half ? NY - 1 : 0][0]) + lane8;
+    toeplitz_fma<NY, OC, 0>(t, acc, xp, xstep);
+    const rsrc_t dst = make_rsrc(po, out_bytes);
+    int y0 = g.y0, y1 = g.y1, pitch = C8;
+    // laundered per row: keeps the NY/2 store offsets and predicates from being hoisted into ~100 live SGPRs
+    asm volatile("" : "+s"(y0), "+s"(y1), "+s"(pitch));
+#pragma unroll
+    for (int o = 0; o < OC; ++o) {
+      const int y = ybase + ysgn * o;
+      if (y >= y0 && y < y1) st_lane(dst, lane8, (y - y0) * pitch, acc[o]);
+    }
     po += rstep * ostep;
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    b ^= 1;
   }
 }
 
-template <int NY, int OC>
+template <int NY>
 int launch(const ToeplitzArgs& g, hipStream_t st) {
-  const int rlanes = 4 / g.nprop;
-  int64_t gy = (g.R + rlanes - 1) / rlanes;
-  const int64_t want = (4096 + g.C / 64 - 1) / (g.C / 64);  // ~16 workgroups per CU over the whole launch
-  if (gy > want) gy = want;
-  if (gy < 1) gy = 1;
-  ToeplitzArgs a = g;
-  a.row_step = rlanes;
-  hipLaunchKernelGGL((toeplitz_y_kernel<NY, OC>), dim3((unsigned)(g.C / 64), (unsigned)gy), dim3(256), 0, st, a);
+  int64_t gy = g.R < 4 ? g.R : 4;  // 256 column blocks x 4 at 64^3: every workgroup sweeps R/4 rows with one table load
+  while ((g.C / 64) * gy < 1024 && gy < g.R) ++gy;
+  hipLaunchKernelGGL((toeplitz_y_kernel<NY>), dim3((unsigned)(g.C / 64), (unsigned)gy), dim3(128 * g.nprop), 0, st, g);
   return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
 }
 
@@ -141,16 +139,13 @@ extern "C" int geobo_toeplitz_y(int ny, int64_t C, int64_t R, int nprop, const d
   if (C <= 0 || C % 64 || (int64_t)ny * C * 8 >= (1ll << 31)) return GEOBO_E_ALIGN;
   ToeplitzArgs g;
   g.in = in; g.tab[0] = tab0; g.tab[1] = nprop == 2 ? tab1 : tab0; g.out[0] = out0; g.out[1] = nprop == 2 ? out1 : out0;
-  g.C = C; g.R = R; g.nprop = nprop; g.y0 = y0; g.y1 = y1; g.row_step = 1;
+  g.C = C; g.R = R; g.nprop = nprop; g.y0 = y0; g.y1 = y1;
   hipStream_t st = (hipStream_t)stream;
   switch (ny) {
-    case 16: return launch<16, 16>(g, st);
-    case 32: return launch<32, 32>(g, st);
-    case 48: return launch<48, 24>(g, st);
-    case 64: {
-      static const int oc = getenv("GEOBO_TOEP_OC") ? atoi(getenv("GEOBO_TOEP_OC")) : 32;
-      return oc == 16 ? launch<64, 16>(g, st) : launch<64, 32>(g, st);
-    }
+    case 16: return launch<16>(g, st);
+    case 32: return launch<32>(g, st);
+    case 48: return launch<48>(g, st);
+    case 64: return launch<64>(g, st);
     default: return GEOBO_E_UNSUPPORTED;  // longer y axes: carry y through the spectrum instead (spectral.py)
   }
 }
