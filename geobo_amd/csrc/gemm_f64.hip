@@ -23,6 +23,9 @@
 // Workgroup -> tile map is XCD aware: block b runs on XCD b%8, so consecutive slots of one XCD get the SAME
 // row tile (they stream the same A rows through that XCD's L2) and different column tiles.
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <mutex>
+#include <vector>
 #include <stdint.h>
 #include <stdlib.h>
 #include "covfun.h"
@@ -56,6 +59,8 @@ struct GemmArgs {
   int64_t k;
   double alpha, beta;
   int nbi, nbj, tri, xcd_map;
+  // xcd_map 3: explicit tile list (bi << 16 | bj), consumed 32 consecutive entries per XCD at a time
+  const int* tiles; int ntiles;
   // batching (blockIdx.y) and store predicates (the compute tile grid may overhang the valid m x n region)
   int64_t sXb, sYb, sCb, m_valid, n_valid; int batch;
   // generator
@@ -93,9 +98,6 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_f64_kernel(const GemmArg
   constexpr int NSTG = ring_depth<WM, WN>();
   double* const Ys = smem + NSTG * XBUF;
 
-  const double* const Xp = a.X + (int64_t)blockIdx.y * a.sXb;
-  const double* const Yp = a.Y + (int64_t)blockIdx.y * a.sYb;
-  double* const Cp = a.C + (int64_t)blockIdx.y * a.sCb;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
@@ -103,6 +105,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_f64_kernel(const GemmArg
 
   // ---- workgroup -> tile ------------------------------------------------------------------------------
   int bi, bj;
+  int batch_idx = blockIdx.y;
   {
     const int b = blockIdx.x;
     if (a.xcd_map == 1) {          // one row tile per XCD at a time (generator modes: only the X operand is streamed)
@@ -113,15 +116,39 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_f64_kernel(const GemmArg
       const int xcd = b & 7, s = b >> 3;
       const int within = s & 31, g = (s >> 5) * 8 + xcd;
       const int nsi = (a.nbi + 3) >> 2;
-      bi = 4 * (g % nsi) + (within & 3);
-      bj = 8 * (g / nsi) + (within >> 2);
+      if (a.tri & TRI_X_LOWER) {
+        // contraction length grows with the row tile: the 32 workgroups an XCD runs together (and the 8 XCDs' groups
+        // dispatched together) must weigh the same -- mixed lengths desynchronise the k sweeps (no operand sharing in L2)
+        // and stall the in-order dispatcher.  One row tile x 32 column tiles, rows heavy-first: measured 67.4 -> 73.0 TF/s
+        // on the posterior shape (a 4 x 8 supertile mixes four lengths; 2 x 16 gives 71.3).
+        const int nsj = (a.nbj + 31) >> 5;
+        bi = g / nsj;
+        bj = 32 * (g % nsj) + within;
+      } else {
+        bi = 4 * (g % nsi) + (within & 3);
+        bj = 8 * (g / nsi) + (within >> 2);
+      }
       if (bj >= a.nbj) return;
+    } else if (a.xcd_map == 3) {
+      // (batch, tile) items from a compact tile list, 32 consecutive items per XCD at a time, 1-D grid: the dispatcher
+      // places workgroup b on XCD b % 8, so every XCD gets the same number of full 32-item groups over the WHOLE launch
+      // (with a (tiles, batch) grid the same XCDs draw the partial groups in every slice and split-K cannot shorten the tail)
+      const int xcd = b & 7, s = b >> 3;
+      const int64_t item = ((int64_t)((s >> 5) * 8 + xcd) << 5) + (s & 31);
+      if (item >= (int64_t)a.ntiles * a.batch) return;
+      batch_idx = (int)(item / a.ntiles);
+      const int packed = a.tiles[item - (int64_t)batch_idx * a.ntiles];
+      bi = packed >> 16;
+      bj = packed & 0xffff;
     } else {
       bi = b % a.nbi;
       bj = b / a.nbi;
     }
   }
   if (bi >= a.nbi) return;
+  const double* const Xp = a.X + (int64_t)batch_idx * a.sXb;
+  const double* const Yp = a.Y + (int64_t)batch_idx * a.sYb;
+  double* const Cp = a.C + (int64_t)batch_idx * a.sCb;
   if (a.tri & TRI_X_LOWER) bi = a.nbi - 1 - bi;  // triangular X: the longest contraction ranges are dispatched first
   const int64_t row0 = (int64_t)bi * TM, col0 = (int64_t)bj * TN;
   if ((a.tri & TRI_LOWER_ONLY) && col0 >= row0 + TM) return;
@@ -510,6 +537,34 @@ __global__ void posterior_finish_kernel(const double* part_mu, const double* par
   var[c] = prior_var - s;
 }
 
+// Memory-mode launches with few, long tiles (AkA, split-K slices, the Cholesky trailing update): the valid tiles (all, or
+// the lower triangle), enumerated in bands of four row tiles, column-major inside a band, so that 32 consecutive entries
+// form a 4 x 8 supertile (4 X panels + 8 Y panels per XCD L2) and every dispatched workgroup has a full tile of work.
+// Built once per shape, kept on the device.
+struct TileList { int nbi, nbj, tm, tn, lower, dev; int* ptr; int n; };
+const int* tile_list(int nbi, int nbj, int tm, int tn, int lower, int* ntiles) {
+  static std::mutex mu;
+  static std::vector<TileList> cache;
+  std::lock_guard<std::mutex> lock(mu);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  for (const TileList& t : cache)
+    if (t.nbi == nbi && t.nbj == nbj && t.tm == tm && t.tn == tn && t.lower == lower && t.dev == dev) { *ntiles = t.n; return t.ptr; }
+  std::vector<int> host;
+  for (int band = 0; band * 4 < nbi; ++band) {
+    const int r0 = band * 4, r1 = std::min(r0 + 4, nbi);
+    for (int bj = 0; bj < nbj; ++bj)
+      for (int bi = r0; bi < r1; ++bi)
+        if (!lower || (int64_t)bj * tn < (int64_t)bi * tm + tm) host.push_back(bi << 16 | bj);
+  }
+  TileList t{nbi, nbj, tm, tn, lower, dev, nullptr, (int)host.size()};
+  if (host.empty() || hipMalloc(&t.ptr, host.size() * sizeof(int)) != hipSuccess) return nullptr;
+  if (hipMemcpy(t.ptr, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  cache.push_back(t);
+  *ntiles = t.n;
+  return t.ptr;
+}
+
 template <int WM, int WN, int YMODE, int EPI, int KID>
 int launch(GemmArgs& a, hipStream_t st) {
   constexpr int NT = 64 * WM * WN;
@@ -529,13 +584,30 @@ int launch(GemmArgs& a, hipStream_t st) {
   // unbalance the tail (AkA 420 -> 499 ms), so triangular-output launches keep the row-per-XCD map
   if ((YMODE == Y_NT || YMODE == Y_NN) && !(a.tri & TRI_LOWER_ONLY) && a.nbi >= 4 && a.nbj >= 8) a.xcd_map = 2;
   if (force_map >= 0 && !(force_map == 1 && a.nbi < 8)) a.xcd_map = force_map;
+  a.tiles = nullptr; a.ntiles = 0;
+  if (a.batch <= 0) a.batch = 1;
+  const int64_t items = (int64_t)a.nbi * a.nbj * a.batch;
+  // up to a few dozen tiles per CU: the tail of the launch matters -> balanced item list (plain and lower_only NT/NN)
+  if ((YMODE == Y_NT || YMODE == Y_NN) && EPI == EPI_STORE && !(a.tri & (TRI_X_LOWER | TRI_Y_LOWER)) && a.batch <= 64 &&
+      a.nbi * a.nbj >= 64 && items <= 65536 && a.nbi < 32768 && a.nbj < 65536 && force_map < 0) {
+    a.tiles = tile_list(a.nbi, a.nbj, 64 * WM, 64 * WN, (a.tri & TRI_LOWER_ONLY) ? 1 : 0, &a.ntiles);
+    if (!a.tiles) return GEOBO_E_LAUNCH;
+    a.xcd_map = 3;
+  }
   int nblocks = a.nbi * a.nbj;
+  if (a.xcd_map == 3) {
+    const int64_t groups = ((int64_t)a.ntiles * a.batch + 31) / 32;
+    nblocks = (int)(8 * 32 * ((groups + 7) / 8));
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(NT), lds, st, a);
+    return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
+  }
   if (a.xcd_map == 1) nblocks = 8 * ((a.nbi + 7) / 8) * a.nbj;
   if (a.xcd_map == 2) {
-    const int nst = ((a.nbi + 3) / 4) * ((a.nbj + 7) / 8);
+    int nst = ((a.nbi + 3) / 4) * ((a.nbj + 7) / 8);
+    if (a.tri & TRI_X_LOWER) nst = a.nbi * ((a.nbj + 31) / 32);
     nblocks = 8 * 32 * ((nst + 7) / 8);
   }
-  hipLaunchKernelGGL(kern, dim3(nblocks, a.batch > 0 ? a.batch : 1), dim3(NT), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(nblocks, a.batch), dim3(NT), lds, st, a);
   return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
 }
 

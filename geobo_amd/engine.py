@@ -322,7 +322,7 @@ class PosteriorEngine:
             tiles = sum(min(2 * (bi + 1), self.Ms_pad // 128) for bi in range(rows // 256))  # lower-only 256x128 tiles
             # a few hundred long tiles do not fill 256 CUs evenly: split the contraction into concurrent slices
             splits = 1
-            for cand in (4, 2):
+            for cand in ((8, 4, 2) if tiles < 512 else (4, 2)):
                 if nc % (16 * cand) == 0 and nc // cand >= 2048 and tiles < 4096:
                     splits = cand
                     break
