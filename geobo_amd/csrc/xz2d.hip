@@ -1,0 +1,220 @@
+// xz2d.hip -- fused two-axis real-DFT passes of the structured covariance product (DESIGN.md section 3;
+// replaces the dense K_sj blocks of kernels.py:158-195 on the grid of kernels.py:27-42).
+//
+// Every (sensor row, y) plane of the forward operator goes   X (nx x nz)  ->  Gx X Gz^T (2nx x 2nz)   into the (x, z)
+// spectrum, and comes back   S (2nx x 2nz)  ->  Gx^T S Gz (nx x nz)   after the y stage (toeplitz.hip).  As two separate
+// batched GEMMs each pass stores its intermediate to HBM and reloads it, and every small tile pays load -> compute ->
+// store in sequence (measured: 155 ms per 64^3 step, half HBM time and half MFMA time, not overlapped).  Here one
+// persistent workgroup carries a plane through BOTH contractions with the intermediate in registers:
+//
+//   step 1   T[ix][oz] = sum_iz In[ix][iz] Mz[oz][iz]     wave w owns 16*CT output columns oz and ALL rows ix;
+//   step 2   O[ox][oz] = sum_ix Mx[ox][ix] T[ix][oz]      the D fragments of step 1 ARE the B fragments of step 2:
+//            v_mfma_f64_16x16x4 returns D[(lane>>4) + 4 reg][lane & 15] and reads B[k = lane>>4][j = lane & 15], so
+//            register `reg` of row tile rt is k-step (rt, reg) with k <-> ix = 16 rt + 4 reg + (lane>>4)  -- no LDS
+//            round trip, no shuffle; the rows of Mx are stored in LDS in that k order.
+//
+// In streams through a ring of 16-row chunks filled by LDS-DMA three chunks ahead (XOR-swizzled 16-byte slots, b128
+// fragment reads, two k values per read); Mz fragments live in registers, Mx (64 KiB) in LDS, both loaded once per
+// workgroup.  Per plane and wave: 384 MFMAs (64^3) against 64 + 128 LDS reads; HBM traffic is the plane in and the plane
+// out, overlapped with the matrix pipe.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "geobo_hip.h"
+
+namespace {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+struct XZArgs {
+  const double* in; int64_t in_row, in_plane;    // plane (r, p) at in + r*in_row + p*in_plane, IN_X x IN_Z row-major
+  double* out; int64_t out_row, out_plane;       // plane (r, p) at out + r*out_row + p*out_plane, OUT_X x OUT_Z
+  const double* Mz; int64_t ldmz;                // OUT_Z x IN_Z
+  const double* Mx; int64_t ldmx;                // OUT_X x IN_X
+  int ppr;                                       // planes per row
+  int64_t nplanes;
+};
+
+constexpr int RING = 4;  // chunks in the LDS ring (prefetch distance RING-1)
+
+// s_waitcnt immediate for vmcnt(v) only (gfx9 encoding: vmcnt[3:0] | expcnt 7 | lgkmcnt 15 | vmcnt[5:4] << 14)
+constexpr int vmcnt_imm(int v) { return (v & 15) | (7 << 4) | (15 << 8) | ((v >> 4) << 14); }
+
+template <int IN_X, int IN_Z, int OUT_X, int OUT_Z>
+struct XZCfg {
+  static constexpr int CT = OUT_Z / 64;               // column tiles per wave (4 waves)
+  static constexpr int RT1 = IN_X / 16;               // row tiles of T = chunks per plane
+  static constexpr int KP = IN_Z / 8;                 // k-step pairs of step 1 (one b128 read each)
+  static constexpr int RT2 = OUT_X / 16;
+  static constexpr int ROWB = IN_Z * 8;               // bytes per input row
+  static constexpr int CHB = 16 * ROWB;               // bytes per chunk
+  static constexpr int ND = CHB / 1024 / 4;           // DMA instructions per wave per chunk
+  static constexpr int LPR = ROWB / 16;               // lanes (16-byte slots) per row
+  static constexpr int RPI = 64 / LPR;                // rows per DMA instruction
+  static constexpr int MXS = IN_X + 2;                // padded row stride of Mx in LDS (doubles)
+  static constexpr int NS = RT2 * CT * 4;             // stores per wave per plane
+  static constexpr size_t LDS = (size_t)RING * CHB + (size_t)OUT_X * MXS * 8;
+  static_assert(CT >= 1 && OUT_Z % 64 == 0 && IN_X % 16 == 0 && IN_Z % 32 == 0 && IN_Z <= 128 && OUT_X % 16 == 0, "shape");
+  static_assert(ND >= 1 && RT1 >= RING - 1, "chunking");
+};
+
+template <int IN_X, int IN_Z, int OUT_X, int OUT_Z>
+__global__ void __launch_bounds__(256, 1) xz2d_kernel(XZArgs g) {
+  using K = XZCfg<IN_X, IN_Z, OUT_X, OUT_Z>;
+  constexpr int CT = K::CT, RT1 = K::RT1, KP = K::KP, RT2 = K::RT2;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  char* const ring = reinterpret_cast<char*>(smem);
+  double* const mx = smem + RING * K::CHB / 8;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, q = lane >> 4;
+
+  // ---- constants: Mx into LDS in the chained k order, Mz fragments into registers ------------------------------------
+  for (int idx = tid; idx < OUT_X * IN_X; idx += 256) {
+    const int ox = idx / IN_X, ix = idx % IN_X;
+    const int rem = ix & 15;                                  // ix = 16 rt + 4 reg + q  ->  slot 16 rt + 4 q + reg
+    mx[ox * K::MXS + (ix & ~15) + 4 * (rem & 3) + (rem >> 2)] = g.Mx[(int64_t)ox * g.ldmx + ix];
+  }
+  double gz[CT][2 * KP];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int t = 0; t < KP; ++t) {
+      const double* p = g.Mz + (int64_t)(16 * (w * CT + ct) + lr) * g.ldmz + 8 * t + 2 * q;
+      gz[ct][2 * t] = p[0];
+      gz[ct][2 * t + 1] = p[1];
+    }
+
+  // ---- chunk stream: chunk c of plane n -> ring slot (n * RT1 + c) % RING ----------------------------------------------
+  const int64_t first = blockIdx.x, pstep = gridDim.x;
+  if (first >= g.nplanes) return;
+  const int drow = lane / K::LPR, dpos = lane % K::LPR;       // this lane's row / 16-byte slot within a DMA instruction
+  auto plane_ptr = [&](int64_t p) { return g.in + (p / g.ppr) * g.in_row + (p % g.ppr) * g.in_plane; };
+  auto stage = [&](const double* plane, int c, int slot) {
+#pragma unroll
+    for (int j = 0; j < K::ND; ++j) {
+      const int ii = w + 4 * j;                               // DMA instruction index within the chunk (1 KiB each)
+      const int row = ii * K::RPI + drow;                     // row within the chunk
+      const char* src = reinterpret_cast<const char*>(plane) + (int64_t)(16 * c + row) * K::ROWB + ((dpos ^ (row & 7)) << 4);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(ring + slot * K::CHB + ii * 1024), 16, 0, 0);
+    }
+  };
+  // prologue: chunks 0 .. RING-2 of the stream (they all belong to the first plane: RT1 >= RING-1)
+  const double* cur = plane_ptr(first);
+  __syncthreads();                                            // Mx visible
+#pragma unroll
+  for (int c = 0; c < RING - 1; ++c) stage(cur, c, c);
+  int slot0 = 0;                                              // ring slot of chunk 0 of the current plane
+  bool warm = false;                                          // false until a plane's stores have been issued
+  for (int64_t p = first; p < g.nplanes; p += pstep) {
+    const int64_t pn = p + pstep < g.nplanes ? p + pstep : p; // past the end: re-stage the last plane (keeps the counts static)
+    const double* nxt = plane_ptr(pn);
+    v4d d1[RT1][CT];
+#pragma unroll
+    for (int c = 0; c < RT1; ++c) {
+      // (1) this wave's share of chunk c has landed: everything issued after it may still be in flight -- the RING-2
+      //     newer chunks and, for the first RING-1 chunks of a plane, the previous plane's NS stores (vmcnt counts both)
+      if (c <= RING - 2 && warm) {
+        constexpr int n = (RING - 2) * K::ND + K::NS;
+        __builtin_amdgcn_s_waitcnt(vmcnt_imm(n > 63 ? 63 : n));
+      } else {
+        __builtin_amdgcn_s_waitcnt(vmcnt_imm((RING - 2) * K::ND));
+      }
+      __syncthreads();  // (2) every share landed; every wave is done with the chunk staged RING-1 ago
+      {                 // (3) refill the slot that was just released
+        const int cn = c + RING - 1;
+        if (cn < RT1) stage(cur, cn, (slot0 + cn) % RING);
+        else stage(nxt, cn - RT1, (slot0 + cn) % RING);
+      }
+      // (4) step 1 on row tile c
+      const char* xs = ring + ((slot0 + c) % RING) * K::CHB + lr * K::ROWB;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) d1[c][ct] = (v4d){0., 0., 0., 0.};
+#pragma unroll
+      for (int t = 0; t < KP; ++t) {
+        const v2d a = *reinterpret_cast<const v2d*>(xs + (((4 * t + q) ^ (lr & 7)) << 4));
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          d1[c][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, gz[ct][2 * t], d1[c][ct], 0, 0, 0);
+          d1[c][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, gz[ct][2 * t + 1], d1[c][ct], 0, 0, 0);
+        }
+      }
+    }
+    // ---- step 2 + stores, half the output row tiles at a time (register budget) ------------------------------------------
+    double* const op = g.out + (p / g.ppr) * g.out_row + (p % g.ppr) * g.out_plane + 16 * (w * CT) + lr;
+    constexpr int HALF = RT2 >= 2 ? RT2 / 2 : 1;
+#pragma unroll
+    for (int h0 = 0; h0 < RT2; h0 += HALF) {
+      v4d acc[HALF][CT];
+#pragma unroll
+      for (int m = 0; m < HALF; ++m)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[m][ct] = (v4d){0., 0., 0., 0.};
+#pragma unroll
+      for (int rt = 0; rt < RT1; ++rt) {
+#pragma unroll
+        for (int m = 0; m < HALF; ++m) {
+          const double* ap = mx + (16 * (h0 + m) + lr) * K::MXS + 16 * rt + 4 * q;
+          const v2d a01 = *reinterpret_cast<const v2d*>(ap), a23 = *reinterpret_cast<const v2d*>(ap + 2);
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) {
+            acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.x, d1[rt][ct][0], acc[m][ct], 0, 0, 0);
+            acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.y, d1[rt][ct][1], acc[m][ct], 0, 0, 0);
+            acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.x, d1[rt][ct][2], acc[m][ct], 0, 0, 0);
+            acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.y, d1[rt][ct][3], acc[m][ct], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < HALF; ++m)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            op[(int64_t)(16 * (h0 + m) + q + 4 * r) * OUT_Z + 16 * ct] = acc[m][ct][r];
+    }
+    warm = true;
+    slot0 = (slot0 + RT1) % RING;
+    cur = nxt;
+  }
+}
+
+template <int IN_X, int IN_Z, int OUT_X, int OUT_Z>
+int launch(const XZArgs& g, hipStream_t st) {
+  using K = XZCfg<IN_X, IN_Z, OUT_X, OUT_Z>;
+  auto kern = xz2d_kernel<IN_X, IN_Z, OUT_X, OUT_Z>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS) != hipSuccess)
+      return GEOBO_E_LAUNCH;
+    attr_set = true;
+  }
+  int64_t nwg = g.nplanes < 1024 ? g.nplanes : 1024;  // persistent: 4 workgroups per CU over the launch, >= 8 planes each at 64^3
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), K::LDS, st, g);
+  return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" int geobo_xz2d(int inverse, int nx, int nz, int64_t rows, int planes_per_row, const double* in, int64_t in_row,
+                          int64_t in_plane, const double* Mx, int64_t ldmx, const double* Mz, int64_t ldmz, double* out,
+                          int64_t out_row, int64_t out_plane, void* stream) {
+  if (!in || !out || !Mx || !Mz) return GEOBO_E_ARG;
+  if (rows <= 0 || planes_per_row <= 0) return GEOBO_OK;
+  if ((in_row & 1) || (in_plane & 1) || ((uintptr_t)in & 15)) return GEOBO_E_ALIGN;
+  XZArgs g;
+  g.in = in; g.in_row = in_row; g.in_plane = in_plane; g.out = out; g.out_row = out_row; g.out_plane = out_plane;
+  g.Mz = Mz; g.ldmz = ldmz; g.Mx = Mx; g.ldmx = ldmx; g.ppr = planes_per_row; g.nplanes = rows * planes_per_row;
+  hipStream_t st = (hipStream_t)stream;
+  if (nz != 64) return GEOBO_E_UNSUPPORTED;
+  if (!inverse) {
+    if (nx == 64) return launch<64, 64, 128, 128>(g, st);
+    if (nx == 48) return launch<48, 64, 96, 128>(g, st);
+  } else {
+    if (nx == 64) return launch<128, 128, 64, 64>(g, st);
+    if (nx == 48) return launch<96, 128, 48, 64>(g, st);
+  }
+  return GEOBO_E_UNSUPPORTED;
+}

@@ -208,6 +208,17 @@ def scale_broadcast2(a, b0, b1, out0, out1):
                                           _p(out0), _p(out1), _stream()), "geobo_scale_broadcast2")
 
 
+XZ2D_SHAPES = ((48, 64), (64, 64))      # (nx, nz) the fused (x, z) transform kernel is instantiated for
+
+
+def xz2d(inverse, nx, nz, rows, ppr, src, in_row, in_plane, Mx, Mz, out, out_row, out_plane):
+    """Fused two-axis transform of rows*ppr planes (geobo_xz2d): X -> Mx X Mz^T."""
+    lib = require_gpu()
+    _lib.check(lib.geobo_xz2d(1 if inverse else 0, int(nx), int(nz), int(rows), int(ppr), _p(_chk(src, "src")), int(in_row),
+                              int(in_plane), _p(_chk(Mx, "Mx")), int(Mx.stride(0)), _p(_chk(Mz, "Mz")), int(Mz.stride(0)),
+                              _p(_chk(out, "out")), int(out_row), int(out_plane), _stream()), "geobo_xz2d")
+
+
 def toeplitz_y(ny, C, R, src, tabs, outs, y0=0, y1=None):
     """outs[j][r, y - y0, c] = sum_y' tabs[j][|y - y'|, c] * src[r, y', c]  (geobo_toeplitz_y); 1 or 2 property blocks."""
     lib = require_gpu()

@@ -88,6 +88,8 @@ class SpectralProduct:
         # y axis: applied as Toeplitz blocks per (x, z) mode (geobo_toeplitz_y) when the kernel has the extent, else carried
         # through the spectrum like x and z
         self.dense_y = ny in (16, 32, 48, 64) and os.environ.get("GEOBO_SPECTRAL_DENSE_Y", "1") != "0"
+        # x and z: one fused kernel per direction (geobo_xz2d) where it is instantiated, else two batched GEMM passes
+        self.fused_xz = (nx, nz) in hip.XZ2D_SHAPES and os.environ.get("GEOBO_SPECTRAL_FUSED_XZ", "1") != "0"
         if rows_per_batch is None:
             per_row = (ny * self.Px * self.Pz if self.dense_y else self.P3) * 8
             rows_per_batch = max(1, min(256 if self.dense_y else 128, (3 << 30) // per_row))  # ~3 GB per work buffer
@@ -106,8 +108,12 @@ class SpectralProduct:
         """src: R volumes of ny*nx*nz doubles, `src_row_stride` doubles apart (default: contiguous)."""
         nx, ny, nz, Px, Pz = self.nx, self.ny, self.nz, self.Px, self.Pz
         rows = R * ny * nx
-        t1 = self.buf("T1", rows * Pz)
         lds = self.N if src_row_stride is None else int(src_row_stride)
+        if self.fused_xz:
+            t2 = self.buf(out_name, R * ny * Px * Pz)
+            hip.xz2d(False, nx, nz, R, ny, src, lds, nx * nz, M["x"], M["z"], t2, ny * Px * Pz, Px * Pz)
+            return t2
+        t1 = self.buf("T1", rows * Pz)
         hip.gemm_batched(False, hip.pad_n(ny * nx), hip.pad_n(Pz), nz, src, nz, lds, M["z"], nz, 0, t1, Pz, ny * nx * Pz, ny * nx, Pz, R)
         t2 = self.buf(out_name, R * ny * Px * Pz)
         hip.gemm_batched(True, hip.pad_n(Px), hip.pad_n(Pz), nx, M["x"], nx, 0, t1, Pz, nx * Pz, t2, Pz, Px * Pz, Px, Pz, R * ny)
@@ -136,6 +142,11 @@ class SpectralProduct:
         (ya, yb, out, ldo): rows of `out` receive the y-slab [ya, yb) of every row."""
         nx, nz, Px, Pz = self.nx, self.nz, self.Px, self.Pz
         Ly = yhi - ylo
+        if self.fused_xz:
+            for ya, yb, out, ldo in targets:
+                hip.xz2d(True, nx, nz, R, yb - ya, u2[(ya - ylo) * Px * Pz:], Ly * Px * Pz, Px * Pz, self.GT["x"], self.GT["z"],
+                         out, ldo, nx * nz)
+            return
         u1 = self.buf("U1", R * Ly * nx * Pz)
         hip.gemm_batched(True, hip.pad_n(nx), hip.pad_n(Pz), Px, self.GT["x"], Px, 0, u2, Pz, Px * Pz, u1, Pz, nx * Pz, nx, Pz,
                          R * Ly)

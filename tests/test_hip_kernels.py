@@ -284,3 +284,23 @@ def test_toeplitz_y_matches_torch(hip, ny, C, R, nprop, y0, y1):
         T = tabs[j][idx]                                                            # [y][y'][c]
         ref = torch.einsum("ypc,rpc->ryc", T, src)[:, y0:y1]
         assert normwise(outs[j].cpu().numpy(), ref.cpu().numpy()) < 1e-14
+
+
+@pytest.mark.parametrize("nx", [48, 64])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_xz2d_matches_torch(hip, nx, inverse):
+    # fused two-axis transform  X -> Mx X Mz^T  per plane, strided rows (asymmetric random operands)
+    nz, rows, ppr = 64, 3, 37
+    ix, iz, ox, oz = (2 * nx, 2 * nz, nx, nz) if inverse else (nx, nz, 2 * nx, 2 * nz)
+    Mx, Mz = _rand((ox, ix), 21), _rand((oz, iz), 22)
+    in_row = ppr * ix * iz + 16
+    src = _rand((rows, in_row), 23)
+    out_row = ppr * ox * oz + 6
+    out = torch.full((rows, out_row), float("nan"), dtype=torch.float64, device="cuda")
+    hip.xz2d(inverse, nx, nz, rows, ppr, src, in_row, ix * iz, Mx, Mz, out, out_row, ox * oz)
+    torch.cuda.synchronize()
+    X = src[:, :ppr * ix * iz].reshape(rows, ppr, ix, iz)
+    ref = torch.einsum("ai,rpik,bk->rpab", Mx, X, Mz)
+    got = out[:, :ppr * ox * oz].reshape(rows, ppr, ox, oz)
+    assert normwise(got.cpu().numpy(), ref.cpu().numpy()) < 1e-14
+    assert torch.isnan(out[:, ppr * ox * oz:]).all()
