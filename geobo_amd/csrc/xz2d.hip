@@ -13,7 +13,7 @@
 //            register `reg` of row tile rt is k-step (rt, reg) with k <-> ix = 16 rt + 4 reg + (lane>>4)  -- no LDS
 //            round trip, no shuffle; the rows of Mx are stored in LDS in that k order.
 //
-// In streams through a ring of 16-row chunks filled by LDS-DMA three chunks ahead (XOR-swizzled 16-byte slots, b128
+// In streams through a ring of 16-row chunks filled by LDS-DMA three chunks ahead (16-byte slots XOR-swizzled by row & 15 to suit ds_read_b128's lane groups, b128
 // fragment reads, two k values per read); Mz fragments live in registers, Mx (64 KiB) in LDS, both loaded once per
 // workgroup.  Per plane and wave: 384 MFMAs (64^3) against 64 + 128 LDS reads; HBM traffic is the plane in and the plane
 // out, overlapped with the matrix pipe.
@@ -42,40 +42,59 @@ constexpr int RING = 4;  // chunks in the LDS ring (prefetch distance RING-1)
 // s_waitcnt immediate for vmcnt(v) only (gfx9 encoding: vmcnt[3:0] | expcnt 7 | lgkmcnt 15 | vmcnt[5:4] << 14)
 constexpr int vmcnt_imm(int v) { return (v & 15) | (7 << 4) | (15 << 8) | ((v >> 4) << 14); }
 
+constexpr int xz_threads(int out_z) { return out_z / 16 >= 8 ? 512 : 256; }
+
 template <int IN_X, int IN_Z, int OUT_X, int OUT_Z>
 struct XZCfg {
-  static constexpr int CT = OUT_Z / 64;               // column tiles per wave (4 waves)
+  static constexpr int NW = xz_threads(OUT_Z) / 64;    // waves per workgroup: two per SIMD when there are 8 column tiles
+  static constexpr int CT = OUT_Z / 16 / NW;          // column tiles per wave
   static constexpr int RT1 = IN_X / 16;               // row tiles of T = chunks per plane
   static constexpr int KP = IN_Z / 8;                 // k-step pairs of step 1 (one b128 read each)
   static constexpr int RT2 = OUT_X / 16;
   static constexpr int ROWB = IN_Z * 8;               // bytes per input row
   static constexpr int CHB = 16 * ROWB;               // bytes per chunk
-  static constexpr int ND = CHB / 1024 / 4;           // DMA instructions per wave per chunk
+  static constexpr int ND = CHB / 1024 / NW;          // DMA instructions per wave per chunk
   static constexpr int LPR = ROWB / 16;               // lanes (16-byte slots) per row
   static constexpr int RPI = 64 / LPR;                // rows per DMA instruction
-  static constexpr int MXS = IN_X + 2;                // padded row stride of Mx in LDS (doubles)
+  static constexpr int MXS = (IN_X + 31) / 32 * 32;   // row stride of Mx in LDS (doubles): whole blocks of 16 XOR-swizzled 16-byte slots
   static constexpr int NS = RT2 * CT * 4;             // stores per wave per plane
   static constexpr size_t LDS = (size_t)RING * CHB + (size_t)OUT_X * MXS * 8;
-  static_assert(CT >= 1 && OUT_Z % 64 == 0 && IN_X % 16 == 0 && IN_Z % 32 == 0 && IN_Z <= 128 && OUT_X % 16 == 0, "shape");
+  static_assert(CT >= 1 && OUT_Z % (16 * NW) == 0 && CHB % (1024 * NW) == 0 && IN_X % 16 == 0 && IN_Z % 32 == 0 && IN_Z <= 128 && OUT_X % 16 == 0, "shape");
   static_assert(ND >= 1 && RT1 >= RING - 1, "chunking");
 };
 
+// step-1 MFMAs of one chunk; fragment t is consumed once the LDS queue has drained down to the KP-1-t reads behind it.
+// NA partial accumulators per tile (summed by the caller) so that at least four independent MFMA chains interleave:
+// dependent MFMAs on one accumulator do not issue back to back.
+template <int KP, int CT, int NA, int T>
+__device__ __forceinline__ void step1(v2d (&a)[KP], const double (&gz)[CT][2 * KP], v4d (&d)[NA][CT]) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a[T]) : "n"(KP - 1 - T));
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+    d[(2 * T) % NA][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[T].x, gz[ct][2 * T], d[(2 * T) % NA][ct], 0, 0, 0);
+    d[(2 * T + 1) % NA][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[T].y, gz[ct][2 * T + 1], d[(2 * T + 1) % NA][ct], 0, 0, 0);
+  }
+  if constexpr (T + 1 < KP) step1<KP, CT, NA, T + 1>(a, gz, d);
+}
+
 template <int IN_X, int IN_Z, int OUT_X, int OUT_Z>
-__global__ void __launch_bounds__(256, 1) xz2d_kernel(XZArgs g) {
+__global__ void __launch_bounds__(xz_threads(OUT_Z), 1) xz2d_kernel(XZArgs g) {
   using K = XZCfg<IN_X, IN_Z, OUT_X, OUT_Z>;
   constexpr int CT = K::CT, RT1 = K::RT1, KP = K::KP, RT2 = K::RT2;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   char* const ring = reinterpret_cast<char*>(smem);
   double* const mx = smem + RING * K::CHB / 8;
+  const unsigned ring_lds = (unsigned)(uintptr_t)(lds_ptr_t)ring;   // LDS byte address of the ring
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, q = lane >> 4;
 
   // ---- constants: Mx into LDS in the chained k order, Mz fragments into registers ------------------------------------
-  for (int idx = tid; idx < OUT_X * IN_X; idx += 256) {
+  for (int idx = tid; idx < OUT_X * IN_X; idx += 64 * K::NW) {
     const int ox = idx / IN_X, ix = idx % IN_X;
-    const int rem = ix & 15;                                  // ix = 16 rt + 4 reg + q  ->  slot 16 rt + 4 q + reg
-    mx[ox * K::MXS + (ix & ~15) + 4 * (rem & 3) + (rem >> 2)] = g.Mx[(int64_t)ox * g.ldmx + ix];
+    const int rem = ix & 15;                                  // ix = 16 rt + 4 reg + q  ->  position 16 rt + 4 q + reg
+    const int pos = (ix & ~15) + 4 * (rem & 3) + (rem >> 2);
+    mx[ox * K::MXS + ((((pos >> 1) ^ (ox & 15)) << 1) | (pos & 1))] = g.Mx[(int64_t)ox * g.ldmx + ix];
   }
   double gz[CT][2 * KP];
 #pragma unroll
@@ -95,9 +114,9 @@ __global__ void __launch_bounds__(256, 1) xz2d_kernel(XZArgs g) {
   auto stage = [&](const double* plane, int c, int slot) {
 #pragma unroll
     for (int j = 0; j < K::ND; ++j) {
-      const int ii = w + 4 * j;                               // DMA instruction index within the chunk (1 KiB each)
+      const int ii = w + K::NW * j;                           // DMA instruction index within the chunk (1 KiB each)
       const int row = ii * K::RPI + drow;                     // row within the chunk
-      const char* src = reinterpret_cast<const char*>(plane) + (int64_t)(16 * c + row) * K::ROWB + ((dpos ^ (row & 7)) << 4);
+      const char* src = reinterpret_cast<const char*>(plane) + (int64_t)(16 * c + row) * K::ROWB + ((dpos ^ (row & 15)) << 4);
       __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(ring + slot * K::CHB + ii * 1024), 16, 0, 0);
     }
   };
@@ -116,35 +135,52 @@ __global__ void __launch_bounds__(256, 1) xz2d_kernel(XZArgs g) {
     for (int c = 0; c < RT1; ++c) {
       // (1) this wave's share of chunk c has landed: everything issued after it may still be in flight -- the RING-2
       //     newer chunks and, for the first RING-1 chunks of a plane, the previous plane's NS stores (vmcnt counts both)
+#ifndef GEOBO_XZ_ABL_NOWAIT
       if (c <= RING - 2 && warm) {
         constexpr int n = (RING - 2) * K::ND + K::NS;
         __builtin_amdgcn_s_waitcnt(vmcnt_imm(n > 63 ? 63 : n));
       } else {
         __builtin_amdgcn_s_waitcnt(vmcnt_imm((RING - 2) * K::ND));
       }
-      __syncthreads();  // (2) every share landed; every wave is done with the chunk staged RING-1 ago
+#endif
+      // (2) every share landed; every wave is done with the chunk staged RING-1 ago.  A bare s_barrier: __syncthreads()
+      //     adds a fence that drains vmcnt to 0, i.e. waits for the prefetched chunks and the output stores as well.
+#ifndef GEOBO_XZ_ABL_NOBARRIER
+      __builtin_amdgcn_s_barrier();
+#endif
       {                 // (3) refill the slot that was just released
         const int cn = c + RING - 1;
+#ifndef GEOBO_XZ_ABL_NODMA
         if (cn < RT1) stage(cur, cn, (slot0 + cn) % RING);
         else stage(nxt, cn - RT1, (slot0 + cn) % RING);
+#endif
       }
-      // (4) step 1 on row tile c
-      const char* xs = ring + ((slot0 + c) % RING) * K::CHB + lr * K::ROWB;
+      // (4) step 1 on row tile c.  The fragment reads are inline asm: for LDS reads it can see, the compiler waits for
+      //     EVERY outstanding LDS-DMA first (vmcnt(0): it cannot tell ring slots apart), which would collapse the
+      //     three-chunk prefetch to one; the waits that matter are (1) and the lgkmcnt below.
+      const unsigned xs = ring_lds + ((slot0 + c) % RING) * K::CHB + lr * K::ROWB;
+      constexpr int NA = CT >= 2 ? 2 : 4;
+      v4d dd[NA][CT];
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct) d1[c][ct] = (v4d){0., 0., 0., 0.};
+      for (int e = 0; e < NA; ++e)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) dd[e][ct] = (v4d){0., 0., 0., 0.};
+      v2d a[KP];
 #pragma unroll
       for (int t = 0; t < KP; ++t) {
-        const v2d a = *reinterpret_cast<const v2d*>(xs + (((4 * t + q) ^ (lr & 7)) << 4));
+        const unsigned addr = xs + (((4 * t + q) ^ lr) << 4);
+        asm volatile("ds_read_b128 %0, %1" : "=v"(a[t]) : "v"(addr));
+      }
+      step1<KP, CT, NA, 0>(a, gz, dd);
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) {
-          d1[c][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, gz[ct][2 * t], d1[c][ct], 0, 0, 0);
-          d1[c][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, gz[ct][2 * t + 1], d1[c][ct], 0, 0, 0);
-        }
+      for (int ct = 0; ct < CT; ++ct) {
+        if constexpr (NA == 4) d1[c][ct] = (dd[0][ct] + dd[1][ct]) + (dd[2][ct] + dd[3][ct]);
+        else d1[c][ct] = dd[0][ct] + dd[1][ct];
       }
     }
     // ---- step 2 + stores, half the output row tiles at a time (register budget) ------------------------------------------
     double* const op = g.out + (p / g.ppr) * g.out_row + (p % g.ppr) * g.out_plane + 16 * (w * CT) + lr;
-    constexpr int HALF = RT2 >= 2 ? RT2 / 2 : 1;
+    constexpr int HALF = (RT2 * CT > 8 && RT2 % 2 == 0) ? RT2 / 2 : RT2;  // <= 8 accumulator tiles at a time
 #pragma unroll
     for (int h0 = 0; h0 < RT2; h0 += HALF) {
       v4d acc[HALF][CT];
@@ -154,18 +190,23 @@ __global__ void __launch_bounds__(256, 1) xz2d_kernel(XZArgs g) {
         for (int ct = 0; ct < CT; ++ct) acc[m][ct] = (v4d){0., 0., 0., 0.};
 #pragma unroll
       for (int rt = 0; rt < RT1; ++rt) {
+        v2d a01[HALF], a23[HALF];
 #pragma unroll
         for (int m = 0; m < HALF; ++m) {
-          const double* ap = mx + (16 * (h0 + m) + lr) * K::MXS + 16 * rt + 4 * q;
-          const v2d a01 = *reinterpret_cast<const v2d*>(ap), a23 = *reinterpret_cast<const v2d*>(ap + 2);
-#pragma unroll
-          for (int ct = 0; ct < CT; ++ct) {
-            acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.x, d1[rt][ct][0], acc[m][ct], 0, 0, 0);
-            acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a01.y, d1[rt][ct][1], acc[m][ct], 0, 0, 0);
-            acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.x, d1[rt][ct][2], acc[m][ct], 0, 0, 0);
-            acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a23.y, d1[rt][ct][3], acc[m][ct], 0, 0, 0);
-          }
+          // 16-byte slot 8 rt + 2 q (+1), XOR row & 15: the 16 lanes of every ds_read_b128 lane group hit 16 different slots
+          const double* ap = mx + (16 * (h0 + m) + lr) * K::MXS;
+          a01[m] = *reinterpret_cast<const v2d*>(ap + (((8 * rt + 2 * q) ^ lr) << 1));
+          a23[m] = *reinterpret_cast<const v2d*>(ap + (((8 * rt + 2 * q + 1) ^ lr) << 1));
         }
+        // k-step outermost: consecutive MFMAs go to different accumulators (HALF*CT independent chains)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+          for (int m = 0; m < HALF; ++m)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+              acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(kk == 0 ? a01[m].x : kk == 1 ? a01[m].y : kk == 2 ? a23[m].x : a23[m].y,
+                                                                d1[rt][ct][kk], acc[m][ct], 0, 0, 0);
       }
 #pragma unroll
       for (int m = 0; m < HALF; ++m)
@@ -173,6 +214,9 @@ __global__ void __launch_bounds__(256, 1) xz2d_kernel(XZArgs g) {
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
+#ifdef GEOBO_XZ_ABL_NOSTORE
+            if (acc[m][ct][r] == 1.2345e-300)
+#endif
             op[(int64_t)(16 * (h0 + m) + q + 4 * r) * OUT_Z + 16 * ct] = acc[m][ct][r];
     }
     warm = true;
@@ -192,7 +236,7 @@ int launch(const XZArgs& g, hipStream_t st) {
     attr_set = true;
   }
   int64_t nwg = g.nplanes < 1024 ? g.nplanes : 1024;  // persistent: 4 workgroups per CU over the launch, >= 8 planes each at 64^3
-  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), K::LDS, st, g);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * K::NW), K::LDS, st, g);
   return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
 }
 

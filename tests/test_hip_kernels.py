@@ -286,11 +286,12 @@ def test_toeplitz_y_matches_torch(hip, ny, C, R, nprop, y0, y1):
         assert normwise(outs[j].cpu().numpy(), ref.cpu().numpy()) < 1e-14
 
 
-@pytest.mark.parametrize("nx", [48, 64])
+@pytest.mark.parametrize("nx,rows,ppr", [(48, 3, 37), (64, 3, 37), (64, 4, 800), (48, 7, 500)])
 @pytest.mark.parametrize("inverse", [False, True])
-def test_xz2d_matches_torch(hip, nx, inverse):
-    # fused two-axis transform  X -> Mx X Mz^T  per plane, strided rows (asymmetric random operands)
-    nz, rows, ppr = 64, 3, 37
+def test_xz2d_matches_torch(hip, nx, rows, ppr, inverse):
+    # fused two-axis transform  X -> Mx X Mz^T  per plane, strided rows (asymmetric random operands); the large cases give
+    # every persistent workgroup several planes (steady state of the chunk ring, manual vmcnt waits)
+    nz = 64
     ix, iz, ox, oz = (2 * nx, 2 * nz, nx, nz) if inverse else (nx, nz, 2 * nx, 2 * nz)
     Mx, Mz = _rand((ox, ix), 21), _rand((oz, iz), 22)
     in_row = ppr * ix * iz + 16
