@@ -27,8 +27,8 @@ SIGNATURES = {
     "geobo_ak_fused": (_int, [_int, _dp, _i64, _i64, _i64, _dp, _dp, _dp, _i64, _i64, _f64, _f64, _f64, _f64, _dp, _i64, _dp]),
     "geobo_cov_table": (_int, [_int, _int, _int, _int, _f64, _f64, _f64, _f64, _f64, _f64, _f64, _dp, _dp]),
     "geobo_ak_fused_grid": (_int, [_dp, _i64, _i64, _i64, _int, _int, _int, _dp, _i64, _i64, _dp, _i64, _dp]),
-    "geobo_gemm_nt": (_int, [_i64, _i64, _i64, _f64, _dp, _i64, _dp, _i64, _f64, _dp, _i64, _int, _dp]),
-    "geobo_gemm_nt_splitk": (_int, [_i64, _i64, _i64, _int, _dp, _i64, _dp, _i64, _dp, _i64, _int, _dp, _sz, _dp]),
+    "geobo_gemm_nt": (_int, [_i64, _i64, _i64, _f64, _dp, _i64, _dp, _i64, _f64, _dp, _i64, _int, _i64, _dp]),
+    "geobo_gemm_nt_splitk": (_int, [_i64, _i64, _i64, _int, _dp, _i64, _dp, _i64, _dp, _i64, _int, _i64, _dp, _sz, _dp]),
     "geobo_gemm_nn": (_int, [_i64, _i64, _i64, _f64, _dp, _i64, _dp, _i64, _f64, _dp, _i64, _int, _int, _dp]),
     "geobo_gemm_batched": (_int, [_int, _i64, _i64, _i64, _f64, _dp, _i64, _i64, _dp, _i64, _i64, _f64, _dp, _i64, _i64, _i64, _i64, _int, _dp]),
     "geobo_scale_broadcast": (_int, [_dp, _dp, _i64, _i64, _dp, _dp]),
@@ -38,7 +38,7 @@ SIGNATURES = {
     "geobo_potrf_ws_bytes": (_sz, [_i64]),
     "geobo_potrf_inv": (_int, [_i64, _dp, _i64, _dp, _i64, _dp, _dp, _sz, _dp]),
     "geobo_posterior_ws_bytes": (_sz, [_i64, _i64]),
-    "geobo_posterior_reduce": (_int, [_i64, _i64, _dp, _i64, _dp, _i64, _dp, _f64, _dp, _dp, _dp, _sz, _dp]),
+    "geobo_posterior_reduce": (_int, [_i64, _i64, _dp, _i64, _dp, _i64, _dp, _f64, _dp, _dp, _i64, _dp, _sz, _dp]),
     "geobo_trmv_stats": (_int, [_i64, _dp, _i64, _dp, _dp, _i64, _dp, _dp, _dp]),
     "geobo_mfma_f64_peak": (_int, [_int, _int, _dp, _dp]),
     "geobo_mfma_mix": (_int, [_int, _int, _int, _int, _dp, _dp]),

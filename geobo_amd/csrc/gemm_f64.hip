@@ -359,9 +359,23 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_f64_kernel(const GemmArg
         }
       }
       __syncthreads();
+      int s0 = 0, s1 = 1, s2 = 2;  // ring stages of chunk c, c+1, c+2
+      if (YMODE != Y_GEN && row0 + wm * 64 >= a.m_valid) {
+        // This wave's 64 rows lie entirely in the zero padding behind m_valid: it keeps staging its share of the operand
+        // tiles and keeps the barriers, but reads no fragments and issues no MFMAs -- the matrix pipe of its SIMD is left to
+        // the co-resident wave (waves w and w+4 share a SIMD and differ by two 64-row groups), so a tile with 64 or 128
+        // valid rows costs a quarter or half of a full one.  Its accumulators stay zero.
+        for (int64_t k0 = kb; k0 < ke; k0 += BK) {
+          int64_t kn = k0 + 2 * BK;
+          if (kn >= ke) kn = ke - BK;
+          stage_x(kn, s2);
+          stage_y(kn, s2);
+          __syncthreads();
+          const int ts = s0; s0 = s1; s1 = s2; s2 = ts;
+        }
+      } else {
       v2d a0[4], b0[4], a1[4], b1[4];
       read_half(0, 0, a0, b0);
-      int s0 = 0, s1 = 1, s2 = 2;  // ring stages of chunk c, c+1, c+2
       for (int64_t k0 = kb; k0 < ke; k0 += BK) {
         int64_t kn = k0 + 2 * BK;
         if (kn >= ke) kn = ke - BK;
@@ -451,6 +465,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_f64_kernel(const GemmArg
         __syncthreads();
   #endif
         const int ts = s0; s0 = s1; s1 = s2; s2 = ts;
+      }
       }
     }
   }
@@ -657,18 +672,19 @@ extern "C" int geobo_ak_fused_grid(const double* A, int64_t Ms_pad, int64_t N_pa
 
 extern "C" int geobo_gemm_nt(int64_t m, int64_t n, int64_t k, double alpha, const double* X, int64_t ldx,
                              const double* Y, int64_t ldy, double beta, double* C, int64_t ldc, int lower_only,
-                             void* stream) {
+                             int64_t m_valid, void* stream) {
   if (!X || !Y || !C) return GEOBO_E_ARG;
   if (k % BK || (ldx & 1) || (ldy & 1)) return GEOBO_E_ALIGN;
   GemmArgs a{};
   a.X = X; a.ldx = ldx; a.Y = Y; a.ldy = ldy; a.C = C; a.ldc = ldc; a.k = k;
   a.alpha = alpha; a.beta = beta; a.tri = lower_only ? TRI_LOWER_ONLY : 0;
+  a.m_valid = m_valid;
   return launch_by_rows<Y_NT, EPI_STORE, COV_D2>(a, m, n, (hipStream_t)stream);
 }
 
 extern "C" int geobo_gemm_nt_splitk(int64_t m, int64_t n, int64_t k, int splits, const double* X, int64_t ldx, const double* Y,
-                                    int64_t ldy, double* C, int64_t ldc, int lower_only, void* ws, size_t ws_bytes,
-                                    void* stream) {
+                                    int64_t ldy, double* C, int64_t ldc, int lower_only, int64_t m_valid, void* ws,
+                                    size_t ws_bytes, void* stream) {
   if (!X || !Y || !C || !ws || splits < 1 || splits > 64) return GEOBO_E_ARG;
   if (k % (BK * splits) || (ldx & 1) || (ldy & 1) || (ldc & 1) || (n & 1)) return GEOBO_E_ALIGN;
   if (ws_bytes < (size_t)splits * m * n * sizeof(double)) return GEOBO_E_ARG;
@@ -678,6 +694,7 @@ extern "C" int geobo_gemm_nt_splitk(int64_t m, int64_t n, int64_t k, int splits,
   a.X = X; a.ldx = ldx; a.Y = Y; a.ldy = ldy; a.C = (double*)ws; a.ldc = n; a.k = k / splits;
   a.alpha = 1.0; a.beta = 0.0; a.tri = lower_only ? TRI_LOWER_ONLY : 0;
   a.sXb = k / splits; a.sYb = k / splits; a.sCb = m * n; a.batch = splits;
+  a.m_valid = m_valid;
   int rc = launch_by_rows<Y_NT, EPI_STORE, COV_D2>(a, m, n, st);
   if (rc) return rc;
   int64_t nblk = (m * (n / 2) + 255) / 256;
@@ -716,7 +733,7 @@ extern "C" size_t geobo_posterior_ws_bytes(int64_t m, int64_t ncols) {
 
 extern "C" int geobo_posterior_reduce(int64_t m, int64_t ncols, const double* Linv, int64_t ldi, const double* AK,
                                       int64_t ldak, const double* u, double prior_var, double* mu, double* var,
-                                      void* ws, size_t ws_bytes, void* stream) {
+                                      int64_t m_valid, void* ws, size_t ws_bytes, void* stream) {
   if (!Linv || !AK || !u || !mu || !var || !ws) return GEOBO_E_ARG;
   if (m % 128 || ncols % 128 || (ldi & 1) || (ldak & 1)) return GEOBO_E_ALIGN;
   if (ws_bytes < geobo_posterior_ws_bytes(m, ncols)) return GEOBO_E_ARG;
@@ -725,6 +742,7 @@ extern "C" int geobo_posterior_reduce(int64_t m, int64_t ncols, const double* Li
   a.X = Linv; a.ldx = ldi; a.Y = AK; a.ldy = ldak; a.C = nullptr; a.ldc = 0; a.k = m;
   a.alpha = 1.0; a.beta = 0.0; a.tri = TRI_X_LOWER;
   a.u = u; a.ncols = ncols;
+  a.m_valid = m_valid;
   const int nbi_max = (int)((m + 127) / 128);
   a.part_mu = (double*)ws;
   a.part_ss = (double*)ws + (size_t)nbi_max * ncols;

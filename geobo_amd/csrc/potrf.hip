@@ -185,9 +185,9 @@ extern "C" int geobo_potrf_inv(int64_t m, double* A, int64_t ld, double* Linv, i
     const int64_t rem = m - kb - NB;
     if (rem > 0) {
       double* P = A + (kb + NB) * ld + kb;
-      int rc = geobo_gemm_nt(rem, NB, NB, 1.0, P, ld, Linv + kb * ldi + kb, ldi, 0.0, P, ld, 0, stream);
+      int rc = geobo_gemm_nt(rem, NB, NB, 1.0, P, ld, Linv + kb * ldi + kb, ldi, 0.0, P, ld, 0, 0, stream);
       if (rc) return rc;
-      rc = geobo_gemm_nt(rem, rem, NB, -1.0, P, ld, P, ld, 1.0, A + (kb + NB) * ld + (kb + NB), ld, 1, stream);
+      rc = geobo_gemm_nt(rem, rem, NB, -1.0, P, ld, P, ld, 1.0, A + (kb + NB) * ld + (kb + NB), ld, 1, 0, stream);
       if (rc) return rc;
     }
   }

@@ -327,11 +327,14 @@ class PosteriorEngine:
                     splits = cand
                     break
             Xv, Yv, Cv = AK[r0:, jj * nc:(jj + 1) * nc], A[:, self.c0:self.c1], AkA[r0:, r0:r0 + self.Ms_pad]
+            mv = off_d + Md - r0                       # rows behind the last drill row are padding: not contracted
+            # executed flop: lower-only tiles, whole 64-row wavefront groups of the last row tile
+            fl = 2.0 * 128 * nc * sum(min(2 * (bi + 1), self.Ms_pad // 128) * rv for bi, rv in enumerate(hip.tile_rows(rows, mv)))
             if splits > 1:
                 ws = self._workspace("aka_ws", (splits * rows * self.Ms_pad,))
-                self._timed("aka_gemm_nt", 2.0 * 256 * 128 * nc * tiles, lambda: hip.gemm_nt_splitk(Xv, Yv, Cv, splits, ws, lower_only=True))
+                self._timed("aka_gemm_nt", fl, lambda: hip.gemm_nt_splitk(Xv, Yv, Cv, splits, ws, lower_only=True, m_valid=mv))
             else:
-                self._timed("aka_gemm_nt", 2.0 * 256 * 128 * nc * tiles, lambda: hip.gemm_nt(Xv, Yv, Cv, lower_only=True))
+                self._timed("aka_gemm_nt", fl, lambda: hip.gemm_nt(Xv, Yv, Cv, lower_only=True, m_valid=mv))
         allreduce_sum_(AkA, self.world, self.group)
         dvec = torch.ones(M_pad, dtype=F64, device=self.device)
         dvec[0:self.Ms] = float(gp_sigma[0]) ** 2
@@ -384,10 +387,11 @@ class PosteriorEngine:
         else:
             out["logl"] = 0.0
         if want_mean_var:
-            # executed flop: lower-triangular Linv, 256-row tiles -> sum_bi 2*256*(256*(bi+1))*ncols
-            fl = 2.0 * 256 * 256 * AK.shape[1] * sum(bi + 1 for bi in range(M_pad // 256))
+            # executed flop: lower-triangular Linv, 256-row tiles (whole 64-row groups of the valid rows) x 256*(bi+1) deep
+            Mv = 2 * self.Ms_pad + len(sel)
+            fl = 2.0 * 256 * AK.shape[1] * sum(rv * (bi + 1) for bi, rv in enumerate(hip.tile_rows(M_pad, Mv)))
             mu_l, var_l = self._timed("posterior_reduce", fl, lambda: hip.posterior_reduce(
-                Linv, AK, u, gp_amp * 1.0, self._workspace("post_ws", (hip.posterior_ws_doubles(M_pad, AK.shape[1]),))))
+                Linv, AK, u, gp_amp * 1.0, self._workspace("post_ws", (hip.posterior_ws_doubles(M_pad, AK.shape[1]),)), m_valid=Mv))
             t = self._tick("posterior", t)
             mu = assemble_columns(gather_slices(mu_l, len(props), self.N_pad, self.world, self.group), props, self.N,
                                   self.N_pad, self.world)

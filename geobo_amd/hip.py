@@ -142,19 +142,19 @@ def ak_fused_grid(A, nx, ny, nz, table, col0, ncols, out):
     return out
 
 
-def gemm_nt(X, Y, C_, alpha=1.0, beta=0.0, lower_only=False):
-    """C = alpha X Y^T + beta C."""
+def gemm_nt(X, Y, C_, alpha=1.0, beta=0.0, lower_only=False, m_valid=0):
+    """C = alpha X Y^T + beta C.  m_valid > 0: rows >= m_valid of X are zero padding (not contracted, not stored)."""
     lib = require_gpu()
     ldx, ldy, ldc = _rowmajor(X, "X"), _rowmajor(Y, "Y"), _rowmajor(C_, "C")
     m, k = X.shape
     n = Y.shape[0]
     assert Y.shape[1] == k and C_.shape[0] >= m and C_.shape[1] >= n
     _lib.check(lib.geobo_gemm_nt(m, n, k, float(alpha), _p(X), ldx, _p(Y), ldy, float(beta), _p(C_), ldc,
-                                 1 if lower_only else 0, _stream()), "geobo_gemm_nt")
+                                 1 if lower_only else 0, int(m_valid), _stream()), "geobo_gemm_nt")
     return C_
 
 
-def gemm_nt_splitk(X, Y, C_, splits, ws, lower_only=False):
+def gemm_nt_splitk(X, Y, C_, splits, ws, lower_only=False, m_valid=0):
     """C = X Y^T with the contraction split into `splits` concurrent slices (ws: >= splits*m*n doubles)."""
     lib = require_gpu()
     ldx, ldy, ldc = _rowmajor(X, "X"), _rowmajor(Y, "Y"), _rowmajor(C_, "C")
@@ -162,7 +162,7 @@ def gemm_nt_splitk(X, Y, C_, splits, ws, lower_only=False):
     n = Y.shape[0]
     assert Y.shape[1] == k and C_.shape[0] >= m and C_.shape[1] >= n and ws.numel() >= splits * m * n
     _lib.check(lib.geobo_gemm_nt_splitk(m, n, k, int(splits), _p(X), ldx, _p(Y), ldy, _p(C_), ldc, 1 if lower_only else 0,
-                                        _p(ws), ws.numel() * 8, _stream()), "geobo_gemm_nt_splitk")
+                                        int(m_valid), _p(ws), ws.numel() * 8, _stream()), "geobo_gemm_nt_splitk")
     return C_
 
 
@@ -219,6 +219,17 @@ def xz2d(inverse, nx, nz, rows, ppr, src, in_row, in_plane, Mx, Mz, out, out_row
                               _p(_chk(out, "out")), int(out_row), int(out_plane), _stream()), "geobo_xz2d")
 
 
+def tile_rows(m, m_valid, tile=256, group=64):
+    """Rows of each `tile`-row tile that take part in the contraction when rows >= m_valid are padding: whole `group`-row
+    wavefront groups (flop accounting of the m_valid argument of geobo_gemm_nt / geobo_posterior_reduce)."""
+    m_valid = m if not m_valid or m_valid > m else m_valid
+    out = []
+    for r0 in range(0, m, tile):
+        v = min(max(m_valid - r0, 0), tile)
+        out.append((v + group - 1) // group * group)
+    return out
+
+
 def toeplitz_y(ny, C, R, src, tabs, outs, y0=0, y1=None):
     """outs[j][r, y - y0, c] = sum_y' tabs[j][|y - y'|, c] * src[r, y', c]  (geobo_toeplitz_y); 1 or 2 property blocks."""
     lib = require_gpu()
@@ -266,7 +277,7 @@ def posterior_ws_doubles(m, ncols):
     return max(_lib.load().geobo_posterior_ws_bytes(int(m), int(ncols)) // 8, 1)
 
 
-def posterior_reduce(Linv, AK, u, prior_var, ws=None):
+def posterior_reduce(Linv, AK, u, prior_var, ws=None, m_valid=0):
     """mu[c] = sum_m (Linv AK)[m,c] u[m],  var[c] = prior_var - sum_m (Linv AK)[m,c]^2 (V never stored)."""
     lib = require_gpu()
     m, ncols = AK.shape
@@ -276,7 +287,8 @@ def posterior_reduce(Linv, AK, u, prior_var, ws=None):
     if ws is None or ws.numel() * 8 < nbytes:
         ws = torch.empty(max(nbytes // 8, 1), dtype=F64, device=AK.device)
     _lib.check(lib.geobo_posterior_reduce(m, ncols, _p(Linv), _rowmajor(Linv, "Linv"), _p(AK), _rowmajor(AK, "AK"),
-                                          _p(_chk(u, "u")), float(prior_var), _p(mu), _p(var), _p(ws), nbytes, _stream()),
+                                          _p(_chk(u, "u")), float(prior_var), _p(mu), _p(var), int(m_valid), _p(ws), nbytes,
+                                          _stream()),
                "geobo_posterior_reduce")
     return mu, var
 

@@ -111,15 +111,19 @@ int geobo_ak_fused_grid(const double* A, int64_t Ms_pad, int64_t N_pad, int64_t 
 
 /* C = alpha * X * Y^T + beta * C   (X: m x k, Y: n x k, both k-contiguous).  inversion.py:96 (AkA = (A K) A^T),
  * Cholesky panel/trailing updates.  m % 256 == 0, n % 128 == 0, k % 16 == 0.
- * lower_only != 0: tiles strictly above the diagonal are skipped (SYRK-style). */
+ * lower_only != 0: tiles strictly above the diagonal are skipped (SYRK-style).
+ * m_valid > 0: rows >= m_valid of X are zero padding -- they are neither contracted (64-row groups that lie entirely in
+ * the padding issue no MFMAs) nor stored (those rows of C are left untouched); 0 = all m rows. */
 int geobo_gemm_nt(int64_t m, int64_t n, int64_t k, double alpha, const double* X, int64_t ldx,
-                  const double* Y, int64_t ldy, double beta, double* C, int64_t ldc, int lower_only, void* stream);
+                  const double* Y, int64_t ldy, double beta, double* C, int64_t ldc, int lower_only, int64_t m_valid,
+                  void* stream);
 
 /* C = X * Y^T with the contraction split into `splits` slices that run concurrently (more, shorter workgroups: fills the
  * chip when m/256 * n/128 is only a few hundred tiles, as in AkA) and are summed in fixed order afterwards (deterministic).
- * ws: splits * m * n doubles.  k % (16 * splits) == 0. */
+ * ws: splits * m * n doubles.  k % (16 * splits) == 0.  m_valid as in geobo_gemm_nt (rows >= m_valid of C become 0). */
 int geobo_gemm_nt_splitk(int64_t m, int64_t n, int64_t k, int splits, const double* X, int64_t ldx, const double* Y,
-                         int64_t ldy, double* C, int64_t ldc, int lower_only, void* ws, size_t ws_bytes, void* stream);
+                         int64_t ldy, double* C, int64_t ldc, int lower_only, int64_t m_valid, void* ws, size_t ws_bytes,
+                         void* stream);
 
 /* C = alpha * X * Y + beta * C      (X: m x k k-contiguous, Y: k x n n-contiguous).
  * x_lower != 0: X is lower triangular (k range clipped to k < row_end of each tile);
@@ -173,11 +177,13 @@ int geobo_potrf_inv(int64_t m, double* A, int64_t ld, double* Linv, int64_t ldi,
 
 /* Posterior mean/variance without storing V = L^-1 (A K)   (inversion.py:114-117 + :238's np.diag):
  *     V = Linv * AK (tile by tile, MFMA),  mu[c] = sum_m V[m,c] u[m],  var[c] = prior_var - sum_m V[m,c]^2
- * AK: (m x ncols, ldak); u: m; ws: geobo_posterior_ws_bytes(m, ncols). m % 256 == 0, ncols % 128 == 0. */
+ * AK: (m x ncols, ldak); u: m; ws: geobo_posterior_ws_bytes(m, ncols). m % 256 == 0, ncols % 128 == 0.
+ * m_valid > 0: rows >= m_valid are padding (identity rows of Linv over zero rows of AK, so V = 0 there): their 64-row
+ * groups are skipped; 0 = all rows. */
 size_t geobo_posterior_ws_bytes(int64_t m, int64_t ncols);
 int geobo_posterior_reduce(int64_t m, int64_t ncols, const double* Linv, int64_t ldi, const double* AK, int64_t ldak,
-                           const double* u, double prior_var, double* mu, double* var, void* ws, size_t ws_bytes,
-                           void* stream);
+                           const double* u, double prior_var, double* mu, double* var, int64_t m_valid, void* ws,
+                           size_t ws_bytes, void* stream);
 
 /* u = Linv * y (lower-triangular mat-vec, wavefront shuffle reduction); also
  * stats[0] = u.u, stats[1] = sum_i log(L_ii^2)   (inversion.py:105-110).  Ldiag = L (m x m, ld). */

@@ -53,7 +53,7 @@ def test_argument_validation_without_gpu(lib):
     """Entry points validate before touching the device: null pointers / misaligned dims give error codes."""
     from geobo_amd import _lib
     L = _lib.load()
-    assert L.geobo_gemm_nt(256, 128, 16, 1.0, None, 16, None, 16, 0.0, None, 128, 0, None) == -1
+    assert L.geobo_gemm_nt(256, 128, 16, 1.0, None, 16, None, 16, 0.0, None, 128, 0, 0, None) == -1
     assert L.geobo_ak_fused(1, None, 256, 256, 256, None, None, None, 0, 128, 1., 1., 1., 1., None, 128, None) == -1
     assert L.geobo_potrf_inv(100, None, 100, None, 100, None, None, 0, None) == -1
 

@@ -305,3 +305,39 @@ def test_xz2d_matches_torch(hip, nx, rows, ppr, inverse):
     got = out[:, :ppr * ox * oz].reshape(rows, ppr, ox, oz)
     assert normwise(got.cpu().numpy(), ref.cpu().numpy()) < 1e-14
     assert torch.isnan(out[:, ppr * ox * oz:]).all()
+
+
+@pytest.mark.parametrize("m_valid", [50, 64, 130, 256, 300])
+def test_gemm_nt_m_valid_skips_padding_rows(hip, m_valid):
+    # rows >= m_valid of X are zero padding: valid rows are unchanged, rows behind them are neither computed nor stored
+    m, n, k = 512, 256, 160
+    X, Y = _rand((m, k), 31), _rand((n, k), 32)
+    X[m_valid:] = 0.0
+    C = torch.full((m, n), 7.0, dtype=torch.float64, device="cuda")
+    hip.gemm_nt(X, Y, C, m_valid=m_valid)
+    ref = X @ Y.t()
+    assert normwise(C[:m_valid].cpu().numpy(), ref[:m_valid].cpu().numpy()) < 1e-14
+    assert (C[m_valid:] == 7.0).all()
+    ws = torch.empty(2 * m * n, dtype=torch.float64, device="cuda")
+    C2 = torch.full((m, n), 7.0, dtype=torch.float64, device="cuda")
+    hip.gemm_nt_splitk(X, Y, C2, 2, ws, m_valid=m_valid)
+    assert normwise(C2[:m_valid].cpu().numpy(), ref[:m_valid].cpu().numpy()) < 1e-14
+    assert (C2[m_valid:] == 0.0).all()
+
+
+def test_posterior_reduce_m_valid(hip):
+    m, ncols, mv = 768, 256, 530
+    g = torch.Generator().manual_seed(5)
+    Linv = torch.tril(torch.rand((m, m), generator=g, dtype=torch.float64)).cuda()
+    Linv[mv:] = 0.0
+    Linv[:, mv:] = 0.0
+    Linv[range(mv, m), range(mv, m)] = 1.0                   # identity on the padding, like the factor of a padded AkA
+    AK = _rand((m, ncols), 41)
+    AK[mv:] = 0.0
+    u = _rand((m,), 42)
+    mu0, var0 = hip.posterior_reduce(Linv, AK, u, 1.5)
+    mu1, var1 = hip.posterior_reduce(Linv, AK, u, 1.5, m_valid=mv)
+    V = Linv @ AK
+    assert normwise(mu1.cpu().numpy(), (V.t() @ u).cpu().numpy()) < 1e-13
+    assert normwise(var1.cpu().numpy(), (1.5 - (V * V).sum(0)).cpu().numpy()) < 1e-13
+    assert torch.equal(mu0, mu1) and torch.equal(var0, var1)
