@@ -364,3 +364,33 @@ def test_row_sharded_exchange_matches_dense_columns():
         rows = np.r_[0:e.Ms, e.Ms_pad:e.Ms_pad + e.Ms]
         diff = (AK[rows] - ref[rows]).abs().max().item()
         assert diff <= 1e-12 * ref.abs().max().item(), (r, diff)
+
+
+@pytest.mark.parametrize("dims", [(48, 32, 64), (64, 48, 64), (32, 16, 64), (16, 80, 16), (64, 64, 64)])
+@pytest.mark.parametrize("kern,cross", [("matern32", True), ("sparse", False)])
+def test_spectral_product_matches_lattice_contraction_on_non_cubic_grids(dims, kern, cross):
+    """Every kernel combination of the spectral route against the dense lattice-table contraction (geobo_ak_fused_grid) on
+    random operator rows: fused (x,z) transform for nx = 48 / 64 with nz = 64, batched-GEMM passes otherwise; Toeplitz y
+    stage for ny <= 64, y through the spectrum for ny = 80; one and two property blocks per sweep."""
+    from geobo_amd import hip
+    from geobo_amd.spectral import SpectralProduct
+    nx, ny, nz = dims
+    N = nx * ny * nz
+    rows = 256
+    g = torch.Generator().manual_seed(nx * 7 + ny)
+    A = torch.zeros((rows, N + 16), dtype=torch.float64, device="cuda")[:, :N]
+    A[:37] = (torch.rand((37, N), generator=g, dtype=torch.float64) * 2 - 1).cuda()
+    sp = SpectralProduct(nx, ny, nz, "cuda")
+    assert sp.fused_xz == ((nx, nz) in ((48, 64), (64, 64))) and sp.dense_y == (ny <= 64)
+    kid = hip.kernel_id(kern, cross)
+    tabs = [hip.cov_table(kid, nx, ny, nz, 100.0, 90.0, 110.0, l1, l2, w, 1.3, "cuda")
+            for l1, l2, w in ((210.0, 170.0, 0.7), (260.0, 240.0, 1.0), (150.0, 300.0, 0.4))]
+    for nblk in (1, 2, 3):
+        outs = [torch.full((rows, N), float("nan"), dtype=torch.float64, device="cuda") for _ in range(nblk)]
+        sp.product(A, 37, [sp.eigenvalues(t) for t in tabs[:nblk]], outs)
+        for j in range(nblk):
+            ref = torch.empty((rows, N), dtype=torch.float64, device="cuda")
+            hip.ak_fused_grid(A, nx, ny, nz, tabs[j], 0, N, ref)
+            d = (outs[j][:37] - ref[:37]).abs().max().item()
+            assert d <= 2e-13 * ref[:37].abs().max().item(), (nblk, j, d)
+            assert torch.isnan(outs[j][37:]).all()
