@@ -61,6 +61,10 @@ def load():
         raise GeoboHipUnavailable(
             "%s not found. Build the HIP extension first: `python -m geobo_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for the inversion hot path." % LIB_PATH)
+    # torch first, always: its wheel bundles the HIP runtime (libamdhip64.so.7) that owns the device allocations and the
+    # stream this library is handed.  Loaded the other way round, this library pulls in /opt/rocm's copy under the same
+    # soname, torch then runs on a runtime it was not built against and the first kernel launch here fails.
+    import torch  # noqa: F401
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:

@@ -394,3 +394,13 @@ def test_spectral_product_matches_lattice_contraction_on_non_cubic_grids(dims, k
             d = (outs[j][:37] - ref[:37]).abs().max().item()
             assert d <= 2e-13 * ref[:37].abs().max().item(), (nblk, j, d)
             assert torch.isnan(outs[j][37:]).all()
+
+
+def test_graft_entry_build_then_smoke_in_one_process():
+    """build() loads the C-ABI library before anything touched the GPU; smoke() must still run in the same process (the
+    library has to come up on the HIP runtime bundled with torch -- geobo_amd/_lib.py imports torch first)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke(); print('OK')"], cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
