@@ -5,6 +5,7 @@ Tiers (hard part 1):
   T3 end to end      -- operators built on the device too: <= 1e-8 normwise per cube (north-star tolerance)
 """
 import json
+import os
 
 import numpy as np
 import pytest
