@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_f64_kernel(const GemmArg
   const double* const Xp = a.X + (int64_t)batch_idx * a.sXb;
   const double* const Yp = a.Y + (int64_t)batch_idx * a.sYb;
   double* const Cp = a.C + (int64_t)batch_idx * a.sCb;
-  if (a.tri & TRI_X_LOWER) bi = a.nbi - 1 - bi;  // triangular X: the longest contraction ranges are dispatched first
+  if ((a.tri & TRI_X_LOWER) && a.xcd_map != 3) bi = a.nbi - 1 - bi;  // triangular X: the longest contraction ranges are dispatched first
   const int64_t row0 = (int64_t)bi * TM, col0 = (int64_t)bj * TN;
   if ((a.tri & TRI_LOWER_ONLY) && col0 >= row0 + TM) return;
   int64_t kb = (a.tri & TRI_Y_LOWER) ? col0 : 0;
@@ -556,23 +556,39 @@ __global__ void posterior_finish_kernel(const double* part_mu, const double* par
 // the lower triangle), enumerated in bands of four row tiles, column-major inside a band, so that 32 consecutive entries
 // form a 4 x 8 supertile (4 X panels + 8 Y panels per XCD L2) and every dispatched workgroup has a full tile of work.
 // Built once per shape, kept on the device.
-struct TileList { int nbi, nbj, tm, tn, lower, dev; int* ptr; int n; };
-const int* tile_list(int nbi, int nbj, int tm, int tn, int lower, int* ntiles) {
+struct TileList { int nbi, nbj, tm, tn, tri, dev; int64_t k; int* ptr; int n; };
+const int* tile_list(int nbi, int nbj, int tm, int tn, int tri, int64_t k, int* ntiles) {
   static std::mutex mu;
   static std::vector<TileList> cache;
   std::lock_guard<std::mutex> lock(mu);
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  const bool weighted = tri & (TRI_X_LOWER | TRI_Y_LOWER);
+  if (!weighted) k = 0;
   for (const TileList& t : cache)
-    if (t.nbi == nbi && t.nbj == nbj && t.tm == tm && t.tn == tn && t.lower == lower && t.dev == dev) { *ntiles = t.n; return t.ptr; }
+    if (t.nbi == nbi && t.nbj == nbj && t.tm == tm && t.tn == tn && t.tri == tri && t.k == k && t.dev == dev) { *ntiles = t.n; return t.ptr; }
   std::vector<int> host;
-  for (int band = 0; band * 4 < nbi; ++band) {
-    const int r0 = band * 4, r1 = std::min(r0 + 4, nbi);
-    for (int bj = 0; bj < nbj; ++bj)
-      for (int bi = r0; bi < r1; ++bi)
-        if (!lower || (int64_t)bj * tn < (int64_t)bi * tm + tm) host.push_back(bi << 16 | bj);
+  if (weighted) {
+    // triangular operands: the contraction range of tile (bi, bj) is [y_lower ? col0 : 0, x_lower ? row0 + tm : k).
+    // Longest first, equal lengths adjacent (they run together: same k sweep, shared panel in the XCD's L2).
+    std::vector<std::pair<int64_t, int>> w;
+    for (int bi = 0; bi < nbi; ++bi)
+      for (int bj = 0; bj < nbj; ++bj) {
+        const int64_t kb = (tri & TRI_Y_LOWER) ? (int64_t)bj * tn : 0;
+        const int64_t ke = (tri & TRI_X_LOWER) ? std::min<int64_t>(k, (int64_t)bi * tm + tm) : k;
+        w.push_back({std::max<int64_t>(ke - kb, 0), bi << 16 | bj});
+      }
+    std::stable_sort(w.begin(), w.end(), [](const std::pair<int64_t, int>& a, const std::pair<int64_t, int>& b) { return a.first > b.first; });
+    for (const auto& e : w) host.push_back(e.second);
+  } else {
+    for (int band = 0; band * 4 < nbi; ++band) {
+      const int r0 = band * 4, r1 = std::min(r0 + 4, nbi);
+      for (int bj = 0; bj < nbj; ++bj)
+        for (int bi = r0; bi < r1; ++bi)
+          if (!(tri & TRI_LOWER_ONLY) || (int64_t)bj * tn < (int64_t)bi * tm + tm) host.push_back(bi << 16 | bj);
+    }
   }
-  TileList t{nbi, nbj, tm, tn, lower, dev, nullptr, (int)host.size()};
+  TileList t{nbi, nbj, tm, tn, tri, dev, k, nullptr, (int)host.size()};
   if (host.empty() || hipMalloc(&t.ptr, host.size() * sizeof(int)) != hipSuccess) return nullptr;
   if (hipMemcpy(t.ptr, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
   cache.push_back(t);
@@ -603,9 +619,11 @@ int launch(GemmArgs& a, hipStream_t st) {
   if (a.batch <= 0) a.batch = 1;
   const int64_t items = (int64_t)a.nbi * a.nbj * a.batch;
   // up to a few dozen tiles per CU: the tail of the launch matters -> balanced item list (plain and lower_only NT/NN)
-  if ((YMODE == Y_NT || YMODE == Y_NN) && EPI == EPI_STORE && !(a.tri & (TRI_X_LOWER | TRI_Y_LOWER)) && a.batch <= 64 &&
-      a.nbi * a.nbj >= 64 && items <= 65536 && a.nbi < 32768 && a.nbj < 65536 && force_map < 0) {
-    a.tiles = tile_list(a.nbi, a.nbj, 64 * WM, 64 * WN, (a.tri & TRI_LOWER_ONLY) ? 1 : 0, &a.ntiles);
+  // (also the triangular-operand merges of the L^-1 build: longest contraction ranges first, equal lengths together)
+  if ((YMODE == Y_NT || YMODE == Y_NN) && EPI == EPI_STORE && a.batch <= 64 &&
+      a.nbi * a.nbj >= ((a.tri & (TRI_X_LOWER | TRI_Y_LOWER)) ? 16 : 64) && items <= 65536 && a.nbi < 32768 && a.nbj < 65536 &&
+      force_map < 0) {
+    a.tiles = tile_list(a.nbi, a.nbj, 64 * WM, 64 * WN, a.tri, a.k, &a.ntiles);
     if (!a.tiles) return GEOBO_E_LAUNCH;
     a.xcd_map = 3;
   }

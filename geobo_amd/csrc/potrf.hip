@@ -145,20 +145,64 @@ __global__ void __launch_bounds__(256) logl_stats_kernel(int64_t m, const double
   if (tid == 0) { stats[0] = s0[0]; stats[1] = s1[0]; }
 }
 
-int build_inverse(int lo, int hi, const double* L, int64_t ld, double* Linv, int64_t ldi, double* T, void* st) {
+// L^-1 by recursive halving.  The two halves of a node are independent until their merge, and the merges near the
+// leaves are a handful of tiles each (latency of ONE tile's k sweep, 0.2-0.5 ms, whatever the chip could do in
+// parallel): the top two levels of the tree fork onto internal streams, so four subtrees run concurrently, and join by
+// events before their parent's merge.  Everything is ordered after / before the caller's stream by the same events.
+struct InvCtx {
+  const double* L; int64_t ld; double* Linv; int64_t ldi; double* ws; size_t ws_doubles;
+  hipStream_t s[4]; hipEvent_t ev[6]; int nev;
+};
+
+int build_inverse(InvCtx& c, int lo, int hi, int depth, int sidx) {
   if (hi - lo <= 1) return GEOBO_OK;
-  const int mid = (lo + hi) / 2;
-  int rc = build_inverse(lo, mid, L, ld, Linv, ldi, T, st);
-  if (rc) return rc;
-  rc = build_inverse(mid, hi, L, ld, Linv, ldi, T, st);
-  if (rc) return rc;
-  const int64_t r = (int64_t)(hi - mid) * NB, c = (int64_t)(mid - lo) * NB;
+  // split on a multiple of two 128-blocks where possible: the merge GEMMs then run on 256-row tiles
+  int mid = (lo + hi) / 2;
+  if (hi - lo > 2 && ((mid - lo) & 1)) ++mid;
+  int rc;
+  if (depth < 2 && hi - lo >= 8) {
+    const int other = sidx + (depth == 0 ? 2 : 1);
+    hipEvent_t fork = c.ev[c.nev++], join = c.ev[c.nev++];
+    if (hipEventRecord(fork, c.s[sidx]) != hipSuccess || hipStreamWaitEvent(c.s[other], fork, 0) != hipSuccess) return GEOBO_E_LAUNCH;
+    rc = build_inverse(c, lo, mid, depth + 1, sidx);
+    if (rc) return rc;
+    rc = build_inverse(c, mid, hi, depth + 1, other);
+    if (rc) return rc;
+    if (hipEventRecord(join, c.s[other]) != hipSuccess || hipStreamWaitEvent(c.s[sidx], join, 0) != hipSuccess) return GEOBO_E_LAUNCH;
+  } else {
+    rc = build_inverse(c, lo, mid, depth + 1, sidx);
+    if (rc) return rc;
+    rc = build_inverse(c, mid, hi, depth + 1, sidx);
+    if (rc) return rc;
+  }
+  // scratch for T: the root owns the whole workspace, its children a half each, everything below a quarter per stream
+  double* T = depth == 0 ? c.ws : depth == 1 ? c.ws + (sidx / 2) * (c.ws_doubles / 2) : c.ws + sidx * (c.ws_doubles / 4);
+  void* st = c.s[sidx];
+  const int64_t r = (int64_t)(hi - mid) * NB, cc = (int64_t)(mid - lo) * NB;
   const int64_t o_lo = (int64_t)lo * NB, o_mid = (int64_t)mid * NB;
   // T = L[mid:hi, lo:mid] * Linv[lo:mid, lo:mid]           (Y lower triangular)
-  rc = geobo_gemm_nn(r, c, c, 1.0, L + o_mid * ld + o_lo, ld, Linv + o_lo * ldi + o_lo, ldi, 0.0, T, c, 0, 1, st);
+  rc = geobo_gemm_nn(r, cc, cc, 1.0, c.L + o_mid * c.ld + o_lo, c.ld, c.Linv + o_lo * c.ldi + o_lo, c.ldi, 0.0, T, cc, 0, 1, st);
   if (rc) return rc;
   // Linv[mid:hi, lo:mid] = -Linv[mid:hi, mid:hi] * T         (X lower triangular)
-  return geobo_gemm_nn(r, c, r, -1.0, Linv + o_mid * ldi + o_mid, ldi, T, c, 0.0, Linv + o_mid * ldi + o_lo, ldi, 1, 0, st);
+  return geobo_gemm_nn(r, cc, r, -1.0, c.Linv + o_mid * c.ldi + o_mid, c.ldi, T, cc, 0.0, c.Linv + o_mid * c.ldi + o_lo, c.ldi, 1, 0, st);
+}
+
+// internal fork streams / events, created on first use (per process; the caller's stream is never replaced)
+bool inverse_streams(InvCtx& c) {
+  static hipStream_t s[3];
+  static hipEvent_t ev[6];
+  static bool ok = false;
+  if (!ok) {
+    for (int i = 0; i < 3; ++i)
+      if (hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking) != hipSuccess) return false;
+    for (int i = 0; i < 6; ++i)
+      if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return false;
+    ok = true;
+  }
+  for (int i = 0; i < 3; ++i) c.s[i + 1] = s[i];
+  for (int i = 0; i < 6; ++i) c.ev[i] = ev[i];
+  c.nev = 0;
+  return true;
 }
 
 }  // namespace
@@ -191,7 +235,11 @@ extern "C" int geobo_potrf_inv(int64_t m, double* A, int64_t ld, double* Linv, i
       if (rc) return rc;
     }
   }
-  return build_inverse(0, (int)(m / NB), A, ld, Linv, ldi, (double*)ws, stream);
+  InvCtx c;
+  c.L = A; c.ld = ld; c.Linv = Linv; c.ldi = ldi; c.ws = (double*)ws; c.ws_doubles = geobo_potrf_ws_bytes(m) / sizeof(double);
+  c.s[0] = st;
+  if (!inverse_streams(c)) return GEOBO_E_LAUNCH;
+  return build_inverse(c, 0, (int)(m / NB), 0, 0);
 }
 
 extern "C" int geobo_trmv_stats(int64_t m, const double* Linv, int64_t ldi, const double* y, const double* L,

@@ -202,7 +202,7 @@ def test_ak_fused_grid_matches_coordinate_path(hip, name, cross, dims):
     assert np.array_equal(sh.cpu().numpy(), got.cpu().numpy()[:, Np - 128:])
 
 
-@pytest.mark.parametrize("m", [256, 512, 1280])
+@pytest.mark.parametrize("m", [256, 512, 1280, 2304, 4224])   # 2304 / 4224: both fork levels of the concurrent L^-1 build
 def test_potrf_inv_matches_torch(hip, m):
     B = _rand((m, m), 20)
     S = B @ B.t() / m + 0.05 * torch.eye(m, dtype=torch.float64, device="cuda")
