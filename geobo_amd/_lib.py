@@ -33,6 +33,9 @@ SIGNATURES = {
     "geobo_gemm_batched": (_int, [_int, _i64, _i64, _i64, _f64, _dp, _i64, _i64, _dp, _i64, _i64, _f64, _dp, _i64, _i64, _i64, _i64, _int, _dp]),
     "geobo_scale_broadcast": (_int, [_dp, _dp, _i64, _i64, _dp, _dp]),
     "geobo_scale_broadcast2": (_int, [_dp, _dp, _dp, _i64, _i64, _dp, _dp, _dp]),
+    "geobo_a_sens_lattice_ws_bytes": (_sz, [_int, _int, _int]),
+    "geobo_a_sens_lattice": (_int, [_int, C.POINTER(_f64), _i64, _int, _int, _int, _dp, _dp, _dp, _dp, _dp, _f64, _f64, _int, _int, _dp, _i64,
+                                    _dp, _sz, _dp]),
     "geobo_xz2d": (_int, [_int, _int, _int, _i64, _int, _dp, _i64, _i64, _dp, _i64, _dp, _i64, _dp, _i64, _i64, _dp]),
     "geobo_toeplitz_y": (_int, [_int, _i64, _i64, _int, _dp, _dp, _dp, _dp, _dp, _int, _int, _dp]),
     "geobo_potrf_ws_bytes": (_sz, [_i64]),

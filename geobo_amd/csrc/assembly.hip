@@ -154,6 +154,56 @@ __global__ void __launch_bounds__(512) a_sens_kernel(const SensArgs a) {
   }
 }
 
+// ---- lattice form of A_sens ---------------------------------------------------------------------------------------------
+// Sensors on a lattice commensurate with the voxel columns (the survey resampled to the cube's x-y grid, the reference's own
+// workflow): the node offsets xe[j] - sx depend on j - jx_s only, so away from the +-1e6-padded planes iy = 0 and ny the
+// 8-corner stencil is translation invariant.  P: potentials on the offset lattice (~(2ny)(2nx)(nz+1) evaluations instead of
+// Ms (ny+1)(nx+1)(nz+1)); Q: the stencil of P, i.e. the operator entry for voxel-offset (ddy, ddx, k); every (sensor, iy) slab
+// of A is then one contiguous copy out of Q.  Same expressions and evaluation order as a_sens_kernel (the caller verifies
+// that the offsets are bit-identical for every pair), so the result is identical.
+template <int FUNC>
+__global__ void __launch_bounds__(256) lattice_potential_kernel(const double* __restrict__ dxv, int ndx, const double* __restrict__ dyv,
+                                                                int ndy, const double* __restrict__ dzv, int ndz, double bx, double by,
+                                                                double bz, double inv_norm_b, double* __restrict__ P) {
+#pragma clang fp contract(off)
+  const int64_t n = (int64_t)ndy * ndx * ndz;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) {
+    const int k = (int)(t % ndz);
+    const int64_t r = t / ndz;
+    const int j = (int)(r % ndx), i = (int)(r / ndx);
+    P[t] = (FUNC == GEOBO_F_GRAV) ? grav_potential(dxv[j], dyv[i], dzv[k]) : magn_potential(dxv[j], dyv[i], dzv[k], bx, by, bz, inv_norm_b);
+  }
+}
+
+__global__ void __launch_bounds__(256) lattice_stencil_kernel(const double* __restrict__ P, int ndx, int ndz, int nqy, int nqx, int nz,
+                                                              double scale_mul, double scale_div, double* __restrict__ Q) {
+#pragma clang fp contract(off)
+  const int64_t n = (int64_t)nqy * nqx * nz;
+  const int64_t plane = (int64_t)ndx * ndz;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) {
+    const int k = (int)(t % nz);
+    const int64_t r = t / nz;
+    const int qj = (int)(r % nqx), qi = (int)(r / nqx);
+    const double* lo = P + qi * plane + (int64_t)qj * ndz + k;   // plane iy (node offsets ddy, ddx)
+    const double* hi = lo + plane;                              // plane iy + 1
+    const double h = ((hi[ndz + 1] - hi[ndz]) - hi[1]) + hi[0];  // sensormodel.py:85-86, left to right
+    const double l = ((lo[ndz + 1] - lo[ndz]) - lo[1]) + lo[0];
+    const double sres = -(h - l);
+    Q[t] = (scale_mul * sres) / scale_div;
+  }
+}
+
+__global__ void __launch_bounds__(256) lattice_gather_kernel(const double* __restrict__ Q, int nqx, int nx, int ny, int nz,
+                                                             const int* __restrict__ jxs, const int* __restrict__ jys, int ia,
+                                                             double* __restrict__ A, int64_t ld) {
+  const int64_t s = blockIdx.x;
+  const int iy = ia + blockIdx.y;
+  const int64_t slab = (int64_t)nx * nz;
+  const double* src = Q + ((int64_t)(iy - jys[s] + ny - 2) * nqx + (nx - 1 - jxs[s])) * nz;   // contiguous nx*nz doubles
+  double* dst = A + s * ld + (int64_t)iy * slab;
+  for (int64_t t = threadIdx.x; t < slab / 2; t += 256) reinterpret_cast<v2d*>(dst)[t] = reinterpret_cast<const v2d*>(src)[t];
+}
+
 __global__ void __launch_bounds__(256) scale_broadcast_kernel(const double* __restrict__ a, const double* __restrict__ b,
                                                               int64_t n2, int64_t nb2, double* __restrict__ out) {
   // 16-byte accesses; nb (the broadcast period) is even, so a pair never straddles the period
@@ -292,6 +342,42 @@ extern "C" int geobo_k_eval(int kernel_id, const double* d2, int64_t n, double l
 extern "C" int geobo_a_sens_slab(int func_id, const double* B3_host, const double* loc, int64_t Ms, int nx, int ny, int nz,
                                  const double* xe, const double* ye, const double* ze, double scale_mul, double scale_div,
                                  int iy0, int iy1, double* A, int64_t ld, void* stream);
+
+extern "C" size_t geobo_a_sens_lattice_ws_bytes(int nx, int ny, int nz) {
+  if (nx <= 0 || ny < 3 || nz <= 0) return 0;
+  const size_t p = (size_t)(2 * ny - 2) * (2 * nx) * (nz + 1), q = (size_t)(2 * ny - 3) * (2 * nx - 1) * nz;
+  return (p + q) * sizeof(double);
+}
+
+extern "C" int geobo_a_sens_lattice(int func_id, const double* B3_host, int64_t Ms, int nx, int ny, int nz, const double* dxv,
+                                    const double* dyv, const double* dzv, const int* jxs, const int* jys, double scale_mul,
+                                    double scale_div, int iy0, int iy1, double* A, int64_t ld, void* ws, size_t ws_bytes,
+                                    void* stream) {
+  if (!B3_host || !dxv || !dyv || !dzv || !jxs || !jys || !A || !ws) return GEOBO_E_ARG;
+  if (Ms <= 0 || nx <= 0 || ny < 3 || nz <= 0 || (nz & 1) || (ld & 1) || ld < (int64_t)nx * ny * nz) return GEOBO_E_ARG;
+  if (iy0 < 0 || iy1 > ny || iy0 >= iy1) return GEOBO_E_ARG;
+  if (func_id != GEOBO_F_GRAV && func_id != GEOBO_F_MAGN) return GEOBO_E_UNSUPPORTED;
+  if (ws_bytes < geobo_a_sens_lattice_ws_bytes(nx, ny, nz)) return GEOBO_E_ARG;
+  const int ia = iy0 > 1 ? iy0 : 1, ib = iy1 < ny - 1 ? iy1 : ny - 1;   // interior slabs of the request
+  if (ia >= ib) return GEOBO_OK;
+  const int ndx = 2 * nx, ndy = 2 * ny - 2, ndz = nz + 1, nqy = 2 * ny - 3, nqx = 2 * nx - 1;
+  double* P = (double*)ws;
+  double* Q = P + (size_t)ndy * ndx * ndz;
+  const double bx = B3_host[0], by = B3_host[1], bz = B3_host[2];
+  const double inb = 1. / sqrt(bx * bx + by * by + bz * bz);
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t np = (int64_t)ndy * ndx * ndz, nq = (int64_t)nqy * nqx * nz;
+  const unsigned gp = (unsigned)((np + 255) / 256 < 65536 ? (np + 255) / 256 : 65536);
+  const unsigned gq = (unsigned)((nq + 255) / 256 < 65536 ? (nq + 255) / 256 : 65536);
+  if (func_id == GEOBO_F_GRAV)
+    hipLaunchKernelGGL(lattice_potential_kernel<GEOBO_F_GRAV>, dim3(gp), dim3(256), 0, st, dxv, ndx, dyv, ndy, dzv, ndz, bx, by, bz, inb, P);
+  else
+    hipLaunchKernelGGL(lattice_potential_kernel<GEOBO_F_MAGN>, dim3(gp), dim3(256), 0, st, dxv, ndx, dyv, ndy, dzv, ndz, bx, by, bz, inb, P);
+  hipLaunchKernelGGL(lattice_stencil_kernel, dim3(gq), dim3(256), 0, st, (const double*)P, ndx, ndz, nqy, nqx, nz, scale_mul, scale_div, Q);
+  hipLaunchKernelGGL(lattice_gather_kernel, dim3((unsigned)Ms, (unsigned)(ib - ia)), dim3(256), 0, st, (const double*)Q, nqx, nx, ny, nz,
+                     jxs, jys, ia, A, ld);
+  return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
+}
 
 extern "C" int geobo_a_sens(int func_id, const double* B3_host, const double* loc, int64_t Ms, int nx, int ny, int nz,
                             const double* xe, const double* ye, const double* ze, double scale_mul, double scale_div,

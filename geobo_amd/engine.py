@@ -91,6 +91,7 @@ class PosteriorEngine:
         if method == "spectral" and not self.use_spectral:
             raise ValueError("spectral method needs grid extents % 16 == 0 and column shards on y-slab boundaries")
         self._spectral = None
+        self._lattice_plan = None
         # row-sharded spectral product (N > 1): every rank transforms Ms/world sensor rows of each operator for ALL voxels
         # and one all-to-all hands each peer the block-columns it owns; needs equal shards
         ncs = {shard_columns(self.N_pad, world, r)[1] - shard_columns(self.N_pad, world, r)[0] for r in range(world)}
@@ -150,6 +151,16 @@ class PosteriorEngine:
             Bv = s.magneticField if B is None else np.asarray(B, dtype=float)
             mul, div = 1.0, s.fcor_mag
         locd, xed, yed, zed = (hip.to_dev(v, self.device) for v in (loc, xe, ye, ze))
+        # survey on the cube's own x-y lattice (the reference's workflow): translation-invariant stencil, ~2000x fewer potentials
+        plan = None
+        if os.environ.get("GEOBO_A_SENS_LATTICE", "1") != "0":
+            pkey = (loc.tobytes(), xe.tobytes(), ye.tobytes(), ze.tobytes())
+            if self._lattice_plan is None or self._lattice_plan[0] != pkey:
+                self._lattice_plan = (pkey, hip.lattice_plan(loc, xe, ye, ze, self.nx, self.ny, self.nz, self.device))
+            plan = self._lattice_plan[1]
+        lws = None
+        if plan is not None:
+            lws = self._workspace("a_sens_lattice_ws", (hip.a_sens_lattice_ws_doubles(self.nx, self.ny, self.nz),))
         if partial:
             plane = self.nx * self.nz
             rows_r = self.Ms // self.world
@@ -157,12 +168,15 @@ class PosteriorEngine:
             loc_r = locd[self.rank * rows_r:(self.rank + 1) * rows_r].contiguous()
 
             def build():
-                hip.a_sens(func, Bv, locd, self.nx, self.ny, self.nz, xed, yed, zed, mul, div, A, self.c0 // plane, self.c1 // plane)
-                hip.a_sens(func, Bv, loc_r, self.nx, self.ny, self.nz, xed, yed, zed, mul, div, Ar)
+                hip.a_sens(func, Bv, locd, self.nx, self.ny, self.nz, xed, yed, zed, mul, div, A, self.c0 // plane, self.c1 // plane,
+                           plan=plan, ws=lws)
+                hip.a_sens(func, Bv, loc_r, self.nx, self.ny, self.nz, xed, yed, zed, mul, div, Ar, plan=plan,
+                           rows=slice(self.rank * rows_r, (self.rank + 1) * rows_r), ws=lws)
             self._timed("a_sens_" + func, 0.0, build)
             self._Arows[func] = Ar
         else:
-            self._timed("a_sens_" + func, 0.0, lambda: hip.a_sens(func, Bv, locd, self.nx, self.ny, self.nz, xed, yed, zed, mul, div, A))
+            self._timed("a_sens_" + func, 0.0, lambda: hip.a_sens(func, Bv, locd, self.nx, self.ny, self.nz, xed, yed, zed, mul, div, A,
+                                                                 plan=plan, ws=lws))
         self._A = {k: v for k, v in self._A.items() if k[0] != func}  # one operator per type stays resident
         self._A[key] = A
         return A

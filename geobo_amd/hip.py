@@ -87,15 +87,70 @@ def k_eval(kid, d2, l1, l2, w=1.0, amp=1.0):
     return out
 
 
-def a_sens(func, B, loc, nx, ny, nz, xe, ye, ze, scale_mul, scale_div, out, iy0=0, iy1=None):
-    """Forward operator rows for the sensors in `loc`; optionally only the voxel slab iy0 <= iy < iy1."""
+def lattice_plan(loc, xe, ye, ze, nx, ny, nz, device="cuda"):
+    """Host-side check for the lattice form of A_sens (geobo_a_sens_lattice): the sensors occupy every column of an nx x ny
+    lattice at one height AND every node offset xe[j] - sx, ye[i] - sy (planes 1 .. ny-1) is bit-identical for all pairs with
+    the same index difference -- then the lattice kernels reproduce geobo_a_sens exactly.  Returns None otherwise (irregular
+    survey, or spacings whose differences round differently from pair to pair: the direct kernel is used)."""
+    loc = np.asarray(loc, dtype=np.float64)
+    xe, ye, ze = (np.asarray(v, dtype=np.float64) for v in (xe, ye, ze))
+    if ny < 3 or nz % 2 or loc.shape != (nx * ny, 3) or np.unique(loc[:, 2]).size != 1:
+        return None
+    ux, uy = np.unique(loc[:, 0]), np.unique(loc[:, 1])
+    if ux.size != nx or uy.size != ny:
+        return None
+    jx, jy = np.searchsorted(ux, loc[:, 0]), np.searchsorted(uy, loc[:, 1])
+    if np.unique(jy * nx + jx).size != nx * ny:
+        return None
+    X = xe[:, None] - ux[None, :]                 # (nx+1, nx): offset of node j from lattice column t
+    Y = ye[1:ny, None] - uy[None, :]              # (ny-1, ny): planes 1 .. ny-1 (planes 0 and ny carry the 1e6 padding)
+    dxv, dyv = np.empty(2 * nx), np.empty(2 * ny - 2)
+    for d in range(-(nx - 1), nx + 1):            # d = j - t
+        v = np.diagonal(X, offset=-d)
+        if not (v == v[0]).all():
+            return None
+        dxv[d + nx - 1] = v[0]
+    for d in range(2 - ny, ny):                   # d = i - t with i = 1 .. ny-1  ->  row index i - 1
+        v = np.diagonal(Y, offset=-(d - 1))
+        if not (v == v[0]).all():
+            return None
+        dyv[d + ny - 2] = v[0]
+    dev = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a, dtype=dt)).to(device)
+    return dict(dxv=dev(dxv, np.float64), dyv=dev(dyv, np.float64), dzv=dev(ze - loc[0, 2], np.float64),
+                jx=dev(jx, np.int32), jy=dev(jy, np.int32))
+
+
+def a_sens(func, B, loc, nx, ny, nz, xe, ye, ze, scale_mul, scale_div, out, iy0=0, iy1=None, plan=None, rows=None, ws=None):
+    """Forward operator rows for the sensors in `loc`; optionally only the voxel slab iy0 <= iy < iy1.
+    plan (lattice_plan) + rows (slice of the plan's sensors that `loc` holds): interior slabs by the lattice kernels, the
+    two 1e6-padded boundary slabs by the direct kernel."""
     lib = require_gpu()
     ld = _rowmajor(out, "A")
     loc = _chk(loc, "loc").contiguous()
     Bh = (C.c_double * 3)(*[float(b) for b in B])
-    _lib.check(lib.geobo_a_sens_slab(FUNC_IDS[func], Bh, _p(loc), loc.shape[0], int(nx), int(ny), int(nz), _p(_chk(xe, "xe")),
-                                     _p(_chk(ye, "ye")), _p(_chk(ze, "ze")), float(scale_mul), float(scale_div), int(iy0),
-                                     int(ny if iy1 is None else iy1), _p(out), ld, _stream()), "geobo_a_sens_slab")
+    iy1 = int(ny if iy1 is None else iy1)
+
+    def direct(a, b):
+        _lib.check(lib.geobo_a_sens_slab(FUNC_IDS[func], Bh, _p(loc), loc.shape[0], int(nx), int(ny), int(nz), _p(_chk(xe, "xe")),
+                                         _p(_chk(ye, "ye")), _p(_chk(ze, "ze")), float(scale_mul), float(scale_div), int(a),
+                                         int(b), _p(out), ld, _stream()), "geobo_a_sens_slab")
+    if plan is None:
+        direct(iy0, iy1)
+        return out
+    rows = slice(0, loc.shape[0]) if rows is None else rows
+    jx, jy = plan["jx"][rows].contiguous(), plan["jy"][rows].contiguous()
+    assert jx.numel() == loc.shape[0]
+    nbytes = lib.geobo_a_sens_lattice_ws_bytes(int(nx), int(ny), int(nz))
+    if ws is None or ws.numel() * 8 < nbytes:
+        ws = torch.empty(nbytes // 8, dtype=F64, device=out.device)
+    _lib.check(lib.geobo_a_sens_lattice(FUNC_IDS[func], Bh, loc.shape[0], int(nx), int(ny), int(nz), _p(plan["dxv"]), _p(plan["dyv"]),
+                                        _p(plan["dzv"]), C.c_void_p(jx.data_ptr()), C.c_void_p(jy.data_ptr()), float(scale_mul),
+                                        float(scale_div), int(iy0), iy1, _p(out), ld, _p(ws), nbytes, _stream()),
+               "geobo_a_sens_lattice")
+    if iy0 == 0:
+        direct(0, 1)
+    if iy1 == ny:
+        direct(ny - 1, ny)
     return out
 
 
@@ -267,6 +322,10 @@ def trmv_stats(Linv, y, L):
     _lib.check(lib.geobo_trmv_stats(m, _p(Linv), _rowmajor(Linv, "Linv"), _p(_chk(y, "y")), _p(L), _rowmajor(L, "L"),
                                     _p(u), _p(stats), _stream()), "geobo_trmv_stats")
     return u, stats
+
+
+def a_sens_lattice_ws_doubles(nx, ny, nz):
+    return max(_lib.load().geobo_a_sens_lattice_ws_bytes(int(nx), int(ny), int(nz)) // 8, 1)
 
 
 def potrf_ws_doubles(m):

@@ -83,6 +83,18 @@ int geobo_a_sens_slab(int func_id, const double* B3_host, const double* loc, int
                       const double* xe, const double* ye, const double* ze, double scale_mul, double scale_div,
                       int iy0, int iy1, double* A, int64_t ld, void* stream);
 
+/* Lattice form of the same operator for sensors on a lattice commensurate with the voxel columns (sensor n at lattice column
+ * jxs[n], jys[n]; all at one height): away from the +-1e6-padded node planes iy = 0 and ny the 8-corner stencil of
+ * sensormodel.py:81-86 depends on (iy - jys, ix - jxs, iz) only.  dxv[2nx]: xe[j] - sx for j - jxs = -(nx-1) .. nx;
+ * dyv[2ny-2]: ye[i] - sy for i - jys = 2-ny .. ny-1 (planes 1 .. ny-1); dzv[nz+1]: ze[k] - sz.  Fills the INTERIOR slabs
+ * max(iy0,1) <= iy < min(iy1, ny-1) of A (the two boundary slabs come from geobo_a_sens_slab); ~2000x fewer potential
+ * evaluations at 64^3, bit-identical to geobo_a_sens when the offsets are exact for every (node, sensor) pair (the caller's
+ * check: geobo_amd/hip.py::lattice_plan).  nz even, ny >= 3; ws: geobo_a_sens_lattice_ws_bytes(nx, ny, nz). */
+size_t geobo_a_sens_lattice_ws_bytes(int nx, int ny, int nz);
+int geobo_a_sens_lattice(int func_id, const double* B3_host, int64_t Ms, int nx, int ny, int nz, const double* dxv,
+                         const double* dyv, const double* dzv, const int* jxs, const int* jys, double scale_mul,
+                         double scale_div, int iy0, int iy1, double* A, int64_t ld, void* ws, size_t ws_bytes, void* stream);
+
 /* Node potential itself, elementwise: out[i] = grav_func(x,y,z) (sensormodel.py:96-110) or
  * magn_func(x,y,z,B) (sensormodel.py:113-133); same arithmetic as inside geobo_a_sens. */
 int geobo_potential(int func_id, const double* B3_host, const double* x, const double* y, const double* z, int64_t n,

