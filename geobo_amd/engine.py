@@ -92,6 +92,7 @@ class PosteriorEngine:
             raise ValueError("spectral method needs grid extents % 16 == 0 and column shards on y-slab boundaries")
         self._spectral = None
         self._lattice_plan = None
+        self._gram, self._lam = None, {}
         # row-sharded spectral product (N > 1): every rank transforms Ms/world sensor rows of each operator for ALL voxels
         # and one all-to-all hands each peer the block-columns it owns; needs equal shards
         ncs = {shard_columns(self.N_pad, world, r)[1] - shard_columns(self.N_pad, world, r)[0] for r in range(world)}
@@ -177,6 +178,8 @@ class PosteriorEngine:
         else:
             self._timed("a_sens_" + func, 0.0, lambda: hip.a_sens(func, Bv, locd, self.nx, self.ny, self.nz, xed, yed, zed, mul, div, A,
                                                                  plan=plan, ws=lws))
+            lam = self._gram_eigen(plan, lws) if plan is not None else None
+            self._lam[func] = None if lam is None else (A, lam)      # valid for exactly this operator tensor
         self._A = {k: v for k, v in self._A.items() if k[0] != func}  # one operator per type stays resident
         self._A[key] = A
         return A
@@ -209,6 +212,7 @@ class PosteriorEngine:
     def clear_operators(self):
         """Drop the resident forward operators (the benchmark rebuilds them inside every timed step)."""
         self._A = {}
+        self._lam = {}
 
     # ---- stages ------------------------------------------------------------------------------------------------
     def _tick(self, name, t0=None):
@@ -320,6 +324,19 @@ class PosteriorEngine:
                 for jj in range(P_c):
                     AK[r0:r0 + rows_r, jj * nc:(jj + 1) * nc].copy_(blocks[s_, jj])
 
+    def _gram_eigen(self, plan, lws):
+        """Eigen-data of the operator's stencil table for the lattice Gram (lattice_gram.py); None -> AkA by the N-deep GEMM."""
+        from .lattice_gram import LatticeGram
+        if (self.world != 1 or not self.use_spectral or not plan["rowmajor"] or self.Ms_pad != self.Ms
+                or not LatticeGram.supported(self.nx, self.ny, self.nz) or os.environ.get("GEOBO_AKA_LATTICE", "1") == "0"):
+            return None
+        if self._spectral is None:
+            from .spectral import SpectralProduct
+            self._spectral = SpectralProduct(self.nx, self.ny, self.nz, self.device)
+        if self._gram is None:
+            self._gram = LatticeGram(self._spectral, self.device)
+        return self._timed("aka_lattice_eigen", 0.0, lambda: self._gram.eigen(hip.a_sens_lattice_stencil(lws, self.nx, self.ny, self.nz)))
+
     def _assemble_AkA(self, AK, M_pad, A_g, A_m, sel_t, lengths, name, amp, gp_sigma, props):
         xyz = self.grid_points()
         nc = self.nc
@@ -342,6 +359,20 @@ class PosteriorEngine:
                     break
             Xv, Yv, Cv = AK[r0:, jj * nc:(jj + 1) * nc], A[:, self.c0:self.c1], AkA[r0:, r0:r0 + self.Ms_pad]
             mv = off_d + Md - r0                       # rows behind the last drill row are padding: not contracted
+            lam = self._lam.get(("grav", "magn")[s_])
+            lam = lam[1] if lam is not None and lam[0] is A else None
+            if lam is not None and self.world == 1:
+                # lattice survey, even stencil: interior y-slabs by the (y, x) correlation, the two padded slabs by a GEMM
+                gram, pl = self._gram, self.nx * self.nz
+                fl = gram.flops(mv) + 2.0 * 2 * pl * 128 * sum(min(2 * (bi + 1), self.Ms_pad // 128) * rv
+                                                                for bi, rv in enumerate(hip.tile_rows(rows, mv)))
+
+                def lattice():
+                    gram.gram_rows(Xv, mv, lam, Cv)
+                    for c0 in (0, (self.ny - 1) * pl):
+                        hip.gemm_nt(Xv[:, c0:c0 + pl], Yv[:, c0:c0 + pl], Cv, alpha=1.0, beta=1.0, lower_only=True, m_valid=mv)
+                self._timed("aka_lattice", fl, lattice)
+                continue
             # executed flop: lower-only tiles, whole 64-row wavefront groups of the last row tile
             fl = 2.0 * 128 * nc * sum(min(2 * (bi + 1), self.Ms_pad // 128) * rv for bi, rv in enumerate(hip.tile_rows(rows, mv)))
             if splits > 1:

@@ -117,7 +117,7 @@ def lattice_plan(loc, xe, ye, ze, nx, ny, nz, device="cuda"):
         dyv[d + ny - 2] = v[0]
     dev = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a, dtype=dt)).to(device)
     return dict(dxv=dev(dxv, np.float64), dyv=dev(dyv, np.float64), dzv=dev(ze - loc[0, 2], np.float64),
-                jx=dev(jx, np.int32), jy=dev(jy, np.int32))
+                jx=dev(jx, np.int32), jy=dev(jy, np.int32), rowmajor=bool((jy * nx + jx == np.arange(nx * ny)).all()))
 
 
 def a_sens(func, B, loc, nx, ny, nz, xe, ye, ze, scale_mul, scale_div, out, iy0=0, iy1=None, plan=None, rows=None, ws=None):
@@ -283,6 +283,20 @@ def tile_rows(m, m_valid, tile=256, group=64):
         v = min(max(m_valid - r0, 0), tile)
         out.append((v + group - 1) // group * group)
     return out
+
+
+def xcorr_reduce(nx, nz, rows, planes, src, in_row, in_plane, Mx, lam, out, out_row, out_plane):
+    """x step + eigenvalue scaling + channel sum of the lattice Gram (geobo_xcorr_reduce)."""
+    lib = require_gpu()
+    _lib.check(lib.geobo_xcorr_reduce(int(nx), int(nz), int(rows), int(planes), _p(_chk(src, "src")), int(in_row), int(in_plane),
+                                      _p(_chk(Mx, "Mx")), int(Mx.stride(0)), _p(_chk(lam, "lam")), _p(_chk(out, "out")),
+                                      int(out_row), int(out_plane), _stream()), "geobo_xcorr_reduce")
+
+
+def a_sens_lattice_stencil(ws, nx, ny, nz):
+    """View of the stencil table Q[(2ny-3)][(2nx-1)][nz] that geobo_a_sens_lattice left in its workspace."""
+    np_ = (2 * ny - 2) * (2 * nx) * (nz + 1)
+    return ws[np_:np_ + (2 * ny - 3) * (2 * nx - 1) * nz].view(2 * ny - 3, 2 * nx - 1, nz)
 
 
 def toeplitz_y(ny, C, R, src, tabs, outs, y0=0, y1=None):

@@ -170,6 +170,14 @@ int geobo_xz2d(int inverse, int nx, int nz, int64_t rows, int planes_per_row, co
                int64_t in_plane, const double* Mx, int64_t ldmx, const double* Mz, int64_t ldmz, double* out,
                int64_t out_row, int64_t out_plane, void* stream);
 
+/* AkA on a lattice survey ("lattice Gram"): the x step of a (y, x) correlation with the z axis as a
+ * channel.  For plane (r, p), r < rows, p < planes, at in + r*in_row + p*in_plane (nx x nz, row-major):
+ *     out[r*out_row + p*out_plane + o] = sum_z lam[(p*2nx + o)*nz + z] * sum_x Mx[o][x] * in[x][z],   o < 2nx
+ * (Mx = G_x, 2nx x nx; lam = eigenvalues of the even stencil table per (y-mode p, x-mode o, channel z)).  nx = nz = 64. */
+int geobo_xcorr_reduce(int nx, int nz, int64_t rows, int planes, const double* in, int64_t in_row, int64_t in_plane,
+                       const double* Mx, int64_t ldmx, const double* lam, double* out, int64_t out_row, int64_t out_plane,
+                       void* stream);
+
 /* y-axis stage of the structured product on a regular grid: for every mode c < C (the (x, z)
  * spectral index, contiguous) and row r < R,   out_j[r][y - y0][c] = sum_{y'} tab_j[|y - y'|][c] * in[r][y'][c]
  * for y in [y0, y1) -- the symmetric Toeplitz blocks of create_cov's K_sj (kernels.py:158-195) applied directly.

@@ -405,3 +405,33 @@ def test_graft_entry_build_then_smoke_in_one_process():
     r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke(); print('OK')"], cwd=root,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("ny", [48, 64])
+def test_lattice_gram_matches_the_gemm(ny, monkeypatch):
+    """AkA by the (y, x) correlation of the lattice survey (lattice_gram.py) against the N-deep GEMM, all blocks incl. drill rows."""
+    import geobo_amd.engine as E
+    nx, nz = 64, 64
+    s = settings_for(nx, ny, nz, kernelfunc="matern32")
+    from geobo_amd.inversion import Inversion
+    inv = Inversion(settings=s, props=(0, 1))
+    inv.create_cubegeometry()
+    xe, ye, ze = inv.engine.node_axes()
+    X, Y = np.meshgrid(0.5 * (xe[:-1] + xe[1:]), 0.5 * (ye[:-1] + ye[1:]))
+    loc = np.c_[X.ravel(), Y.ravel(), np.full(nx * ny, 1.0)]
+    W = E.weight_matrix(s.gp_coeff)
+    lengths = [float(v) for v in E.create_cov_lengths(np.array([200.0, 202.0, 204.0]))]
+    sel_t = torch.as_tensor(np.array([5, 777, 12345, 100000]), device="cuda")
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("GEOBO_AKA_LATTICE", flag)
+        eng = E.PosteriorEngine(s)
+        A_g, A_m = eng.operator("grav", loc), eng.operator("magn", loc)
+        assert (eng._lam.get("grav") is not None) == (flag == "1")
+        AK, M_pad = eng._assemble_AK(A_g, A_m, sel_t, lengths, W, "matern32", 1.0, (0, 1))
+        AkA = eng._assemble_AkA(AK, M_pad, A_g, A_m, sel_t, lengths, "matern32", 1.0, s.gp_err, (0, 1))
+        out[flag] = torch.tril(AkA).clone()
+        del eng, A_g, A_m, AK, AkA
+        torch.cuda.empty_cache()
+    d = (out["0"] - out["1"]).abs().max().item()
+    assert d <= 1e-12 * out["0"].abs().max().item(), d
