@@ -35,12 +35,7 @@ struct XZArgs {
   const double* Mx; int64_t ldmx;                // OUT_X x IN_X
   int ppr;                                       // planes per row
   int64_t nplanes;
-  // EPI_SCALE_REDUCE (geobo_xcorr_reduce): planes are numbered plane-major (p -> row p % rows, plane p / rows), the result of
-  // the x step is multiplied elementwise by lam[plane][OUT_X][OUT_Z] and summed over z: out[row][plane][OUT_X]
-  const double* lam; int64_t rows;
 };
-
-enum { EPI_PLANE = 0, EPI_SCALE_REDUCE = 1 };
 
 constexpr int RING = 4;  // chunks in the LDS ring (prefetch distance RING-1)
 
@@ -63,7 +58,7 @@ struct XZCfg {
   static constexpr int RPI = 64 / LPR;                // rows per DMA instruction
   static constexpr int MXS = (IN_X + 31) / 32 * 32;   // row stride of Mx in LDS (doubles): whole blocks of 16 XOR-swizzled 16-byte slots
   static constexpr int NS = RT2 * CT * 4;             // stores per wave per plane
-  static constexpr size_t LDS = (size_t)RING * CHB + (size_t)OUT_X * MXS * 8 + 2 * 4 * OUT_X * 8;   // ring + Mx + reduction scratch
+  static constexpr size_t LDS = (size_t)RING * CHB + (size_t)OUT_X * MXS * 8;
   static_assert(CT >= 1 && OUT_Z % (16 * NW) == 0 && CHB % (1024 * NW) == 0 && IN_X % 16 == 0 && IN_Z % 32 == 0 && IN_Z <= 128 && OUT_X % 16 == 0, "shape");
   static_assert(ND >= 1 && RT1 >= RING - 1, "chunking");
 };
@@ -82,10 +77,9 @@ __device__ __forceinline__ void step1(v2d (&a)[KP], const double (&gz)[CT][2 * K
   if constexpr (T + 1 < KP) step1<KP, CT, NA, T + 1>(a, gz, d);
 }
 
-template <int IN_X, int IN_Z, int OUT_X, int OUT_Z, int EPI>
+template <int IN_X, int IN_Z, int OUT_X, int OUT_Z>
 __global__ void __launch_bounds__(xz_threads(OUT_Z), 1) xz2d_kernel(XZArgs g) {
   using K = XZCfg<IN_X, IN_Z, OUT_X, OUT_Z>;
-  static_assert(EPI == EPI_PLANE || (IN_Z == OUT_Z && K::CT == 1 && K::NW == 4), "scale-reduce: x step only, one column tile per wave");
   constexpr int CT = K::CT, RT1 = K::RT1, KP = K::KP, RT2 = K::RT2;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   char* const ring = reinterpret_cast<char*>(smem);
@@ -103,25 +97,20 @@ __global__ void __launch_bounds__(xz_threads(OUT_Z), 1) xz2d_kernel(XZArgs g) {
     mx[ox * K::MXS + ((((pos >> 1) ^ (ox & 15)) << 1) | (pos & 1))] = g.Mx[(int64_t)ox * g.ldmx + ix];
   }
   double gz[CT][2 * KP];
-  if constexpr (EPI == EPI_PLANE) {
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
+  for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-      for (int t = 0; t < KP; ++t) {
-        const double* p = g.Mz + (int64_t)(16 * (w * CT + ct) + lr) * g.ldmz + 8 * t + 2 * q;
-        gz[ct][2 * t] = p[0];
-        gz[ct][2 * t + 1] = p[1];
-      }
-  }
+    for (int t = 0; t < KP; ++t) {
+      const double* p = g.Mz + (int64_t)(16 * (w * CT + ct) + lr) * g.ldmz + 8 * t + 2 * q;
+      gz[ct][2 * t] = p[0];
+      gz[ct][2 * t + 1] = p[1];
+    }
 
   // ---- chunk stream: chunk c of plane n -> ring slot (n * RT1 + c) % RING ----------------------------------------------
   const int64_t first = blockIdx.x, pstep = gridDim.x;
   if (first >= g.nplanes) return;
   const int drow = lane / K::LPR, dpos = lane % K::LPR;       // this lane's row / 16-byte slot within a DMA instruction
-  auto plane_ptr = [&](int64_t p) {
-    if constexpr (EPI == EPI_SCALE_REDUCE) return g.in + (p % g.rows) * g.in_row + (p / g.rows) * g.in_plane;
-    else return g.in + (p / g.ppr) * g.in_row + (p % g.ppr) * g.in_plane;
-  };
+  auto plane_ptr = [&](int64_t p) { return g.in + (p / g.ppr) * g.in_row + (p % g.ppr) * g.in_plane; };
   auto stage = [&](const double* plane, int c, int slot) {
 #pragma unroll
     for (int j = 0; j < K::ND; ++j) {
@@ -147,7 +136,7 @@ __global__ void __launch_bounds__(xz_threads(OUT_Z), 1) xz2d_kernel(XZArgs g) {
       // (1) this wave's share of chunk c has landed: everything issued after it may still be in flight -- the RING-2
       //     newer chunks and, for the first RING-1 chunks of a plane, the previous plane's NS stores (vmcnt counts both)
 #ifndef GEOBO_XZ_ABL_NOWAIT
-      if (EPI == EPI_PLANE && c <= RING - 2 && warm) {
+      if (c <= RING - 2 && warm) {
         constexpr int n = (RING - 2) * K::ND + K::NS;
         __builtin_amdgcn_s_waitcnt(vmcnt_imm(n > 63 ? 63 : n));
       } else {
@@ -169,18 +158,6 @@ __global__ void __launch_bounds__(xz_threads(OUT_Z), 1) xz2d_kernel(XZArgs g) {
       // (4) step 1 on row tile c.  The fragment reads are inline asm: for LDS reads it can see, the compiler waits for
       //     EVERY outstanding LDS-DMA first (vmcnt(0): it cannot tell ring slots apart), which would collapse the
       //     three-chunk prefetch to one; the waits that matter are (1) and the lgkmcnt below.
-      if constexpr (EPI == EPI_SCALE_REDUCE) {
-        // no z step: the chunk itself, read in the D layout (row (lane>>4) + 4 reg, column 16 w + (lane&15)), is the B operand
-        const unsigned xs = ring_lds + ((slot0 + c) % RING) * K::CHB;
-        const int col = 16 * w + lr;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int row = q + 4 * reg;
-          const unsigned addr = xs + row * K::ROWB + ((((col >> 1) ^ row) << 4) | ((col & 1) << 3));
-          asm volatile("ds_read_b64 %0, %1" : "=v"(d1[c][0][reg]) : "v"(addr));
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d1[c][0][0]), "+v"(d1[c][0][1]), "+v"(d1[c][0][2]), "+v"(d1[c][0][3]));
-      } else {
       const unsigned xs = ring_lds + ((slot0 + c) % RING) * K::CHB + lr * K::ROWB;
       constexpr int NA = CT >= 2 ? 2 : 4;
       v4d dd[NA][CT];
@@ -200,11 +177,9 @@ __global__ void __launch_bounds__(xz_threads(OUT_Z), 1) xz2d_kernel(XZArgs g) {
         if constexpr (NA == 4) d1[c][ct] = (dd[0][ct] + dd[1][ct]) + (dd[2][ct] + dd[3][ct]);
         else d1[c][ct] = dd[0][ct] + dd[1][ct];
       }
-      }
     }
     // ---- step 2 + stores, half the output row tiles at a time (register budget) ------------------------------------------
-    double* const op = (EPI == EPI_SCALE_REDUCE) ? g.out + (p % g.rows) * g.out_row + (p / g.rows) * g.out_plane
-                                                 : g.out + (p / g.ppr) * g.out_row + (p % g.ppr) * g.out_plane + 16 * (w * CT) + lr;
+    double* const op = g.out + (p / g.ppr) * g.out_row + (p % g.ppr) * g.out_plane + 16 * (w * CT) + lr;
     constexpr int HALF = (RT2 * CT > 8 && RT2 % 2 == 0) ? RT2 / 2 : RT2;  // <= 8 accumulator tiles at a time
 #pragma unroll
     for (int h0 = 0; h0 < RT2; h0 += HALF) {
@@ -233,28 +208,6 @@ __global__ void __launch_bounds__(xz_threads(OUT_Z), 1) xz2d_kernel(XZArgs g) {
               acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(kk == 0 ? a01[m].x : kk == 1 ? a01[m].y : kk == 2 ? a23[m].x : a23[m].y,
                                                                 d1[rt][ct][kk], acc[m][ct], 0, 0, 0);
       }
-      if constexpr (EPI == EPI_SCALE_REDUCE) {
-        // out[kx] = sum_z lam[plane][kx][z] * (Mx X)[kx][z]: this lane holds z = 16 w + (lane&15), kx = 16 m + (lane>>4) + 4 r
-        static_assert(HALF == RT2, "one pass over the output row tiles");
-        const double* lp = g.lam + (p / g.rows) * (int64_t)(OUT_X * OUT_Z) + 16 * w + lr;
-        double* red = reinterpret_cast<double*>(ring + RING * K::CHB) + OUT_X * K::MXS + ((p / pstep) & 1) * (4 * OUT_X);
-#pragma unroll
-        for (int m = 0; m < HALF; ++m)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            double v = acc[m][0][r] * lp[(int64_t)(16 * m + q + 4 * r) * OUT_Z];
-            v += __shfl_xor(v, 1);
-            v += __shfl_xor(v, 2);
-            v += __shfl_xor(v, 4);
-            v += __shfl_xor(v, 8);
-            if (lr == 0) red[w * OUT_X + 16 * m + q + 4 * r] = v;
-          }
-        // the four column-tile partial sums of this plane are in LDS (double-buffered by plane parity); explicit LDS drain +
-        // bare barrier: __syncthreads() would also drain the prefetched chunks (vmcnt)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (tid < OUT_X) op[tid] = (red[tid] + red[OUT_X + tid]) + (red[2 * OUT_X + tid] + red[3 * OUT_X + tid]);
-      } else {
 #pragma unroll
       for (int m = 0; m < HALF; ++m)
 #pragma unroll
@@ -265,7 +218,6 @@ __global__ void __launch_bounds__(xz_threads(OUT_Z), 1) xz2d_kernel(XZArgs g) {
             if (acc[m][ct][r] == 1.2345e-300)
 #endif
             op[(int64_t)(16 * (h0 + m) + q + 4 * r) * OUT_Z + 16 * ct] = acc[m][ct][r];
-      }
     }
     warm = true;
     slot0 = (slot0 + RT1) % RING;
@@ -273,10 +225,10 @@ __global__ void __launch_bounds__(xz_threads(OUT_Z), 1) xz2d_kernel(XZArgs g) {
   }
 }
 
-template <int IN_X, int IN_Z, int OUT_X, int OUT_Z, int EPI = EPI_PLANE>
+template <int IN_X, int IN_Z, int OUT_X, int OUT_Z>
 int launch(const XZArgs& g, hipStream_t st) {
   using K = XZCfg<IN_X, IN_Z, OUT_X, OUT_Z>;
-  auto kern = xz2d_kernel<IN_X, IN_Z, OUT_X, OUT_Z, EPI>;
+  auto kern = xz2d_kernel<IN_X, IN_Z, OUT_X, OUT_Z>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS) != hipSuccess)
@@ -286,6 +238,116 @@ int launch(const XZArgs& g, hipStream_t st) {
   int64_t nwg = g.nplanes < 1024 ? g.nplanes : 1024;  // persistent: 4 workgroups per CU over the launch, >= 8 planes each at 64^3
   hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * K::NW), K::LDS, st, g);
   return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
+}
+
+// ---- lattice Gram, x step (geobo_xcorr_reduce) ----------------------------------------------------------------------------
+// For every (row r, y-mode p) plane X (nx x nz):   out[r][p][o] = sum_z lamT[p][z][o] * sum_x Gx[o][x] X[x][z],  o < 2nx.
+// The product is formed TRANSPOSED, D[z][o] = sum_x X^T[z][x] Gx^T[x][o], so that the sum over z runs over accumulator
+// registers and the four 16-lane groups of a wave (two cross-lane steps per value) instead of over the 16 lanes of a group
+// (four steps for each of 32 values: that version spent 80 % of its time in the reduction).  Wave w owns z rows 16w..16w+15
+// and all 2nx columns; X streams through the same LDS-DMA chunk ring as xz2d (16 x rows = four k-steps per chunk), Gx^T
+// (64 KiB, padded rows) sits in LDS, the eigenvalue planes lamT (z-major, 64 KiB per y-mode) come from L2: planes are
+// numbered p-major so that the workgroups of a round share a handful of them.
+struct XCArgs {
+  const double* in; int64_t in_row, in_plane;   // plane (r, p) at in + r*in_row + p*in_plane
+  const double* Mx; int64_t ldmx;               // Gx, PX x NX
+  const double* lamT;                           // [planes][NZ][PX]
+  double* out; int64_t out_row, out_plane;      // out + r*out_row + p*out_plane + o
+  int64_t rows, nplanes;
+};
+
+template <int NX, int NZ, int PX>
+__global__ void __launch_bounds__(256, 1) xcorr_kernel(XCArgs g) {
+  static_assert(NZ == 64 && NX % 16 == 0 && PX % 16 == 0, "four waves, one 16-row z tile each");
+  constexpr int CT = PX / 16, NCH = NX / 16, ROWB = NZ * 8, CHB = 16 * ROWB, LPR = ROWB / 16, RPI = 64 / LPR;
+  constexpr int ND = CHB / 1024 / 4, GS = PX + 16;
+  static_assert(ND >= 1 && NCH >= RING - 1, "chunking");
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  char* const ring = reinterpret_cast<char*>(smem);
+  double* const gxt = smem + RING * CHB / 8;           // [NX][GS]: Gx^T, row stride 2nx + 16 (conflict-free b64 fragment reads)
+  double* const red = gxt + NX * GS;                   // [2][4][PX]
+  const unsigned ring_lds = (unsigned)(uintptr_t)(lds_ptr_t)ring;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, q = lane >> 4;
+  for (int idx = tid; idx < PX * NX; idx += 256) {
+    const int o = idx / NX, x = idx % NX;
+    gxt[x * GS + o] = g.Mx[(int64_t)o * g.ldmx + x];
+  }
+  const int64_t first = blockIdx.x, pstep = gridDim.x;
+  if (first >= g.nplanes) return;
+  const int drow = lane / LPR, dpos = lane % LPR;
+  auto plane_ptr = [&](int64_t p) { return g.in + (p % g.rows) * g.in_row + (p / g.rows) * g.in_plane; };
+  auto stage = [&](const double* plane, int c, int slot) {
+#pragma unroll
+    for (int j = 0; j < ND; ++j) {
+      const int ii = w + 4 * j;
+      const int row = ii * RPI + drow;
+      const char* src = reinterpret_cast<const char*>(plane) + (int64_t)(16 * c + row) * ROWB + ((dpos ^ (row & 15)) << 4);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(ring + slot * CHB + ii * 1024), 16, 0, 0);
+    }
+  };
+  const double* cur = plane_ptr(first);
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < RING - 1; ++c) stage(cur, c, c);
+  int slot0 = 0, it = 0;
+  const int col = 16 * w + lr;                         // this lane's z (row i of the transposed product)
+  for (int64_t p = first; p < g.nplanes; p += pstep, ++it) {
+    const int64_t pn = p + pstep < g.nplanes ? p + pstep : p;
+    const double* nxt = plane_ptr(pn);
+    v4d acc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) acc[ct] = (v4d){0., 0., 0., 0.};
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      // conservative wait (no term for this wave's later loads / stores: they only make it stricter), bare barrier, refill
+      __builtin_amdgcn_s_waitcnt(vmcnt_imm((RING - 2) * ND));
+      __builtin_amdgcn_s_barrier();
+      {
+        const int cn = c + RING - 1;
+        if (cn < NCH) stage(cur, cn, (slot0 + cn) % RING);
+        else stage(nxt, cn - NCH, (slot0 + cn) % RING);
+      }
+      const unsigned xs = ring_lds + ((slot0 + c) % RING) * CHB;
+      double a[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {                    // A[i = z][k = x]: X[x = 16c + 4s + q][z = col]
+        const int row = 4 * s + q;
+        const unsigned addr = xs + row * ROWB + ((((col >> 1) ^ row) << 4) | ((col & 1) << 3));
+        asm volatile("ds_read_b64 %0, %1" : "=v"(a[s]) : "v"(addr));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const double* bp = gxt + (16 * c + 4 * s + q) * GS + lr;   // B[k = x][j = o]
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], bp[16 * ct], acc[ct], 0, 0, 0);
+      }
+    }
+    // ---- scale by the eigenvalues and sum over z: registers (4 z per lane), then the four 16-lane groups, then the waves --
+    const int64_t pl = p / g.rows;
+    const double* lp = g.lamT + pl * (int64_t)(NZ * PX) + (int64_t)(16 * w + q) * PX + lr;
+    double* const rp = red + (it & 1) * (4 * PX) + w * PX;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      double v = acc[ct][0] * lp[16 * ct];
+      v = __builtin_fma(acc[ct][1], lp[4 * PX + 16 * ct], v);
+      v = __builtin_fma(acc[ct][2], lp[8 * PX + 16 * ct], v);
+      v = __builtin_fma(acc[ct][3], lp[12 * PX + 16 * ct], v);
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (q == 0) rp[16 * ct + lr] = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (tid < PX) {
+      const double* r4 = red + (it & 1) * (4 * PX) + tid;
+      g.out[(p % g.rows) * g.out_row + pl * g.out_plane + tid] = (r4[0] + r4[PX]) + (r4[2 * PX] + r4[3 * PX]);
+    }
+    slot0 = (slot0 + NCH) % RING;
+    cur = nxt;
+  }
 }
 
 }  // namespace
@@ -299,7 +361,6 @@ extern "C" int geobo_xz2d(int inverse, int nx, int nz, int64_t rows, int planes_
   XZArgs g;
   g.in = in; g.in_row = in_row; g.in_plane = in_plane; g.out = out; g.out_row = out_row; g.out_plane = out_plane;
   g.Mz = Mz; g.ldmz = ldmz; g.Mx = Mx; g.ldmx = ldmx; g.ppr = planes_per_row; g.nplanes = rows * planes_per_row;
-  g.lam = nullptr; g.rows = rows;
   hipStream_t st = (hipStream_t)stream;
   if (nz != 64) return GEOBO_E_UNSUPPORTED;
   if (!inverse) {
@@ -313,15 +374,25 @@ extern "C" int geobo_xz2d(int inverse, int nx, int nz, int64_t rows, int planes_
 }
 
 extern "C" int geobo_xcorr_reduce(int nx, int nz, int64_t rows, int planes, const double* in, int64_t in_row, int64_t in_plane,
-                                  const double* Mx, int64_t ldmx, const double* lam, double* out, int64_t out_row,
+                                  const double* Mx, int64_t ldmx, const double* lamT, double* out, int64_t out_row,
                                   int64_t out_plane, void* stream) {
-  if (!in || !out || !Mx || !lam) return GEOBO_E_ARG;
+  if (!in || !out || !Mx || !lamT) return GEOBO_E_ARG;
   if (rows <= 0 || planes <= 0) return GEOBO_OK;
   if ((in_row & 1) || (in_plane & 1) || ((uintptr_t)in & 15)) return GEOBO_E_ALIGN;
   if (nx != 64 || nz != 64) return GEOBO_E_UNSUPPORTED;
-  XZArgs g;
-  g.in = in; g.in_row = in_row; g.in_plane = in_plane; g.out = out; g.out_row = out_row; g.out_plane = out_plane;
-  g.Mz = nullptr; g.ldmz = 0; g.Mx = Mx; g.ldmx = ldmx; g.ppr = planes; g.nplanes = rows * planes;
-  g.lam = lam; g.rows = rows;
-  return launch<64, 64, 128, 64, EPI_SCALE_REDUCE>(g, (hipStream_t)stream);
+  XCArgs g;
+  g.in = in; g.in_row = in_row; g.in_plane = in_plane; g.Mx = Mx; g.ldmx = ldmx; g.lamT = lamT;
+  g.out = out; g.out_row = out_row; g.out_plane = out_plane; g.rows = rows; g.nplanes = rows * planes;
+  constexpr int NX = 64, NZ = 64, PX = 128;
+  constexpr size_t lds = (size_t)RING * 16 * NZ * 8 + (size_t)NX * (PX + 16) * 8 + 2 * 4 * PX * 8;
+  auto kern = xcorr_kernel<NX, NZ, PX>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return GEOBO_E_LAUNCH;
+    attr_set = true;
+  }
+  const int64_t nwg = g.nplanes < 1024 ? g.nplanes : 1024;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, (hipStream_t)stream, g);
+  return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
 }

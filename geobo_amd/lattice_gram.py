@@ -44,7 +44,7 @@ class LatticeGram:
         return nx == 64 and nz == 64 and ny in (48, 64)
 
     def eigen(self, Q, tol=1e-11):
-        """Lambda[ky][kx][z] / (Py Px) from the stencil table Q[(2ny-3)][(2nx-1)][nz]; None if Q is not even in both offsets."""
+        """Lambda^T[ky][z][kx] / (Py Px) from the stencil table Q[(2ny-3)][(2nx-1)][nz]; None if Q is not even in both offsets."""
         nx, ny, nz, Px, Py = self.nx, self.ny, self.nz, self.Px, self.Py
         cy, cx = ny - 2, nx - 1                                         # index of offset 0
         sp = self.sp
@@ -62,7 +62,7 @@ class LatticeGram:
         lam = torch.empty(Py * Px * nz + 4096, dtype=F64, device=self.device)
         hip.gemm_batched(True, hip.pad_n(Py), hip.pad_n(Px * nz), ny, sp.E["y"], ny, 0, T, Px * nz, 0, lam, Px * nz, 0, Py, Px * nz, 1)
         lam[:Py * Px * nz].mul_(1.0 / float(Py * Px))
-        return lam
+        return lam[:Py * Px * nz].view(Py, Px, nz).transpose(1, 2).contiguous().view(-1)       # z-major planes: [ky][z][kx]
 
     def flops(self, rows):
         nx, ny, nz, Px, Py = self.nx, self.ny, self.nz, self.Px, self.Py

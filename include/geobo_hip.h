@@ -172,10 +172,10 @@ int geobo_xz2d(int inverse, int nx, int nz, int64_t rows, int planes_per_row, co
 
 /* AkA on a lattice survey ("lattice Gram"): the x step of a (y, x) correlation with the z axis as a
  * channel.  For plane (r, p), r < rows, p < planes, at in + r*in_row + p*in_plane (nx x nz, row-major):
- *     out[r*out_row + p*out_plane + o] = sum_z lam[(p*2nx + o)*nz + z] * sum_x Mx[o][x] * in[x][z],   o < 2nx
- * (Mx = G_x, 2nx x nx; lam = eigenvalues of the even stencil table per (y-mode p, x-mode o, channel z)).  nx = nz = 64. */
+ *     out[r*out_row + p*out_plane + o] = sum_z lamT[(p*nz + z)*2nx + o] * sum_x Mx[o][x] * in[x][z],   o < 2nx
+ * (Mx = G_x, 2nx x nx; lamT = eigenvalues of the even stencil table per (y-mode p, channel z, x-mode o)).  nx = nz = 64. */
 int geobo_xcorr_reduce(int nx, int nz, int64_t rows, int planes, const double* in, int64_t in_row, int64_t in_plane,
-                       const double* Mx, int64_t ldmx, const double* lam, double* out, int64_t out_row, int64_t out_plane,
+                       const double* Mx, int64_t ldmx, const double* lamT, double* out, int64_t out_row, int64_t out_plane,
                        void* stream);
 
 /* y-axis stage of the structured product on a regular grid: for every mode c < C (the (x, z)
