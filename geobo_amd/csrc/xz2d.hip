@@ -299,10 +299,20 @@ __global__ void __launch_bounds__(256, 1) xcorr_kernel(XCArgs g) {
     v4d acc[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) acc[ct] = (v4d){0., 0., 0., 0.};
+    // this plane's eigenvalues: issued now, consumed after the MFMAs (their L2 latency hides under the chunk loop)
+    const int64_t pl = p / g.rows;
+    const double* lp = g.lamT + pl * (int64_t)(NZ * PX) + (int64_t)(16 * w + q) * PX + lr;
+    double lam[CT][4];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lam[ct][r] = lp[4 * r * PX + 16 * ct];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      // conservative wait (no term for this wave's later loads / stores: they only make it stricter), bare barrier, refill
-      __builtin_amdgcn_s_waitcnt(vmcnt_imm((RING - 2) * ND));
+      // chunk c has landed when at most the newer operations are in flight: RING-2 chunks, plus -- for the chunks that were
+      // requested during the previous plane -- the 4 CT eigenvalue loads above (conservative for the <= 1 result store)
+      if (c <= RING - 2) __builtin_amdgcn_s_waitcnt(vmcnt_imm((RING - 2) * ND + 4 * CT > 63 ? 63 : (RING - 2) * ND + 4 * CT));
+      else __builtin_amdgcn_s_waitcnt(vmcnt_imm((RING - 2) * ND));
       __builtin_amdgcn_s_barrier();
       {
         const int cn = c + RING - 1;
@@ -326,15 +336,13 @@ __global__ void __launch_bounds__(256, 1) xcorr_kernel(XCArgs g) {
       }
     }
     // ---- scale by the eigenvalues and sum over z: registers (4 z per lane), then the four 16-lane groups, then the waves --
-    const int64_t pl = p / g.rows;
-    const double* lp = g.lamT + pl * (int64_t)(NZ * PX) + (int64_t)(16 * w + q) * PX + lr;
     double* const rp = red + (it & 1) * (4 * PX) + w * PX;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
-      double v = acc[ct][0] * lp[16 * ct];
-      v = __builtin_fma(acc[ct][1], lp[4 * PX + 16 * ct], v);
-      v = __builtin_fma(acc[ct][2], lp[8 * PX + 16 * ct], v);
-      v = __builtin_fma(acc[ct][3], lp[12 * PX + 16 * ct], v);
+      double v = acc[ct][0] * lam[ct][0];
+      v = __builtin_fma(acc[ct][1], lam[ct][1], v);
+      v = __builtin_fma(acc[ct][2], lam[ct][2], v);
+      v = __builtin_fma(acc[ct][3], lam[ct][3], v);
       v += __shfl_xor(v, 16);
       v += __shfl_xor(v, 32);
       if (q == 0) rp[16 * ct + lr] = v;
