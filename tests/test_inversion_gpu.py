@@ -435,3 +435,27 @@ def test_lattice_gram_matches_the_gemm(ny, monkeypatch):
         torch.cuda.empty_cache()
     d = (out["0"] - out["1"]).abs().max().item()
     assert d <= 1e-12 * out["0"].abs().max().item(), d
+
+
+def test_lattice_gram_needs_an_even_stencil():
+    """An inclined magnetic field makes the operator's stencil table odd in x / y: the lattice Gram must step aside (GEMM)."""
+    import geobo_amd.engine as E
+    nx, ny, nz = 64, 48, 64
+    s = settings_for(nx, ny, nz, kernelfunc="exp")
+    from geobo_amd.inversion import Inversion
+    inv = Inversion(settings=s, props=(0, 1))
+    inv.create_cubegeometry()
+    xe, ye, ze = inv.engine.node_axes()
+    X, Y = np.meshgrid(0.5 * (xe[:-1] + xe[1:]), 0.5 * (ye[:-1] + ye[1:]))
+    loc = np.c_[X.ravel(), Y.ravel(), np.full(nx * ny, 1.0)]
+    eng = E.PosteriorEngine(s)
+    eng.operator("grav", loc)
+    eng.operator("magn", loc, B=(0.4, -0.3, 0.85))
+    assert eng._lam["grav"] is not None and eng._lam["magn"] is None
+    eng.operator("magn", loc, B=(0.0, 0.0, 1.0))
+    assert eng._lam["magn"] is not None
+    # a survey off the lattice: no plan at all
+    loc2 = loc.copy(); loc2[:, 0] += 3.0
+    eng2 = E.PosteriorEngine(s)
+    eng2.operator("grav", loc2)
+    assert eng2._lam.get("grav") is None
