@@ -256,11 +256,12 @@ struct XCArgs {
   int64_t rows, nplanes;
 };
 
-template <int NX, int NZ, int PX>
-__global__ void __launch_bounds__(256, 1) xcorr_kernel(XCArgs g) {
-  static_assert(NZ == 64 && NX % 16 == 0 && PX % 16 == 0, "four waves, one 16-row z tile each");
-  constexpr int CT = PX / 16, NCH = NX / 16, ROWB = NZ * 8, CHB = 16 * ROWB, LPR = ROWB / 16, RPI = 64 / LPR;
-  constexpr int ND = CHB / 1024 / 4, GS = PX + 16;
+template <int NX, int NZ, int PX, int NW>
+__global__ void __launch_bounds__(64 * NW, 1) xcorr_kernel(XCArgs g) {
+  static_assert(NZ == 64 && NX % 16 == 0 && PX % 32 == 0 && (NW == 4 || NW == 8), "one 16-row z tile per wave (pair)");
+  // NW = 8: two waves per SIMD; waves w and w + 4 share a z tile and split the 2nx output columns
+  constexpr int CT = PX / 16 / (NW / 4), NCH = NX / 16, ROWB = NZ * 8, CHB = 16 * ROWB, LPR = ROWB / 16, RPI = 64 / LPR;
+  constexpr int ND = CHB / 1024 / NW, GS = PX + 16;
   static_assert(ND >= 1 && NCH >= RING - 1, "chunking");
   extern __shared__ __attribute__((aligned(16))) double smem[];
   char* const ring = reinterpret_cast<char*>(smem);
@@ -268,9 +269,10 @@ __global__ void __launch_bounds__(256, 1) xcorr_kernel(XCArgs g) {
   double* const red = gxt + NX * GS;                   // [2][4][PX]
   const unsigned ring_lds = (unsigned)(uintptr_t)(lds_ptr_t)ring;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int w = wv & 3, ct0 = (wv >> 2) * CT;          // z tile, first output column tile of this wave
   const int lr = lane & 15, q = lane >> 4;
-  for (int idx = tid; idx < PX * NX; idx += 256) {
+  for (int idx = tid; idx < PX * NX; idx += 64 * NW) {
     const int o = idx / NX, x = idx % NX;
     gxt[x * GS + o] = g.Mx[(int64_t)o * g.ldmx + x];
   }
@@ -281,7 +283,7 @@ __global__ void __launch_bounds__(256, 1) xcorr_kernel(XCArgs g) {
   auto stage = [&](const double* plane, int c, int slot) {
 #pragma unroll
     for (int j = 0; j < ND; ++j) {
-      const int ii = w + 4 * j;
+      const int ii = wv + NW * j;
       const int row = ii * RPI + drow;
       const char* src = reinterpret_cast<const char*>(plane) + (int64_t)(16 * c + row) * ROWB + ((dpos ^ (row & 15)) << 4);
       __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(ring + slot * CHB + ii * 1024), 16, 0, 0);
@@ -301,7 +303,7 @@ __global__ void __launch_bounds__(256, 1) xcorr_kernel(XCArgs g) {
     for (int ct = 0; ct < CT; ++ct) acc[ct] = (v4d){0., 0., 0., 0.};
     // this plane's eigenvalues: issued now, consumed after the MFMAs (their L2 latency hides under the chunk loop)
     const int64_t pl = p / g.rows;
-    const double* lp = g.lamT + pl * (int64_t)(NZ * PX) + (int64_t)(16 * w + q) * PX + lr;
+    const double* lp = g.lamT + pl * (int64_t)(NZ * PX) + (int64_t)(16 * w + q) * PX + 16 * ct0 + lr;
     double lam[CT][4];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
@@ -330,13 +332,13 @@ __global__ void __launch_bounds__(256, 1) xcorr_kernel(XCArgs g) {
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const double* bp = gxt + (16 * c + 4 * s + q) * GS + lr;   // B[k = x][j = o]
+        const double* bp = gxt + (16 * c + 4 * s + q) * GS + 16 * ct0 + lr;   // B[k = x][j = o]
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], bp[16 * ct], acc[ct], 0, 0, 0);
       }
     }
     // ---- scale by the eigenvalues and sum over z: registers (4 z per lane), then the four 16-lane groups, then the waves --
-    double* const rp = red + (it & 1) * (4 * PX) + w * PX;
+    double* const rp = red + (it & 1) * (4 * PX) + w * PX + 16 * ct0;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
       double v = acc[ct][0] * lam[ct][0];
@@ -393,7 +395,8 @@ extern "C" int geobo_xcorr_reduce(int nx, int nz, int64_t rows, int planes, cons
   g.out = out; g.out_row = out_row; g.out_plane = out_plane; g.rows = rows; g.nplanes = rows * planes;
   constexpr int NX = 64, NZ = 64, PX = 128;
   constexpr size_t lds = (size_t)RING * 16 * NZ * 8 + (size_t)NX * (PX + 16) * 8 + 2 * 4 * PX * 8;
-  auto kern = xcorr_kernel<NX, NZ, PX>;
+  constexpr int NW = 8;
+  auto kern = xcorr_kernel<NX, NZ, PX, NW>;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -401,6 +404,6 @@ extern "C" int geobo_xcorr_reduce(int nx, int nz, int64_t rows, int planes, cons
     attr_set = true;
   }
   const int64_t nwg = g.nplanes < 1024 ? g.nplanes : 1024;
-  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, (hipStream_t)stream, g);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * NW), lds, (hipStream_t)stream, g);
   return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
 }
