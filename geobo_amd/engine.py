@@ -96,8 +96,11 @@ class PosteriorEngine:
         # row-sharded spectral product (N > 1): every rank transforms Ms/world sensor rows of each operator for ALL voxels
         # and one all-to-all hands each peer the block-columns it owns; needs equal shards
         ncs = {shard_columns(self.N_pad, world, r)[1] - shard_columns(self.N_pad, world, r)[0] for r in range(world)}
+        # Worth it from 4 ranks: with 2 the exchange moves a quarter of A K (8.8 GB at 64^3) over ONE xGMI link (~0.1 s),
+        # more than the forward passes it saves; replicated forward passes + slab-cropped backward passes win there.
+        xmode = os.environ.get("GEOBO_SPECTRAL_EXCHANGE", "auto")
         self.exchange = (self.use_spectral and world > 1 and self.Ms % world == 0 and len(ncs) == 1
-                         and os.environ.get("GEOBO_SPECTRAL_EXCHANGE", "1") != "0")
+                         and xmode != "0" and (world >= 4 or xmode == "1"))
         self._Arows = {}
         self.kernel_events = None  # set to [] to record (name, flops, start, stop) HIP events per fused launch
 
