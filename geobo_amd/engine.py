@@ -178,6 +178,8 @@ class PosteriorEngine:
                            rows=slice(self.rank * rows_r, (self.rank + 1) * rows_r), ws=lws)
             self._timed("a_sens_" + func, 0.0, build)
             self._Arows[func] = Ar
+            lam = self._gram_eigen(plan, lws) if plan is not None else None
+            self._lam[func] = None if lam is None else (A, lam)
         else:
             self._timed("a_sens_" + func, 0.0, lambda: hip.a_sens(func, Bv, locd, self.nx, self.ny, self.nz, xed, yed, zed, mul, div, A,
                                                                  plan=plan, ws=lws))
@@ -330,7 +332,12 @@ class PosteriorEngine:
     def _gram_eigen(self, plan, lws):
         """Eigen-data of the operator's stencil table for the lattice Gram (lattice_gram.py); None -> AkA by the N-deep GEMM."""
         from .lattice_gram import LatticeGram
-        if (self.world != 1 or not self.use_spectral or not plan["rowmajor"] or self.Ms_pad != self.Ms
+        plane = self.nx * self.nz
+        Ly = (self.c1 - self.c0) // plane
+        # column-sharded runs: every rank correlates its own y-slab of the A K rows (the partial results add up in the all-reduce
+        # of AkA); the x step and the back-transform are not divided, so from ~5 ranks the N-deep GEMM over N/G columns is cheaper
+        if (not self.use_spectral or not plan["rowmajor"] or self.Ms_pad != self.Ms or self.world > 4
+                or (self.c1 - self.c0) % plane or Ly % 16 or self.c1 > self.N
                 or not LatticeGram.supported(self.nx, self.ny, self.nz) or os.environ.get("GEOBO_AKA_LATTICE", "1") == "0"):
             return None
         if self._spectral is None:
@@ -364,15 +371,17 @@ class PosteriorEngine:
             mv = off_d + Md - r0                       # rows behind the last drill row are padding: not contracted
             lam = self._lam.get(("grav", "magn")[s_])
             lam = lam[1] if lam is not None and lam[0] is A else None
-            if lam is not None and self.world == 1:
+            if lam is not None:
                 # lattice survey, even stencil: interior y-slabs by the (y, x) correlation, the two padded slabs by a GEMM
                 gram, pl = self._gram, self.nx * self.nz
-                fl = gram.flops(mv) + 2.0 * 2 * pl * 128 * sum(min(2 * (bi + 1), self.Ms_pad // 128) * rv
-                                                                for bi, rv in enumerate(hip.tile_rows(rows, mv)))
+                ya, yb = self.c0 // pl, self.c1 // pl                      # this rank's y-slab
+                edges = [c for iy, c in ((0, 0), (self.ny - 1, (self.ny - 1 - ya) * pl)) if ya <= iy < yb]
+                fl = gram.flops(mv, yb - ya) + 2.0 * len(edges) * pl * 128 * sum(
+                    min(2 * (bi + 1), self.Ms_pad // 128) * rv for bi, rv in enumerate(hip.tile_rows(rows, mv)))
 
                 def lattice():
-                    gram.gram_rows(Xv, mv, lam, Cv)
-                    for c0 in (0, (self.ny - 1) * pl):
+                    gram.gram_rows(Xv, mv, lam, Cv, ya, yb)
+                    for c0 in edges:
                         hip.gemm_nt(Xv[:, c0:c0 + pl], Yv[:, c0:c0 + pl], Cv, alpha=1.0, beta=1.0, lower_only=True, m_valid=mv)
                 self._timed("aka_lattice", fl, lattice)
                 continue

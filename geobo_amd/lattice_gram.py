@@ -64,23 +64,29 @@ class LatticeGram:
         lam[:Py * Px * nz].mul_(1.0 / float(Py * Px))
         return lam[:Py * Px * nz].view(Py, Px, nz).transpose(1, 2).contiguous().view(-1)       # z-major planes: [ky][z][kx]
 
-    def flops(self, rows):
+    def flops(self, rows, Ly=None):
         nx, ny, nz, Px, Py = self.nx, self.ny, self.nz, self.Px, self.Py
-        return rows * 2.0 * (hip.pad_n(Py) * nx * nz * ny + Py * Px * nx * nz + ny * Py * Px + ny * nx * Px)
+        Ly = ny if Ly is None else Ly
+        return rows * 2.0 * (hip.pad_n(Py) * nx * nz * Ly + Py * Px * nx * nz + ny * Py * Px + ny * nx * Px)
 
-    def gram_rows(self, X, nrows, lam, out):
-        """out[r, :ny*nx] = interior-slab part of (A K)[r] . A^T for r < nrows.  X: (>= nrows x >= N) rows of A K for the block's
-        property (row-major view); out: (>= nrows x >= ny*nx) view of the AkA block column."""
+    def gram_rows(self, X, nrows, lam, out, y0=0, y1=None):
+        """out[r, :ny*nx] = interior-slab part of (A K)[r] . A^T for r < nrows.  X: (>= nrows x >= (y1-y0)*nx*nz) rows of A K for
+        the block's property, voxel columns of the y-slab [y0, y1) only (a rank of a column-sharded run holds just its slab: the
+        partial correlations add up in the all-reduce of AkA); out: (>= nrows x >= ny*nx) view of the AkA block column."""
         nx, ny, nz, Px, Py = self.nx, self.ny, self.nz, self.Px, self.Py
+        y1 = ny if y1 is None else y1
+        Ly = y1 - y0
+        assert Ly % 16 == 0
         sp = self.sp
         plane = nx * nz
         assert X.stride(1) == 1 and out.stride(1) == 1 and X.stride(0) % 2 == 0 and out.stride(0) % 2 == 0
+        gy = self.Gy0[:, y0:]                        # columns of this slab (row stride ny; rows behind are padding / slack)
         for r0 in range(0, nrows, self.R):
             R = min(self.R, nrows - r0)
-            y1 = sp.buf("LG_Y1", R * Py * plane)
-            hip.gemm_batched(True, hip.pad_n(Py), hip.pad_n(plane), ny, self.Gy0, ny, 0, X[r0:], plane, X.stride(0), y1, plane,
+            y1b = sp.buf("LG_Y1", R * Py * plane)
+            hip.gemm_batched(True, hip.pad_n(Py), hip.pad_n(plane), Ly, gy, ny, 0, X[r0:], plane, X.stride(0), y1b, plane,
                              Py * plane, Py, plane, R)
             s = sp.buf("LG_S", R * Py * Px)
-            hip.xcorr_reduce(nx, nz, R, Py, y1, Py * plane, plane, sp.G["x"], lam, s, Py * Px, Px)
+            hip.xcorr_reduce(nx, nz, R, Py, y1b, Py * plane, plane, sp.G["x"], lam, s, Py * Px, Px)
             # "x" of geobo_xz2d is this grid's y axis, its "z" this grid's x axis: S_r (Py x Px) -> Gy^T S_r Gx (ny x nx)
             hip.xz2d(True, ny, nx, R, 1, s, Py * Px, Py * Px, sp.GT["y"], sp.GT["x"], out[r0:], out.stride(0), ny * nx)
