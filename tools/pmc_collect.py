@@ -14,7 +14,11 @@ GROUPS = [["GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES"],
           ["FETCH_SIZE"], ["WRITE_SIZE"],     # FETCH_SIZE costs 3 of the 4 TCC slots: one pass each
           ["TCC_HIT_sum", "TCC_MISS_sum"]]
 DRIVERS = {"posterior": ("run_posterior_once.py", "gemm_f64_kernel<4, 2, 2, 1", "pmc_posterior_reduce.json"),
-           "fused": ("run_fused_once.py", "gemm_f64_kernel<4, 2, 3", "pmc_ak_fused_grid.json")}
+           "fused": ("run_fused_once.py", "gemm_f64_kernel<4, 2, 3", "pmc_ak_fused_grid.json"),
+           "xz2d_fwd": ("run_spectral_kernels_once.py xz2d_fwd", "xz2d_kernel<64, 64, 128, 128>", "pmc_xz2d_fwd.json"),
+           "xz2d_bwd": ("run_spectral_kernels_once.py xz2d_bwd", "xz2d_kernel<128, 128, 64, 64>", "pmc_xz2d_bwd.json"),
+           "toeplitz": ("run_spectral_kernels_once.py toeplitz", "toeplitz_y_kernel", "pmc_toeplitz_y.json"),
+           "xcorr": ("run_spectral_kernels_once.py xcorr", "xcorr_kernel", "pmc_xcorr.json")}
 
 
 def main():
@@ -23,13 +27,18 @@ def main():
     counters, text = {}, ""
     for grp in GROUPS:
         d = tempfile.mkdtemp(prefix="pmc_", dir="/tmp")
-        cmd = ["rocprofv3", "--pmc", *grp, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.join(HERE, script)]
+        sc = script.split()
+        cmd = ["rocprofv3", "--pmc", *grp, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.join(HERE, sc[0]), *sc[1:]]
         r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True)
         text = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else text
+        ndisp = {}
         for f in glob.glob(os.path.join(d, "*", "*counter_collection.csv")):
             for row in csv.DictReader(open(f)):
                 if kmatch in row["Kernel_Name"]:
                     counters[row["Counter_Name"]] = counters.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+                    ndisp.setdefault(row["Counter_Name"], set()).add(row["Dispatch_Id"])
+        for c, ids in ndisp.items():          # drivers that launch the kernel twice (warm-up + timed): per-launch average
+            counters[c] /= len(ids)
     m = re.search(r"([0-9.]+) s, ([0-9.]+) TF/s", text)
     secs = float(m.group(1)) if m else None
     mf = re.search(r"flop ([0-9]+)", text)

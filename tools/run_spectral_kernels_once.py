@@ -1,0 +1,41 @@
+"""One launch of each kernel of the spectral route / lattice Gram at the 64^3 batch shapes (for rocprofv3 PMC passes):
+xz2d forward and inverse (256 sensor rows x 64 y-planes), toeplitz_y (256 rows, 2 property blocks), xcorr (256 rows x 128 y-modes)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from geobo_amd import hip
+n, R = 64, 256
+P = 2 * n
+dev = "cuda"
+rnd = lambda *shape: torch.rand(shape, dtype=torch.float64, device=dev) * 2 - 1
+def timed(name, flop, gbytes, f):
+    f(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); f(); e1.record(); torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) * 1e-3
+    print("%s: %.4f s, %.1f TF/s executed, flop %.0f; algorithmic bytes %.3e (%.2f TB/s)" % (name, t, flop / t / 1e12, flop, gbytes, gbytes / t / 1e12), flush=True)
+which = sys.argv[1] if len(sys.argv) > 1 else "all"
+Gx, Gz, GxT, GzT = rnd(P, n), rnd(P, n), rnd(n, P), rnd(n, P)
+if which in ("all", "xz2d_fwd"):
+    src, out = rnd(R, n * n * n), torch.empty((R, n * P * P), dtype=torch.float64, device=dev)
+    timed("xz2d_fwd", R * n * 2.0 * (n * n * P + P * n * P), R * n * (n * n + P * P) * 8.0,
+          lambda: hip.xz2d(False, n, n, R, n, src, src.stride(0), n * n, Gx, Gz, out, out.stride(0), P * P))
+    del src, out
+if which in ("all", "xz2d_bwd"):
+    src, out = rnd(R, n * P * P), torch.empty((R, n * n * n), dtype=torch.float64, device=dev)
+    timed("xz2d_bwd", R * n * 2.0 * (P * P * n + n * P * n), R * n * (n * n + P * P) * 8.0,
+          lambda: hip.xz2d(True, n, n, R, n, src, src.stride(0), P * P, GxT, GzT, out, out.stride(0), n * n))
+    del src, out
+if which in ("all", "toeplitz"):
+    C = P * P
+    src = rnd(R * n * C)
+    tabs = [rnd(n * C), rnd(n * C)]
+    outs = [torch.empty(R * n * C, dtype=torch.float64, device=dev) for _ in range(2)]
+    timed("toeplitz_y", R * C * 2.0 * n * n * 2, R * n * C * 8.0 * 3, lambda: hip.toeplitz_y(n, C, R, src, tabs, outs))
+    del src, tabs, outs
+if which in ("all", "xcorr"):
+    src = rnd(R, P * n * n)
+    lam = rnd(P * n * P)
+    out = torch.empty((R, P * P), dtype=torch.float64, device=dev)
+    timed("xcorr", R * P * 2.0 * P * n * n, R * P * (n * n + P) * 8.0,
+          lambda: hip.xcorr_reduce(n, n, R, P, src, src.stride(0), n * n, Gx, lam, out, out.stride(0), P))
