@@ -256,6 +256,11 @@ struct XCArgs {
   int64_t rows, nplanes;
 };
 
+// slot swizzle of the xcorr input chunks: a ds_read_b64 serves lanes 0-31 together = two consecutive x rows (q = 0, 1) of 16
+// z columns each; bit 0 of the row goes to bit 3 of the slot XOR, so the two rows land in different 128-byte halves of the
+// 256-byte bank row
+__device__ __forceinline__ int xswz(int row) { return ((row & 1) << 3) | ((row >> 1) & 7); }
+
 template <int NX, int NZ, int PX, int NW>
 __global__ void __launch_bounds__(64 * NW, 1) xcorr_kernel(XCArgs g) {
   static_assert(NZ == 64 && NX % 16 == 0 && PX % 32 == 0 && (NW == 4 || NW == 8), "one 16-row z tile per wave (pair)");
@@ -285,7 +290,7 @@ __global__ void __launch_bounds__(64 * NW, 1) xcorr_kernel(XCArgs g) {
     for (int j = 0; j < ND; ++j) {
       const int ii = wv + NW * j;
       const int row = ii * RPI + drow;
-      const char* src = reinterpret_cast<const char*>(plane) + (int64_t)(16 * c + row) * ROWB + ((dpos ^ (row & 15)) << 4);
+      const char* src = reinterpret_cast<const char*>(plane) + (int64_t)(16 * c + row) * ROWB + ((dpos ^ xswz(row)) << 4);
       __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(ring + slot * CHB + ii * 1024), 16, 0, 0);
     }
   };
@@ -326,7 +331,7 @@ __global__ void __launch_bounds__(64 * NW, 1) xcorr_kernel(XCArgs g) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {                    // A[i = z][k = x]: X[x = 16c + 4s + q][z = col]
         const int row = 4 * s + q;
-        const unsigned addr = xs + row * ROWB + ((((col >> 1) ^ row) << 4) | ((col & 1) << 3));
+        const unsigned addr = xs + row * ROWB + ((((col >> 1) ^ xswz(row)) << 4) | ((col & 1) << 3));
         asm volatile("ds_read_b64 %0, %1" : "=v"(a[s]) : "v"(addr));
       }
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
