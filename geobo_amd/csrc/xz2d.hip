@@ -133,15 +133,12 @@ __global__ void __launch_bounds__(xz_threads(OUT_Z), 1) xz2d_kernel(XZArgs g) {
     v4d d1[RT1][CT];
 #pragma unroll
     for (int c = 0; c < RT1; ++c) {
-      // (1) this wave's share of chunk c has landed: everything issued after it may still be in flight -- the RING-2
-      //     newer chunks and, for the first RING-1 chunks of a plane, the previous plane's NS stores (vmcnt counts both)
+      // (1) this wave's share of chunk c has landed.  Chunks 0 .. RING-2 of a plane were requested during the previous plane
+      //     and waited for there (the vmcnt(0) in front of its stores); for the others -- and in the first plane -- everything
+      //     issued after chunk c is RING-2 newer chunks.  The waits never have to see past stores: vmcnt counts loads and
+      //     stores together, and nothing here relies on the two completing in issue order relative to each other.
 #ifndef GEOBO_XZ_ABL_NOWAIT
-      if (c <= RING - 2 && warm) {
-        constexpr int n = (RING - 2) * K::ND + K::NS;
-        __builtin_amdgcn_s_waitcnt(vmcnt_imm(n > 63 ? 63 : n));
-      } else {
-        __builtin_amdgcn_s_waitcnt(vmcnt_imm((RING - 2) * K::ND));
-      }
+      if (!(c <= RING - 2 && warm)) __builtin_amdgcn_s_waitcnt(vmcnt_imm((RING - 2) * K::ND));
 #endif
       // (2) every share landed; every wave is done with the chunk staged RING-1 ago.  A bare s_barrier: __syncthreads()
       //     adds a fence that drains vmcnt to 0, i.e. waits for the prefetched chunks and the output stores as well.
@@ -208,6 +205,9 @@ __global__ void __launch_bounds__(xz_threads(OUT_Z), 1) xz2d_kernel(XZArgs g) {
               acc[m][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(kk == 0 ? a01[m].x : kk == 1 ? a01[m].y : kk == 2 ? a23[m].x : a23[m].y,
                                                                 d1[rt][ct][kk], acc[m][ct], 0, 0, 0);
       }
+      // the next plane's first RING-1 chunks were requested at least one step 2 ago: drain them here (free), so that no
+      // later wait has this plane's stores between itself and the chunk it waits for
+      if (h0 == 0) __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
 #pragma unroll
       for (int m = 0; m < HALF; ++m)
 #pragma unroll
