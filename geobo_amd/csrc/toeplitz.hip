@@ -41,23 +41,44 @@ __device__ __forceinline__ void st_lane(rsrc_t rs, unsigned lane8, int soff, dou
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rs, lane8, soff, 0);
 }
 
+// s_waitcnt immediate for vmcnt(v) only (gfx9 encoding: vmcnt[3:0] | expcnt 7 | lgkmcnt 15 | vmcnt[5:4] << 14)
+constexpr int vmcnt_only(int v) { return (v & 15) | (7 << 4) | (15 << 8) | ((v >> 4) << 14); }
+
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
 // NY x (NY/2) multiply-adds of one wave-row, all table indices compile-time constants.  The wave computes outputs
 // o = 0..OC-1 of the row as stored in LDS; the second half of the outputs uses the SAME code on the reversed row
 // (T is persymmetric: out[NY-1-o] = sum_y'' t(|o - y''|) in[NY-1-y'']), selected by the sign of `xstep`.
-template <int NY, int OC, int YP>
-__device__ __forceinline__ void toeplitz_fma(const double (&t)[NY], double (&acc)[OC], const char* xp, int xstep) {
-  // compiler barrier every 8 inputs: the scheduler may run LDS reads ahead, but not all NY of them (spills)
-  if constexpr (YP % 8 == 0) asm volatile("" ::: "memory");
-  const double x = *reinterpret_cast<const double*>(xp);
+// The LDS reads of the row are inline asm: for LDS reads it can see, the compiler first waits for EVERY outstanding LDS-DMA
+// (vmcnt(0): it cannot tell the two ring halves apart), i.e. for the NEXT row that was requested a moment ago -- no prefetch
+// at all.  Groups of GX inputs, double buffered: group g+1 is requested before the FMAs of group g.
+constexpr int GX = 4;
+
+template <int NY, int OC, int G>
+__device__ __forceinline__ void toeplitz_group(const double (&t)[NY], double (&acc)[OC], double (&xb)[2][GX], unsigned xaddr, int xstep) {
+  constexpr int NGX = NY / GX;
+  __builtin_amdgcn_sched_barrier(0);   // keep the groups apart: interleaving them costs registers the table needs
+  if constexpr (G + 1 < NGX) {
 #pragma unroll
-  for (int o = 0; o < OC; ++o) {
-    const int d = o - YP;
-    acc[o] = (YP == 0) ? t[d < 0 ? -d : d] * x : __builtin_fma(t[d < 0 ? -d : d], x, acc[o]);
+    for (int i = 0; i < GX; ++i)
+      asm volatile("ds_read_b64 %0, %1" : "=v"(xb[(G + 1) & 1][i]) : "v"(xaddr + (unsigned)(((G + 1) * GX + i) * xstep)));
+    // group G (requested one group earlier) is complete once only the GX reads just issued are outstanding
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(xb[G & 1][0]), "+v"(xb[G & 1][1]), "+v"(xb[G & 1][2]), "+v"(xb[G & 1][3]) : "n"(GX));
+  } else {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xb[G & 1][0]), "+v"(xb[G & 1][1]), "+v"(xb[G & 1][2]), "+v"(xb[G & 1][3]));
   }
-  if constexpr (YP + 1 < NY) toeplitz_fma<NY, OC, YP + 1>(t, acc, xp + xstep, xstep);
+#pragma unroll
+  for (int i = 0; i < GX; ++i) {
+    const int yp = G * GX + i;
+    const double x = xb[G & 1][i];
+#pragma unroll
+    for (int o = 0; o < OC; ++o) {
+      const int d = o - yp;
+      acc[o] = (yp == 0) ? t[d < 0 ? -d : d] * x : __builtin_fma(t[d < 0 ? -d : d], x, acc[o]);
+    }
+  }
+  if constexpr (G + 1 < NGX) toeplitz_group<NY, OC, G + 1>(t, acc, xb, xaddr, xstep);
 }
 
 // Workgroup = 2 * nprop waves sharing ONE row at a time: wave (prop, half).  The next row streams into the other half
@@ -103,9 +124,18 @@ __global__ void __launch_bounds__(256, 2) toeplitz_y_kernel(ToeplitzArgs g) {
       ps += rstep * NY * C;
       stage(ps, b ^ 1);
     }
-    double acc[OC];
-    const char* xp = reinterpret_cast<const char*>(&xs[b][half ? NY - 1 : 0][0]) + lane8;
-    toeplitz_fma<NY, OC, 0>(t, acc, xp, xstep);
+    double acc[OC], xb[2][GX];
+    const unsigned xaddr = (unsigned)(uintptr_t)(lds_ptr_t)&xs[b][half ? NY - 1 : 0][0] + lane8;
+#pragma unroll
+    for (int i = 0; i < GX; ++i) asm volatile("ds_read_b64 %0, %1" : "=v"(xb[0][i]) : "v"(xaddr + (unsigned)(i * xstep)));
+    toeplitz_group<NY, OC, 0>(t, acc, xb, xaddr, xstep);
+    // pin the sums here: otherwise the tail of every sum is sunk into its (predicated) store block, which keeps the last
+    // inputs and half the table live across all of them (spills; scratch reloads are VMEM and drain the prefetch)
+#pragma unroll
+    for (int o = 0; o < OC; ++o) asm volatile("" : "+v"(acc[o]));
+    // the next row was requested a whole row of arithmetic ago: drain it BEFORE the stores (free), so that the barrier below
+    // does not have to wait for the stores as well
+    __builtin_amdgcn_s_waitcnt(vmcnt_only(0));
     const rsrc_t dst = make_rsrc(po, out_bytes);
     int y0 = g.y0, y1 = g.y1, pitch = C8;
     // laundered per row: keeps the NY/2 store offsets and predicates from being hoisted into ~100 live SGPRs
@@ -116,8 +146,7 @@ __global__ void __launch_bounds__(256, 2) toeplitz_y_kernel(ToeplitzArgs g) {
       if (y >= y0 && y < y1) st_lane(dst, lane8, (y - y0) * pitch, acc[o]);
     }
     po += rstep * ostep;
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
+    __builtin_amdgcn_s_barrier();   // every wave has drained its share of the next row and is done reading this one
     b ^= 1;
   }
 }
