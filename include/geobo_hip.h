@@ -170,8 +170,8 @@ int geobo_xz2d(int inverse, int nx, int nz, int64_t rows, int planes_per_row, co
                int64_t in_plane, const double* Mx, int64_t ldmx, const double* Mz, int64_t ldmz, double* out,
                int64_t out_row, int64_t out_plane, void* stream);
 
-/* AkA on a lattice survey ("lattice Gram"): the x step of a (y, x) correlation with the z axis as a
- * channel.  For plane (r, p), r < rows, p < planes, at in + r*in_row + p*in_plane (nx x nz, row-major):
+/* AkA = (A K) A^T (inversion.py:96) on a lattice survey ("lattice Gram"): the x step of a (y, x)
+ * correlation of the rows of A K with the operator's stencil table, the z axis acting as a channel.  For plane (r, p), r < rows, p < planes, at in + r*in_row + p*in_plane (nx x nz, row-major):
  *     out[r*out_row + p*out_plane + o] = sum_z lamT[(p*nz + z)*2nx + o] * sum_x Mx[o][x] * in[x][z],   o < 2nx
  * (Mx = G_x, 2nx x nx; lamT = eigenvalues of the even stencil table per (y-mode p, channel z, x-mode o)).  nx = nz = 64. */
 int geobo_xcorr_reduce(int nx, int nz, int64_t rows, int planes, const double* in, int64_t in_row, int64_t in_plane,
