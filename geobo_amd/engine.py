@@ -336,7 +336,8 @@ class PosteriorEngine:
         Ly = (self.c1 - self.c0) // plane
         # column-sharded runs: every rank correlates its own y-slab of the A K rows (the partial results add up in the all-reduce
         # of AkA); the x step and the back-transform are not divided, so from ~5 ranks the N-deep GEMM over N/G columns is cheaper
-        if (not self.use_spectral or not plan["rowmajor"] or self.Ms_pad != self.Ms or self.world > 4
+        # (with the row exchange -- 4 ranks and more -- the GEMM over N/G columns is within a few ms of it: not used there)
+        if (not self.use_spectral or not plan["rowmajor"] or self.Ms_pad != self.Ms or self.world > 4 or self.exchange
                 or (self.c1 - self.c0) % plane or Ly % 16 or self.c1 > self.N
                 or not LatticeGram.supported(self.nx, self.ny, self.nz) or os.environ.get("GEOBO_AKA_LATTICE", "1") == "0"):
             return None
