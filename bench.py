@@ -83,7 +83,7 @@ def pmc_traffic(kernel, flops_per_launch):
         return None
 
 
-def cpu_baseline(inv, lengths, target_seconds=15.0):
+def cpu_baseline(inv, lengths, target_seconds=30.0):
     """Oracle ("port") on the host cores, bounded sample: the fused A.K product + the V solve / reductions for `b`
     voxel columns x 2 properties of THIS workload, operators and Cholesky factor taken as given (so the CPU rate is
     an upper bound: A_sens, AkA and the factorisation are not charged)."""
