@@ -68,25 +68,37 @@ def synthetic_inputs(inv, md):
     return grav, mag, loc, drill0
 
 
-PMC_FILES = {"ak_fused_grid": "r01_pmc_ak_fused_grid_v2.json", "posterior_reduce": "r01_pmc_posterior_reduce.json"}
+PMC_FILES = {"ak_fused_grid": "r01_pmc_ak_fused_grid_v2.json", "posterior_reduce": "r02_pmc_posterior_reduce.json"}
+GPU_DENSE_ROUTE = "profiles/r01_bench64_dense.json"   # builder-run bench line of `--method dense` (same algorithm as the CPU sample)
 
 
-def pmc_traffic(kernel, flops_per_launch):
+def pmc_traffic(kernel, executed_flop_per_launch):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (separate --pmc runs of
     tools/run_fused_once.py / tools/run_posterior_once.py: FETCH_SIZE x2 (gfx950 half-count of wide loads,
-    MI355X_MICROARCH.md) + WRITE_SIZE, KiB), scaled from the profiled launch to this launch by its flop count.
-    None if no PMC summary is committed for that kernel."""
+    MI355X_MICROARCH.md) + WRITE_SIZE, KiB), scaled from the profiled launch to this launch by the executed flop count.
+    Returns (bytes or None, source): the figure is a committed measurement of the same kernel and shape, not of this run."""
+    for name in (PMC_FILES.get(kernel, ""), PMC_FILES.get(kernel, "").replace("r02_", "r01_")):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+            return d["derived"]["hbm_bytes_per_launch_corrected"] * executed_flop_per_launch / d["flop"], "profiles/" + name
+        except Exception:
+            continue
+    return None, None
+
+
+def host_threads():
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", PMC_FILES[kernel])))
-        return d["derived"]["hbm_bytes_per_launch_corrected"] * flops_per_launch / d["flop"]
+        from threadpoolctl import threadpool_info
+        return int(max([p.get("num_threads", 1) for p in threadpool_info()] + [1]))
     except Exception:
-        return None
+        return int(os.cpu_count() or 1)
 
 
-def cpu_baseline(inv, lengths, target_seconds=30.0):
-    """Oracle ("port") on the host cores, bounded sample: the fused A.K product + the V solve / reductions for `b`
-    voxel columns x 2 properties of THIS workload, operators and Cholesky factor taken as given (so the CPU rate is
-    an upper bound: A_sens, AkA and the factorisation are not charged)."""
+def cpu_baseline(inv, lengths, target_seconds=20.0):
+    """Oracle ("port") on the host cores, bounded sample of THIS workload: the fused A.K product (dense algorithm: the
+    covariance block evaluated from squared distances, N-deep contraction) + the V solve / reductions for `b` voxel columns
+    x 2 properties, operators and Cholesky factor taken as given (so the CPU rate is an upper bound: A_sens, AkA and the
+    factorisation are not charged)."""
     from oracle import geobo_oracle as O
     from scipy.linalg import solve_triangular
     eng = inv.engine
@@ -102,13 +114,14 @@ def cpu_baseline(inv, lengths, target_seconds=30.0):
     W = O.weight_matrix(s.gp_coeff)
     sel = inv._sel
     name = s.kernelfunc
+    M = L.shape[0]
 
     def sample(b, c0):
         t0 = time.perf_counter()
         D2 = O.sqdist(P3, P3[c0:c0 + b])
         out = []
         for j in (0, 1):
-            AK = np.empty((L.shape[0], b))
+            AK = np.empty((M, b))
             AK[:Ms] = A_g @ O.k_block(name, D2, lengths, W, 0, j)
             AK[Ms:2 * Ms] = A_m @ O.k_block(name, D2, lengths, W, 1, j)
             if sel.size:
@@ -121,16 +134,69 @@ def cpu_baseline(inv, lengths, target_seconds=30.0):
     t_small, _ = sample(16, c0)
     b = int(max(16, min(2048, 16 * target_seconds / max(t_small, 1e-3))))
     t, out = sample(b, c0)
-    # sanity: the sample must agree with the GPU posterior on the same columns
-    try:
-        from threadpoolctl import threadpool_info
-        thr = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-    except Exception:
-        thr = os.cpu_count()
-    return dict(value=2.0 * b / t, unit="voxel-properties/s", cores=int(thr), kind="port",
+    flop = 2.0 * b * (2.0 * (2 * Ms) * N + 1.0 * M * M + 4.0 * M)       # section 8(d) terms for b columns x 2 properties
+    return dict(value=2.0 * b / t, unit="voxel-properties/s", cores=host_threads(), kind="port",
+                algorithm="dense (covariance evaluated from squared distances, N-deep contraction): SURVEY 8(d) flop model",
+                gflops=flop / t / 1e9,
                 sample="%d of %d voxel columns x 2 properties of the same workload: fused A.K + triangular solve + "
                        "mean/variance reductions in NumPy/OpenBLAS (oracle/geobo_oracle.py); operators and Cholesky factor "
                        "given, so this is an upper bound on the CPU rate; %.1f s" % (b, N, t)), (c0, b, out)
+
+
+def cpu_baseline_forms(sizes, dense_sizes, F64, gflops_sample):
+    """SURVEY.md section 8(d) CPU forms on this box's host cores: (b) the oracle's full matrix-free inversion (operators, A K,
+    AkA, Cholesky, solves, reductions -- the whole step, same synthetic survey formulas) at the given cube edges, (a) the
+    reference-shaped form (full K and full posterior covariance, inversion.py:77-122) at `dense_sizes`; the 64^3 time is
+    EXTRAPOLATED from the largest measured matrix-free size by the 8(d) flop model and labelled so."""
+    from oracle import geobo_oracle as O
+    forms = {}
+
+    def flop_model(n, md):
+        N, Ms = n ** 3, 2 * n * n
+        M = Ms + md
+        return 2.0 * Ms * N * N * 2 + 2.0 * M * Ms * N + M ** 3 / 3.0 + 1.0 * M * M * 2 * N + 4.0 * M * 2 * N + M * M
+
+    last = None
+    for n, dense in [(n, False) for n in sizes] + [(n, True) for n in dense_sizes]:
+        G = O.Grid(nx=n, ny=n, nz=n, xmax=100.0 * n, ymax=100.0 * n, zLcube=100.0 * n, kernelfunc="matern32")
+        t0 = time.perf_counter()
+        sv = O.synthetic_survey(G, 50 if n >= 16 else 5)
+        d0 = sv["drilldata0"]
+        O.cubing(G, sv["gravfield"], sv["magfield"], d0[d0 != 0], sv["sensor_locations"], d0,
+                 gp_length=np.array([2.00, 2.02, 2.04]) * 100.0, dense=dense, props=(0, 1, 2) if dense else (0, 1), A=sv["A"])
+        t = time.perf_counter() - t0
+        key = ("reference_shaped_%d" if dense else "matrix_free_%d") % n
+        forms[key] = dict(seconds=t, voxel_properties_per_s=2.0 * n ** 3 / t, measured=True,
+                          what=("full K + full posterior covariance like inversion.py:77-122" if dense else
+                                "whole step incl. A_sens, A K, AkA, Cholesky, solves, reductions") + ", oracle/geobo_oracle.py")
+        if not dense:
+            last = (n, t)
+    if last is not None:
+        n, t = last
+        t64 = t * F64 / flop_model(n, 50)
+        forms["matrix_free_64_extrapolated"] = dict(seconds=t64, voxel_properties_per_s=2.0 * 64 ** 3 / t64, measured=False,
+                                                    what="EXTRAPOLATED from matrix_free_%d by the section 8(d) flop model "
+                                                         "(%.3e / %.3e flop)" % (n, F64, flop_model(n, 50)))
+    if gflops_sample:
+        t64 = F64 / (gflops_sample * 1e9)
+        forms["dense_algorithm_64_from_sample_rate"] = dict(seconds=t64, voxel_properties_per_s=2.0 * 64 ** 3 / t64, measured=False,
+                                                            what="section 8(d) flop count of the 64^3 step / the GFLOP/s the bounded sample achieved")
+    return forms
+
+
+def relaunch_with_ranks(a):
+    """`python bench.py --gpus N` without a launcher in the environment: start the N ranks ourselves (one process per GPU,
+    torch.distributed.run, rendezvous on 127.0.0.1) and exit with their status."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % a.gpus, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver (RCCL needs it)
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -144,21 +210,36 @@ def main():
     ap.add_argument("--method", default="auto", choices=["auto", "dense", "spectral"],
                     help="A.K route: dense = fused in-kernel covariance generation; spectral = real-DFT on batched MFMA GEMMs")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-forms", default="16", help="comma list of cube edges for the full matrix-free CPU oracle step "
+                    "(SURVEY 8(d) form (b)); '16,32' adds the 32^3 run (minutes)")
+    ap.add_argument("--cpu-dense-forms", default="", help="cube edges for the reference-shaped CPU form (a), e.g. '16' (~30 s) or '16,20'")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU dry runs)")
+    ap.add_argument("--oversubscribe", action="store_true", help="dry runs: allow several ranks per device (gloo backend)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_with_ranks(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world and world > 1:
-        raise SystemExit("--gpus must equal WORLD_SIZE")
-    local = local % max(torch.cuda.device_count(), 1)   # (dry runs may put several ranks on one device)
+    if a.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s); refusing to print a line for a different job size" % (a.gpus, world))
+    ndev = torch.cuda.device_count()
+    if ndev < world and not (a.oversubscribe and a.backend != "nccl"):
+        raise SystemExit("bench.py: --gpus %d needs %d visible devices, found %d" % (a.gpus, world, ndev))
+    local = local % max(ndev, 1)   # (--oversubscribe dry runs put several ranks on one device)
     torch.cuda.set_device(local)
     dist = None
+    ranks_reported = 1
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend=a.backend, rank=rank, world_size=world)
+        ones = torch.ones(1, dtype=torch.float64, device="cuda")
+        dist.all_reduce(ones)                      # the rank count the backend itself reports (RCCL for "nccl")
+        ranks_reported = int(round(float(ones.item())))
+        if ranks_reported != a.gpus or dist.get_world_size() != a.gpus:
+            raise SystemExit("bench.py: backend reports %d ranks, --gpus %d" % (ranks_reported, a.gpus))
 
     from geobo_amd.config_loader import Settings
     from geobo_amd.inversion import Inversion
@@ -188,8 +269,10 @@ def main():
     inv.engine.kernel_events = []
     fence()
     t0 = time.perf_counter()
+    marks = [t0]
     for _ in range(a.steps):
-        cubes = step()
+        cubes = step()                         # ends with the D2H of the cubes (synchronous): the marks need no extra sync
+        marks.append(time.perf_counter())
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -200,16 +283,17 @@ def main():
     inv.engine.kernel_events = None
     # per-stage / per-kernel device time from HIP events recorded on the launch stream (torch's current stream)
     stages = {}
-    for name, fl, e0, e1 in ev:
-        d = stages.setdefault(name, dict(calls=0, seconds=0.0, flop=0.0))
+    for name, fl, alg, valu, e0, e1 in ev:
+        d = stages.setdefault(name, dict(calls=0, seconds=0.0, flop=0.0, alg=0.0, valu=0.0, durs=[]))
         d["calls"] += 1
-        d["seconds"] += e0.elapsed_time(e1) * 1e-3
+        sec = e0.elapsed_time(e1) * 1e-3
+        d["seconds"] += sec
+        d["durs"].append(sec)
         d["flop"] += fl
+        d["alg"] += alg
+        d["valu"] += valu
     single = [k for k in stages if k in ("ak_fused_grid", "ak_fused", "posterior_reduce", "aka_gemm_nt")]
     dom = max(single, key=lambda k: stages[k]["seconds"]) if single else None
-    ach = stages[dom]["flop"] / stages[dom]["seconds"] / 1e12 if dom else 0.0
-    flops = stages[dom]["flop"] / stages[dom]["calls"] if dom else 0.0
-    durs = [stages[dom]["seconds"] / stages[dom]["calls"]] * stages[dom]["calls"] if dom else []
     kernel_names = {"ak_fused_grid": "geobo_ak_fused_grid (gemm_f64_kernel<4,2,TAB>)", "ak_fused": "geobo_ak_fused (gemm_f64_kernel<4,2,GEN>)",
                     "posterior_reduce": "geobo_posterior_reduce (gemm_f64_kernel<4,2,NN,REDUCE>)",
                     "aka_gemm_nt": "geobo_gemm_nt (gemm_f64_kernel<4,2,NT>)"}
@@ -222,33 +306,64 @@ def main():
         M = 2 * eng.Ms + int((drill0 != 0).sum())
         Msd = 2 * eng.Ms
         F = 2.0 * Msd * N * N * p_out + 2.0 * M * Msd * N + M ** 3 / 3.0 + 1.0 * M * M * p_out * N + 4.0 * M * p_out * N + M * M
-        F_exec = sum(d["flop"] for d in stages.values()) / a.steps   # flop actually executed by the MFMA kernels of this route
+        mfma = {k: v for k, v in stages.items() if v["flop"] > 0}
+        F_mfma = sum(d["flop"] - d["valu"] for d in mfma.values()) / a.steps   # `flop` = everything executed, `valu` = its fp64-VALU part
+        F_valu = sum(d["valu"] for d in mfma.values()) / a.steps
+        step_ms = sorted(1e3 * (b - a_) for a_, b in zip(marks[:-1], marks[1:]))
+        roof = None
+        if dom:
+            d = stages[dom]
+            calls = d["calls"]
+            mean_s = d["seconds"] / calls
+            alg, exe = d["alg"] / calls, d["flop"] / calls
+            traffic, tsrc = pmc_traffic(dom, exe)
+            ach = alg / mean_s / 1e12
+            roof = {"bound": "mfma", "kernel": kernel_names.get(dom), "achieved": ach, "peak": FP64_MATRIX_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": ach / FP64_MATRIX_PEAK_TFLOPS, "traffic": traffic,
+                    "traffic_source": None if tsrc is None else tsrc + " (committed rocprofv3 --pmc passes of the same kernel and "
+                    "shape: FETCH_SIZE x2 + WRITE_SIZE; not collected in this run)",
+                    "launches_timed": calls, "flop_per_launch": alg, "flop_per_launch_is": "algorithmic, SURVEY 8(d): unpadded M, "
+                    "triangular L^-1 (M^2 P_c nc + 4 M P_c nc for the posterior; 2 Ms N ncols for the fused product)",
+                    "executed_flop_per_launch": exe, "achieved_executed": exe / mean_s / 1e12,
+                    "mean_launch_s": mean_s, "median_launch_s": sorted(d["durs"])[calls // 2]}
         out = {
             "metric": "voxels/sec posterior (mean+var) for 64^3 x 2-prop joint inversion; fp64 roofline %",
-            "value": value, "unit": "voxel-properties/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "value": value, "unit": "voxel-properties/s", "n_gpus": ranks_reported, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%d^3 voxel cube (100 m), gravity+magnetics joint inversion, %s kernel lengths (2.00,2.02,2.04)x100 m, "
                                    "%d drill constraints, M=%d rows, density+magsus cubes (P_out=2)" % (n, a.kernel, a.drill, M),
                        "N_voxels": N, "M_rows": M, "props_out": p_out, "parallelism": "voxel-column shards x%d" % world,
+                       "backend": a.backend if world > 1 else None, "ranks_reported_by_backend": ranks_reported,
                        "method": "spectral" if inv.engine.use_spectral else "dense",
                        "row_exchange": bool(inv.engine.exchange),
+                       "ms_per_step_median": step_ms[len(step_ms) // 2], "ms_per_step_all_rank0": [round(v, 2) for v in step_ms],
                        "cube_checksums": [float(np.abs(c).sum()) for c in (cubes[0], cubes[1], cubes[3], cubes[4])],
-                       "dense_algorithmic_flop_per_step": F, "executed_mfma_flop_per_step_rank0": F_exec,
-                       "end_to_end_fp64_roofline_frac_of_executed_flop": F_exec * a.steps / dt / (FP64_MATRIX_PEAK_TFLOPS * 1e12),
+                       "dense_algorithmic_flop_per_step": F,
+                       "executed_mfma_flop_per_step_rank0": F_mfma, "executed_valu_flop_per_step_rank0": F_valu,
+                       "mfma_time_frac_of_step_rank0": sum(d["seconds"] for d in mfma.values()) / dt,
                        "stage_ms_per_step_rank0": {k: round(1e3 * v["seconds"] / a.steps, 3) for k, v in stages.items()},
-                       "mfma_kernels_tflops_rank0": {k: round(v["flop"] / v["seconds"] / 1e12, 2) for k, v in stages.items() if v["flop"] > 0}},
-            "roofline": {"bound": "mfma", "kernel": kernel_names.get(dom), "achieved": ach, "peak": FP64_MATRIX_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach / FP64_MATRIX_PEAK_TFLOPS, "traffic": pmc_traffic(dom, flops),
-                         "launches_timed": len(durs), "flop_per_launch": flops, "mean_launch_s": (sum(durs) / len(durs)) if durs else None},
+                       "kernel_tflops_executed_rank0": {k: round(v["flop"] / v["seconds"] / 1e12, 2) for k, v in stages.items() if v["flop"] > 0}},
+            "roofline": roof,
         }
         if not a.no_cpu and world == 1:   # CPU baseline: rank 0 at N = 1 only
             lengths = inv.gp_length
             cb, (c0, b, smp) = cpu_baseline(inv, [float(v) for v in lengths])
             got_mu = inv.mu_rec[c0:c0 + b]
             cb["sample_max_abs_diff_vs_gpu_mu"] = float(np.abs(smp[0][0] - got_mu).max())
+            sizes = [int(v) for v in a.cpu_forms.split(",") if v]
+            dsizes = [int(v) for v in a.cpu_dense_forms.split(",") if v]
+            F64 = 2.0 * 8192 * 262144.0 ** 2 * 2 + 2.0 * 8242 * 8192 * 262144 + 8242 ** 3 / 3.0 + 8242.0 ** 2 * 2 * 262144 + 4.0 * 8242 * 2 * 262144 + 8242 ** 2
+            cb["forms"] = cpu_baseline_forms(sizes, dsizes, F64, cb["gflops"])
             out["cpu_baseline"] = cb
             out["config"]["speedup_vs_cpu_baseline"] = value / cb["value"]
+            try:   # the same (dense) algorithm on the GPU: committed bench line of `--method dense`
+                dense = json.load(open(os.path.join(ROOT, GPU_DENSE_ROUTE)))
+                out["config"]["speedup_same_algorithm_dense_route"] = {
+                    "gpu_dense_route_voxel_properties_per_s": dense["value"], "source": GPU_DENSE_ROUTE,
+                    "ratio_vs_cpu_sample": dense["value"] / cb["value"]}
+            except Exception:
+                pass
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -28,6 +28,7 @@ SIGNATURES = {
     "geobo_cov_table": (_int, [_int, _int, _int, _int, _f64, _f64, _f64, _f64, _f64, _f64, _f64, _dp, _dp]),
     "geobo_ak_fused_grid": (_int, [_dp, _i64, _i64, _i64, _int, _int, _int, _dp, _i64, _i64, _dp, _i64, _dp]),
     "geobo_gemm_nt": (_int, [_i64, _i64, _i64, _f64, _dp, _i64, _dp, _i64, _f64, _dp, _i64, _int, _i64, _dp]),
+    "geobo_tile_order": (_i64, [_int, _int, _int, _int, _int, _int, _int, C.POINTER(_int), _i64]),
     "geobo_gemm_nt_splitk": (_int, [_i64, _i64, _i64, _int, _dp, _i64, _dp, _i64, _dp, _i64, _int, _i64, _dp, _sz, _dp]),
     "geobo_gemm_nn": (_int, [_i64, _i64, _i64, _f64, _dp, _i64, _dp, _i64, _f64, _dp, _i64, _int, _int, _dp]),
     "geobo_gemm_batched": (_int, [_int, _i64, _i64, _i64, _f64, _dp, _i64, _i64, _dp, _i64, _i64, _f64, _dp, _i64, _i64, _i64, _i64, _int, _dp]),
@@ -40,7 +41,9 @@ SIGNATURES = {
     "geobo_xcorr_reduce": (_int, [_int, _int, _i64, _int, _dp, _i64, _i64, _dp, _i64, _dp, _dp, _i64, _i64, _dp]),
     "geobo_toeplitz_y": (_int, [_int, _i64, _i64, _int, _dp, _dp, _dp, _dp, _dp, _int, _int, _dp]),
     "geobo_potrf_ws_bytes": (_sz, [_i64]),
-    "geobo_potrf_inv": (_int, [_i64, _dp, _i64, _dp, _i64, _dp, _dp, _sz, _dp]),
+    "geobo_potrf_ctx_create": (_int, [C.POINTER(C.c_void_p)]),
+    "geobo_potrf_ctx_destroy": (_int, [_dp]),
+    "geobo_potrf_inv": (_int, [_i64, _dp, _i64, _dp, _i64, _dp, _dp, _sz, _dp, _dp]),
     "geobo_posterior_ws_bytes": (_sz, [_i64, _i64]),
     "geobo_posterior_reduce": (_int, [_i64, _i64, _dp, _i64, _dp, _i64, _dp, _f64, _dp, _dp, _i64, _dp, _sz, _dp]),
     "geobo_trmv_stats": (_int, [_i64, _dp, _i64, _dp, _dp, _i64, _dp, _dp, _dp]),

@@ -23,11 +23,8 @@
 // Workgroup -> tile map is XCD aware: block b runs on XCD b%8, so consecutive slots of one XCD get the SAME
 // row tile (they stream the same A rows through that XCD's L2) and different column tiles.
 #include <hip/hip_runtime.h>
-#include <algorithm>
-#include <mutex>
-#include <vector>
+#include <atomic>
 #include <stdint.h>
-#include <stdlib.h>
 #include "covfun.h"
 #include "geobo_hip.h"
 
@@ -59,8 +56,8 @@ struct GemmArgs {
   int64_t k;
   double alpha, beta;
   int nbi, nbj, tri, xcd_map;
-  // xcd_map 3: explicit tile list (bi << 16 | bj), consumed 32 consecutive entries per XCD at a time
-  const int* tiles; int ntiles;
+  // xcd_map 3: balanced item order (tile_of_item), consumed 32 consecutive items per XCD at a time; ntiles = items per batch
+  int ntiles;
   // batching (blockIdx.y) and store predicates (the compute tile grid may overhang the valid m x n region)
   int64_t sXb, sYb, sCb, m_valid, n_valid; int batch;
   // generator
@@ -71,6 +68,52 @@ struct GemmArgs {
   // reduce epilogue
   const double* u; double* part_mu; double* part_ss; int64_t ncols;
 };
+
+// Item order of memory-mode launches with few, long tiles (AkA, split-K slices, Cholesky trailing updates, L^-1 merges).
+// Pure arithmetic on wave-uniform values (SALU), shared by host (item count) and device (decode): nothing is allocated,
+// copied or cached for a launch.
+//   plain / lower_only: bands of four row tiles, column-major inside a band, tiles strictly above the diagonal skipped, so
+//     32 consecutive items form a 4 x 8 supertile (4 X + 8 Y panels per XCD L2) and every workgroup has a full tile of work;
+//   triangular X (k range [0, row_end)): longest contraction first = row tiles descending, equal lengths adjacent;
+//   triangular Y (k range [col0, k)):    longest first = column tiles ascending.
+__host__ __device__ inline int lower_cols(int bi, int nbj, int tm, int tn) {   // column tiles of row tile bi at or below the diagonal
+  const int64_t c = ((int64_t)(bi + 1) * tm + tn - 1) / tn;
+  return c < nbj ? (int)c : nbj;
+}
+__host__ __device__ inline int64_t tile_items(int nbi, int nbj, int tm, int tn, int tri) {
+  if (!(tri & TRI_LOWER_ONLY)) return (int64_t)nbi * nbj;
+  int64_t n = 0;
+  for (int bi = 0; bi < nbi; ++bi) n += lower_cols(bi, nbj, tm, tn);
+  return n;
+}
+__host__ __device__ __forceinline__ void tile_of_item(int t, int nbi, int nbj, int tm, int tn, int tri, int& bi, int& bj) {
+  if (tri & TRI_X_LOWER) { bi = nbi - 1 - t / nbj; bj = t % nbj; return; }
+  if (tri & TRI_Y_LOWER) { bj = t / nbi; bi = t % nbi; return; }
+  if (!(tri & TRI_LOWER_ONLY)) {
+    const int band = t / (4 * nbj), r0 = 4 * band;
+    const int rows = nbi - r0 < 4 ? nbi - r0 : 4;
+    t -= band * 4 * nbj;
+    bj = t / rows; bi = r0 + t % rows;
+    return;
+  }
+  int r0 = 0;
+  for (;; r0 += 4) {                                   // <= nbi / 4 iterations (lower_only launches have nbi <= a few dozen)
+    int cnt = 0;
+    for (int i = r0; i < r0 + 4 && i < nbi; ++i) cnt += lower_cols(i, nbj, tm, tn);
+    if (t < cnt || r0 + 4 >= nbi) break;
+    t -= cnt;
+  }
+  const int r1 = r0 + 4 < nbi ? r0 + 4 : nbi;
+  for (bj = 0; bj < nbj; ++bj) {                        // column bj holds the band's rows bi >= floor(bj tn / tm)
+    const int first = (int)(((int64_t)bj * tn) / tm);
+    const int lo = first > r0 ? first : r0;
+    const int c = r1 - lo;
+    if (c <= 0) continue;
+    if (t < c) { bi = lo + t; return; }
+    t -= c;
+  }
+  bi = nbi; bj = 0;                                     // past the end (not reached: the grid is cut at the item count)
+}
 
 template <int WM, int WN>
 constexpr int ring_depth() { return (WM * WN >= 8) ? NST : 2; }
@@ -130,16 +173,14 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_f64_kernel(const GemmArg
       }
       if (bj >= a.nbj) return;
     } else if (a.xcd_map == 3) {
-      // (batch, tile) items from a compact tile list, 32 consecutive items per XCD at a time, 1-D grid: the dispatcher
+      // (batch, tile) items in the balanced order of tile_of_item, 32 consecutive items per XCD at a time, 1-D grid: the dispatcher
       // places workgroup b on XCD b % 8, so every XCD gets the same number of full 32-item groups over the WHOLE launch
       // (with a (tiles, batch) grid the same XCDs draw the partial groups in every slice and split-K cannot shorten the tail)
       const int xcd = b & 7, s = b >> 3;
       const int64_t item = ((int64_t)((s >> 5) * 8 + xcd) << 5) + (s & 31);
       if (item >= (int64_t)a.ntiles * a.batch) return;
       batch_idx = (int)(item / a.ntiles);
-      const int packed = a.tiles[item - (int64_t)batch_idx * a.ntiles];
-      bi = packed >> 16;
-      bj = packed & 0xffff;
+      tile_of_item((int)(item - (int64_t)batch_idx * a.ntiles), a.nbi, a.nbj, TM, TN, a.tri, bi, bj);
     } else {
       bi = b % a.nbi;
       bj = b / a.nbi;
@@ -379,12 +420,8 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_f64_kernel(const GemmArg
       for (int64_t k0 = kb; k0 < ke; k0 += BK) {
         int64_t kn = k0 + 2 * BK;
         if (kn >= ke) kn = ke - BK;
-  #ifndef GEOBO_ABL_NO_XLOAD
         stage_x(kn, s2);
-  #endif
-  #ifndef GEOBO_ABL_NO_YLOAD
         if constexpr (YMODE != Y_GEN) stage_y(kn, s2);
-  #endif
         const int64_t p0 = kn + gsub * EPT;  // generator: wave-uniform -> scalar loads of the p coordinates
         read_half(s0, 1, a1, b1);
   #pragma unroll
@@ -406,50 +443,13 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_f64_kernel(const GemmArg
         }
         if constexpr (YMODE != Y_GEN) {
           // Issue-order hints under the matrix pipe (integer VALU, SALU, VMEM and DS issue do not compete with v_mfma_f64
-          // for the FP pipe).  GEOBO_SCHED selects the pattern (tuned on MI355X):
-  #ifndef GEOBO_SCHED
-  #define GEOBO_SCHED 5
-  #endif
-  #if GEOBO_SCHED == 1   // 64 x {MFMA, <=3 of (VALU|SALU|VMEM read|DS read)}
-  #pragma unroll
-          for (int i = 0; i < 64; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x126, 3, 0);
-          }
-  #elif GEOBO_SCHED == 2  // 2 x { 8 x {MFMA, DS read}, 24 x {MFMA, <=3 others} }
-  #pragma unroll
-          for (int half = 0; half < 2; ++half) {
-  #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-              __builtin_amdgcn_sched_group_barrier(0x100, (YMODE == Y_NN) ? 3 : 1, 0);
-            }
-  #pragma unroll
-            for (int i = 0; i < 24; ++i) {
-              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-              __builtin_amdgcn_sched_group_barrier(0x026, 3, 0);
-            }
-          }
-  #elif GEOBO_SCHED == 3  // 64 x {MFMA, <=2 others}
-  #pragma unroll
-          for (int i = 0; i < 64; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x126, 2, 0);
-          }
-  #elif GEOBO_SCHED == 4  // 64 x {MFMA, <=1 DS read, <=2 others}
-  #pragma unroll
-          for (int i = 0; i < 64; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x026, 2, 0);
-          }
-  #elif GEOBO_SCHED == 5  // 64 x {MFMA, <=4 others}
+          // for the FP pipe): 64 x {1 MFMA, <= 4 others}.  Tuned on MI355X against tighter patterns (<= 2 / <= 3 others, DS
+          // reads pinned to the first MFMAs of each half): this one keeps the LDS-DMA issue spread over the whole chunk.
   #pragma unroll
           for (int i = 0; i < 64; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x126, 4, 0);
           }
-  #endif
         }
         if constexpr (YMODE == Y_GEN && (KID <= COV_MATERN32_X)) {
           // 64 x { 1 MFMA, up to GEN_VALU VALU }: interleave the generator into the matrix-pipe shadow
@@ -461,9 +461,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_f64_kernel(const GemmArg
           }
         }
         if constexpr (YMODE == Y_GEN) store_gen(s2);
-  #ifndef GEOBO_ABL_NO_BARRIER
         __syncthreads();
-  #endif
         const int ts = s0; s0 = s1; s1 = s2; s2 = ts;
       }
       }
@@ -552,80 +550,36 @@ __global__ void posterior_finish_kernel(const double* part_mu, const double* par
   var[c] = prior_var - s;
 }
 
-// Memory-mode launches with few, long tiles (AkA, split-K slices, the Cholesky trailing update): the valid tiles (all, or
-// the lower triangle), enumerated in bands of four row tiles, column-major inside a band, so that 32 consecutive entries
-// form a 4 x 8 supertile (4 X panels + 8 Y panels per XCD L2) and every dispatched workgroup has a full tile of work.
-// Built once per shape, kept on the device.
-struct TileList { int nbi, nbj, tm, tn, tri, dev; int64_t k; int* ptr; int n; };
-const int* tile_list(int nbi, int nbj, int tm, int tn, int tri, int64_t k, int* ntiles) {
-  static std::mutex mu;
-  static std::vector<TileList> cache;
-  std::lock_guard<std::mutex> lock(mu);
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  const bool weighted = tri & (TRI_X_LOWER | TRI_Y_LOWER);
-  if (!weighted) k = 0;
-  for (const TileList& t : cache)
-    if (t.nbi == nbi && t.nbj == nbj && t.tm == tm && t.tn == tn && t.tri == tri && t.k == k && t.dev == dev) { *ntiles = t.n; return t.ptr; }
-  std::vector<int> host;
-  if (weighted) {
-    // triangular operands: the contraction range of tile (bi, bj) is [y_lower ? col0 : 0, x_lower ? row0 + tm : k).
-    // Longest first, equal lengths adjacent (they run together: same k sweep, shared panel in the XCD's L2).
-    std::vector<std::pair<int64_t, int>> w;
-    for (int bi = 0; bi < nbi; ++bi)
-      for (int bj = 0; bj < nbj; ++bj) {
-        const int64_t kb = (tri & TRI_Y_LOWER) ? (int64_t)bj * tn : 0;
-        const int64_t ke = (tri & TRI_X_LOWER) ? std::min<int64_t>(k, (int64_t)bi * tm + tm) : k;
-        w.push_back({std::max<int64_t>(ke - kb, 0), bi << 16 | bj});
-      }
-    std::stable_sort(w.begin(), w.end(), [](const std::pair<int64_t, int>& a, const std::pair<int64_t, int>& b) { return a.first > b.first; });
-    for (const auto& e : w) host.push_back(e.second);
-  } else {
-    for (int band = 0; band * 4 < nbi; ++band) {
-      const int r0 = band * 4, r1 = std::min(r0 + 4, nbi);
-      for (int bj = 0; bj < nbj; ++bj)
-        for (int bi = r0; bi < r1; ++bi)
-          if (!(tri & TRI_LOWER_ONLY) || (int64_t)bj * tn < (int64_t)bi * tm + tm) host.push_back(bi << 16 | bj);
-    }
-  }
-  TileList t{nbi, nbj, tm, tn, tri, dev, k, nullptr, (int)host.size()};
-  if (host.empty() || hipMalloc(&t.ptr, host.size() * sizeof(int)) != hipSuccess) return nullptr;
-  if (hipMemcpy(t.ptr, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
-  cache.push_back(t);
-  *ntiles = t.n;
-  return t.ptr;
-}
-
 template <int WM, int WN, int YMODE, int EPI, int KID>
 int launch(GemmArgs& a, hipStream_t st) {
   constexpr int NT = 64 * WM * WN;
   constexpr size_t lds = sizeof(double) * lds_doubles<WM, WN, YMODE>();
   auto kern = gemm_f64_kernel<WM, WN, YMODE, EPI, KID>;
-  static bool attr_set = false;  // one-time opt-in to >64 KiB dynamic LDS (idempotent, race-benign)
-  if (!attr_set) {
+  // opt-in to > 64 KiB dynamic LDS, once per DEVICE (the attribute lives with the device's code object); idempotent
+  static std::atomic<uint64_t> attr_done{0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return GEOBO_E_LAUNCH;
+  if (!((attr_done.load(std::memory_order_acquire) >> dev) & 1)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return GEOBO_E_LAUNCH;
-    attr_set = true;
+    attr_done.fetch_or((uint64_t)1 << dev, std::memory_order_release);
   }
   if (a.m_valid <= 0) a.m_valid = (int64_t)1 << 62;
   if (a.n_valid <= 0) a.n_valid = (int64_t)1 << 62;
-  static const int force_map = getenv("GEOBO_TILE_MAP") ? atoi(getenv("GEOBO_TILE_MAP")) : -1;  // experiment switch
   a.xcd_map = (a.nbi >= 8) ? 1 : 0;
   // supertiles help when both operands stream (measured: posterior_reduce 59 -> 66 TF/s); with lower_only skipping they
   // unbalance the tail (AkA 420 -> 499 ms), so triangular-output launches keep the row-per-XCD map
   if ((YMODE == Y_NT || YMODE == Y_NN) && !(a.tri & TRI_LOWER_ONLY) && a.nbi >= 4 && a.nbj >= 8) a.xcd_map = 2;
-  if (force_map >= 0 && !(force_map == 1 && a.nbi < 8)) a.xcd_map = force_map;
-  a.tiles = nullptr; a.ntiles = 0;
+  a.ntiles = 0;
   if (a.batch <= 0) a.batch = 1;
   const int64_t items = (int64_t)a.nbi * a.nbj * a.batch;
   // up to a few dozen tiles per CU: the tail of the launch matters -> balanced item list (plain and lower_only NT/NN)
   // (also the triangular-operand merges of the L^-1 build: longest contraction ranges first, equal lengths together)
   if ((YMODE == Y_NT || YMODE == Y_NN) && EPI == EPI_STORE && a.batch <= 64 &&
-      a.nbi * a.nbj >= ((a.tri & (TRI_X_LOWER | TRI_Y_LOWER)) ? 16 : 64) && items <= 65536 && a.nbi < 32768 && a.nbj < 65536 &&
-      force_map < 0) {
-    a.tiles = tile_list(a.nbi, a.nbj, 64 * WM, 64 * WN, a.tri, a.k, &a.ntiles);
-    if (!a.tiles) return GEOBO_E_LAUNCH;
-    a.xcd_map = 3;
+      a.nbi * a.nbj >= ((a.tri & (TRI_X_LOWER | TRI_Y_LOWER)) ? 16 : 64) && items <= 65536 && a.nbi <= 4096 &&
+      (a.tri & (TRI_X_LOWER | TRI_Y_LOWER)) != (TRI_X_LOWER | TRI_Y_LOWER)) {
+    a.ntiles = (int)tile_items(a.nbi, a.nbj, 64 * WM, 64 * WN, a.tri);
+    if (a.ntiles > 0) a.xcd_map = 3;
   }
   int nblocks = a.nbi * a.nbj;
   if (a.xcd_map == 3) {
@@ -648,13 +602,26 @@ template <int YMODE, int EPI, int KID>
 int launch_by_rows(GemmArgs& a, int64_t m, int64_t n, hipStream_t st) {
   if (n % 128) return GEOBO_E_ALIGN;
   a.nbj = (int)(n / 128);
-  static const bool force128 = getenv("GEOBO_TILE128") != nullptr;  // experiment switch: 2 independent 4-wave WGs per CU
-  if (m % 256 == 0 && !force128) { a.nbi = (int)(m / 256); return launch<4, 2, YMODE, EPI, KID>(a, st); }
+  if (m % 256 == 0) { a.nbi = (int)(m / 256); return launch<4, 2, YMODE, EPI, KID>(a, st); }
   if (m % 128 == 0) { a.nbi = (int)(m / 128); return launch<2, 2, YMODE, EPI, KID>(a, st); }
   return GEOBO_E_ALIGN;
 }
 
 }  // namespace
+
+extern "C" int64_t geobo_tile_order(int nbi, int nbj, int tm, int tn, int lower_only, int x_lower, int y_lower, int* out_host,
+                                    int64_t capacity) {
+  if (nbi <= 0 || nbj <= 0 || tm <= 0 || tn <= 0 || (x_lower && y_lower)) return GEOBO_E_ARG;
+  const int tri = (lower_only ? TRI_LOWER_ONLY : 0) | (x_lower ? TRI_X_LOWER : 0) | (y_lower ? TRI_Y_LOWER : 0);
+  const int64_t n = tile_items(nbi, nbj, tm, tn, tri);
+  if (out_host)
+    for (int64_t t = 0; t < n && t < capacity; ++t) {
+      int bi, bj;
+      tile_of_item((int)t, nbi, nbj, tm, tn, tri, bi, bj);
+      out_host[t] = bi << 16 | bj;
+    }
+  return n;
+}
 
 extern "C" int geobo_ak_fused(int kernel_id, const double* A, int64_t Ms_pad, int64_t N_pad, int64_t lda,
                               const double* x, const double* y, const double* z, int64_t col0, int64_t ncols,

@@ -11,6 +11,7 @@
 // L^-1 is then assembled by recursive halving, two MFMA GEMMs per merge:
 //   Linv[hi,lo] = -Linv[hi,hi] * (L[hi,lo] * Linv[lo,lo]).
 #include <hip/hip_runtime.h>
+#include <new>
 #include <stdint.h>
 #include "geobo_hip.h"
 
@@ -147,11 +148,12 @@ __global__ void __launch_bounds__(256) logl_stats_kernel(int64_t m, const double
 
 // L^-1 by recursive halving.  The two halves of a node are independent until their merge, and the merges near the
 // leaves are a handful of tiles each (latency of ONE tile's k sweep, 0.2-0.5 ms, whatever the chip could do in
-// parallel): the top two levels of the tree fork onto internal streams, so four subtrees run concurrently, and join by
-// events before their parent's merge.  Everything is ordered after / before the caller's stream by the same events.
+// parallel): with a fork context (geobo_potrf_ctx_create) the top two levels of the tree fork onto the context's streams, so
+// four subtrees run concurrently, and join by events before their parent's merge.  Everything is ordered after / before
+// the caller's stream by the same events.  Without a context the whole tree runs on the caller's stream.
 struct InvCtx {
   const double* L; int64_t ld; double* Linv; int64_t ldi; double* ws; size_t ws_doubles;
-  hipStream_t s[4]; hipEvent_t ev[6]; int nev;
+  hipStream_t s[4]; hipEvent_t ev[6]; int nev; bool fork;
 };
 
 int build_inverse(InvCtx& c, int lo, int hi, int depth, int sidx) {
@@ -160,7 +162,7 @@ int build_inverse(InvCtx& c, int lo, int hi, int depth, int sidx) {
   int mid = (lo + hi) / 2;
   if (hi - lo > 2 && ((mid - lo) & 1)) ++mid;
   int rc;
-  if (depth < 2 && hi - lo >= 8) {
+  if (c.fork && depth < 2 && hi - lo >= 8) {
     const int other = sidx + (depth == 0 ? 2 : 1);
     hipEvent_t fork = c.ev[c.nev++], join = c.ev[c.nev++];
     if (hipEventRecord(fork, c.s[sidx]) != hipSuccess || hipStreamWaitEvent(c.s[other], fork, 0) != hipSuccess) return GEOBO_E_LAUNCH;
@@ -187,23 +189,9 @@ int build_inverse(InvCtx& c, int lo, int hi, int depth, int sidx) {
   return geobo_gemm_nn(r, cc, r, -1.0, c.Linv + o_mid * c.ldi + o_mid, c.ldi, T, cc, 0.0, c.Linv + o_mid * c.ldi + o_lo, c.ldi, 1, 0, st);
 }
 
-// internal fork streams / events, created on first use (per process; the caller's stream is never replaced)
-bool inverse_streams(InvCtx& c) {
-  static hipStream_t s[3];
-  static hipEvent_t ev[6];
-  static bool ok = false;
-  if (!ok) {
-    for (int i = 0; i < 3; ++i)
-      if (hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking) != hipSuccess) return false;
-    for (int i = 0; i < 6; ++i)
-      if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return false;
-    ok = true;
-  }
-  for (int i = 0; i < 3; ++i) c.s[i + 1] = s[i];
-  for (int i = 0; i < 6; ++i) c.ev[i] = ev[i];
-  c.nev = 0;
-  return true;
-}
+// Fork context (geobo_potrf_ctx_create): three streams + six events on the device that was current at creation, owned by
+// the caller.  Nothing here is process-global: two engines (or two devices, or two threads) each bring their own.
+struct PotrfCtx { int dev; hipStream_t s[3]; hipEvent_t ev[6]; };
 
 }  // namespace
 
@@ -213,9 +201,40 @@ extern "C" size_t geobo_potrf_ws_bytes(int64_t m) {
   return (size_t)(half * half) * sizeof(double);
 }
 
+extern "C" int geobo_potrf_ctx_create(void** ctx) {
+  if (!ctx) return GEOBO_E_ARG;
+  PotrfCtx* c = new (std::nothrow) PotrfCtx();
+  if (!c) return GEOBO_E_LAUNCH;
+  int ns = 0, ne = 0;   // streams / events created so far
+  bool ok = hipGetDevice(&c->dev) == hipSuccess;
+  while (ok && ns < 3) { ok = hipStreamCreateWithFlags(&c->s[ns], hipStreamNonBlocking) == hipSuccess; ns += ok; }
+  while (ok && ne < 6) { ok = hipEventCreateWithFlags(&c->ev[ne], hipEventDisableTiming) == hipSuccess; ne += ok; }
+  if (!ok) {
+    for (int i = 0; i < ne; ++i) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < ns; ++i) (void)hipStreamDestroy(c->s[i]);
+    delete c;
+    return GEOBO_E_LAUNCH;
+  }
+  *ctx = c;
+  return GEOBO_OK;
+}
+
+extern "C" int geobo_potrf_ctx_destroy(void* ctx) {
+  if (!ctx) return GEOBO_OK;
+  PotrfCtx* c = (PotrfCtx*)ctx;
+  for (int i = 0; i < 6; ++i) (void)hipEventDestroy(c->ev[i]);
+  for (int i = 0; i < 3; ++i) (void)hipStreamDestroy(c->s[i]);
+  delete c;
+  return GEOBO_OK;
+}
+
 extern "C" int geobo_potrf_inv(int64_t m, double* A, int64_t ld, double* Linv, int64_t ldi, int* info, void* ws,
-                               size_t ws_bytes, void* stream) {
+                               size_t ws_bytes, void* ctx, void* stream) {
   if (!A || !Linv || !info || !ws) return GEOBO_E_ARG;
+  if (ctx) {   // the fork streams belong to one device: refuse a context made for another one
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != ((PotrfCtx*)ctx)->dev) return GEOBO_E_ARG;
+  }
   if (m <= 0 || m % NB || (ld & 1) || (ldi & 1) || ld < m || ldi < m) return GEOBO_E_ALIGN;
   if (ws_bytes < geobo_potrf_ws_bytes(m)) return GEOBO_E_ARG;
   hipStream_t st = (hipStream_t)stream;
@@ -238,7 +257,13 @@ extern "C" int geobo_potrf_inv(int64_t m, double* A, int64_t ld, double* Linv, i
   InvCtx c;
   c.L = A; c.ld = ld; c.Linv = Linv; c.ldi = ldi; c.ws = (double*)ws; c.ws_doubles = geobo_potrf_ws_bytes(m) / sizeof(double);
   c.s[0] = st;
-  if (!inverse_streams(c)) return GEOBO_E_LAUNCH;
+  c.nev = 0;
+  c.fork = ctx != nullptr;
+  if (c.fork) {
+    const PotrfCtx* pc = (const PotrfCtx*)ctx;
+    for (int i = 0; i < 3; ++i) c.s[i + 1] = pc->s[i];
+    for (int i = 0; i < 6; ++i) c.ev[i] = pc->ev[i];
+  }
   return build_inverse(c, 0, (int)(m / NB), 0, 0);
 }
 

@@ -18,10 +18,21 @@
 // workgroup.  Per plane and wave: 384 MFMAs (64^3) against 64 + 128 LDS reads; HBM traffic is the plane in and the plane
 // out, overlapped with the matrix pipe.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include "geobo_hip.h"
 
 namespace {
+
+// opt-in to > 64 KiB dynamic LDS, once per DEVICE (not per process: a second device needs its own call); idempotent
+int ensure_lds_attr(std::atomic<uint64_t>& done, const void* kern, size_t lds) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return GEOBO_E_LAUNCH;
+  if ((done.load(std::memory_order_acquire) >> dev) & 1) return GEOBO_OK;
+  if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GEOBO_E_LAUNCH;
+  done.fetch_or((uint64_t)1 << dev, std::memory_order_release);
+  return GEOBO_OK;
+}
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
@@ -137,20 +148,14 @@ __global__ void __launch_bounds__(xz_threads(OUT_Z), 1) xz2d_kernel(XZArgs g) {
       //     and waited for there (the vmcnt(0) in front of its stores); for the others -- and in the first plane -- everything
       //     issued after chunk c is RING-2 newer chunks.  The waits never have to see past stores: vmcnt counts loads and
       //     stores together, and nothing here relies on the two completing in issue order relative to each other.
-#ifndef GEOBO_XZ_ABL_NOWAIT
       if (!(c <= RING - 2 && warm)) __builtin_amdgcn_s_waitcnt(vmcnt_imm((RING - 2) * K::ND));
-#endif
       // (2) every share landed; every wave is done with the chunk staged RING-1 ago.  A bare s_barrier: __syncthreads()
       //     adds a fence that drains vmcnt to 0, i.e. waits for the prefetched chunks and the output stores as well.
-#ifndef GEOBO_XZ_ABL_NOBARRIER
       __builtin_amdgcn_s_barrier();
-#endif
       {                 // (3) refill the slot that was just released
         const int cn = c + RING - 1;
-#ifndef GEOBO_XZ_ABL_NODMA
         if (cn < RT1) stage(cur, cn, (slot0 + cn) % RING);
         else stage(nxt, cn - RT1, (slot0 + cn) % RING);
-#endif
       }
       // (4) step 1 on row tile c.  The fragment reads are inline asm: for LDS reads it can see, the compiler waits for
       //     EVERY outstanding LDS-DMA first (vmcnt(0): it cannot tell ring slots apart), which would collapse the
@@ -214,9 +219,6 @@ __global__ void __launch_bounds__(xz_threads(OUT_Z), 1) xz2d_kernel(XZArgs g) {
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-#ifdef GEOBO_XZ_ABL_NOSTORE
-            if (acc[m][ct][r] == 1.2345e-300)
-#endif
             op[(int64_t)(16 * (h0 + m) + q + 4 * r) * OUT_Z + 16 * ct] = acc[m][ct][r];
     }
     warm = true;
@@ -229,12 +231,8 @@ template <int IN_X, int IN_Z, int OUT_X, int OUT_Z>
 int launch(const XZArgs& g, hipStream_t st) {
   using K = XZCfg<IN_X, IN_Z, OUT_X, OUT_Z>;
   auto kern = xz2d_kernel<IN_X, IN_Z, OUT_X, OUT_Z>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)K::LDS) != hipSuccess)
-      return GEOBO_E_LAUNCH;
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  if (int rc = ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), K::LDS)) return rc;
   int64_t nwg = g.nplanes < 1024 ? g.nplanes : 1024;  // persistent: 4 workgroups per CU over the launch, >= 8 planes each at 64^3
   hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * K::NW), K::LDS, st, g);
   return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
@@ -402,12 +400,8 @@ extern "C" int geobo_xcorr_reduce(int nx, int nz, int64_t rows, int planes, cons
   constexpr size_t lds = (size_t)RING * 16 * NZ * 8 + (size_t)NX * (PX + 16) * 8 + 2 * 4 * PX * 8;
   constexpr int NW = 8;
   auto kern = xcorr_kernel<NX, NZ, PX, NW>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return GEOBO_E_LAUNCH;
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  if (int rc = ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), lds)) return rc;
   const int64_t nwg = g.nplanes < 1024 ? g.nplanes : 1024;
   hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * NW), lds, (hipStream_t)stream, g);
   return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;

@@ -61,11 +61,27 @@ def weight_matrix(crossweights):
     return [[1.0, w3, w1], [w3, 1.0, w2], [w1, w2, 1.0]]
 
 
+def _on_device(fn):
+    """Entry points run with the engine's device current: every launch takes torch's current stream, and the C-ABI is
+    handed raw pointers -- an engine on cuda:1 driven while cuda:0 is current would launch on the wrong device."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kw):
+        with torch.cuda.device(self.device):
+            return fn(self, *args, **kw)
+    return wrapper
+
+
 class PosteriorEngine:
     def __init__(self, settings, device=None, rank=0, world=1, group=None, profile=False, method="auto"):
         hip.require_gpu()
         self.s = settings
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        if self.device.type != "cuda":
+            raise ValueError("PosteriorEngine needs a CUDA (ROCm) device, got %r" % (device,))
+        if self.device.index is None:
+            self.device = torch.device("cuda:%d" % torch.cuda.current_device())
         self.rank, self.world, self.group = rank, world, group
         self.profile = profile
         self.timings = {}
@@ -102,6 +118,7 @@ class PosteriorEngine:
         self.exchange = (self.use_spectral and world > 1 and self.Ms % world == 0 and len(ncs) == 1
                          and xmode != "0" and (world >= 4 or xmode == "1"))
         self._Arows = {}
+        self._potrf_ctx = None
         self.kernel_events = None  # set to [] to record (name, flops, start, stop) HIP events per fused launch
 
     # ---- geometry --------------------------------------------------------------------------------------------
@@ -131,6 +148,7 @@ class PosteriorEngine:
         return xe, ye, -ze
 
     # ---- forward operators -----------------------------------------------------------------------------------
+    @_on_device
     def operator(self, func, sensor_locations, B=None, axes=None, full=False):
         """A_sens on the device: (Ms_pad x N_pad) zero padded tensor (sensormodel.py:29-93).
         In the row-sharded multi-GPU form (self.exchange) only what this rank needs is built unless `full`: the voxel
@@ -189,15 +207,17 @@ class PosteriorEngine:
         self._A[key] = A
         return A
 
-    def _timed(self, name, flops, fn):
-        """Run fn(); when kernel_events is a list, bracket it with HIP events on the launch stream (torch's current one)."""
+    def _timed(self, name, flops, fn, alg=0.0, valu=0.0):
+        """Run fn(); when kernel_events is a list, bracket it with HIP events on the launch stream (torch's current one).
+        flops = executed flop (padded compute extents), alg = algorithmic flop of SURVEY.md 8(d) for the same work (unpadded),
+        valu = the part of `flops` that runs on the fp64 VALU instead of the matrix pipe."""
         if self.kernel_events is None:
             return fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         r = fn()
         e1.record()
-        self.kernel_events.append((name, float(flops), e0, e1))
+        self.kernel_events.append((name, float(flops), float(alg), float(valu), e0, e1))
         return r
 
     def _workspace(self, name, shape):
@@ -261,10 +281,12 @@ class PosteriorEngine:
                                         lengths[j], lengths[s_], W[s_][j], amp, self.device)
                 if self.use_grid:
                     self._timed("ak_fused_grid", 2.0 * self.Ms_pad * self.N_pad * nc,
-                                lambda: hip.ak_fused_grid(A, self.nx, self.ny, self.nz, tab, self.c0, nc, out))
+                                lambda: hip.ak_fused_grid(A, self.nx, self.ny, self.nz, tab, self.c0, nc, out),
+                                alg=2.0 * self.Ms * self.N * min(nc, max(self.N - self.c0, 0)))
                 else:
                     self._timed("ak_fused", 2.0 * self.Ms_pad * self.N_pad * nc,
-                                lambda: hip.ak_fused(kid, A, xyz, self.c0, nc, lengths[j], lengths[s_], W[s_][j], amp, out))
+                                lambda: hip.ak_fused(kid, A, xyz, self.c0, nc, lengths[j], lengths[s_], W[s_][j], amp, out),
+                                alg=2.0 * self.Ms * self.N * min(nc, max(self.N - self.c0, 0)))
             if Md:
                 rows = tuple(c[sel_t] for c in xyz)
                 colc = tuple(c[self.c0:self.c1] for c in xyz)
@@ -289,7 +311,8 @@ class PosteriorEngine:
                                     sset.zvoxsize, lengths[j], lengths[s_], W[s_][j], amp, self.device)
                 lams.append(sp.eigenvalues(tab))
                 outs.append(AK[s_ * self.Ms_pad:s_ * self.Ms_pad + self.Ms, jj * nc:(jj + 1) * nc])
-            self._timed("spectral_product", sp.flops(self.Ms, len(props), y1 - y0), lambda: sp.product(A, self.Ms, lams, outs, y0, y1))
+            self._timed("spectral_product", sp.flops(self.Ms, len(props), y1 - y0), lambda: sp.product(A, self.Ms, lams, outs, y0, y1),
+                        valu=sp.flops_valu(self.Ms, len(props)))
 
     def _assemble_AK_spectral_exchange(self, AK, lengths, W, name, amp, props):
         """Row-sharded spectral product + all-to-all (multi-GPU): rank r transforms sensor rows [r*Ms/G, (r+1)*Ms/G) of both
@@ -316,7 +339,8 @@ class PosteriorEngine:
             slabs = [(slabs_of[d][0], slabs_of[d][1], [send[d].view(2, P_c, rows_r, nc)[s_, jj] for jj in range(P_c)])
                      for d in range(G)]
             Ar = self._Arows[func]
-            self._timed("spectral_product", sp.flops(rows_r, P_c, self.ny), lambda: sp.product(Ar, rows_r, lams, None, slabs=slabs))
+            self._timed("spectral_product", sp.flops(rows_r, P_c, self.ny), lambda: sp.product(Ar, rows_r, lams, None, slabs=slabs),
+                        valu=sp.flops_valu(rows_r, P_c))
         return send
 
     def _exchange_place(self, AK, recv, props):
@@ -388,11 +412,14 @@ class PosteriorEngine:
                 continue
             # executed flop: lower-only tiles, whole 64-row wavefront groups of the last row tile
             fl = 2.0 * 128 * nc * sum(min(2 * (bi + 1), self.Ms_pad // 128) * rv for bi, rv in enumerate(hip.tile_rows(rows, mv)))
+            # 8(d): 2 M Ms N for the full block column; the lower triangle that is consumed is half of the square part
+            nv = min(nc, max(self.N - self.c0, 0))
+            alg = 2.0 * nv * (self.Ms * (self.Ms + 1) / 2.0 + (mv - self.Ms_pad) * self.Ms)
             if splits > 1:
                 ws = self._workspace("aka_ws", (splits * rows * self.Ms_pad,))
-                self._timed("aka_gemm_nt", fl, lambda: hip.gemm_nt_splitk(Xv, Yv, Cv, splits, ws, lower_only=True, m_valid=mv))
+                self._timed("aka_gemm_nt", fl, lambda: hip.gemm_nt_splitk(Xv, Yv, Cv, splits, ws, lower_only=True, m_valid=mv), alg=alg)
             else:
-                self._timed("aka_gemm_nt", fl, lambda: hip.gemm_nt(Xv, Yv, Cv, lower_only=True, m_valid=mv))
+                self._timed("aka_gemm_nt", fl, lambda: hip.gemm_nt(Xv, Yv, Cv, lower_only=True, m_valid=mv), alg=alg)
         allreduce_sum_(AkA, self.world, self.group)
         dvec = torch.ones(M_pad, dtype=F64, device=self.device)
         dvec[0:self.Ms] = float(gp_sigma[0]) ** 2
@@ -414,6 +441,7 @@ class PosteriorEngine:
             y[2 * self.Ms_pad:2 * self.Ms_pad + len(y_d)] = y_d
         return hip.to_dev(y, self.device)
 
+    @_on_device
     def posterior(self, A_g, A_m, sel, y_g, y_m, y_d, lengths, crossweights, kernelfunc, gp_sigma, gp_amp=1.0,
                   props=(0, 1, 2), calclogl=True, want_mean_var=True):
         """Posterior mean / variance / log-likelihood.  `lengths` must already carry the create_cov mutation.
@@ -428,8 +456,11 @@ class PosteriorEngine:
         t = self._tick("ak_fused", t)
         AkA = self._assemble_AkA(AK, M_pad, A_g, A_m, sel_t, lengths, kernelfunc, gp_amp, gp_sigma, props)
         t = self._tick("aka", t)
+        if self._potrf_ctx is None:
+            self._potrf_ctx = hip.PotrfContext()       # fork streams of the L^-1 build: per engine, on this engine's device
         Linv, info = self._timed("potrf_inv", 2.0 * M_pad ** 3 / 3.0, lambda: hip.potrf_inv(
-            AkA, self._workspace("Linv", (M_pad, M_pad)), self._workspace("potrf_ws", (hip.potrf_ws_doubles(M_pad),))))  # AkA now holds L
+            AkA, self._workspace("Linv", (M_pad, M_pad)), self._workspace("potrf_ws", (hip.potrf_ws_doubles(M_pad),)),
+            ctx=self._potrf_ctx), alg=(2 * self.Ms + len(sel)) ** 3 * 2.0 / 3.0)  # AkA now holds L
         L = AkA
         y = self._pad_y(y_g, y_m, y_d, M_pad)
         u, stats = hip.trmv_stats(Linv, y, L)
@@ -448,8 +479,11 @@ class PosteriorEngine:
             # executed flop: lower-triangular Linv, 256-row tiles (whole 64-row groups of the valid rows) x 256*(bi+1) deep
             Mv = 2 * self.Ms_pad + len(sel)
             fl = 2.0 * 256 * AK.shape[1] * sum(rv * (bi + 1) for bi, rv in enumerate(hip.tile_rows(M_pad, Mv)))
+            Mu = 2 * self.Ms + len(sel)                                  # unpadded observation rows
+            nv = len(props) * min(self.nc, max(self.N - self.c0, 0))     # this rank's voxel-property columns
             mu_l, var_l = self._timed("posterior_reduce", fl, lambda: hip.posterior_reduce(
-                Linv, AK, u, gp_amp * 1.0, self._workspace("post_ws", (hip.posterior_ws_doubles(M_pad, AK.shape[1]),)), m_valid=Mv))
+                Linv, AK, u, gp_amp * 1.0, self._workspace("post_ws", (hip.posterior_ws_doubles(M_pad, AK.shape[1]),)), m_valid=Mv),
+                alg=(1.0 * Mu * Mu + 4.0 * Mu) * nv)
             t = self._tick("posterior", t)
             mu = assemble_columns(gather_slices(mu_l, len(props), self.N_pad, self.world, self.group), props, self.N,
                                   self.N_pad, self.world)

@@ -311,8 +311,34 @@ def toeplitz_y(ny, C, R, src, tabs, outs, y0=0, y1=None):
                                     _p(outs[0]), _p(o1), int(y0), int(y1), _stream()), "geobo_toeplitz_y")
 
 
-def potrf_inv(A, Linv=None, ws=None):
-    """In-place lower Cholesky of A (m x m, m % 128 == 0); returns (Linv, info_tensor).  Linv / ws may be caller-owned."""
+class PotrfContext:
+    """Fork streams / events of geobo_potrf_inv on the device that is current at construction (owned by the caller: one per
+    engine; never shared between concurrent factorisations)."""
+
+    def __init__(self):
+        lib = require_gpu()
+        self._h = C.c_void_p()
+        _lib.check(lib.geobo_potrf_ctx_create(C.byref(self._h)), "geobo_potrf_ctx_create")
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _lib.load().geobo_potrf_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def potrf_inv(A, Linv=None, ws=None, ctx=None):
+    """In-place lower Cholesky of A (m x m, m % 128 == 0); returns (Linv, info_tensor).  Linv / ws may be caller-owned;
+    ctx: PotrfContext (concurrent L^-1 subtrees) or None (serial on the current stream)."""
     lib = require_gpu()
     ld = _rowmajor(A, "A")
     m = A.shape[0]
@@ -322,8 +348,8 @@ def potrf_inv(A, Linv=None, ws=None):
     nbytes = lib.geobo_potrf_ws_bytes(m)
     if ws is None or ws.numel() * 8 < nbytes:
         ws = torch.empty(max(nbytes // 8, 1), dtype=F64, device=A.device)
-    _lib.check(lib.geobo_potrf_inv(m, _p(A), ld, _p(Linv), Linv.stride(0), _p(info), _p(ws), nbytes, _stream()),
-               "geobo_potrf_inv")
+    _lib.check(lib.geobo_potrf_inv(m, _p(A), ld, _p(Linv), Linv.stride(0), _p(info), _p(ws), nbytes,
+                                   ctx.handle if ctx is not None else None, _stream()), "geobo_potrf_inv")
     return Linv, info
 
 

@@ -168,6 +168,10 @@ class SpectralProduct:
             bwd += 2.0 * pn(slab) * Px * Pz * Py
         return rows * (fwd + nblocks * bwd)
 
+    def flops_valu(self, rows, nblocks):
+        """The part of flops() executed on the fp64 VALU (the Toeplitz y stage); everything else is MFMA."""
+        return rows * nblocks * 2.0 * self.ny * self.ny * self.Px * self.Pz if self.dense_y else 0.0
+
     def eigenvalues(self, table_mirrored):
         """What product() needs of one covariance block, from the (z-mirrored) lattice table of geobo_cov_table:
         dense-y route: the Toeplitz generators t[d][ox][oz] = (E_x E_z k)(d, ox, oz) / (Px Pz)   ([ny][Px*Pz]);

@@ -1,0 +1,40 @@
+"""Worker for the multi-rank tests: one rank of a 32^3 Matern inversion under torch.distributed (backend from argv), rank 0
+saves the six cubes.  Started by `python -m torch.distributed.run --nproc-per-node N tests/_rank_worker.py <backend> <out.npz>`."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    backend, out = sys.argv[1], sys.argv[2]
+    size = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+    local = int(os.environ["LOCAL_RANK"]) % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local)
+    dist.init_process_group(backend)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    from conftest import settings_for
+    from geobo_amd.inversion import Inversion
+    import bench
+    s = settings_for(size, size, size, kernelfunc="matern32")
+    inv = Inversion(settings=s, rank=rank, world=world, device="cuda:%d" % local)
+    grav, mag, loc, drill0 = bench.synthetic_inputs(inv, 20)
+    inv.engine.clear_operators()
+    inv.gp_length = np.array([200.0, 202.0, 204.0])
+    cubes = inv.cubing(grav, mag, drill0[drill0 != 0], loc, drill0)
+    ones = torch.ones(1, device="cuda")
+    dist.all_reduce(ones)
+    if rank == 0:
+        np.savez(out, cubes=np.asarray(cubes), logl=inv.logl, world=int(ones.item()), exchange=bool(inv.engine.exchange))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -43,7 +43,7 @@ def test_host_side_helpers(lib):
     lib.geobo_pad_n.argtypes = [ctypes.c_int64]
     lib.geobo_potrf_ws_bytes.restype = ctypes.c_size_t
     lib.geobo_potrf_ws_bytes.argtypes = [ctypes.c_int64]
-    assert lib.geobo_version() == 100
+    assert lib.geobo_version() == 200
     assert lib.geobo_pad_m(8242) == 8448 and lib.geobo_pad_m(256) == 256 and lib.geobo_pad_m(1) == 256
     assert lib.geobo_pad_n(480) == 512 and lib.geobo_pad_n(262144) == 262144
     assert lib.geobo_potrf_ws_bytes(8448) == (33 * 128) ** 2 * 8
@@ -55,7 +55,32 @@ def test_argument_validation_without_gpu(lib):
     L = _lib.load()
     assert L.geobo_gemm_nt(256, 128, 16, 1.0, None, 16, None, 16, 0.0, None, 128, 0, 0, None) == -1
     assert L.geobo_ak_fused(1, None, 256, 256, 256, None, None, None, 0, 128, 1., 1., 1., 1., None, 128, None) == -1
-    assert L.geobo_potrf_inv(100, None, 100, None, 100, None, None, 0, None) == -1
+    assert L.geobo_potrf_inv(100, None, 100, None, 100, None, None, 0, None, None) == -1
+
+
+@pytest.mark.parametrize("nbi,nbj,tm,tn", [(33, 32, 256, 128), (33, 66, 256, 128), (66, 66, 128, 128), (5, 3, 128, 128), (4, 64, 256, 128),
+                                            (17, 9, 256, 128)])
+def test_tile_order_visits_every_tile_once(nbi, nbj, tm, tn):
+    """The arithmetic item order the GEMM launches decode on the device (no tile lists in device memory any more): every
+    valid tile exactly once, for the plain, lower-only and triangular-operand forms."""
+    import numpy as np
+    from geobo_amd import _lib
+    L = _lib.load()
+    for lower, xl, yl in ((0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1)):
+        buf = (ctypes.c_int * (nbi * nbj))()
+        n = L.geobo_tile_order(nbi, nbj, tm, tn, lower, xl, yl, buf, nbi * nbj)
+        got = [(v >> 16, v & 0xffff) for v in list(buf)[:n]]
+        want = {(bi, bj) for bi in range(nbi) for bj in range(nbj) if not lower or bj * tn < (bi + 1) * tm}
+        assert n == len(want) and len(set(got)) == n and set(got) == want, (lower, xl, yl)
+        if lower or not (xl or yl):
+            # 32 consecutive items = at most 4 row tiles (one band): the supertile an XCD's L2 holds
+            for g in range(0, n, 32):
+                rows = {bi for bi, _ in got[g:g + 32]}
+                assert max(rows) - min(rows) <= 7
+        if xl:
+            assert [bi for bi, _ in got] == sorted((bi for bi, _ in got), reverse=True)   # longest contraction first
+        if yl:
+            assert [bj for _, bj in got] == sorted(bj for _, bj in got)
 
 
 def test_product_never_imports_the_oracle():

@@ -202,12 +202,13 @@ def test_ak_fused_grid_matches_coordinate_path(hip, name, cross, dims):
     assert np.array_equal(sh.cpu().numpy(), got.cpu().numpy()[:, Np - 128:])
 
 
+@pytest.mark.parametrize("fork", [False, True])
 @pytest.mark.parametrize("m", [256, 512, 1280, 2304, 4224])   # 2304 / 4224: both fork levels of the concurrent L^-1 build
-def test_potrf_inv_matches_torch(hip, m):
+def test_potrf_inv_matches_torch(hip, m, fork):
     B = _rand((m, m), 20)
     S = B @ B.t() / m + 0.05 * torch.eye(m, dtype=torch.float64, device="cuda")
     L = S.clone()
-    Linv, info = hip.potrf_inv(L)
+    Linv, info = hip.potrf_inv(L, ctx=hip.PotrfContext() if fork else None)
     assert int(info.item()) == 0
     Lref = torch.linalg.cholesky(S)
     assert (torch.tril(L) - Lref).abs().max().item() < 1e-12
@@ -222,6 +223,55 @@ def test_potrf_inv_matches_torch(hip, m):
     st = stats.cpu().numpy()
     assert abs(st[0] - float(uref @ uref)) < 1e-9 * float(uref @ uref)
     assert abs(st[1] - float(torch.log(torch.diag(Lref) ** 2).sum())) < 1e-9
+
+
+def test_concurrent_factorisations_on_two_streams(hip):
+    """Two host threads, two caller streams, one fork context each: the library holds no process-global streams / events /
+    caches, so the factorisations may overlap freely and must each match torch (run several rounds to let them interleave)."""
+    import threading
+    m = 2304
+    mats, refs = [], []
+    for seed in (40, 41):
+        B = _rand((m, m), seed)
+        S = B @ B.t() / m + 0.05 * torch.eye(m, dtype=torch.float64, device="cuda")
+        mats.append(S)
+        refs.append(torch.linalg.cholesky(S))
+    torch.cuda.synchronize()
+    errs = [[], []]
+
+    def worker(i):
+        st = torch.cuda.Stream()
+        ctx = hip.PotrfContext()
+        with torch.cuda.stream(st):
+            for _ in range(6):
+                L = mats[i].clone()
+                Linv, info = hip.potrf_inv(L, ctx=ctx)
+                st.synchronize()
+                e1 = (torch.tril(L) - refs[i]).abs().max().item()
+                e2 = (Linv @ refs[i] - torch.eye(m, dtype=torch.float64, device="cuda")).abs().max().item()
+                errs[i].append((int(info.item()), e1, e2))
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in (0, 1)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for i in (0, 1):
+        assert len(errs[i]) == 6
+        for info, e1, e2 in errs[i]:
+            assert info == 0 and e1 < 1e-12 and e2 < 1e-10, (i, info, e1, e2)
+
+
+def test_soak_hand_synchronised_kernels():
+    """Short form of tools/soak_kernels.py: randomised plane / row counts through geobo_xz2d (both directions), geobo_xcorr_reduce
+    and geobo_toeplitz_y against torch einsum references -- the counted vmcnt waits of the LDS-DMA rings must never let a tile be
+    read before it has landed."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import soak_kernels
+    it, bad = soak_kernels.soak(seed=7, iters=25, verbose=False)
+    assert it == 25 and bad == 0
 
 
 def test_potrf_reports_first_bad_pivot(hip):

@@ -109,3 +109,21 @@ def test_kernel_id_mapping():
     with pytest.raises(ValueError):
         hip.kernel_id("rbf", False)
     assert hip.pad_m(8242) == 8448 and hip.pad_n(480) == 512
+
+
+def test_bench_refuses_a_line_for_another_job_size():
+    """bench.py --gpus N: under a launcher WORLD_SIZE must equal N; without one it starts N ranks itself (here, without GPUs,
+    those ranks stop at the device check -- which shows the relaunch happened)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"], env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and "refusing" in r.stderr
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and "needs 2 visible devices" in r.stderr

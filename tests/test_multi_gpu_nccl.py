@@ -1,0 +1,64 @@
+"""RCCL path on real hardware: the same 32^3 inversion on 2 (and 4) `nccl` ranks, one process per GPU, against the 1-rank
+run.  Skipped on boxes with fewer devices (the driver's single-GPU tier); the gloo tests cover the host logic on CPU."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import normwise
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_ranks(n, backend, out, size=32):
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "_rank_worker.py"), backend, out, str(size)]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    return dict(np.load(out))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_nccl_ranks_match_single_rank(world, tmp_path):
+    if torch.cuda.device_count() < world:
+        pytest.skip("needs %d GPUs (have %d)" % (world, torch.cuda.device_count()))
+    one = _run_ranks(1, "nccl", str(tmp_path / "r1.npz"))
+    many = _run_ranks(world, "nccl", str(tmp_path / "rN.npz"))
+    assert int(many["world"]) == world
+    for a, b in zip(many["cubes"], one["cubes"]):
+        assert normwise(a, b) <= 1e-10
+    assert abs(float(many["logl"]) - float(one["logl"])) <= 1e-10 * abs(float(one["logl"]))
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus N` without a launcher must start N ranks itself and print a line with n_gpus == N."""
+    import json
+    n = 2
+    if torch.cuda.device_count() < n:
+        pytest.skip("needs 2 GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--size", "32", "--steps", "1", "--warmup",
+                        "1", "--no-cpu"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == n and line["config"]["ranks_reported_by_backend"] == n
+
+
+def test_single_device_gloo_ranks_match_single_rank(tmp_path):
+    """Two ranks sharing the one device of this box (gloo transport, device tensors staged through the host by torch): the
+    whole multi-rank host path -- shards, collectives, assembly -- through the HIP kernels, against the 1-rank run."""
+    one = _run_ranks(1, "gloo", str(tmp_path / "g1.npz"))
+    two = _run_ranks(2, "gloo", str(tmp_path / "g2.npz"))
+    assert int(two["world"]) == 2
+    for a, b in zip(two["cubes"], one["cubes"]):
+        assert normwise(a, b) <= 1e-10
