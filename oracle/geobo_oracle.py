@@ -349,7 +349,7 @@ def posterior_blocked(P3, A_g, A_m, sel, y, lengths, W, name, gp_sigma, gp_amp=1
 
 
 def cubing(grid: Grid, gravfield, magfield, drillfield, sensor_locations, drilldata0, gp_length=None,
-           dense=False, props=(0, 1, 2), A=None, block=2048):
+           dense=False, props=(0, 1, 2), A=None, block=2048, gp_amp=1.0):
     """inversion.py:182-248 -- z-score the data (population std), build operators, posterior,
     reshape to (3, ny, nx, nz), scale by the data std / std^2 (means are NOT added back).
 
@@ -375,9 +375,10 @@ def cubing(grid: Grid, gravfield, magfield, drillfield, sensor_locations, drilld
     lengths = mutate_lengths(gl)
     W = weight_matrix(grid.gp_coeff)
     if dense:
-        r = posterior_dense(P3, A_g, A_m, sel, y, lengths, W, grid.kernelfunc, grid.gp_err)
+        r = posterior_dense(P3, A_g, A_m, sel, y, lengths, W, grid.kernelfunc, grid.gp_err, gp_amp=gp_amp)
     else:
-        r = posterior_blocked(P3, A_g, A_m, sel, y, lengths, W, grid.kernelfunc, grid.gp_err, props=props, block=block)
+        r = posterior_blocked(P3, A_g, A_m, sel, y, lengths, W, grid.kernelfunc, grid.gp_err, gp_amp=gp_amp, props=props,
+                              block=block)
     shp = (3, grid.ny, grid.nx, grid.nz)
     rec = r["mu"].reshape(shp)
     var = r["var"].reshape(shp)
@@ -385,6 +386,40 @@ def cubing(grid: Grid, gravfield, magfield, drillfield, sensor_locations, drilld
         cubes = np.asarray([rec[0] * gs, rec[1] * ms, rec[2] * ds, var[0] * gs ** 2, var[1] * ms ** 2, var[2] * ds ** 2])
     r.update(cubes=cubes, gp_length=lengths, A_g=A_g, A_m=A_m, sel=sel, Fs3=y)
     return r
+
+
+def neg_logl(grid: Grid, params, P3, A_g, A_m, sel, y):
+    """inversion.py:125-152 (calc_logl) -- negative marginal log-likelihood for (amplitude, lengthscale in x-voxels, w1, w2, w3);
+    no N log 2pi term (:147-149); any failure -> +inf (:150-152)."""
+    try:
+        lengths = mutate_lengths(params[1] * np.asarray([grid.sx, grid.sx, grid.sx]))
+        r = posterior_dense(P3, A_g, A_m, sel, y, lengths, weight_matrix(params[2:]), grid.kernelfunc, grid.gp_err,
+                            gp_amp=params[0])
+        v = 0.5 * (r["u"] @ r["u"] + np.log(np.diag(r["L"]) ** 2).sum())
+        return v if np.isfinite(v) else np.inf
+    except Exception:
+        return np.inf
+
+
+def ak_row_fft(grid: Grid, a_row, name, lengths, W, s, j, gp_amp=1.0):
+    """One row of A K for block (s, j):  w[q] = sum_p a[p] K_sj[p, q], by a zero-padded FFT convolution -- on the grid of
+    calcGridPoints3D (kernels.py:27-42) K_sj[p, q] = k(dy*sy, dx*sx, dz*sz) depends on the index difference only.  Same numbers
+    as `a_row @ k_block(name, sqdist(P3), ...)` (checked at small sizes in tests/test_oracle_golden.py); this is the form that
+    reaches 64^3 on a CPU, for independent spot checks of rows of A K and entries of AkA."""
+    ny, nx, nz = grid.ny, grid.nx, grid.nz
+    dy = np.arange(-(ny - 1), ny) * grid.sy
+    dx = np.arange(-(nx - 1), nx) * grid.sx
+    dz = np.arange(-(nz - 1), nz) * grid.sz
+    d2 = 0 + (dx[None, :, None]) ** 2 + (dy[:, None, None]) ** 2 + (dz[None, None, :]) ** 2   # same summation order as sqdist
+    kk = gp_amp * k_block(name, d2, lengths, W, s, j)                                        # (2ny-1, 2nx-1, 2nz-1), offset n-1
+    shape = (2 * ny, 2 * nx, 2 * nz)
+    kpad = np.zeros(shape)
+    kpad[:2 * ny - 1, :2 * nx - 1, :2 * nz - 1] = kk
+    kpad = np.roll(kpad, (-(ny - 1), -(nx - 1), -(nz - 1)), axis=(0, 1, 2))                  # offset 0 at index 0, negatives wrapped
+    apad = np.zeros(shape)
+    apad[:ny, :nx, :nz] = np.asarray(a_row).reshape(ny, nx, nz)
+    w = np.fft.irfftn(np.fft.rfftn(apad) * np.fft.rfftn(kpad), s=shape, axes=(0, 1, 2))
+    return w[:ny, :nx, :nz].reshape(-1)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -22,8 +22,15 @@ Fixtures written (all float64, little endian, np.savez_compressed):
   F3  example{1,2}.npz         cubing() inputs captured from run_geobo.py on the shipped examples,
                                its six output cubes, and the committed examples/results/*/*.vtk cubes
   F4  forward_kat.npz          simcube_cylinders.csv -> simsurveydata_cylinders.csv (A_sens known answer)
+  F5  config1_exp16.npz        BASELINE config 1: examples/settings_example1.yaml extents (3050 x 1952 x 800 m -> anisotropic
+                               190.6 x 122 x 50 m voxels) with xNcube = yNcube = zNcube = 16, kernelfunc 'exp',
+                               gp_coeff = [0, 0, 0] ("gravity only": the blocks decouple), no drill rows
+  F6  illcond_<name>.npz       long length scales / small noise / amplitude 2 (the regime optimize_gp explores): tiny grid with
+                               the reference's operators, AkA and factor diagonal, and a 16^3 cube
+  F7  optimize_tiny_exp.npz    Inversion.optimize_gp() (SHGO over 5 hyper-parameters) on the tiny grid: optimum, objective there,
+                               and calc_logl at a few fixed parameter vectors
 
-Usage:  python tests/golden/make_golden.py [F0 F1 F2 F3 F4]
+Usage:  python tests/golden/make_golden.py [F0 F1 F2 F3 F4 F5 F6 F7]
 """
 import json
 import os
@@ -66,7 +73,7 @@ sys.argv = ["x", job["settings_yaml"]]
 import geobo.config_loader as cfg
 import geobo.kernels as K, geobo.sensormodel as sm, geobo.inversion as inv
 
-def synthetic_inputs(I, md):
+def synthetic_inputs(I, md, chi_factor=None):
     """cylinders ground truth (simcube.py:83-92 semantics) -> survey through the reference A_sens,
     rounded through float32 like the GeoTIFF round trip (simcube.py:196-199)."""
     nx, ny, nz = cfg.xNcube, cfg.yNcube, cfg.zNcube
@@ -81,7 +88,7 @@ def synthetic_inputs(I, md):
     # smooth trend on top of the reference's cylinders model so that small grids (where no voxel
     # centre falls inside a cylinder) still give non-degenerate survey and drill data
     rho = rho + 0.02 * (x3 / cfg.xLcube + 2. * y3 / cfg.yLcube - z3 / cfg.zLcube)
-    chi = cfg.gp_coeff[1] * rho
+    chi = (cfg.gp_coeff[1] if chi_factor is None else chi_factor) * rho   # (gp_coeff = 0 would give a constant-zero magnetic survey)
     xs = np.linspace(0.5, nx - 0.5, nx) * cfg.xvoxsize
     ys = np.linspace(0.5, ny - 0.5, ny) * cfg.yvoxsize
     X, Y, Z = np.meshgrid(xs, ys, cfg.zmax + cfg.zoff)
@@ -119,9 +126,12 @@ if mode == "kat":
     out["points3D"] = K.calcGridPoints3D((3, 2, 4), (10., 20., 5.))
 elif mode == "cubing":
     I = inv.Inversion(); vox = I.create_cubegeometry()
-    grav, mag, loc, drill0, rho, chi = synthetic_inputs(I, job["md"])
+    grav, mag, loc, drill0, rho, chi = synthetic_inputs(I, job["md"], job.get("chi_factor"))
     if job.get("gp_length") is not None:
         I.gp_length = np.array(job["gp_length"], dtype=float)
+    if job.get("gp_amp") is not None:
+        I.gp_amp = float(job["gp_amp"])
+    out["gp_amp"] = float(I.gp_amp)
     out["gp_length_in"] = np.array(I.gp_length, dtype=float)
     cubes = I.cubing(grav, mag, drill0[drill0 != 0], loc, drill0)
     out.update(gravfield=grav, magfield=mag, sensor_locations=loc, drilldata0=drill0, rho=rho, chi=chi,
@@ -136,6 +146,27 @@ elif mode == "cubing":
     if job.get("save_AkA", False):
         out["AkA"] = AkA
     out["cond_AkA"] = np.linalg.cond(AkA)
+    if job.get("save_Ldiag", False):
+        import scipy.linalg as sl
+        out["L_diag"] = np.diag(sl.cholesky(AkA, lower=True))
+    if job.get("optimize", False):
+        # Inversion.optimize_gp (inversion.py:155-178) on the state cubing() left behind.  NB the reference then stores the bare
+        # scalar lengthscale in self.gp_length (:175), after which create_cov can no longer index it -- so it is called here,
+        # after cubing, not through the YAML switch
+        import io, contextlib
+        probes = [[1.0, 2.0, 1.0, 0.2, 0.2], [1.3, 1.7, 0.8, 0.25, 0.3], [0.6, 6.0, 0.9, 0.5, 0.15], [2.0, 18.0, 0.6, 0.9, 0.9]]
+        out["probe_params"] = np.asarray(probes)
+        out["probe_values"] = np.asarray([I.calc_logl(np.asarray(pp)) for pp in probes])
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            I.optimize_gp()
+        out["opt_stdout"] = buf.getvalue()
+        out["opt_gp_amp"] = float(I.gp_amp)
+        out["opt_gp_length"] = np.asarray(I.gp_length, dtype=float)      # scalar multiple of the voxel size (sic)
+        out["opt_coeffm"] = np.asarray(I.coeffm, dtype=float)
+        xo = np.r_[float(I.gp_amp), float(np.asarray(I.gp_length).reshape(-1)[0]), np.asarray(I.coeffm, dtype=float)]
+        out["opt_x"] = xo
+        out["opt_fun"] = I.calc_logl(xo)
     # row-class statistics of the operators (used for the T2 operator-parity tier)
     out["A_g_absmax"] = np.abs(I.Asens3[:ng, :rho.size]).max()
     out["A_m_absmax"] = np.abs(I.Asens3[ng:2*ng, rho.size:2*rho.size]).max()
@@ -294,5 +325,32 @@ def main(which):
               np.abs(d["magnetic_ref"] - d["magnetic_csv"]).max() / np.abs(d["magnetic_csv"]).max())
 
 
+    if "F5" in which:
+        import yaml
+        s = yaml.safe_load(open(os.path.join(REF, "examples/settings_example1.yaml")))
+        s.update(inpath="/tmp/geobo_golden/in/", outpath="/tmp/geobo_golden/out/", gen_simulation=False, xNcube=16, yNcube=16,
+                 zNcube=16, kernelfunc="exp", gp_coeff=[0.0, 0.0, 0.0], plot3d=False, plot_vertical=False,
+                 bayesopt_vertical=False, bayesopt_nonvertical=False)
+        job("cubing", s, "config1_exp16.npz", md=0, gp_length=None, chi_factor=0.2)
+        d = dict(np.load(os.path.join(HERE, "config1_exp16.npz")))
+        d["settings_json"] = np.asarray(json.dumps({k: v for k, v in s.items() if k not in ("inpath", "outpath")}))
+        np.savez_compressed(os.path.join(HERE, "config1_exp16.npz"), **d)
+    if "F6" in which:
+        hard = dict(BASE_SETTINGS, gp_lengthscale=8, gp_err=[0.01, 0.01, 0.01])
+        job("cubing", dict(hard, kernelfunc="exp"), "illcond_tiny_exp.npz", md=5, gp_length=None, gp_amp=2.0, save_A=True,
+            save_AkA=True, save_Ldiag=True)
+        job("cubing", dict(hard, kernelfunc="matern32", gp_lengthscale=10), "illcond_tiny_matern32.npz", md=5,
+            gp_length=[1000.0, 1010.0, 1020.0], gp_amp=2.0, save_A=True, save_AkA=True, save_Ldiag=True)
+        cube = dict(hard, xmax=1600, ymax=1600, zLcube=1600.0, xNcube=16, yNcube=16, zNcube=16)
+        job("cubing", dict(cube, kernelfunc="matern32", gp_lengthscale=10), "illcond_cube16_matern32.npz", md=50,
+            gp_length=[1000.0, 1010.0, 1020.0], gp_amp=2.0, save_Ldiag=True)
+        for n in ("illcond_tiny_exp", "illcond_tiny_matern32", "illcond_cube16_matern32"):
+            print("   cond(AkA) %s = %.3e" % (n, float(np.load(os.path.join(HERE, n + ".npz"))["cond_AkA"])))
+    if "F7" in which:
+        job("cubing", dict(BASE_SETTINGS, kernelfunc="exp"), "optimize_tiny_exp.npz", md=5, gp_length=None, optimize=True)
+        d = np.load(os.path.join(HERE, "optimize_tiny_exp.npz"))
+        print("   optimum", d["opt_x"], "objective", float(d["opt_fun"]))
+
+
 if __name__ == "__main__":
-    main(sys.argv[1:] or ["F0", "F1", "F2", "F3", "F4"])
+    main(sys.argv[1:] or ["F0", "F1", "F2", "F3", "F4", "F5", "F6", "F7"])

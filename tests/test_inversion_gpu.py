@@ -27,15 +27,27 @@ def _inv(s, **kw):
     return inv
 
 
-def _check_cubes(cubes, ref, tol, what):
-    errs = []
+def elementwise_rel(c, r, floor=1e-3):
+    """max |c - r| / |r| over the voxels where |r| > floor * max|r| (element-wise relative error is only meaningful away from
+    the zero crossings of the posterior mean; the normwise figure covers the rest)."""
+    c, r = np.asarray(c), np.asarray(r)
+    m = np.abs(r) > floor * np.abs(r).max()
+    return float((np.abs(c - r)[m] / np.abs(r)[m]).max()) if m.any() else 0.0
+
+
+def _check_cubes(cubes, ref, tol, what, tol_elem=None):
+    errs, elem = [], []
     for c, r in zip(cubes, ref):
         if np.isnan(r).all():
             assert np.isnan(c).all(), what
             continue
         errs.append(normwise(c, r))
-    print(what, " ".join("%.2e" % e for e in errs))
+        elem.append(elementwise_rel(c, r))
+    print(what, "normwise", " ".join("%.2e" % e for e in errs), "| element-wise rel (|ref| > 1e-3 max)", " ".join("%.2e" % e for e in elem))
     assert max(errs) <= tol, (what, errs)
+    # north_star says "1e-8 relative": besides the normwise bound, the element-wise relative error on every voxel that is not
+    # near a zero crossing is bounded as well (100 x the normwise tolerance; observed ~1e-9 on the shipped fixtures)
+    assert max(elem) <= (100 * tol if tol_elem is None else tol_elem), (what, elem)
 
 
 @pytest.mark.parametrize("name", ["tiny_exp", "tiny_sparse", "tiny_matern32", "tiny_exp_nodrill"])
@@ -108,6 +120,109 @@ def test_shipped_examples(name):
     cubes = inv.cubing(f["gravfield"], f["magfield"], f["drillfield"], f["sensor_locations"], f["drilldata0"])
     _check_cubes(cubes, f["cubes"], TOL_T3, name + " vs reference re-run")
     _check_cubes(cubes, f["vtk_cubes"], 5e-8, name + " vs committed VTK")   # the re-run itself differs by <= 3.7e-8
+
+
+@pytest.mark.parametrize("method", ["dense", "spectral"])
+def test_baseline_config1_against_the_reference(method):
+    """BASELINE.json configs[0]: examples/settings_example1.yaml extents (3050 x 1952 x 800 m -> anisotropic voxels), 16^3,
+    'exp', gp_coeff = [0, 0, 0], no drill rows -- the reference's own CPU-runnable case; fixture = its output
+    (tests/golden/make_golden.py F5).  The product has no CPU path by design: the plumbing case runs on the HIP path."""
+    from geobo_amd.config_loader import Settings
+    f = load_golden("config1_exp16.npz")
+    s = Settings(json.loads(str(f["settings_json"])))
+    assert abs(s.xvoxsize - 190.625) < 1e-12 and s.yvoxsize == 122.0 and s.zvoxsize == 50.0
+    inv = _inv(s, method=method)
+    assert np.array_equal(inv.gp_length, f["gp_length_in"])
+    d0 = f["drilldata0"]
+    cubes = inv.cubing(f["gravfield"], f["magfield"], d0[d0 != 0], f["sensor_locations"], d0)
+    _check_cubes(cubes, f["cubes"], TOL_T3, "config 1 (%s)" % method)
+    assert abs(inv.logl - float(f["logl"])) <= 1e-8 * abs(float(f["logl"]))
+    assert np.array_equal(inv.gp_length, f["gp_length_out"])
+
+
+ILLCOND = [("illcond_tiny_exp", (10, 8, 6), "exp", 8), ("illcond_tiny_matern32", (10, 8, 6), "matern32", 10),
+           ("illcond_cube16_matern32", (16, 16, 16), "matern32", 10)]
+
+
+@pytest.mark.parametrize("name,dims,kern,ls", ILLCOND)
+def test_ill_conditioned_regime_end_to_end(name, dims, kern, ls):
+    """Length scales of 8-10 voxels, noise 0.01, amplitude 2 -- the corner optimize_gp explores; cond(AkA) = 2.6e6 .. 1.8e7,
+    300 x the other fixtures.  The path forms L^-1 explicitly where the reference calls solve_triangular twice
+    (inversion.py:105,114): this is where the two could part."""
+    f = load_golden(name + ".npz")
+    nx, ny, nz = dims
+    s = settings_for(nx, ny, nz, kernelfunc=kern, gp_lengthscale=ls, gp_err=[0.01, 0.01, 0.01])
+    inv = _inv(s)
+    inv.gp_length = f["gp_length_in"].copy()
+    inv.gp_amp = 2.0
+    d0 = f["drilldata0"]
+    cubes = inv.cubing(f["gravfield"], f["magfield"], d0[d0 != 0], f["sensor_locations"], d0)
+    print("cond(AkA) = %.2e" % float(f["cond_AkA"]))
+    _check_cubes(cubes, f["cubes"], TOL_T3, name + " T3", tol_elem=1e-5)
+    assert abs(inv.logl - float(f["logl"])) <= 1e-8 * abs(float(f["logl"]))
+    eng = inv.engine
+    Md = f["sel"].size
+    rows = np.r_[0:eng.Ms, eng.Ms_pad:eng.Ms_pad + eng.Ms, 2 * eng.Ms_pad:2 * eng.Ms_pad + Md]
+    Ld = torch.diagonal(eng.last["L"]).cpu().numpy()[rows]
+    assert normwise(Ld, f["L_diag"]) <= 1e-9
+
+
+@pytest.mark.parametrize("name,dims,kern,ls", ILLCOND[:2])
+def test_ill_conditioned_solver_parity_with_reference_operators(name, dims, kern, ls):
+    """T1 in the same regime: the reference's A_g / A_m fed in, so only assembly + factorisation + L^-1 + reductions differ."""
+    from geobo_amd import hip
+    from geobo_amd.engine import PosteriorEngine, create_cov_lengths
+    f = load_golden(name + ".npz")
+    s = settings_for(*dims, kernelfunc=kern, gp_lengthscale=ls, gp_err=[0.01, 0.01, 0.01])
+    eng = PosteriorEngine(s)
+
+    def padA(A):
+        out = torch.zeros((eng.Ms_pad, eng.N_pad), dtype=torch.float64, device="cuda")
+        out[:A.shape[0], :A.shape[1]] = hip.to_dev(A)
+        return out
+    lengths = create_cov_lengths(f["gp_length_in"].copy())
+    y = f["Fs3"]
+    ng = f["gravfield"].size
+    r = eng.posterior(padA(f["A_g"]), padA(f["A_m"]), f["sel"], y[:ng], y[ng:2 * ng], y[2 * ng:], [float(v) for v in lengths],
+                      s.gp_coeff, kern, s.gp_err, gp_amp=2.0)
+    # the prior variance is amp * k(0) = 2 here: var = 2 - sum V^2
+    e_mu, e_var = normwise(r["mu"], f["mu"]), normwise(r["var"], f["var"])
+    print("T1 %s mu %.2e var %.2e (cond %.2e)" % (name, e_mu, e_var, float(f["cond_AkA"])))
+    assert e_mu <= 1e-9 and e_var <= 1e-9
+    Md = f["sel"].size
+    rows = np.r_[0:ng, eng.Ms_pad:eng.Ms_pad + ng, 2 * eng.Ms_pad:2 * eng.Ms_pad + Md]
+    Lh = torch.tril(eng.last["L"]).cpu().numpy()[np.ix_(rows, rows)]
+    assert normwise(Lh @ Lh.T, f["AkA"]) <= 1e-12
+    assert normwise(np.diag(Lh), f["L_diag"]) <= 1e-10
+
+
+def test_optimize_gp_reaches_the_reference_optimum():
+    """f1 row: calc_logl at fixed hyper-parameters and the SHGO optimum of Inversion.optimize_gp on the tiny grid against a run
+    of the reference (fixture F7); one full sweep timed on the GPU path.  The reference stores the bare scalar lengthscale in
+    gp_length afterwards (inversion.py:175), which its own create_cov cannot index; this path keeps the 3-vector
+    lengthscale * xvoxsize (pinned below)."""
+    import time
+    f = load_golden("optimize_tiny_exp.npz")
+    s = settings_for(**TINY, kernelfunc="exp")
+    inv = _inv(s)
+    d0 = f["drilldata0"]
+    inv.cubing(f["gravfield"], f["magfield"], d0[d0 != 0], f["sensor_locations"], d0)
+    for p, v in zip(f["probe_params"], f["probe_values"]):
+        got = inv.calc_logl(p)
+        assert abs(got - v) <= 1e-8 * abs(v), (p, got, v)
+    t0 = time.perf_counter()
+    inv.optimize_gp()
+    dt = time.perf_counter() - t0
+    x = np.r_[inv.gp_amp, inv.gp_length[0] / s.xvoxsize, inv.coeffm]
+    fun = inv.calc_logl(x)
+    ref_x, ref_fun = f["opt_x"], float(f["opt_fun"])
+    print("optimize_gp: %.1f s; optimum %s objective %.8f (reference %s %.8f)" % (dt, np.round(x, 5), fun, np.round(ref_x, 5), ref_fun))
+    assert inv.gp_length.shape == (3,) and np.all(inv.gp_length == inv.gp_length[0])
+    assert abs(fun - ref_fun) <= 1e-6 * abs(ref_fun)
+    assert np.abs(x - ref_x).max() <= 1e-3 * np.abs(ref_x).max()
+    # the optimised state must be usable (the reference's is not): one more inversion with it
+    cubes = inv.cubing(f["gravfield"], f["magfield"], d0[d0 != 0], f["sensor_locations"], d0)
+    assert np.isfinite(cubes[0]).all()
 
 
 def test_props_subset_and_errors():
@@ -270,6 +385,55 @@ def test_full_size_64cube_properties():
     assert np.abs(smp[0][1] - var[c0:c0 + b]).max() <= 1e-10
     assert np.abs(smp[1][0] - inv.mu_rec[N + c0:N + c0 + b]).max() <= 1e-10 * np.abs(inv.mu_rec[N:2 * N]).max()
     assert all(c.shape == (n, n, n) for c in cubes)
+
+    # ---- independent spot checks: nothing below borrows A, A K, AkA or L from the device -------------------------------------
+    from oracle import geobo_oracle as O
+    from conftest import oracle_grid
+    G = oracle_grid(s)
+    lengths = np.array([float(x) for x in inv.gp_length])
+    W = O.weight_matrix(s.gp_coeff)
+    edges = G.edges()
+    # (a) forward operators: 8 sensors incl. the first / last sensor row (voxel slabs iy = 0 and ny-1 carry the 1e6 padding)
+    sens = [0, 37, n * 31 + 5, n * 32 + 40, n * (n - 1) + 9, n * n - 1, n * 17 + 63, n * 63]
+    Ag_o = O.a_sens(G, G.B * 0., loc, edges, "grav", rows=sens)
+    Am_o = O.a_sens(G, G.B, loc, edges, "magn", rows=sens)
+    Ag_d, Am_d = A_g[sens, :N].cpu().numpy(), A_m[sens, :N].cpu().numpy()
+    e_g = np.abs(Ag_d - Ag_o).max() / np.abs(Ag_o).max()
+    e_m = np.abs(Am_d - Am_o).max() / np.abs(Am_o).max()
+    print("64^3 A_sens rows vs oracle: grav %.2e magn %.2e" % (e_g, e_m))
+    assert e_g <= 1e-10 and e_m <= 1e-12                                     # the T2 tier
+    # (b) rows of A K and entries of AkA: oracle operator rows through the oracle's FFT form of the covariance product
+    L = eng.last["L"]
+    Lt = torch.tril(L)
+    sel = inv._sel
+    off = {0: 0, 1: eng.Ms_pad, 2: 2 * eng.Ms_pad}
+    AK = eng.last["AK"]
+    for s_, A_o, gs in ((0, Ag_o, 0.1), (1, Am_o, 0.1)):
+        for k in (1, 4):
+            r = sens[k]
+            w = {j: O.ak_row_fft(G, A_o[k], "matern32", lengths, W, s_, j) for j in (0, 1, 2)}
+            for jj, j in enumerate((0, 1)):                                  # rows of A K (the spectral product, P_c = 2)
+                got = AK[off[s_] + r, jj * N:(jj + 1) * N].cpu().numpy()
+                e = np.abs(got - w[j]).max() / np.abs(w[j]).max()
+                print("64^3 A K row %d block (%d,%d) vs oracle: %.2e" % (r, s_, j, e))
+                assert e <= 1e-9, (s_, r, j)       # the operator tier's 1e-10 times the covariance's row sum
+            want = np.r_[Ag_o @ w[0], Am_o @ w[1], w[2][sel]]
+            cols = np.r_[np.array(sens), eng.Ms_pad + np.array(sens), 2 * eng.Ms_pad + np.arange(sel.size)]
+            got = (Lt[off[s_] + r] @ Lt[cols].t()).cpu().numpy()            # (L L^T)[row, cols]
+            want[(cols == off[s_] + r)] += gs ** 2                           # sigma^2 on the diagonal
+            e = np.abs(got - want).max() / np.abs(want).max()
+            print("64^3 AkA row %d block %d vs oracle: %.2e" % (r, s_, e))
+            assert e <= 1e-9
+    # (c) the factor itself: || tril(L) tril(L)^T - AkA || / || AkA || on the device (AkA re-assembled from the resident A K)
+    Lc = Lt.clone()
+    M_pad = L.shape[0]
+    sel_t = torch.as_tensor(sel, device="cuda")
+    AkA2 = eng._assemble_AkA(AK, M_pad, A_g, A_m, sel_t, [float(x) for x in lengths], "matern32", 1.0, s.gp_err, (0, 1))
+    AkA2 = torch.tril(AkA2)
+    R = torch.tril(Lc @ Lc.t()) - AkA2
+    e = (torch.linalg.matrix_norm(R) / torch.linalg.matrix_norm(AkA2)).item()
+    print("64^3 ||L L^T - AkA||_F / ||AkA||_F = %.2e" % e)
+    assert e <= 1e-13
 
 
 def test_spectral_y_slab_shards_match_dense(monkeypatch):

@@ -101,6 +101,69 @@ def test_F3_shipped_examples(name):
     assert np.array_equal(r["gp_length"], f["gp_length_out"])
 
 
+def test_F5_baseline_config1():
+    """BASELINE config 1: settings_example1 extents (anisotropic 190.6 x 122 x 50 m voxels), 16^3, 'exp', gp_coeff = 0."""
+    f = load_golden("config1_exp16.npz")
+    s = json.loads(str(f["settings_json"]))
+    assert (s["xNcube"], s["yNcube"], s["zNcube"], s["kernelfunc"], s["gp_coeff"]) == (16, 16, 16, "exp", [0.0, 0.0, 0.0])
+    assert (s["xmax"], s["ymax"], s["zLcube"]) == (3050, 1952, 800.0)
+    G = O.Grid.from_settings(s)
+    d0 = f["drilldata0"]
+    r = O.cubing(G, f["gravfield"], f["magfield"], d0[d0 != 0], f["sensor_locations"], d0)
+    for i in (0, 1, 3, 4):
+        assert normwise(r["cubes"][i], f["cubes"][i]) < 1e-10
+    assert np.isnan(f["cubes"][2]).all() and np.isnan(r["cubes"][2]).all()
+    assert abs(r["logl"] - float(f["logl"])) < 1e-9 * abs(float(f["logl"]))
+
+
+@pytest.mark.parametrize("name,dims,kern,ls", [("illcond_tiny_exp", (10, 8, 6), "exp", 8), ("illcond_tiny_matern32", (10, 8, 6), "matern32", 10),
+                                               ("illcond_cube16_matern32", (16, 16, 16), "matern32", 10)])
+def test_F6_ill_conditioned_regime(name, dims, kern, ls):
+    """Length scales of 8-10 voxels, noise 0.01, amplitude 2 (where optimize_gp goes): cond(AkA) 2.6e6 .. 1.8e7."""
+    f = load_golden(name + ".npz")
+    nx, ny, nz = dims
+    G = O.Grid(nx=nx, ny=ny, nz=nz, xmax=100.0 * nx, ymax=100.0 * ny, zLcube=100.0 * nz, kernelfunc=kern, gp_lengthscale=ls,
+               gp_err=(0.01, 0.01, 0.01))
+    assert float(f["cond_AkA"]) > 1e6 and float(f["gp_amp"]) == 2.0
+    d0 = f["drilldata0"]
+    r = O.cubing(G, f["gravfield"], f["magfield"], d0[d0 != 0], f["sensor_locations"], d0, gp_length=f["gp_length_in"].copy(),
+                 gp_amp=2.0, dense=(nx == 10))
+    errs = [normwise(a, b) for a, b in zip(r["cubes"], f["cubes"])]
+    assert max(errs) < 1e-8, errs
+    assert abs(r["logl"] - float(f["logl"])) < 1e-8 * abs(float(f["logl"]))
+    assert normwise(np.diag(r["L"]), f["L_diag"]) < 1e-9
+
+
+def test_F7_calc_logl_and_optimum():
+    f = load_golden("optimize_tiny_exp.npz")
+    G = _grid_for(f, 10, 8, 6, "exp")
+    P3 = O.grid_points((10, 8, 6), (100., 100., 100.))
+    loc = f["sensor_locations"]
+    A_g = O.a_sens(G, G.B * 0, loc, G.edges(), "grav")
+    A_m = O.a_sens(G, G.B, loc, G.edges(), "magn")
+    for p, v in zip(f["probe_params"], f["probe_values"]):
+        got = O.neg_logl(G, p, P3, A_g, A_m, f["sel"], f["Fs3"])
+        assert abs(got - v) <= 1e-9 * abs(v)
+    got = O.neg_logl(G, f["opt_x"], P3, A_g, A_m, f["sel"], f["Fs3"])
+    assert abs(got - float(f["opt_fun"])) <= 1e-9 * abs(float(f["opt_fun"]))
+    assert (f["opt_fun"] <= f["probe_values"]).all()               # the optimum is below every probe
+
+
+@pytest.mark.parametrize("kern", ["exp", "matern32", "sparse"])
+def test_ak_row_fft_equals_direct_contraction(kern):
+    """The FFT form used for the independent 64^3 spot checks equals the direct row-times-block product."""
+    G = O.Grid(nx=7, ny=5, nz=6, xmax=700., ymax=450., zLcube=660., kernelfunc=kern)
+    P3 = O.grid_points((7, 5, 6), (G.sx, G.sy, G.sz))
+    D2 = O.sqdist(P3)
+    lengths = np.array([200., 204., 230.])
+    W = O.weight_matrix([0.7, 0.3, 0.2])
+    a = np.random.default_rng(3).standard_normal(G.N)
+    for s_, j in ((0, 0), (0, 1), (1, 2), (2, 0)):
+        ref = a @ (1.3 * O.k_block(kern, D2, lengths, W, s_, j))
+        got = O.ak_row_fft(G, a, kern, lengths, W, s_, j, gp_amp=1.3)
+        assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max()
+
+
 def test_F4_forward_model_known_answer():
     f = load_golden("forward_kat.npz")
     G = O.Grid(nx=25, ny=16, nz=16, xmax=3050, ymax=1952, zLcube=800.)
