@@ -218,8 +218,14 @@ def test_optimize_gp_reaches_the_reference_optimum():
     ref_x, ref_fun = f["opt_x"], float(f["opt_fun"])
     print("optimize_gp: %.1f s; optimum %s objective %.8f (reference %s %.8f)" % (dt, np.round(x, 5), fun, np.round(ref_x, 5), ref_fun))
     assert inv.gp_length.shape == (3,) and np.all(inv.gp_length == inv.gp_length[0])
-    assert abs(fun - ref_fun) <= 1e-6 * abs(ref_fun)
-    assert np.abs(x - ref_x).max() <= 1e-3 * np.abs(ref_x).max()
+    # Same objective (the probes above and the reference's optimum below agree to 1e-8), but SHGO's local SLSQP steps use
+    # forward differences with h = 1.5e-8: rounding-level differences of the objective (1e-12 relative) move the gradient by
+    # ~1e-2, so two correct implementations stop at slightly different points of the flat valley.  Pinned: the optimum found here
+    # is at least as good as the reference's, within 0.5 % of its objective and 10 % of its coordinates.
+    assert abs(inv.calc_logl(ref_x) - ref_fun) <= 1e-8 * abs(ref_fun)
+    assert fun <= ref_fun + 1e-6 * abs(ref_fun)
+    assert abs(fun - ref_fun) <= 5e-3 * abs(ref_fun)
+    assert (np.abs(x - ref_x) <= 0.1 * np.abs(ref_x)).all()
     # the optimised state must be usable (the reference's is not): one more inversion with it
     cubes = inv.cubing(f["gravfield"], f["magfield"], d0[d0 != 0], f["sensor_locations"], d0)
     assert np.isfinite(cubes[0]).all()
@@ -416,14 +422,14 @@ def test_full_size_64cube_properties():
                 got = AK[off[s_] + r, jj * N:(jj + 1) * N].cpu().numpy()
                 e = np.abs(got - w[j]).max() / np.abs(w[j]).max()
                 print("64^3 A K row %d block (%d,%d) vs oracle: %.2e" % (r, s_, j, e))
-                assert e <= 1e-9, (s_, r, j)       # the operator tier's 1e-10 times the covariance's row sum
+                assert e <= 1e-10, (s_, r, j)      # observed 3e-12 (gravity rows: the operator's own 1.5e-11) / 5e-15 (magnetic)
             want = np.r_[Ag_o @ w[0], Am_o @ w[1], w[2][sel]]
             cols = np.r_[np.array(sens), eng.Ms_pad + np.array(sens), 2 * eng.Ms_pad + np.arange(sel.size)]
             got = (Lt[off[s_] + r] @ Lt[cols].t()).cpu().numpy()            # (L L^T)[row, cols]
             want[(cols == off[s_] + r)] += gs ** 2                           # sigma^2 on the diagonal
             e = np.abs(got - want).max() / np.abs(want).max()
             print("64^3 AkA row %d block %d vs oracle: %.2e" % (r, s_, e))
-            assert e <= 1e-9
+            assert e <= 1e-11                                                # observed <= 8e-14
     # (c) the factor itself: || tril(L) tril(L)^T - AkA || / || AkA || on the device (AkA re-assembled from the resident A K)
     Lc = Lt.clone()
     M_pad = L.shape[0]
