@@ -29,7 +29,7 @@ import time
 import numpy as np
 import torch
 
-from . import hip
+from . import geometry, hip
 from .sharding import allreduce_sum_, assemble_columns, exchange_blocks, gather_slices, shard_columns
 
 F64 = hip.F64
@@ -141,11 +141,7 @@ class PosteriorEngine:
 
     def node_axes(self):
         """1-D node coordinates behind inversion.py:58-66 (Edges = meshgrid(xedge, yedge, zedge), z negated)."""
-        s = self.s
-        xe = np.linspace(0, self.nx, self.nx + 1) * s.xvoxsize
-        ye = np.linspace(0, self.ny, self.ny + 1) * s.yvoxsize
-        ze = np.linspace(0, -self.nz, self.nz + 1) * s.zvoxsize + s.zmax
-        return xe, ye, -ze
+        return geometry.node_axes(self.s)
 
     # ---- forward operators -----------------------------------------------------------------------------------
     @_on_device
@@ -468,7 +464,7 @@ class PosteriorEngine:
         t = self._tick("cholesky", t)
         if info_h != 0:
             raise CholeskyError(info_h)
-        out = dict(info=0, M_pad=M_pad)
+        out = dict(info=0, M_pad=M_pad, lengths=[float(v) for v in lengths])
         if calclogl:
             st = stats.cpu().numpy()
             out["uu"], out["logdet"] = float(st[0]), float(st[1])
@@ -491,5 +487,34 @@ class PosteriorEngine:
                                    self.N_pad, self.world)
             out["mu"], out["var"] = mu, var
             self._tick("d2h", t)
-        self.last = dict(L=L, Linv=Linv, u=u, AK=AK)
+        self.last = dict(L=L, Linv=Linv, u=u, AK=AK, props=props, sel=sel)
         return out
+
+    @_on_device
+    def posterior_covariance(self, kernelfunc, lengths, crossweights, gp_amp=1.0, limit_bytes=48 << 30):
+        """Full (3N x 3N) posterior covariance  K - V^T V  (inversion.py:117) from the state the last posterior() call left on
+        the device (A K, L^-1) -- what `predict3(full_cov=True)` returns.  Small cubes only: 9 N^2 doubles are built on the
+        device and copied to the host, exactly the object the matrix-free path exists to avoid."""
+        last = getattr(self, "last", None)
+        if last is None or tuple(last["props"]) != (0, 1, 2) or self.world != 1:
+            raise RuntimeError("full covariance needs a single-rank posterior() with all three property blocks")
+        n3 = 3 * self.N_pad
+        if n3 * n3 * 8 * 2 > limit_bytes:
+            raise MemoryError("full posterior covariance of %d voxels needs %.1f GB; use the diagonal (np.diag(cov))"
+                              % (self.N, n3 * n3 * 8 / 1e9))
+        W = weight_matrix(crossweights)
+        Linv, AK = last["Linv"], last["AK"]
+        M_pad = Linv.shape[0]
+        V = torch.empty((M_pad, n3), dtype=F64, device=self.device)
+        hip.gemm_nn(Linv, AK, V, x_lower=True)                             # V = L^-1 (A K), block columns [prop][voxel]
+        Vt = V.t().contiguous()
+        del V
+        C = torch.empty((n3, n3), dtype=F64, device=self.device)
+        xyz = self.grid_points()
+        for i in range(3):
+            for j in range(3):
+                hip.k_block(hip.kernel_id(kernelfunc, i != j), xyz, xyz, lengths[i], lengths[j], W[i][j], gp_amp,
+                            C[i * self.N_pad:(i + 1) * self.N_pad, j * self.N_pad:(j + 1) * self.N_pad])
+        hip.gemm_nt(Vt, Vt, C, alpha=-1.0, beta=1.0)
+        idx = torch.cat([torch.arange(self.N, device=self.device) + j * self.N_pad for j in range(3)])
+        return C[idx][:, idx].cpu().numpy()

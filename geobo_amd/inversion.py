@@ -19,25 +19,51 @@ import sys
 
 import numpy as np
 
-from . import config_loader
+from . import config_loader, geometry
 from . import kernels as kernel
 from . import sensormodel as sm
 from .engine import CholeskyError, PosteriorEngine, create_cov_lengths
 
 
 class DiagonalCovariance:
-    """What `predict3` returns in place of the (3N,3N) posterior covariance: only its diagonal exists.
-    `np.diag(obj)` / `obj.diagonal()` work; anything needing off-diagonal entries raises."""
+    """What `predict3` returns in place of the (3N,3N) posterior covariance unless `full_cov=True`: only its diagonal exists.
+
+    The reference consumes nothing but `np.diag(self.cov_rec)` (inversion.py:238).  That idiom works on this object:
+    `np.diag(obj)` / `np.diagonal(obj)` are answered through NumPy's `__array_function__` protocol with the stored diagonal
+    (no (3N)^2 array is ever built); `.diagonal()` and `.shape` behave like the matrix's.  Anything that needs off-diagonal
+    entries (`np.asarray(obj)`, arithmetic) raises TypeError -- ask `predict3(full_cov=True)` for the matrix on small cubes."""
 
     def __init__(self, diag):
         self._d = np.asarray(diag)
         self.shape = (self._d.size, self._d.size)
+        self.ndim = 2
+        self.dtype = self._d.dtype
 
-    def diagonal(self):
+    def diagonal(self, offset=0):
+        if offset != 0:
+            raise TypeError("only the main diagonal of the posterior covariance is kept")
         return self._d
 
+    def __array_function__(self, func, types, args, kwargs):
+        if func in (np.diag, np.diagonal) and args and args[0] is self:
+            k = kwargs.get("k", kwargs.get("offset", args[1] if len(args) > 1 else 0))
+            return self.diagonal(k)
+        if func is np.shape:
+            return self.shape
+        return NotImplemented
+
     def __array__(self, dtype=None, copy=None):
-        raise TypeError("the MI355X path keeps only the diagonal of the posterior covariance; use .diagonal()")
+        raise TypeError("the MI355X path keeps only the diagonal of the posterior covariance; use np.diag(obj) / "
+                        ".diagonal(), or predict3(full_cov=True) on a cube small enough to hold (3N)^2 doubles")
+
+
+def _zscore(v):
+    """(v - mean) / std with the population std, and that std (inversion.py:209-214); NaN for an empty vector."""
+    with np.errstate(all="ignore"):
+        if not v.size:
+            return v - np.nan, np.nan
+        std = v.std()
+        return (v - v.mean()) / std, std
 
 
 class Inversion:
@@ -57,17 +83,13 @@ class Inversion:
 
     # ---- geometry (host, inversion.py:54-74) -------------------------------------------------------------------
     def create_cubegeometry(self):
+        """Node grid `Edges` (3, yN+1, xN+1, zN+1; z negated), voxel centres `xxx, yyy, zzz` (yN, xN, zN) and the (3, N)
+        centre list `voxelpos` it returns, all expanded from the 1-D axes of geobo_amd.geometry."""
         s = self.settings
-        xedge = np.linspace(0, s.xNcube, s.xNcube + 1) * s.xvoxsize
-        yedge = np.linspace(0, s.yNcube, s.yNcube + 1) * s.yvoxsize
-        zedge = np.linspace(0, -s.zNcube, s.zNcube + 1) * s.zvoxsize + s.zmax
-        xEdges, yEdges, zEdges = np.meshgrid(xedge, yedge, zedge)
-        self.Edges = np.asarray([xEdges, yEdges, -zEdges])
-        xnew = np.arange(s.xvoxsize / 2., s.xLcube + s.xvoxsize / 2., s.xvoxsize)
-        ynew = np.arange(s.yvoxsize / 2., s.yLcube + s.yvoxsize / 2., s.yvoxsize)
-        znew = s.zmax - np.arange(s.zvoxsize / 2., s.zLcube + s.zvoxsize / 2., s.zvoxsize)
-        self.xxx, self.yyy, self.zzz = np.meshgrid(xnew, ynew, znew)
-        self.voxelpos = np.vstack([self.xxx.flatten(), self.yyy.flatten(), self.zzz.flatten()])
+        self.Edges = geometry.expand(*geometry.node_axes(s))
+        centres = geometry.expand(*geometry.centre_axes(s))
+        self.xxx, self.yyy, self.zzz = centres[0], centres[1], centres[2]
+        self.voxelpos = centres.reshape(3, -1).copy()
         return self.voxelpos
 
     # ---- engine --------------------------------------------------------------------------------------------------
@@ -100,16 +122,26 @@ class Inversion:
                                      calclogl=calclogl, want_mean_var=want_mean_var)
 
     # ---- inversion.py:77-122 ----------------------------------------------------------------------------------------
-    def predict3(self, calclogl=False):
-        """Mean, covariance (diagonal only) and log-likelihood of the GP with the 3x3 block kernel."""
+    def predict3(self, calclogl=False, full_cov=False):
+        """Mean, covariance and log-likelihood of the GP with the 3x3 block kernel.
+        The covariance is a diagonal-backed object (`np.diag(cov)` works, inversion.py:238) unless `full_cov=True`, which
+        returns the (3N, 3N) matrix K - V^T V of inversion.py:117 -- only for cubes where 9 N^2 doubles fit (tests, small N)."""
         self.datastd = np.mean([np.nanstd(self.gravfield), np.nanstd(self.magfield), np.nanstd(self.drillfield)])
         try:
             r = self._run(self.gp_amp, self.gp_length, None, calclogl, True)
         except CholeskyError:
+            if self.settings.kernelfunc == "matern32" and len(set(np.asarray(self.gp_length, dtype=float).tolist())) < 3:
+                # the reference exits here too (its Matern cross term is 0/0 at equal lengths, kernels.py:148-156, and
+                # create_cov turns the default [l,l,l] into [l,1.02l,l]); say why before the two reference lines
+                print("matern32 needs three DISTINCT length scales: gp_length = %s has equal entries, which makes the "
+                      "cross-covariance NaN. Set e.g. inv.gp_length = l * np.array([1.00, 1.02, 1.04])." % (self.gp_length,))
             print("Cholesky decompostion failed, AkA matrix i likely not positive semitive.")
             print("Change GP parameter settings")
             sys.exit(1)
-        return r["mu"], DiagonalCovariance(r["var"]), r["logl"]
+        cov = DiagonalCovariance(r["var"])
+        if full_cov:
+            cov = self.engine.posterior_covariance(self.settings.kernelfunc, r["lengths"], self.coeffm, self.gp_amp)
+        return r["mu"], cov, r["logl"]
 
     # ---- inversion.py:125-152 ---------------------------------------------------------------------------------------
     def calc_logl(self, params):
@@ -128,26 +160,37 @@ class Inversion:
         return -logl
 
     # ---- inversion.py:155-178 ---------------------------------------------------------------------------------------
-    def optimize_gp(self):
-        from scipy.optimize import shgo
+    def hyper_bounds(self):
+        """Search box of optimize_gp: amplitude, lengthscale (in x-voxels) and the three cross-correlation weights."""
         s = self.settings
+        box = [(0.5, 2), (0.5 * s.gp_lengthscale, 10 * s.gp_lengthscale)]
+        return tuple(box + [(0.5 * w, 1) for w in s.gp_coeff])
+
+    def set_hyperparameters(self, x):
+        """Adopt a hyper-parameter vector (amplitude, lengthscale in x-voxels, w1, w2, w3).
+        The reference keeps the bare lengthscale scalar in gp_length at this point (inversion.py:175), which its own create_cov
+        can no longer index; everywhere else gp_length is lengthscale * x-voxel size for all three blocks (:48, :137), so
+        that is what is stored here."""
+        x = np.asarray(x, dtype=float)
+        self.gp_amp = x[0]
+        self.gp_length = x[1] * np.full(3, self.settings.xvoxsize)
+        self.coeffm = x[2:5].copy()
+
+    def optimize_gp(self):
+        """Maximise the marginal likelihood over the box of hyper_bounds() with SciPy's SHGO (10 Sobol points x 10
+        iterations, as the reference); every objective evaluation is one AkA + Cholesky + log-det on the device."""
+        from scipy.optimize import shgo
         print("Optimizing GP hyperparameters and correlation coefficients, this may take a while...")
-        self.datastd = np.mean([np.nanstd(self.gravfield), np.nanstd(self.magfield), np.nanstd(self.drillfield)])
-        bopt_res = shgo(self.calc_logl, bounds=((0.5, 2), (0.5 * s.gp_lengthscale, 10 * s.gp_lengthscale),
-                                                (0.5 * s.gp_coeff[0], 1), (0.5 * s.gp_coeff[1], 1), (0.5 * s.gp_coeff[2], 1)),
-                        n=10, iters=10, sampling_method='sobol')
-        if not bopt_res.success:
-            print('WARNING: ' + bopt_res.message)
-        else:
-            print("Initial parameter [amplitude, lengthscale, corr1, corr2, corr3]:")
-            print(self.gp_amp, self.gp_length, self.coeffm)
-            self.gp_amp = bopt_res.x[0]
-            # the reference stores the bare scalar here (inversion.py:175), which breaks create_cov's indexing
-            # afterwards; the lengthscale is a multiple of the voxel size everywhere else (:48,:137), so keep that
-            self.gp_length = bopt_res.x[1] * np.asarray([s.xvoxsize, s.xvoxsize, s.xvoxsize])
-            self.coeffm = np.asarray([bopt_res.x[2:]]).flatten()
-            print("Optimized parameter [amplitude, lengthscale, corr1, corr2, corr3]:")
-            print(self.gp_amp, self.gp_length, self.coeffm)
+        self.datastd = np.mean([np.nanstd(v) for v in (self.gravfield, self.magfield, self.drillfield)])
+        found = shgo(self.calc_logl, bounds=self.hyper_bounds(), n=10, iters=10, sampling_method="sobol")
+        if not found.success:
+            print("WARNING: " + found.message)     # parameters stay as they were
+            return found
+        report = lambda title: print(title + "\n" + " ".join(str(v) for v in (self.gp_amp, self.gp_length, self.coeffm)))
+        report("Initial parameter [amplitude, lengthscale, corr1, corr2, corr3]:")
+        self.set_hyperparameters(found.x)
+        report("Optimized parameter [amplitude, lengthscale, corr1, corr2, corr3]:")
+        return found
 
     # ---- inversion.py:182-248 ---------------------------------------------------------------------------------------
     def cubing(self, gravfield, magfield, drillfield, sensor_locations, drilldata0):
@@ -162,16 +205,11 @@ class Inversion:
         self.drilldata0 = drilldata0
         if not hasattr(self, "voxelpos"):
             self.create_cubegeometry()
-        with np.errstate(all="ignore"):
-            grav_mean, grav_std = self.gravfield.mean(), self.gravfield.std()
-            gravfield_norm = (self.gravfield - grav_mean) / grav_std
-            magn_mean, magn_std = self.magfield.mean(), self.magfield.std()
-            magfield_norm = (self.magfield - magn_mean) / magn_std
-            if self.drillfield.size:
-                drill_mean, drill_std = self.drillfield.mean(), self.drillfield.std()
-            else:
-                drill_mean, drill_std = np.nan, np.nan
-            drillfield_norm = (self.drillfield - drill_mean) / drill_std
+        # population z-score of each data vector in the dtype it arrives in; an empty drill vector gives NaN statistics
+        # (and NaN drill cubes), like the reference
+        gravfield_norm, grav_std = _zscore(self.gravfield)
+        magfield_norm, magn_std = _zscore(self.magfield)
+        drillfield_norm, drill_std = _zscore(self.drillfield)
         self.points3D = kernel.calcGridPoints3D((s.xNcube, s.yNcube, s.zNcube), (s.xvoxsize, s.yvoxsize, s.zvoxsize))
         self._sel = self._drill_selection()
         if self._sel.size != self.drillfield.size:
@@ -180,14 +218,13 @@ class Inversion:
         if s.optimize_gp:
             self.optimize_gp()
         self.mu_rec, self.cov_rec, self.logl = self.predict3(calclogl=True)
-        shp = (3, s.yNcube, s.xNcube, s.zNcube)
-        results_rec = self.mu_rec.reshape(shp)
-        results_var = self.cov_rec.diagonal().reshape(shp)
+        shape = (3, s.yNcube, s.xNcube, s.zNcube)
+        mean_cubes = self.mu_rec.reshape(shape)
+        var_cubes = np.diag(self.cov_rec).reshape(shape)           # the reference's own idiom (inversion.py:238)
+        # deviations from the data means, back in data units (the means themselves are not restored, inversion.py:242-247)
+        # (the std scalars keep the survey's dtype: a float32 survey squares its std in float32, as the reference does)
+        scale = (grav_std, magn_std, drill_std)
         with np.errstate(all="ignore"):
-            density_rec = results_rec[0] * grav_std  # model represents deviation from the mean (means are not added back)
-            density_var = results_var[0] * grav_std ** 2
-            magsus_rec = results_rec[1] * magn_std
-            magsus_var = results_var[1] * magn_std ** 2
-            drill_rec = results_rec[2] * drill_std
-            drill_var = results_var[2] * drill_std ** 2
-        return density_rec, magsus_rec, drill_rec, density_var, magsus_var, drill_var
+            rec = [mean_cubes[i] * scale[i] for i in range(3)]
+            var = [var_cubes[i] * scale[i] ** 2 for i in range(3)]
+        return rec[0], rec[1], rec[2], var[0], var[1], var[2]

@@ -39,10 +39,22 @@ def _xyz_dev(points):
 
 
 def calcDistanceMatrix(nDimPoints, distFunc=None):
-    """kernels.py:45-61 -- (N,N) matrix of squared distances D2[p,q] = |x_q - x_p|^2 (3-D points)."""
-    if distFunc is not None:
-        raise NotImplementedError("custom distFunc is not supported on the HIP path")
-    xyz = _xyz_dev(nDimPoints)
+    """kernels.py:45-61 -- (N,N) matrix of squared distances D2[p,q] = |x_q - x_p|^2.
+
+    3-D points with the default metric go through the HIP kernel (geobo_k_block, family D2).  A caller-supplied `distFunc`
+    (the reference hands it the list of per-dimension difference matrices delta[d][p,q] = x_q[d] - x_p[d]) or points of
+    another dimension cannot run inside a compiled kernel: the difference matrices are then formed as device tensors and
+    the callable is applied to them (any function built from arithmetic / sum works on tensors as on arrays)."""
+    pts = np.asarray(nDimPoints, dtype=np.float64)
+    if distFunc is not None or pts.ndim != 2 or pts.shape[1] != 3:
+        if pts.ndim != 2:
+            raise ValueError("expected an (N,dim) array of points")
+        dev = hip.to_dev(pts)
+        delta = [dev[None, :, d] - dev[:, None, d] for d in range(pts.shape[1])]
+        f = distFunc if distFunc is not None else (lambda dl: sum(v ** 2 for v in dl))
+        out = f(delta)
+        return out.cpu().numpy() if isinstance(out, torch.Tensor) else np.asarray(out)
+    xyz = _xyz_dev(pts)
     n = xyz[0].numel()
     out = torch.empty((n, n), dtype=hip.F64, device=xyz[0].device)
     hip.k_block(hip.KERNEL_IDS["d2"], xyz, xyz, 1.0, 1.0, 1.0, 1.0, out)

@@ -35,7 +35,12 @@ def A_sens(magneticField, locations, Edges, func, settings=None):
         raise ValueError(func)
     nx, ny, nz = int(s.xNcube), int(s.yNcube), int(s.zNcube)
     xe, ye, ze = _edge_axes(Edges, nx, ny, nz)
-    loc = np.ascontiguousarray(np.asarray(locations, dtype=np.float64)[:nx * ny])
+    loc = np.asarray(locations, dtype=np.float64)
+    if loc.ndim != 2 or loc.shape[0] < nx * ny or loc.shape[1] < 3:
+        # the reference loops over exactly xNcube*yNcube sensors (sensormodel.py:54,58) and runs off the end of a shorter list
+        raise IndexError("A_sens needs xNcube*yNcube = %d sensor locations (x, y, z), got an array of shape %s"
+                         % (nx * ny, loc.shape))
+    loc = np.ascontiguousarray(loc[:nx * ny, :3])
     N = nx * ny * nz
     A = torch.empty((nx * ny, N), dtype=hip.F64, device="cuda")
     if func == "grav":

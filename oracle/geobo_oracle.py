@@ -277,7 +277,7 @@ def _noise(gp_sigma, mg, mm, md):
     return np.hstack([np.full(mg, gp_sigma[0]), np.full(mm, gp_sigma[1]), np.full(md, gp_sigma[2])])
 
 
-def posterior_dense(P3, A_g, A_m, sel, y, lengths, W, name, gp_sigma, gp_amp=1.0, n_voxels_for_logl=None):
+def posterior_dense(P3, A_g, A_m, sel, y, lengths, W, name, gp_sigma, gp_amp=1.0, n_voxels_for_logl=None, return_cov=False):
     """inversion.py:77-122, literally: full K, A3 (K A3^T), Cholesky, V, mu, full covariance."""
     N = P3.shape[0]
     mg, mm, md = A_g.shape[0], A_m.shape[0], len(sel)
@@ -295,7 +295,10 @@ def posterior_dense(P3, A_g, A_m, sel, y, lengths, W, name, gp_sigma, gp_amp=1.0
     V = solve_triangular(L, A3 @ K, lower=True)
     mu = V.T @ u
     cov = K - V.T @ V
-    return dict(mu=mu, var=np.diag(cov).copy(), logl=logl, AkA=AkA, L=L, u=u)
+    res = dict(mu=mu, var=np.diag(cov).copy(), logl=logl, AkA=AkA, L=L, u=u)
+    if return_cov:
+        res["cov"] = cov
+    return res
 
 
 def posterior_blocked(P3, A_g, A_m, sel, y, lengths, W, name, gp_sigma, gp_amp=1.0, props=(0, 1, 2),

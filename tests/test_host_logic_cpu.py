@@ -51,7 +51,7 @@ def test_inversion_surface_and_geometry():
     assert np.array_equal(vox, f["voxelpos"]) and np.array_equal(inv.Edges, f["Edges"])
     assert inv.xxx.shape == (8, 10, 6)
     for name, params in (("cubing", ["gravfield", "magfield", "drillfield", "sensor_locations", "drilldata0"]),
-                         ("predict3", ["calclogl"]), ("calc_logl", ["params"]), ("optimize_gp", []), ("create_cubegeometry", [])):
+                         ("predict3", ["calclogl", "full_cov"]), ("calc_logl", ["params"]), ("optimize_gp", []), ("create_cubegeometry", [])):
         assert list(inspect.signature(getattr(Inversion, name)).parameters)[1:] == params
 
 
@@ -98,8 +98,31 @@ def test_diagonal_covariance_object():
     from geobo_amd.inversion import DiagonalCovariance
     d = DiagonalCovariance(np.arange(6.0))
     assert d.shape == (6, 6) and np.array_equal(d.diagonal(), np.arange(6.0))
+    # the reference's idiom on predict3's second return value (inversion.py:238) -- without building a (3N)^2 array
+    assert np.array_equal(np.diag(d), np.arange(6.0)) and np.array_equal(np.diagonal(d), np.arange(6.0))
+    assert np.shape(d) == (6, 6)
     with pytest.raises(TypeError):
         np.asarray(d)
+    with pytest.raises(TypeError):
+        np.diag(d, 1)
+    with pytest.raises(TypeError):
+        np.sum(d)
+
+
+def test_vertical_utility_table_equals_the_per_column_formula():
+    """acquisition.column_utility (one vectorised reduction) against the reference's per-call expression, C- and F-ordered cubes."""
+    from geobo_amd.acquisition import Acquisition
+    s = settings_for(7, 5, 6, kappa=1.3, beta=0.4)
+    rng = np.random.default_rng(0)
+    for order in ("C", "F"):
+        mean, var, cost = (np.asarray(rng.random((5, 7, 6)), order=order) for _ in range(3))
+        acq = Acquisition(s, mean, var, cost)
+        for i0 in range(1, 4):
+            for i1 in range(1, 6):
+                want = np.sum(mean[i0, i1, :]) + s.kappa * np.sqrt(np.sum(var[i0, i1, :])) - s.beta * np.sum(cost[i0, i1, :])
+                assert acq.futility_vertical([i0 + 0.2, i1 - 0.3]) == -want
+        assert acq.futility_vertical([0, 3]) == np.inf and acq.futility_vertical([4, 3]) == np.inf
+        assert acq.futility_vertical([2, np.inf]) == np.inf
 
 
 def test_kernel_id_mapping():
