@@ -143,7 +143,11 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_f64_kernel(const GemmArg
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
+  // Waves w and w + 4 share a SIMD.  With four 64-row groups per tile the pairs are (group 0, group 3) and (group 1, group 2):
+  // whenever the groups carry unequal work -- the diagonal block of a triangular X operand gives group g a contraction
+  // g + 1 quarter-blocks deep, the last row tile has only its first groups valid -- both SIMD pairs get the same total.
+  const int wrow = wave / WN, wn = wave % WN;
+  const int wm = (WM == 4) ? (wrow < 2 ? wrow : 5 - wrow) : wrow;
   const int lr = lane & 15, lg = lane >> 4;
 
   // ---- workgroup -> tile ------------------------------------------------------------------------------
@@ -401,23 +405,21 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_f64_kernel(const GemmArg
       }
       __syncthreads();
       int s0 = 0, s1 = 1, s2 = 2;  // ring stages of chunk c, c+1, c+2
-      if (YMODE != Y_GEN && row0 + wm * 64 >= a.m_valid) {
-        // This wave's 64 rows lie entirely in the zero padding behind m_valid: it keeps staging its share of the operand
-        // tiles and keeps the barriers, but reads no fragments and issues no MFMAs -- the matrix pipe of its SIMD is left to
-        // the co-resident wave (waves w and w+4 share a SIMD and differ by two 64-row groups), so a tile with 64 or 128
-        // valid rows costs a quarter or half of a full one.  Its accumulators stay zero.
-        for (int64_t k0 = kb; k0 < ke; k0 += BK) {
-          int64_t kn = k0 + 2 * BK;
-          if (kn >= ke) kn = ke - BK;
-          stage_x(kn, s2);
-          stage_y(kn, s2);
-          __syncthreads();
-          const int ts = s0; s0 = s1; s1 = s2; s2 = ts;
-        }
-      } else {
+      // Per-wave end of the useful contraction range:
+      //   * 64 rows entirely in the zero padding behind m_valid: nothing to do (kw = kb);
+      //   * triangular X (L^-1 in geobo_posterior_reduce): row group g of the diagonal block is zero beyond column
+      //     row0 + 64 (g + 1) -- 3.4 % of the executed flop of a full sweep at 64^3 were spent on those zeros.
+      // Past kw the wave keeps staging its share of the operand tiles and keeps the barriers, but reads no fragments and
+      // issues no MFMAs: the matrix pipe of its SIMD is left to the co-resident wave.
+      int64_t kw = ke;
+      if constexpr (YMODE != Y_GEN) {
+        if ((a.tri & TRI_X_LOWER) && kw > row0 + 64 * (wm + 1)) kw = row0 + 64 * (wm + 1);
+        if (row0 + wm * 64 >= a.m_valid || kw < kb) kw = kb;
+      }
+      if (kw > kb) {
       v2d a0[4], b0[4], a1[4], b1[4];
       read_half(0, 0, a0, b0);
-      for (int64_t k0 = kb; k0 < ke; k0 += BK) {
+      for (int64_t k0 = kb; k0 < kw; k0 += BK) {
         int64_t kn = k0 + 2 * BK;
         if (kn >= ke) kn = ke - BK;
         stage_x(kn, s2);
@@ -464,6 +466,17 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_f64_kernel(const GemmArg
         __syncthreads();
         const int ts = s0; s0 = s1; s1 = s2; s2 = ts;
       }
+      }
+      if constexpr (YMODE != Y_GEN) {
+        // idle tail: this wave's rows have no operand left, the workgroup's other waves still do
+        for (int64_t k0 = kw; k0 < ke; k0 += BK) {
+          int64_t kn = k0 + 2 * BK;
+          if (kn >= ke) kn = ke - BK;
+          stage_x(kn, s2);
+          stage_y(kn, s2);
+          __syncthreads();
+          const int ts = s0; s0 = s1; s1 = s2; s2 = ts;
+        }
       }
     }
   }

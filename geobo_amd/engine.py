@@ -472,9 +472,11 @@ class PosteriorEngine:
         else:
             out["logl"] = 0.0
         if want_mean_var:
-            # executed flop: lower-triangular Linv, 256-row tiles (whole 64-row groups of the valid rows) x 256*(bi+1) deep
+            # executed flop: lower-triangular Linv in 256-row tiles; 64-row group g of a tile contracts 256 bi + 64 (g + 1)
+            # columns (whole groups of the valid rows only)
             Mv = 2 * self.Ms_pad + len(sel)
-            fl = 2.0 * 256 * AK.shape[1] * sum(rv * (bi + 1) for bi, rv in enumerate(hip.tile_rows(M_pad, Mv)))
+            fl = 2.0 * AK.shape[1] * sum(64.0 * (256 * bi + 64 * (g + 1)) for bi, rv in enumerate(hip.tile_rows(M_pad, Mv))
+                                         for g in range(rv // 64))
             Mu = 2 * self.Ms + len(sel)                                  # unpadded observation rows
             nv = len(props) * min(self.nc, max(self.N - self.c0, 0))     # this rank's voxel-property columns
             mu_l, var_l = self._timed("posterior_reduce", fl, lambda: hip.posterior_reduce(

@@ -16,5 +16,5 @@ torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); hip.posterior_reduce(Linv, AK, u, 1.0, ws); e1.record(); torch.cuda.synchronize()
 t = e0.elapsed_time(e1) * 1e-3
-fl = 2.0 * 256 * 256 * ncols * sum(b + 1 for b in range(m // 256))
+fl = 2.0 * ncols * sum(64.0 * (256 * b + 64 * (g + 1)) for b in range(m // 256) for g in range(4))
 print("posterior_reduce m=%d ncols=%d: %.4f s, %.1f TF/s executed, flop %.0f; algorithmic bytes: AK %.3e + Linv(lower) %.3e" % (m, ncols, t, fl / t / 1e12, fl, m * ncols * 8.0, m * m * 4.0))
