@@ -104,8 +104,9 @@ def cpu_baseline(inv, lengths, target_seconds=20.0):
     eng = inv.engine
     s = inv.settings
     N, Ms = eng.N, eng.Ms
-    A_g = eng._A[[k for k in eng._A if k[0] == "grav"][0]][:Ms, :N].cpu().numpy()
-    A_m = eng._A[[k for k in eng._A if k[0] == "magn"][0]][:Ms, :N].cpu().numpy()
+    # resident copies of the operators (in the streamed-operator mode the timed steps never held them)
+    A_g = eng.operator("grav", inv.sensor_locations, B=s.magneticField * 0., full=True)[:Ms, :N].cpu().numpy()
+    A_m = eng.operator("magn", inv.sensor_locations, B=s.magneticField, full=True)[:Ms, :N].cpu().numpy()
     L = torch.tril(eng.last["L"]).cpu().numpy()
     rows = np.r_[0:Ms, eng.Ms_pad:eng.Ms_pad + Ms, 2 * eng.Ms_pad:2 * eng.Ms_pad + inv._sel.size]
     L = L[np.ix_(rows, rows)]
@@ -209,6 +210,9 @@ def main():
     ap.add_argument("--drill", type=int, default=50)
     ap.add_argument("--method", default="auto", choices=["auto", "dense", "spectral"],
                     help="A.K route: dense = fused in-kernel covariance generation; spectral = real-DFT on batched MFMA GEMMs")
+    ap.add_argument("--assembly", default="f64", choices=["f64", "f32"], help="f32 = BASELINE config 5's fp32 kernel assembly (A K and the "
+                    "covariance tables in fp32, fp64 accumulation and factorisation); NOT the headline configuration")
+    ap.add_argument("--operators", default="resident", choices=["resident", "streamed"])
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-forms", default="16", help="comma list of cube edges for the full matrix-free CPU oracle step "
                     "(SURVEY 8(d) form (b)); '16,32' adds the 32^3 run (minutes)")
@@ -247,7 +251,8 @@ def main():
     s = Settings(dict(xmin=0, xmax=100.0 * n, ymin=0, ymax=100.0 * n, zmax=0, zoff=1, zLcube=100.0 * n, xNcube=n, yNcube=n,
                       zNcube=n, gp_lengthscale=2, gp_err=[0.1, 0.1, 0.1], gp_coeff=[1.0, 0.2, 0.2], kernelfunc=a.kernel,
                       XMAG=0, YMAG=0, ZMAG=1))
-    inv = Inversion(settings=s, props=(0, 1), rank=rank, world=world, device="cuda:%d" % local, method=a.method)
+    inv = Inversion(settings=s, props=(0, 1), rank=rank, world=world, device="cuda:%d" % local, method=a.method,
+                    assembly=a.assembly, operators=a.operators)
     grav, mag, loc, drill0 = synthetic_inputs(inv, a.drill)
     gp_length = np.array([2.00, 2.02, 2.04]) * s.xvoxsize if a.kernel == "matern32" else None
 
@@ -330,12 +335,12 @@ def main():
             "metric": "voxels/sec posterior (mean+var) for 64^3 x 2-prop joint inversion; fp64 roofline %",
             "value": value, "unit": "voxel-properties/s", "n_gpus": ranks_reported, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64" if a.assembly == "f64" else "f32 assembly / f64 accumulate+factorise", "data": "synthetic",
             "config": {"workload": "%d^3 voxel cube (100 m), gravity+magnetics joint inversion, %s kernel lengths (2.00,2.02,2.04)x100 m, "
                                    "%d drill constraints, M=%d rows, density+magsus cubes (P_out=2)" % (n, a.kernel, a.drill, M),
                        "N_voxels": N, "M_rows": M, "props_out": p_out, "parallelism": "voxel-column shards x%d" % world,
                        "backend": a.backend if world > 1 else None, "ranks_reported_by_backend": ranks_reported,
-                       "method": "spectral" if inv.engine.use_spectral else "dense",
+                       "method": "spectral" if inv.engine.use_spectral else "dense", "assembly": a.assembly, "operators": a.operators,
                        "row_exchange": bool(inv.engine.exchange),
                        "ms_per_step_median": step_ms[len(step_ms) // 2], "ms_per_step_all_rank0": [round(v, 2) for v in step_ms],
                        "cube_checksums": [float(np.abs(c).sum()) for c in (cubes[0], cubes[1], cubes[3], cubes[4])],

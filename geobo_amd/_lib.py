@@ -20,6 +20,9 @@ SIGNATURES = {
     "geobo_pad_m": (_i64, [_i64]),
     "geobo_pad_n": (_i64, [_i64]),
     "geobo_k_block": (_int, [_int, _dp, _dp, _dp, _i64, _dp, _dp, _dp, _i64, _f64, _f64, _f64, _f64, _dp, _i64, _dp]),
+    "geobo_k_block_f32": (_int, [_int, _dp, _dp, _dp, _i64, _dp, _dp, _dp, _i64, _f64, _f64, _f64, _f64, _dp, _i64, _dp]),
+    "geobo_convert": (_int, [_int, _dp, _i64, _dp, _i64, _i64, _i64, _dp]),
+    "geobo_round_f32": (_int, [_dp, _i64, _dp]),
     "geobo_k_eval": (_int, [_int, _dp, _i64, _f64, _f64, _f64, _f64, _dp, _dp]),
     "geobo_a_sens": (_int, [_int, C.POINTER(_f64), _dp, _i64, _int, _int, _int, _dp, _dp, _dp, _f64, _f64, _dp, _i64, _dp]),
     "geobo_a_sens_slab": (_int, [_int, C.POINTER(_f64), _dp, _i64, _int, _int, _int, _dp, _dp, _dp, _f64, _f64, _int, _int, _dp, _i64, _dp]),

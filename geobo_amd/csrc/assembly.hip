@@ -22,31 +22,32 @@ namespace {
 // stores, 1 KiB per wavefront store instruction) and walks KB_ROWS rows whose coordinates are wave-uniform.
 constexpr int KB_ROWS = 32;
 
-template <int ID>
+template <int ID, typename OUT>
 __global__ void __launch_bounds__(256) k_block_kernel(const double* __restrict__ rx, const double* __restrict__ ry,
                                                       const double* __restrict__ rz, int64_t nr,
                                                       const double* __restrict__ cx, const double* __restrict__ cy,
                                                       const double* __restrict__ cz, int64_t nc, const CovParams p,
-                                                      double* __restrict__ out, int64_t ld) {
+                                                      OUT* __restrict__ out, int64_t ld) {
   const int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
   const int64_t r0 = (int64_t)blockIdx.y * KB_ROWS;
   if (c0 >= nc) return;
   const bool two = (c0 + 1) < nc;
   const double qx0 = cx[c0], qy0 = cy[c0], qz0 = cz[c0];
   const double qx1 = two ? cx[c0 + 1] : qx0, qy1 = two ? cy[c0 + 1] : qy0, qz1 = two ? cz[c0 + 1] : qz0;
-  const bool vec = two && ((ld & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+  typedef OUT pair_t __attribute__((ext_vector_type(2)));   // fp64: 16-byte stores; fp32 (config-5 assembly): 8-byte stores
+  const bool vec = two && ((ld & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & (2 * sizeof(OUT) - 1)) == 0);
   const int rows = (int)((nr - r0) < KB_ROWS ? (nr - r0) : KB_ROWS);
   for (int i = 0; i < rows; ++i) {
     const int64_t r = r0 + i;
     const double px = rx[r], py = ry[r], pz = rz[r];  // uniform -> scalar loads
     const double v0 = p.scale * cov_eval<ID>(p, sqdist3(px, py, pz, qx0, qy0, qz0));
     const double v1 = p.scale * cov_eval<ID>(p, sqdist3(px, py, pz, qx1, qy1, qz1));
-    double* dst = out + r * ld + c0;
+    OUT* dst = out + r * ld + c0;
     if (vec) {
-      *reinterpret_cast<v2d*>(dst) = (v2d){v0, v1};
+      *reinterpret_cast<pair_t*>(dst) = (pair_t){(OUT)v0, (OUT)v1};
     } else {
-      dst[0] = v0;
-      if (two) dst[1] = v1;
+      dst[0] = (OUT)v0;
+      if (two) dst[1] = (OUT)v1;
     }
   }
 }
@@ -70,6 +71,26 @@ __global__ void __launch_bounds__(256) cov_table_kernel(int nx, int ny, int nz, 
     const double d2 = sqdist3(1.0 * sx, 1.0 * sy, 1.0 * sz, (double)(dx + 1) * sx, (double)(dy + 1) * sy, (double)(dz + 1) * sz);
     table[i] = p.scale * cov_eval<ID>(p, d2);
   }
+}
+
+// 2-D strided precision conversion (rows x cols, cols even): the fp32-assembly mode keeps A K in fp32 in HBM and hands the fp64
+// MFMA kernels fp64 panels.  Pure streaming: 12 B per element.
+template <typename SRC, typename DST>
+__global__ void __launch_bounds__(256) convert_kernel(const SRC* __restrict__ src, int64_t lds_, DST* __restrict__ dst, int64_t ldd,
+                                                      int64_t rows, int64_t cols2) {
+  typedef SRC s2 __attribute__((ext_vector_type(2)));
+  typedef DST d2 __attribute__((ext_vector_type(2)));
+  const int64_t total = rows * cols2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / cols2, c = (i - r * cols2) * 2;
+    const s2 v = *reinterpret_cast<const s2*>(src + r * lds_ + c);
+    *reinterpret_cast<d2*>(dst + r * ldd + c) = (d2){(DST)v[0], (DST)v[1]};
+  }
+}
+
+// in-place round trip through fp32 (what storing K in fp32 does to it)
+__global__ void __launch_bounds__(256) round_f32_kernel(double* __restrict__ x, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] = (double)(float)x[i];
 }
 
 template <int ID>
@@ -305,9 +326,50 @@ extern "C" int geobo_k_block(int kernel_id, const double* rx, const double* ry, 
   const CovParams p = make_cov(kernel_id, l1, l2, w, amp);
   const dim3 grid((unsigned)((nc + 511) / 512), (unsigned)((nr + KB_ROWS - 1) / KB_ROWS));
   hipStream_t st = (hipStream_t)stream;
-#define GEOBO_KB(ID) hipLaunchKernelGGL(k_block_kernel<ID>, grid, dim3(256), 0, st, rx, ry, rz, nr, cx, cy, cz, nc, p, out, ld)
+#define GEOBO_KB(ID) hipLaunchKernelGGL((k_block_kernel<ID, double>), grid, dim3(256), 0, st, rx, ry, rz, nr, cx, cy, cz, nc, p, out, ld)
   COV_DISPATCH(kernel_id, GEOBO_KB);
 #undef GEOBO_KB
+  return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
+}
+
+extern "C" int geobo_k_block_f32(int kernel_id, const double* rx, const double* ry, const double* rz, int64_t nr,
+                                 const double* cx, const double* cy, const double* cz, int64_t nc, double l1, double l2,
+                                 double w, double amp, float* out, int64_t ld, void* stream) {
+  if (!rx || !ry || !rz || !cx || !cy || !cz || !out) return GEOBO_E_ARG;
+  if (nr <= 0 || nc <= 0) return GEOBO_OK;
+  if (ld < nc) return GEOBO_E_ARG;
+  const CovParams p = make_cov(kernel_id, l1, l2, w, amp);
+  const dim3 grid((unsigned)((nc + 511) / 512), (unsigned)((nr + KB_ROWS - 1) / KB_ROWS));
+  hipStream_t st = (hipStream_t)stream;
+#define GEOBO_KB(ID) hipLaunchKernelGGL((k_block_kernel<ID, float>), grid, dim3(256), 0, st, rx, ry, rz, nr, cx, cy, cz, nc, p, out, ld)
+  COV_DISPATCH(kernel_id, GEOBO_KB);
+#undef GEOBO_KB
+  return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
+}
+
+extern "C" int geobo_convert(int to_f32, const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int64_t cols,
+                             void* stream) {
+  if (!src || !dst) return GEOBO_E_ARG;
+  if (rows <= 0 || cols <= 0) return GEOBO_OK;
+  if ((cols & 1) || (ld_src & 1) || (ld_dst & 1) || ld_src < cols || ld_dst < cols) return GEOBO_E_ALIGN;
+  int64_t nb = (rows * (cols / 2) + 255) / 256;
+  if (nb > 256 * 64) nb = 256 * 64;
+  hipStream_t st = (hipStream_t)stream;
+  if (to_f32)
+    hipLaunchKernelGGL((convert_kernel<double, float>), dim3((unsigned)nb), dim3(256), 0, st, (const double*)src, ld_src, (float*)dst,
+                       ld_dst, rows, cols / 2);
+  else
+    hipLaunchKernelGGL((convert_kernel<float, double>), dim3((unsigned)nb), dim3(256), 0, st, (const float*)src, ld_src, (double*)dst,
+                       ld_dst, rows, cols / 2);
+  return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
+}
+
+extern "C" int geobo_round_f32(double* x, int64_t n, void* stream) {
+  if (!x) return GEOBO_E_ARG;
+  if (n <= 0) return GEOBO_OK;
+  int64_t nb = (n + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(round_f32_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, n);
   return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
 }
 
@@ -354,8 +416,9 @@ extern "C" int geobo_a_sens_lattice(int func_id, const double* B3_host, int64_t 
                                     double scale_div, int iy0, int iy1, double* A, int64_t ld, void* ws, size_t ws_bytes,
                                     void* stream) {
   if (!B3_host || !dxv || !dyv || !dzv || !jxs || !jys || !A || !ws) return GEOBO_E_ARG;
-  if (Ms <= 0 || nx <= 0 || ny < 3 || nz <= 0 || (nz & 1) || (ld & 1) || ld < (int64_t)nx * ny * nz) return GEOBO_E_ARG;
   if (iy0 < 0 || iy1 > ny || iy0 >= iy1) return GEOBO_E_ARG;
+  // ld covers at least the requested slab (a caller holding only that slab passes A moved back by iy0*nx*nz elements)
+  if (Ms <= 0 || nx <= 0 || ny < 3 || nz <= 0 || (nz & 1) || (ld & 1) || ld < (int64_t)(iy1 - iy0) * nx * nz) return GEOBO_E_ARG;
   if (func_id != GEOBO_F_GRAV && func_id != GEOBO_F_MAGN) return GEOBO_E_UNSUPPORTED;
   if (ws_bytes < geobo_a_sens_lattice_ws_bytes(nx, ny, nz)) return GEOBO_E_ARG;
   const int ia = iy0 > 1 ? iy0 : 1, ib = iy1 < ny - 1 ? iy1 : ny - 1;   // interior slabs of the request
@@ -390,7 +453,7 @@ extern "C" int geobo_a_sens_slab(int func_id, const double* B3_host, const doubl
                                  int iy0, int iy1, double* A, int64_t ld, void* stream) {
   if (!B3_host || !loc || !xe || !ye || !ze || !A) return GEOBO_E_ARG;
   if (iy0 < 0 || iy1 > ny || iy0 >= iy1) return GEOBO_E_ARG;
-  if (Ms <= 0 || nx <= 0 || ny <= 0 || nz <= 0 || ld < (int64_t)nx * ny * nz) return GEOBO_E_ARG;
+  if (Ms <= 0 || nx <= 0 || ny <= 0 || nz <= 0 || ld < (int64_t)(iy1 - iy0) * nx * nz) return GEOBO_E_ARG;
   if (func_id != GEOBO_F_GRAV && func_id != GEOBO_F_MAGN) return GEOBO_E_UNSUPPORTED;
   SensArgs a;
   a.loc = loc; a.Ms = Ms; a.nx = nx; a.ny = ny; a.nz = nz;

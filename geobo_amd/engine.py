@@ -73,9 +73,51 @@ def _on_device(fn):
     return wrapper
 
 
+class StreamedOperator:
+    """A forward operator that is never resident: its rows (all voxels of a batch of sensors) or its column slabs (one y-range
+    of every sensor) are generated on demand straight from the survey geometry -- on a lattice survey by one contiguous copy
+    per (sensor, y-slab) out of the stencil table Q (geobo_a_sens_lattice), otherwise by the direct kernel.  What BASELINE
+    config 5 needs: at 128^3 one operator is 275 GB (SURVEY.md section 8 size table)."""
+
+    def __init__(self, eng, func, Bv, mul, div, locd, axes_dev, plan, lws):
+        self.eng, self.func, self.Bv, self.mul, self.div = eng, func, Bv, mul, div
+        self.locd, self.axes_dev, self.plan, self.lws = locd, axes_dev, plan, lws
+
+    def rows_into(self, buf, r0, R):
+        """buf[:R, :N_pad] <- operator rows r0 .. r0+R-1 (voxel padding columns zero)."""
+        e = self.eng
+        out = buf[:R, :e.N_pad]
+        if e.N_pad > e.N:
+            out[:, e.N:].zero_()
+        xed, yed, zed = self.axes_dev
+        hip.a_sens(self.func, self.Bv, self.locd[r0:r0 + R].contiguous(), e.nx, e.ny, e.nz, xed, yed, zed, self.mul, self.div, out,
+                   plan=self.plan, rows=slice(r0, r0 + R), ws=self.lws)
+        return out
+
+    def slab_into(self, buf, iy0, iy1):
+        """buf[:Ms_pad, :(iy1-iy0)*nx*nz] <- columns of the y-slabs iy0 .. iy1-1 for every sensor (rows >= Ms zero)."""
+        e = self.eng
+        w = (iy1 - iy0) * e.nx * e.nz
+        out = buf[:e.Ms_pad, :w]
+        if e.Ms_pad > e.Ms:
+            out[e.Ms:].zero_()
+        xed, yed, zed = self.axes_dev
+        hip.a_sens(self.func, self.Bv, self.locd, e.nx, e.ny, e.nz, xed, yed, zed, self.mul, self.div, out, iy0, iy1,
+                   plan=self.plan, ws=self.lws, col_origin=iy0 * e.nx * e.nz)
+        return out
+
+
 class PosteriorEngine:
-    def __init__(self, settings, device=None, rank=0, world=1, group=None, profile=False, method="auto"):
+    def __init__(self, settings, device=None, rank=0, world=1, group=None, profile=False, method="auto", assembly="f64",
+                 operators="resident"):
+        """assembly "f32": covariance tables rounded through fp32 and A K kept in fp32 in HBM (BASELINE config 5, "fp32 kernel
+        assembly + fp64 Cholesky"); every contraction still accumulates in fp64 on fp64 panels converted on the fly.
+        operators "streamed": A_g / A_m are generated in row batches / column slabs when needed instead of being resident."""
         hip.require_gpu()
+        if assembly not in ("f64", "f32") or operators not in ("resident", "streamed"):
+            raise ValueError("assembly must be 'f64' or 'f32', operators 'resident' or 'streamed'")
+        self.f32 = assembly == "f32"
+        self.streamed = operators == "streamed"
         self.s = settings
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         if self.device.type != "cuda":
@@ -116,7 +158,9 @@ class PosteriorEngine:
         # more than the forward passes it saves; replicated forward passes + slab-cropped backward passes win there.
         xmode = os.environ.get("GEOBO_SPECTRAL_EXCHANGE", "auto")
         self.exchange = (self.use_spectral and world > 1 and self.Ms % world == 0 and len(ncs) == 1
-                         and xmode != "0" and (world >= 4 or xmode == "1"))
+                         and xmode != "0" and (world >= 4 or xmode == "1") and not self.f32 and not self.streamed)
+        if self.streamed and not self.use_spectral:
+            raise ValueError("streamed operators feed the spectral product: needs the spectral method's grid conditions")
         self._Arows = {}
         self._potrf_ctx = None
         self.kernel_events = None  # set to [] to record (name, flops, start, stop) HIP events per fused launch
@@ -153,15 +197,17 @@ class PosteriorEngine:
         loc = np.ascontiguousarray(sensor_locations, dtype=np.float64)
         assert loc.shape == (self.Ms, 3), "A_sens handles exactly xNcube*yNcube sensors (sensormodel.py:54,58)"
         partial = self.exchange and not full
-        key = (func, loc.tobytes(), None if B is None else tuple(np.asarray(B, dtype=float)), partial)
+        key = (func, loc.tobytes(), None if B is None else tuple(np.asarray(B, dtype=float)), partial, self.streamed and not full)
         if key in self._A:
             return self._A[key]
         xe, ye, ze = self.node_axes() if axes is None else axes
-        A = self._workspace2d("A_" + func, self.Ms_pad, self.N_pad)
-        if self.Ms_pad > self.Ms:
-            A[self.Ms:].zero_()
-        if self.N_pad > self.N:
-            A[:, self.N:].zero_()
+        stream_it = self.streamed and not full
+        if not stream_it:
+            A = self._workspace2d("A_" + func, self.Ms_pad, self.N_pad)
+            if self.Ms_pad > self.Ms:
+                A[self.Ms:].zero_()
+            if self.N_pad > self.N:
+                A[:, self.N:].zero_()
         if func == "grav":
             Bv = np.zeros(3) if B is None else np.asarray(B, dtype=float)
             mul, div = s.c_MILLIGALS_UNITS, s.fcor_grav
@@ -179,7 +225,16 @@ class PosteriorEngine:
         lws = None
         if plan is not None:
             lws = self._workspace("a_sens_lattice_ws", (hip.a_sens_lattice_ws_doubles(self.nx, self.ny, self.nz),))
-        if partial:
+        if stream_it:
+            A = StreamedOperator(self, func, Bv, mul, div, locd, (xed, yed, zed), plan, lws)
+            lam = None
+            if plan is not None:
+                # one two-sensor call leaves the stencil table Q in the lattice workspace (the Gram's eigen-data come from it)
+                tmp = self._workspace2d("op_rows", 2, self.N_pad)
+                self._timed("a_sens_" + func, 0.0, lambda: A.rows_into(tmp, 0, 2))
+                lam = self._gram_eigen(plan, lws)
+            self._lam[func] = None if lam is None else (A, lam)
+        elif partial:
             plane = self.nx * self.nz
             rows_r = self.Ms // self.world
             Ar = self._workspace2d("Arows_" + func, rows_r, self.N_pad)
@@ -216,19 +271,36 @@ class PosteriorEngine:
         self.kernel_events.append((name, float(flops), float(alg), float(valu), e0, e1))
         return r
 
-    def _workspace(self, name, shape):
+    def _workspace(self, name, shape, dtype=F64):
         """Persistent uninitialised device tensor; reallocated only when the shape changes (large hipMallocs are slow)."""
         t = self._ws.get(name)
-        if t is None or tuple(t.shape) != tuple(shape):
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
             self._ws.pop(name, None)
-            t = self._ws[name] = torch.empty(shape, dtype=F64, device=self.device)
+            t = self._ws[name] = torch.empty(shape, dtype=dtype, device=self.device)
         return t
 
-    def _workspace2d(self, name, rows, cols, pad=16):
+    def _workspace2d(self, name, rows, cols, pad=16, dtype=F64):
         """(rows x cols) view of a persistent buffer whose leading dimension is cols + pad.  Power-of-two row strides
         (4 MiB for AK at 64^3) alias rows onto the same cache sets / channels and cost the GEMMs ~12 %; 128 bytes of
         padding per row remove it (profiles/r01_row_stride.txt)."""
-        return self._workspace(name, (rows, cols + pad))[:, :cols]
+        return self._workspace(name, (rows, cols + pad), dtype)[:, :cols]
+
+    def _panel64(self, name, src, rows=None, cols=None):
+        """fp64 view of a block of A K for the MFMA kernels: the block itself when A K is kept in fp64, else a conversion into a
+        persistent scratch panel of capacity rows x cols (12 B of HBM traffic per element -- small beside the M-deep
+        contraction that consumes it)."""
+        if src.dtype == F64:
+            return src
+        buf = self._workspace2d(name, src.shape[0] if rows is None else rows, src.shape[1] if cols is None else cols)
+        view = buf[:src.shape[0], :src.shape[1]]
+        hip.convert(src, view)
+        return view
+
+    def _cov_table(self, kid, lj, ls, w, amp):
+        """Lattice table of one covariance block; rounded through fp32 in the fp32-assembly mode."""
+        sset = self.s
+        tab = hip.cov_table(kid, self.nx, self.ny, self.nz, sset.xvoxsize, sset.yvoxsize, sset.zvoxsize, lj, ls, w, amp, self.device)
+        return hip.round_f32_(tab) if self.f32 else tab
 
     def clear_operators(self):
         """Drop the resident forward operators (the benchmark rebuilds them inside every timed step)."""
@@ -251,7 +323,7 @@ class PosteriorEngine:
         off_d = 2 * self.Ms_pad
         M_pad = hip.pad_m(off_d + Md)
         nc = self.nc
-        AK = self._workspace2d("AK", M_pad, len(props) * nc)
+        AK = self._workspace2d("AK", M_pad, len(props) * nc, dtype=hip.F32 if self.f32 else F64)
         # every sensor/drill row is overwritten below; only the padding must be defined: rows behind each row block
         # (zero, so that AkA / V get zero rows) and voxel columns >= N of the last shard (finite: they meet zero A columns)
         for r0, r1 in ((self.Ms, self.Ms_pad), (self.Ms_pad + self.Ms, off_d), (off_d + Md, M_pad)):
@@ -270,19 +342,19 @@ class PosteriorEngine:
                 kid = hip.kernel_id(name, s_ != j)
                 # block (row-block s, col-block j) of create_cov is w * k2(l_j, l_s)  (kernels.py:183-195)
                 out = AK[s_ * self.Ms_pad:(s_ + 1) * self.Ms_pad, cols]
+                out64 = out if not self.f32 else self._workspace2d("ak_block64", self.Ms_pad, nc)
                 if self.use_grid:
                     # regular grid: covariance = table on the index-difference lattice (built once per block, N doubles)
-                    sset = self.s
-                    tab = hip.cov_table(kid, self.nx, self.ny, self.nz, sset.xvoxsize, sset.yvoxsize, sset.zvoxsize,
-                                        lengths[j], lengths[s_], W[s_][j], amp, self.device)
-                if self.use_grid:
+                    tab = self._cov_table(kid, lengths[j], lengths[s_], W[s_][j], amp)
                     self._timed("ak_fused_grid", 2.0 * self.Ms_pad * self.N_pad * nc,
-                                lambda: hip.ak_fused_grid(A, self.nx, self.ny, self.nz, tab, self.c0, nc, out),
+                                lambda: hip.ak_fused_grid(A, self.nx, self.ny, self.nz, tab, self.c0, nc, out64),
                                 alg=2.0 * self.Ms * self.N * min(nc, max(self.N - self.c0, 0)))
                 else:
                     self._timed("ak_fused", 2.0 * self.Ms_pad * self.N_pad * nc,
-                                lambda: hip.ak_fused(kid, A, xyz, self.c0, nc, lengths[j], lengths[s_], W[s_][j], amp, out),
+                                lambda: hip.ak_fused(kid, A, xyz, self.c0, nc, lengths[j], lengths[s_], W[s_][j], amp, out64),
                                 alg=2.0 * self.Ms * self.N * min(nc, max(self.N - self.c0, 0)))
+                if self.f32:
+                    hip.convert(out64, out)
             if Md:
                 rows = tuple(c[sel_t] for c in xyz)
                 colc = tuple(c[self.c0:self.c1] for c in xyz)
@@ -303,12 +375,29 @@ class PosteriorEngine:
         for s_, A in ((0, A_g), (1, A_m)):
             lams, outs = [], []
             for jj, j in enumerate(props):
-                tab = hip.cov_table(hip.kernel_id(name, s_ != j), self.nx, self.ny, self.nz, sset.xvoxsize, sset.yvoxsize,
-                                    sset.zvoxsize, lengths[j], lengths[s_], W[s_][j], amp, self.device)
+                tab = self._cov_table(hip.kernel_id(name, s_ != j), lengths[j], lengths[s_], W[s_][j], amp)
                 lams.append(sp.eigenvalues(tab))
                 outs.append(AK[s_ * self.Ms_pad:s_ * self.Ms_pad + self.Ms, jj * nc:(jj + 1) * nc])
-            self._timed("spectral_product", sp.flops(self.Ms, len(props), y1 - y0), lambda: sp.product(A, self.Ms, lams, outs, y0, y1),
-                        valu=sp.flops_valu(self.Ms, len(props)))
+            fl, fv = sp.flops(self.Ms, len(props), y1 - y0), sp.flops_valu(self.Ms, len(props))
+            if not self.f32 and not isinstance(A, StreamedOperator):
+                self._timed("spectral_product", fl, lambda: sp.product(A, self.Ms, lams, outs, y0, y1), valu=fv)
+                continue
+
+            def batches():
+                # row batches: operator rows generated on demand (streamed) and / or the product written to an fp64 scratch and
+                # stored as fp32 (fp32 assembly); one batch = the spectral product's own batch size
+                Rb = sp.R
+                abuf = self._workspace2d("op_rows", Rb, self.N_pad) if isinstance(A, StreamedOperator) else None
+                scr = [self._workspace2d("ak_rows64_%d" % jj, Rb, nc) for jj in range(len(props))] if self.f32 else None
+                for r0 in range(0, self.Ms, Rb):
+                    R = min(Rb, self.Ms - r0)
+                    src = A.rows_into(abuf, r0, R) if abuf is not None else A[r0:r0 + R]
+                    dst = [b[:R] for b in scr] if scr is not None else [o[r0:r0 + R] for o in outs]
+                    sp.product(src, R, lams, dst, y0, y1)
+                    if scr is not None:
+                        for jj in range(len(props)):
+                            hip.convert(dst[jj], outs[jj][r0:r0 + R])
+            self._timed("spectral_product", fl, batches, valu=fv)
 
     def _assemble_AK_spectral_exchange(self, AK, lengths, W, name, amp, props):
         """Row-sharded spectral product + all-to-all (multi-GPU): rank r transforms sensor rows [r*Ms/G, (r+1)*Ms/G) of both
@@ -329,8 +418,7 @@ class PosteriorEngine:
         for s_, func in ((0, "grav"), (1, "magn")):
             lams = []
             for j in props:
-                tab = hip.cov_table(hip.kernel_id(name, s_ != j), self.nx, self.ny, self.nz, sset.xvoxsize, sset.yvoxsize,
-                                    sset.zvoxsize, lengths[j], lengths[s_], W[s_][j], amp, self.device)
+                tab = self._cov_table(hip.kernel_id(name, s_ != j), lengths[j], lengths[s_], W[s_][j], amp)
                 lams.append(sp.eigenvalues(tab))
             slabs = [(slabs_of[d][0], slabs_of[d][1], [send[d].view(2, P_c, rows_r, nc)[s_, jj] for jj in range(P_c)])
                      for d in range(G)]
@@ -388,22 +476,38 @@ class PosteriorEngine:
                 if nc % (16 * cand) == 0 and nc // cand >= 2048 and tiles < 4096:
                     splits = cand
                     break
-            Xv, Yv, Cv = AK[r0:, jj * nc:(jj + 1) * nc], A[:, self.c0:self.c1], AkA[r0:, r0:r0 + self.Ms_pad]
+            streamed = isinstance(A, StreamedOperator)
+            Xv, Cv = AK[r0:, jj * nc:(jj + 1) * nc], AkA[r0:, r0:r0 + self.Ms_pad]
+            Yv = None if streamed else A[:, self.c0:self.c1]
             mv = off_d + Md - r0                       # rows behind the last drill row are padding: not contracted
+            pl = self.nx * self.nz
+            ya, yb = self.c0 // pl, self.c1 // pl      # this rank's y-slab (slab-aligned shards only where it is used)
+
+            def operand_cols(cs, ce):
+                """Columns [cs, ce) of this rank's slice of the operator, for every sensor."""
+                if Yv is not None:
+                    return Yv[:, cs:ce]
+                return A.slab_into(self._workspace2d("op_slab", self.Ms_pad, pw_stream), ya + cs // pl, ya + ce // pl)
             lam = self._lam.get(("grav", "magn")[s_])
             lam = lam[1] if lam is not None and lam[0] is A else None
             if lam is not None:
                 # lattice survey, even stencil: interior y-slabs by the (y, x) correlation, the two padded slabs by a GEMM
-                gram, pl = self._gram, self.nx * self.nz
-                ya, yb = self.c0 // pl, self.c1 // pl                      # this rank's y-slab
+                gram = self._gram
+                pw_stream = pl
                 edges = [c for iy, c in ((0, 0), (self.ny - 1, (self.ny - 1 - ya) * pl)) if ya <= iy < yb]
                 fl = gram.flops(mv, yb - ya) + 2.0 * len(edges) * pl * 128 * sum(
                     min(2 * (bi + 1), self.Ms_pad // 128) * rv for bi, rv in enumerate(hip.tile_rows(rows, mv)))
 
                 def lattice():
-                    gram.gram_rows(Xv, mv, lam, Cv, ya, yb)
+                    if Xv.dtype == F64:
+                        gram.gram_rows(Xv, mv, lam, Cv, ya, yb)
+                    else:
+                        for rb in range(0, mv, gram.R):       # fp32 A K: the Gram's own row batches, converted on the way in
+                            R = min(gram.R, mv - rb)
+                            gram.gram_rows(self._panel64("gram_rows64", Xv[rb:rb + R], rows=gram.R), R, lam, Cv[rb:], ya, yb)
                     for c0 in edges:
-                        hip.gemm_nt(Xv[:, c0:c0 + pl], Yv[:, c0:c0 + pl], Cv, alpha=1.0, beta=1.0, lower_only=True, m_valid=mv)
+                        hip.gemm_nt(self._panel64("aka_panel64", Xv[:, c0:c0 + pl]), operand_cols(c0, c0 + pl), Cv, alpha=1.0,
+                                    beta=1.0, lower_only=True, m_valid=mv)
                 self._timed("aka_lattice", fl, lattice)
                 continue
             # executed flop: lower-only tiles, whole 64-row wavefront groups of the last row tile
@@ -411,7 +515,18 @@ class PosteriorEngine:
             # 8(d): 2 M Ms N for the full block column; the lower triangle that is consumed is half of the square part
             nv = min(nc, max(self.N - self.c0, 0))
             alg = 2.0 * nv * (self.Ms * (self.Ms + 1) / 2.0 + (mv - self.Ms_pad) * self.Ms)
-            if splits > 1:
+            if Xv.dtype != F64 or streamed:
+                # column panels: A K converted to fp64 and / or the operator's columns generated panel by panel, accumulated
+                unit = pl if streamed else 2048
+                pw_stream = pw = max(unit, min(nc, int((3 << 30) // (8 * rows)) // unit * unit))
+
+                def panels():
+                    for cs in range(0, nc, pw):
+                        ce = min(nc, cs + pw)
+                        hip.gemm_nt(self._panel64("aka_panel64", Xv[:, cs:ce], cols=pw), operand_cols(cs, ce), Cv, alpha=1.0,
+                                    beta=1.0, lower_only=True, m_valid=mv)
+                self._timed("aka_gemm_nt", fl, panels, alg=alg)
+            elif splits > 1:
                 ws = self._workspace("aka_ws", (splits * rows * self.Ms_pad,))
                 self._timed("aka_gemm_nt", fl, lambda: hip.gemm_nt_splitk(Xv, Yv, Cv, splits, ws, lower_only=True, m_valid=mv), alg=alg)
             else:
@@ -479,9 +594,20 @@ class PosteriorEngine:
                                          for g in range(rv // 64))
             Mu = 2 * self.Ms + len(sel)                                  # unpadded observation rows
             nv = len(props) * min(self.nc, max(self.N - self.c0, 0))     # this rank's voxel-property columns
-            mu_l, var_l = self._timed("posterior_reduce", fl, lambda: hip.posterior_reduce(
-                Linv, AK, u, gp_amp * 1.0, self._workspace("post_ws", (hip.posterior_ws_doubles(M_pad, AK.shape[1]),)), m_valid=Mv),
-                alg=(1.0 * Mu * Mu + 4.0 * Mu) * nv)
+            if AK.dtype == F64:
+                mu_l, var_l = self._timed("posterior_reduce", fl, lambda: hip.posterior_reduce(
+                    Linv, AK, u, gp_amp * 1.0, self._workspace("post_ws", (hip.posterior_ws_doubles(M_pad, AK.shape[1]),)), m_valid=Mv),
+                    alg=(1.0 * Mu * Mu + 4.0 * Mu) * nv)
+            else:
+                ncols = AK.shape[1]
+                pw = max(128, min(ncols, int((3 << 30) // (8 * M_pad)) // 128 * 128))
+
+                def panels():
+                    ws = self._workspace("post_ws", (hip.posterior_ws_doubles(M_pad, pw),))
+                    parts = [hip.posterior_reduce(Linv, self._panel64("post_panel64", AK[:, cs:min(ncols, cs + pw)], cols=pw), u,
+                                                  gp_amp * 1.0, ws, m_valid=Mv) for cs in range(0, ncols, pw)]
+                    return torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
+                mu_l, var_l = self._timed("posterior_reduce", fl, panels, alg=(1.0 * Mu * Mu + 4.0 * Mu) * nv)
             t = self._tick("posterior", t)
             mu = assemble_columns(gather_slices(mu_l, len(props), self.N_pad, self.world, self.group), props, self.N,
                                   self.N_pad, self.world)
@@ -498,8 +624,8 @@ class PosteriorEngine:
         the device (A K, L^-1) -- what `predict3(full_cov=True)` returns.  Small cubes only: 9 N^2 doubles are built on the
         device and copied to the host, exactly the object the matrix-free path exists to avoid."""
         last = getattr(self, "last", None)
-        if last is None or tuple(last["props"]) != (0, 1, 2) or self.world != 1:
-            raise RuntimeError("full covariance needs a single-rank posterior() with all three property blocks")
+        if last is None or tuple(last["props"]) != (0, 1, 2) or self.world != 1 or last["AK"].dtype != F64:
+            raise RuntimeError("full covariance needs a single-rank fp64 posterior() with all three property blocks")
         n3 = 3 * self.N_pad
         if n3 * n3 * 8 * 2 > limit_bytes:
             raise MemoryError("full posterior covariance of %d voxels needs %.1f GB; use the diagonal (np.diag(cov))"

@@ -65,17 +65,41 @@ def version():
     return _lib.load().geobo_version()
 
 
+F32 = torch.float32
+
+
 def k_block(kid, rows_xyz, cols_xyz, l1, l2, w, amp, out):
-    """out[r,c] = w*amp*k(|rows_r - cols_c|^2).  rows_xyz / cols_xyz: tuples of three 1-D tensors."""
+    """out[r,c] = w*amp*k(|rows_r - cols_c|^2).  rows_xyz / cols_xyz: tuples of three 1-D tensors; out fp64 or fp32."""
     lib = require_gpu()
     rx, ry, rz = (_chk(t, "rows") for t in rows_xyz)
     cx, cy, cz = (_chk(t, "cols") for t in cols_xyz)
-    ld = _rowmajor(out, "out")
+    if not (isinstance(out, torch.Tensor) and out.is_cuda and out.dtype in (F64, F32) and out.dim() == 2 and out.stride(1) == 1):
+        raise TypeError("out must be a 2-D CUDA float64 / float32 tensor with unit column stride")
+    ld = out.stride(0)
     nr, nc = rx.numel(), cx.numel()
     assert out.shape[0] >= nr and out.shape[1] >= nc
-    _lib.check(lib.geobo_k_block(kid, _p(rx), _p(ry), _p(rz), nr, _p(cx), _p(cy), _p(cz), nc, float(l1), float(l2),
-                                 float(w), float(amp), _p(out), ld, _stream()), "geobo_k_block")
+    fn, name = (lib.geobo_k_block, "geobo_k_block") if out.dtype == F64 else (lib.geobo_k_block_f32, "geobo_k_block_f32")
+    _lib.check(fn(kid, _p(rx), _p(ry), _p(rz), nr, _p(cx), _p(cy), _p(cz), nc, float(l1), float(l2), float(w), float(amp),
+                  _p(out), ld, _stream()), name)
     return out
+
+
+def convert(src, dst):
+    """dst[r, c] = src[r, c] across fp64 <-> fp32 (2-D views, unit column stride, even widths and leading dimensions)."""
+    lib = require_gpu()
+    assert src.shape == dst.shape and src.dim() == 2 and src.stride(1) == 1 and dst.stride(1) == 1
+    assert {src.dtype, dst.dtype} == {F64, F32}, "one side float64, the other float32"
+    _lib.check(lib.geobo_convert(1 if dst.dtype == F32 else 0, _p(src), src.stride(0), _p(dst), dst.stride(0), src.shape[0],
+                                 src.shape[1], _stream()), "geobo_convert")
+    return dst
+
+
+def round_f32_(x):
+    """In place x <- (double)(float)x."""
+    lib = require_gpu()
+    assert _chk(x, "x").is_contiguous()
+    _lib.check(lib.geobo_round_f32(_p(x), x.numel(), _stream()), "geobo_round_f32")
+    return x
 
 
 def k_eval(kid, d2, l1, l2, w=1.0, amp=1.0):
@@ -120,12 +144,19 @@ def lattice_plan(loc, xe, ye, ze, nx, ny, nz, device="cuda"):
                 jx=dev(jx, np.int32), jy=dev(jy, np.int32), rowmajor=bool((jy * nx + jx == np.arange(nx * ny)).all()))
 
 
-def a_sens(func, B, loc, nx, ny, nz, xe, ye, ze, scale_mul, scale_div, out, iy0=0, iy1=None, plan=None, rows=None, ws=None):
+def a_sens(func, B, loc, nx, ny, nz, xe, ye, ze, scale_mul, scale_div, out, iy0=0, iy1=None, plan=None, rows=None, ws=None,
+           col_origin=0):
     """Forward operator rows for the sensors in `loc`; optionally only the voxel slab iy0 <= iy < iy1.
     plan (lattice_plan) + rows (slice of the plan's sensors that `loc` holds): interior slabs by the lattice kernels, the
-    two 1e6-padded boundary slabs by the direct kernel."""
+    two 1e6-padded boundary slabs by the direct kernel.
+    col_origin: voxel column that out[:, 0] stands for (a compact slab buffer holds columns col_origin .. only; the kernels
+    address columns absolutely, so the base pointer is moved back by col_origin elements -- they never touch anything outside
+    the requested slab)."""
     lib = require_gpu()
     ld = _rowmajor(out, "A")
+    col_origin = int(col_origin)
+    assert col_origin == 0 or (col_origin == int(iy0) * nx * nz and out.shape[1] >= (int(ny if iy1 is None else iy1) - int(iy0)) * nx * nz)
+    base = C.c_void_p(out.data_ptr() - 8 * col_origin)
     loc = _chk(loc, "loc").contiguous()
     Bh = (C.c_double * 3)(*[float(b) for b in B])
     iy1 = int(ny if iy1 is None else iy1)
@@ -133,7 +164,7 @@ def a_sens(func, B, loc, nx, ny, nz, xe, ye, ze, scale_mul, scale_div, out, iy0=
     def direct(a, b):
         _lib.check(lib.geobo_a_sens_slab(FUNC_IDS[func], Bh, _p(loc), loc.shape[0], int(nx), int(ny), int(nz), _p(_chk(xe, "xe")),
                                          _p(_chk(ye, "ye")), _p(_chk(ze, "ze")), float(scale_mul), float(scale_div), int(a),
-                                         int(b), _p(out), ld, _stream()), "geobo_a_sens_slab")
+                                         int(b), base, ld, _stream()), "geobo_a_sens_slab")
     if plan is None:
         direct(iy0, iy1)
         return out
@@ -145,7 +176,7 @@ def a_sens(func, B, loc, nx, ny, nz, xe, ye, ze, scale_mul, scale_div, out, iy0=
         ws = torch.empty(nbytes // 8, dtype=F64, device=out.device)
     _lib.check(lib.geobo_a_sens_lattice(FUNC_IDS[func], Bh, loc.shape[0], int(nx), int(ny), int(nz), _p(plan["dxv"]), _p(plan["dyv"]),
                                         _p(plan["dzv"]), C.c_void_p(jx.data_ptr()), C.c_void_p(jy.data_ptr()), float(scale_mul),
-                                        float(scale_div), int(iy0), iy1, _p(out), ld, _p(ws), nbytes, _stream()),
+                                        float(scale_div), int(iy0), iy1, base, ld, _p(ws), nbytes, _stream()),
                "geobo_a_sens_lattice")
     if iy0 == 0:
         direct(0, 1)

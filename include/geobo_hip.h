@@ -63,6 +63,20 @@ int geobo_k_block(int kernel_id, const double* rx, const double* ry, const doubl
                   const double* cx, const double* cy, const double* cz, int64_t nc,
                   double l1, double l2, double w, double amp, double* out, int64_t ld, void* stream);
 
+/* The same block written in fp32 ("fp32 kernel assembly" of BASELINE config 5: 128^3 x 3 properties does not fit fp64 storage):
+ * covariance evaluated in fp64, rounded once on the store; 4 B written per element. */
+int geobo_k_block_f32(int kernel_id, const double* rx, const double* ry, const double* rz, int64_t nr,
+                      const double* cx, const double* cy, const double* cz, int64_t nc,
+                      double l1, double l2, double w, double amp, float* out, int64_t ld, void* stream);
+
+/* fp32-assembly mode (config 5): A K lives in HBM as fp32 and the fp64 MFMA kernels are handed fp64 panels.
+ *   geobo_convert: 2-D strided precision conversion, to_f32 = 1: dst(float)[r*ld_dst + c] = (float)src(double)[r*ld_src + c],
+ *                  to_f32 = 0: float -> double; cols and both leading dimensions even, 8-byte aligned bases;
+ *   geobo_round_f32: x[i] = (double)(float)x[i] in place (a covariance table as fp32 storage would hold it). */
+int geobo_convert(int to_f32, const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int64_t cols,
+                  void* stream);
+int geobo_round_f32(double* x, int64_t n, void* stream);
+
 /* out[i] = w * amp * k(d2[i]; l1, l2), elementwise on a caller-supplied squared-distance array
  * (the literal signature of kernels.py:81-156: gpkernel(D2, gamma) ...). */
 int geobo_k_eval(int kernel_id, const double* d2, int64_t n, double l1, double l2, double w, double amp,
@@ -78,7 +92,9 @@ int geobo_a_sens(int func_id, const double* B3_host, const double* loc, int64_t 
                  double* A, int64_t ld, void* stream);
 
 /* The same operator restricted to the voxel slab iy0 <= iy < iy1 (columns p = (iy*nx+ix)*nz+iz of that slab only; the rest of
- * A is not touched): a rank of a column-sharded run only needs its own y-slab of every sensor row. */
+ * A is not touched): a rank of a column-sharded run only needs its own y-slab of every sensor row.  Columns are addressed
+ * absolutely; a caller that holds ONLY the slab (ld >= (iy1-iy0)*nx*nz) passes A moved back by iy0*nx*nz elements.  The same
+ * holds for geobo_a_sens_lattice.  (Streamed operators of the 128^3 configuration: A is 275 GB per type and never resident.) */
 int geobo_a_sens_slab(int func_id, const double* B3_host, const double* loc, int64_t Ms, int nx, int ny, int nz,
                       const double* xe, const double* ye, const double* ze, double scale_mul, double scale_div,
                       int iy0, int iy1, double* A, int64_t ld, void* stream);

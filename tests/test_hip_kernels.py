@@ -274,6 +274,29 @@ def test_soak_hand_synchronised_kernels():
     assert it == 25 and bad == 0
 
 
+def test_fp32_assembly_primitives(hip):
+    """geobo_k_block_f32 = the fp64 block rounded once; geobo_convert both ways on strided views; geobo_round_f32."""
+    g = torch.Generator().manual_seed(5)
+    rows = tuple((torch.rand(37, generator=g, dtype=torch.float64) * 1000).cuda() for _ in range(3))
+    cols = tuple((torch.rand(301, generator=g, dtype=torch.float64) * 1000).cuda() for _ in range(3))
+    for kid in (1, 4, 6):
+        o64 = torch.empty((37, 301 + 3), dtype=torch.float64, device="cuda")[:, :301]
+        o32 = torch.empty((37, 301 + 5), dtype=torch.float32, device="cuda")[:, :301]
+        hip.k_block(kid, rows, cols, 210.0, 260.0, 0.7, 1.3, o64)
+        hip.k_block(kid, rows, cols, 210.0, 260.0, 0.7, 1.3, o32)
+        assert torch.equal(o32, o64.to(torch.float32))
+    src = _rand((50, 130), 9)[:, :128]
+    d32 = torch.zeros((50, 144), dtype=torch.float32, device="cuda")[:, :128]
+    hip.convert(src, d32)
+    assert torch.equal(d32, src.to(torch.float32))
+    back = torch.zeros((50, 128), dtype=torch.float64, device="cuda")
+    hip.convert(d32, back)
+    assert torch.equal(back, src.to(torch.float32).to(torch.float64))
+    x = _rand((1001,), 10)
+    want = x.to(torch.float32).to(torch.float64)
+    assert torch.equal(hip.round_f32_(x), want)
+
+
 def test_potrf_reports_first_bad_pivot(hip):
     m = 256
     S = torch.eye(m, dtype=torch.float64, device="cuda")

@@ -271,6 +271,77 @@ def test_reference_api_odds_and_ends():
         sensormodel.A_sens(s.magneticField, f["sensor_locations"][:50], f["Edges"], "grav", settings=s)
 
 
+# "fp32 K at 16^3 gives mu 3e-5 .. 3e-4, sigma^2 1e-7 .. 8e-7 normwise" -> relaxed tolerances
+TOL_F32_MU, TOL_F32_VAR = 3e-4, 1e-6
+
+
+@pytest.mark.parametrize("method", ["dense", "spectral"])
+@pytest.mark.parametrize("name,kern", [("cube16_exp", "exp"), ("cube16_matern32", "matern32"), ("cube16_sparse", "sparse")])
+def test_fp32_assembly_against_the_reference(name, kern, method):
+    """BASELINE config 5's precision mode (fp32 kernel assembly: covariance tables and A K stored in fp32; fp64 accumulation,
+    fp64 Cholesky) against the reference's fp64 cubes at the relaxed tolerance SURVEY 8(d) gives for it."""
+    f = load_golden(name + ".npz")
+    s = settings_for(16, 16, 16, kernelfunc=kern)
+    inv = _inv(s, method=method, assembly="f32")
+    inv.gp_length = f["gp_length_in"].copy()
+    d0 = f["drilldata0"]
+    cubes = inv.cubing(f["gravfield"], f["magfield"], d0[d0 != 0], f["sensor_locations"], d0)
+    assert inv.engine.last["AK"].dtype == torch.float32
+    errs = [normwise(c, r) for c, r in zip(cubes, f["cubes"]) if not np.isnan(r).all()]
+    k = len(errs) // 2
+    print(name, method, "fp32 assembly: mean", " ".join("%.1e" % e for e in errs[:k]), "| var", " ".join("%.1e" % e for e in errs[k:]))
+    assert max(errs[:k]) <= TOL_F32_MU and max(errs[k:]) <= TOL_F32_VAR
+    assert max(errs) > 1e-9          # it really is the fp32 path
+    assert abs(inv.logl - float(f["logl"])) <= 1e-5 * abs(float(f["logl"]))
+
+
+@pytest.mark.parametrize("assembly", ["f64", "f32"])
+def test_streamed_operators_give_the_same_cubes(assembly):
+    """operators="streamed": A_g / A_m are generated in row batches (spectral product) and column slabs (AkA) instead of being
+    resident -- the same kernels on the same numbers, so the cubes must be bit-identical to the resident run; 32^3 (batched-GEMM
+    passes + N-deep AkA panels) and 64 x 48 x 64 (fused kernels + lattice Gram)."""
+    import bench
+    for dims in ((32, 32, 32), (64, 48, 64)):
+        s = settings_for(*dims, kernelfunc="matern32")
+        out = {}
+        for mode in ("resident", "streamed"):
+            inv = _inv(s, props=(0, 1), assembly=assembly, operators=mode)
+            grav, mag, loc, drill0 = bench.synthetic_inputs(inv, 20)
+            inv.engine.clear_operators()
+            inv.gp_length = np.array([200.0, 202.0, 204.0])
+            out[mode] = inv.cubing(grav, mag, drill0[drill0 != 0], loc, drill0)
+            if mode == "streamed":
+                from geobo_amd.engine import StreamedOperator
+                assert all(isinstance(v, StreamedOperator) for v in inv.engine._A.values())
+            del inv
+            torch.cuda.empty_cache()
+        for a, b in zip(out["resident"], out["streamed"]):
+            if assembly == "f64" and dims[0] == 64:
+                assert np.array_equal(a, b, equal_nan=True)
+            else:    # AkA panels accumulate in a different order than the split-K slices / one sweep
+                assert np.isnan(b).all() if np.isnan(a).all() else normwise(b, a) <= 1e-11
+
+
+def test_fp32_assembly_tracks_fp64_at_32_and_the_headline_shape():
+    """fp32 assembly vs the fp64 route on the same inputs: 32^3 (config 2's size) and 64^3 x 2 properties (headline shape)."""
+    import bench
+    for n in (32, 64):
+        s = settings_for(n, n, n, kernelfunc="matern32")
+        out = {}
+        for assembly in ("f64", "f32"):
+            inv = _inv(s, props=(0, 1), assembly=assembly)
+            grav, mag, loc, drill0 = bench.synthetic_inputs(inv, 50)
+            inv.engine.clear_operators()
+            inv.gp_length = np.array([200.0, 202.0, 204.0])
+            out[assembly] = inv.cubing(grav, mag, drill0[drill0 != 0], loc, drill0)
+            del inv
+            torch.cuda.empty_cache()
+        e_mu = max(normwise(out["f32"][i], out["f64"][i]) for i in (0, 1))
+        e_var = max(normwise(out["f32"][i], out["f64"][i]) for i in (3, 4))
+        print("%d^3 fp32 assembly vs fp64: mean %.2e var %.2e" % (n, e_mu, e_var))
+        assert e_mu <= TOL_F32_MU and e_var <= TOL_F32_VAR
+
+
 def test_props_subset_and_errors():
     f = load_golden("tiny_exp.npz")
     s = settings_for(**TINY, kernelfunc="exp")
