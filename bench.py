@@ -55,12 +55,13 @@ def synthetic_inputs(inv, md):
     loc = np.asarray([X.flatten(), Y.flatten(), Z.flatten()]).T
     inv.sensor_locations = loc
     eng = inv.engine
-    # full operators on every rank for the synthetic data (the timed steps build only what each rank needs)
-    A_g = eng.operator("grav", loc, B=s.magneticField * 0., full=True)
-    A_m = eng.operator("magn", loc, B=s.magneticField, full=True)
-    pad = lambda v: torch.cat([hip.to_dev(v.reshape(-1), eng.device), torch.zeros(eng.N_pad - eng.N, dtype=torch.float64, device=eng.device)])
-    grav = (A_g @ pad(rho))[:eng.Ms].cpu().numpy().astype(np.float32).astype(np.float64)
-    mag = (A_m @ pad(chi))[:eng.Ms].cpu().numpy().astype(np.float32).astype(np.float64)
+    # full operators on every rank for the synthetic data (the timed steps build only what each rank needs); in the
+    # streamed-operator mode they are generated in row batches here as well (never resident)
+    full = not eng.streamed
+    A_g = eng.operator("grav", loc, B=s.magneticField * 0., full=full)
+    A_m = eng.operator("magn", loc, B=s.magneticField, full=full)
+    grav = eng.apply_operator(A_g, rho).cpu().numpy().astype(np.float32).astype(np.float64)
+    mag = eng.apply_operator(A_m, chi).cpu().numpy().astype(np.float32).astype(np.float64)
     drill0 = np.zeros_like(rho)
     if md > 0:
         sel = np.random.default_rng(2020).choice(rho.size, md, replace=False)
@@ -208,6 +209,8 @@ def main():
     ap.add_argument("--size", type=int, default=64, help="cube edge in voxels (64 = BASELINE headline)")
     ap.add_argument("--kernel", default="matern32")
     ap.add_argument("--drill", type=int, default=50)
+    ap.add_argument("--props", type=int, default=2, choices=[2, 3], help="property blocks computed (2 = density + magsus, the headline; "
+                    "3 adds the drill property: BASELINE config 5)")
     ap.add_argument("--method", default="auto", choices=["auto", "dense", "spectral"],
                     help="A.K route: dense = fused in-kernel covariance generation; spectral = real-DFT on batched MFMA GEMMs")
     ap.add_argument("--assembly", default="f64", choices=["f64", "f32"], help="f32 = BASELINE config 5's fp32 kernel assembly (A K and the "
@@ -251,7 +254,7 @@ def main():
     s = Settings(dict(xmin=0, xmax=100.0 * n, ymin=0, ymax=100.0 * n, zmax=0, zoff=1, zLcube=100.0 * n, xNcube=n, yNcube=n,
                       zNcube=n, gp_lengthscale=2, gp_err=[0.1, 0.1, 0.1], gp_coeff=[1.0, 0.2, 0.2], kernelfunc=a.kernel,
                       XMAG=0, YMAG=0, ZMAG=1))
-    inv = Inversion(settings=s, props=(0, 1), rank=rank, world=world, device="cuda:%d" % local, method=a.method,
+    inv = Inversion(settings=s, props=(0, 1, 2)[:a.props], rank=rank, world=world, device="cuda:%d" % local, method=a.method,
                     assembly=a.assembly, operators=a.operators)
     grav, mag, loc, drill0 = synthetic_inputs(inv, a.drill)
     gp_length = np.array([2.00, 2.02, 2.04]) * s.xvoxsize if a.kernel == "matern32" else None
@@ -306,7 +309,7 @@ def main():
     if rank == 0:
         eng = inv.engine
         N = eng.N
-        p_out = 2
+        p_out = a.props
         value = p_out * N * a.steps / dt
         M = 2 * eng.Ms + int((drill0 != 0).sum())
         Msd = 2 * eng.Ms
@@ -337,13 +340,13 @@ def main():
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64" if a.assembly == "f64" else "f32 assembly / f64 accumulate+factorise", "data": "synthetic",
             "config": {"workload": "%d^3 voxel cube (100 m), gravity+magnetics joint inversion, %s kernel lengths (2.00,2.02,2.04)x100 m, "
-                                   "%d drill constraints, M=%d rows, density+magsus cubes (P_out=2)" % (n, a.kernel, a.drill, M),
+                                   "%d drill constraints, M=%d rows, %s cubes (P_out=%d)" % (n, a.kernel, a.drill, M, "density+magsus" + ("+drill" if p_out == 3 else ""), p_out),
                        "N_voxels": N, "M_rows": M, "props_out": p_out, "parallelism": "voxel-column shards x%d" % world,
                        "backend": a.backend if world > 1 else None, "ranks_reported_by_backend": ranks_reported,
                        "method": "spectral" if inv.engine.use_spectral else "dense", "assembly": a.assembly, "operators": a.operators,
                        "row_exchange": bool(inv.engine.exchange),
                        "ms_per_step_median": step_ms[len(step_ms) // 2], "ms_per_step_all_rank0": [round(v, 2) for v in step_ms],
-                       "cube_checksums": [float(np.abs(c).sum()) for c in (cubes[0], cubes[1], cubes[3], cubes[4])],
+                       "cube_checksums": [float(np.abs(cubes[i]).sum()) for i in ((0, 1, 3, 4) if p_out == 2 else range(6))],
                        "dense_algorithmic_flop_per_step": F,
                        "executed_mfma_flop_per_step_rank0": F_mfma, "executed_valu_flop_per_step_rank0": F_valu,
                        "mfma_time_frac_of_step_rank0": sum(d["seconds"] for d in mfma.values()) / dt,

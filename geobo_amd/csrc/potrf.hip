@@ -189,9 +189,10 @@ int build_inverse(InvCtx& c, int lo, int hi, int depth, int sidx) {
   return geobo_gemm_nn(r, cc, r, -1.0, c.Linv + o_mid * c.ldi + o_mid, c.ldi, T, cc, 0.0, c.Linv + o_mid * c.ldi + o_lo, c.ldi, 1, 0, st);
 }
 
-// Fork context (geobo_potrf_ctx_create): three streams + six events on the device that was current at creation, owned by
+// Fork context (geobo_potrf_ctx_create): three streams + a few events on the device that was current at creation, owned by
 // the caller.  Nothing here is process-global: two engines (or two devices, or two threads) each bring their own.
-struct PotrfCtx { int dev; hipStream_t s[3]; hipEvent_t ev[6]; };
+constexpr int NEV = 14;   // 6 for the L^-1 tree, 2 x 4 for the look-ahead rings of the factorisation
+struct PotrfCtx { int dev; hipStream_t s[3]; hipEvent_t ev[NEV]; };
 
 }  // namespace
 
@@ -208,7 +209,7 @@ extern "C" int geobo_potrf_ctx_create(void** ctx) {
   int ns = 0, ne = 0;   // streams / events created so far
   bool ok = hipGetDevice(&c->dev) == hipSuccess;
   while (ok && ns < 3) { ok = hipStreamCreateWithFlags(&c->s[ns], hipStreamNonBlocking) == hipSuccess; ns += ok; }
-  while (ok && ne < 6) { ok = hipEventCreateWithFlags(&c->ev[ne], hipEventDisableTiming) == hipSuccess; ne += ok; }
+  while (ok && ne < NEV) { ok = hipEventCreateWithFlags(&c->ev[ne], hipEventDisableTiming) == hipSuccess; ne += ok; }
   if (!ok) {
     for (int i = 0; i < ne; ++i) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < ns; ++i) (void)hipStreamDestroy(c->s[i]);
@@ -222,7 +223,7 @@ extern "C" int geobo_potrf_ctx_create(void** ctx) {
 extern "C" int geobo_potrf_ctx_destroy(void* ctx) {
   if (!ctx) return GEOBO_OK;
   PotrfCtx* c = (PotrfCtx*)ctx;
-  for (int i = 0; i < 6; ++i) (void)hipEventDestroy(c->ev[i]);
+  for (int i = 0; i < NEV; ++i) (void)hipEventDestroy(c->ev[i]);
   for (int i = 0; i < 3; ++i) (void)hipStreamDestroy(c->s[i]);
   delete c;
   return GEOBO_OK;
@@ -241,7 +242,23 @@ extern "C" int geobo_potrf_inv(int64_t m, double* A, int64_t ld, double* Linv, i
   if (hipMemsetAsync(info, 0, sizeof(int), st) != hipSuccess) return GEOBO_E_LAUNCH;
   if (hipMemset2DAsync(Linv, (size_t)ldi * sizeof(double), 0, (size_t)m * sizeof(double), (size_t)m, st) != hipSuccess)
     return GEOBO_E_LAUNCH;
-  for (int64_t kb = 0; kb < m; kb += NB) {
+  // Right-looking factorisation with ONE STEP OF LOOK-AHEAD when a fork context is given.  The trailing update of step c is
+  // split into (a) the next panel's column block and (b) everything right of it; (b) runs on the context's first stream while
+  // the caller's stream already factors the next diagonal block and solves the next panel, which need (a)_c and (b)_(c-2) only:
+  //     caller's stream:  [wait (b)_(c-2)] potf2(c), panel(c) -> event P_c;  [wait (b)_(c-1): same column block] (a)_c
+  //     side stream:      [wait P_c] (b)_c -> event B_c
+  // The two small latency-bound launches of a step (86 + 74 us at M = 8448) disappear behind the previous step's (b).  Every
+  // element still receives the same updates in the same order: the result is bit-identical to the serial schedule.
+  const PotrfCtx* pc = (const PotrfCtx*)ctx;
+  hipStream_t side = pc ? pc->s[0] : st;
+  const hipEvent_t* Pev = pc ? pc->ev + 6 : nullptr;
+  const hipEvent_t* Bev = pc ? pc->ev + 10 : nullptr;
+  int step = 0, last_b = -1, prev_b = -1;   // steps whose (b) was launched most recently
+  if (pc) {   // the side stream starts after everything already queued on the caller's stream (the memsets above, the producer of A)
+    if (hipEventRecord(Pev[3], st) != hipSuccess || hipStreamWaitEvent(side, Pev[3], 0) != hipSuccess) return GEOBO_E_LAUNCH;
+  }
+  for (int64_t kb = 0; kb < m; kb += NB, ++step) {
+    if (pc && prev_b >= 0 && hipStreamWaitEvent(st, Bev[prev_b & 3], 0) != hipSuccess) return GEOBO_E_LAUNCH;
     hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(256), 0, st, A + kb * ld + kb, ld, Linv + kb * ldi + kb, ldi,
                        (int)kb, info);
     if (hipGetLastError() != hipSuccess) return GEOBO_E_LAUNCH;
@@ -250,10 +267,29 @@ extern "C" int geobo_potrf_inv(int64_t m, double* A, int64_t ld, double* Linv, i
       double* P = A + (kb + NB) * ld + kb;
       int rc = geobo_gemm_nt(rem, NB, NB, 1.0, P, ld, Linv + kb * ldi + kb, ldi, 0.0, P, ld, 0, 0, stream);
       if (rc) return rc;
-      rc = geobo_gemm_nt(rem, rem, NB, -1.0, P, ld, P, ld, 1.0, A + (kb + NB) * ld + (kb + NB), ld, 1, 0, stream);
+      if (!pc) {
+        rc = geobo_gemm_nt(rem, rem, NB, -1.0, P, ld, P, ld, 1.0, A + (kb + NB) * ld + (kb + NB), ld, 1, 0, stream);
+        if (rc) return rc;
+        continue;
+      }
+      if (hipEventRecord(Pev[step & 3], st) != hipSuccess) return GEOBO_E_LAUNCH;
+      if (last_b >= 0 && hipStreamWaitEvent(st, Bev[last_b & 3], 0) != hipSuccess) return GEOBO_E_LAUNCH;
+      // (a)_c: column block c+1, rows >= c+1
+      rc = geobo_gemm_nt(rem, NB, NB, -1.0, P, ld, P, ld, 1.0, A + (kb + NB) * ld + (kb + NB), ld, 0, 0, stream);
       if (rc) return rc;
+      prev_b = last_b;
+      if (rem > NB) {
+        // (b)_c: columns >= c+2, lower tiles
+        if (hipStreamWaitEvent(side, Pev[step & 3], 0) != hipSuccess) return GEOBO_E_LAUNCH;
+        double* P2 = P + NB * ld;
+        rc = geobo_gemm_nt(rem - NB, rem - NB, NB, -1.0, P2, ld, P2, ld, 1.0, A + (kb + 2 * NB) * ld + (kb + 2 * NB), ld, 1, 0, side);
+        if (rc) return rc;
+        if (hipEventRecord(Bev[step & 3], side) != hipSuccess) return GEOBO_E_LAUNCH;
+        last_b = step;
+      }
     }
   }
+  if (pc && last_b >= 0 && hipStreamWaitEvent(st, Bev[last_b & 3], 0) != hipSuccess) return GEOBO_E_LAUNCH;
   InvCtx c;
   c.L = A; c.ld = ld; c.Linv = Linv; c.ldi = ldi; c.ws = (double*)ws; c.ws_doubles = geobo_potrf_ws_bytes(m) / sizeof(double);
   c.s[0] = st;

@@ -230,7 +230,7 @@ class PosteriorEngine:
             lam = None
             if plan is not None:
                 # one two-sensor call leaves the stencil table Q in the lattice workspace (the Gram's eigen-data come from it)
-                tmp = self._workspace2d("op_rows", 2, self.N_pad)
+                tmp = self._op_rows_buffer()
                 self._timed("a_sens_" + func, 0.0, lambda: A.rows_into(tmp, 0, 2))
                 lam = self._gram_eigen(plan, lws)
             self._lam[func] = None if lam is None else (A, lam)
@@ -296,11 +296,32 @@ class PosteriorEngine:
         hip.convert(src, view)
         return view
 
+    def _op_rows_buffer(self):
+        """Row-batch buffer of the streamed operators: one size for every user (no reallocation between stages)."""
+        if self._spectral is None:
+            from .spectral import SpectralProduct
+            self._spectral = SpectralProduct(self.nx, self.ny, self.nz, self.device)
+        return self._workspace2d("op_rows", max(256, self._spectral.R), self.N_pad)
+
     def _cov_table(self, kid, lj, ls, w, amp):
         """Lattice table of one covariance block; rounded through fp32 in the fp32-assembly mode."""
         sset = self.s
         tab = hip.cov_table(kid, self.nx, self.ny, self.nz, sset.xvoxsize, sset.yvoxsize, sset.zvoxsize, lj, ls, w, amp, self.device)
         return hip.round_f32_(tab) if self.f32 else tab
+
+    @_on_device
+    def apply_operator(self, A, v):
+        """A @ v for a resident or streamed forward operator (the synthetic surveys of bench.py: data = A rho); v: (N,) host or
+        device vector, returns the (Ms,) device vector.  Streamed operators are generated 256 rows at a time."""
+        vd = v if isinstance(v, torch.Tensor) else hip.to_dev(np.asarray(v, dtype=np.float64).reshape(-1), self.device)
+        if not isinstance(A, StreamedOperator):
+            return A[:self.Ms, :self.N] @ vd
+        buf = self._op_rows_buffer()
+        out = torch.empty(self.Ms, dtype=F64, device=self.device)
+        for r0 in range(0, self.Ms, 256):
+            R = min(256, self.Ms - r0)
+            out[r0:r0 + R] = A.rows_into(buf, r0, R)[:, :self.N] @ vd
+        return out
 
     def clear_operators(self):
         """Drop the resident forward operators (the benchmark rebuilds them inside every timed step)."""
@@ -387,7 +408,7 @@ class PosteriorEngine:
                 # row batches: operator rows generated on demand (streamed) and / or the product written to an fp64 scratch and
                 # stored as fp32 (fp32 assembly); one batch = the spectral product's own batch size
                 Rb = sp.R
-                abuf = self._workspace2d("op_rows", Rb, self.N_pad) if isinstance(A, StreamedOperator) else None
+                abuf = self._op_rows_buffer() if isinstance(A, StreamedOperator) else None
                 scr = [self._workspace2d("ak_rows64_%d" % jj, Rb, nc) for jj in range(len(props))] if self.f32 else None
                 for r0 in range(0, self.Ms, Rb):
                     R = min(Rb, self.Ms - r0)

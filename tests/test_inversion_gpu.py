@@ -303,10 +303,15 @@ def test_streamed_operators_give_the_same_cubes(assembly):
     import bench
     for dims in ((32, 32, 32), (64, 48, 64)):
         s = settings_for(*dims, kernelfunc="matern32")
-        out = {}
+        out, inputs = {}, None
         for mode in ("resident", "streamed"):
             inv = _inv(s, props=(0, 1), assembly=assembly, operators=mode)
-            grav, mag, loc, drill0 = bench.synthetic_inputs(inv, 20)
+            if inputs is None:
+                inputs = bench.synthetic_inputs(inv, 20)            # one survey for both modes
+            else:
+                g2, m2, _, _ = bench.synthetic_inputs(inv, 20)      # the streamed generator of the survey itself: same data
+                assert np.abs(g2 - inputs[0]).max() <= 1e-6 * np.abs(inputs[0]).max() and np.abs(m2 - inputs[1]).max() <= 1e-6 * np.abs(inputs[1]).max()
+            grav, mag, loc, drill0 = inputs
             inv.engine.clear_operators()
             inv.gp_length = np.array([200.0, 202.0, 204.0])
             out[mode] = inv.cubing(grav, mag, drill0[drill0 != 0], loc, drill0)
@@ -340,6 +345,25 @@ def test_fp32_assembly_tracks_fp64_at_32_and_the_headline_shape():
         e_var = max(normwise(out["f32"][i], out["f64"][i]) for i in (3, 4))
         print("%d^3 fp32 assembly vs fp64: mean %.2e var %.2e" % (n, e_mu, e_var))
         assert e_mu <= TOL_F32_MU and e_var <= TOL_F32_VAR
+
+
+def test_config5_sequential_shards_equal_the_single_rank_run(tmp_path):
+    """tools/dryrun_config5.py --sequential (all column shards of an 8-rank fp32-assembly run executed on one device, partial AkA
+    summed where the all-reduce would be) against the same tool with one shard: same posterior checksums."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for world in (1, 4):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "dryrun_config5.py"), "--size", "32", "--world", str(world),
+                            "--sequential"], cwd=root, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[world] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    for key in ("sum_abs_mu", "sum_var"):
+        a, b = np.array(res[1]["checksums"][key]), np.array(res[4]["checksums"][key])
+        assert np.abs(a - b).max() <= 1e-9 * np.abs(a).max(), (key, a, b)
+    c = res[4]["checks"]
+    assert c["finite"] and 0.0 < c["var_min"] and c["var_max"] <= 1.0 + 1e-6 and c["rms_residual_grav"] < 0.1 and c["rms_residual_magn"] < 0.1
 
 
 def test_props_subset_and_errors():
