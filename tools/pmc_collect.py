@@ -18,7 +18,10 @@ DRIVERS = {"posterior": ("run_posterior_once.py", "gemm_f64_kernel<4, 2, 2, 1", 
            "xz2d_fwd": ("run_spectral_kernels_once.py xz2d_fwd", "xz2d_kernel<64, 64, 128, 128>", "pmc_xz2d_fwd.json"),
            "xz2d_bwd": ("run_spectral_kernels_once.py xz2d_bwd", "xz2d_kernel<128, 128, 64, 64>", "pmc_xz2d_bwd.json"),
            "toeplitz": ("run_spectral_kernels_once.py toeplitz", "toeplitz_y_kernel", "pmc_toeplitz_y.json"),
-           "xcorr": ("run_spectral_kernels_once.py xcorr", "xcorr_kernel", "pmc_xcorr.json")}
+           "xcorr": ("run_spectral_kernels_once.py xcorr", "xcorr_kernel", "pmc_xcorr.json"),
+           "kblock_exp": ("run_k_block_once.py exp f64", "k_block_kernel", "pmc_k_block_exp_f64.json"),
+           "kblock_matern": ("run_k_block_once.py matern32 f64", "k_block_kernel", "pmc_k_block_matern32_f64.json"),
+           "kblock_exp_f32": ("run_k_block_once.py exp f32", "k_block_kernel", "pmc_k_block_exp_f32.json")}
 
 
 def main():
@@ -39,8 +42,9 @@ def main():
                     ndisp.setdefault(row["Counter_Name"], set()).add(row["Dispatch_Id"])
         for c, ids in ndisp.items():          # drivers that launch the kernel twice (warm-up + timed): per-launch average
             counters[c] /= len(ids)
-    m = re.search(r"([0-9.]+) s, ([0-9.]+) TF/s", text)
+    m = re.search(r"([0-9.]+) s, ([0-9.]+) T[FB]/s", text)
     secs = float(m.group(1)) if m else None
+    mb = re.search(r"algorithmic bytes ([0-9]+)", text)
     mf = re.search(r"flop ([0-9]+)", text)
     out = {"flop": float(mf.group(1)) if mf else (float(m.group(2)) * 1e12 * secs if m else None),"note": "rocprofv3 --pmc passes (separate runs, one launch each) of tools/%s: %s" % (script, text),
            "seconds_unprofiled_event": secs, "counters": counters, "derived": {}}
@@ -55,6 +59,11 @@ def main():
         d["FETCH_GB_x2_gfx950_correction"] = counters["FETCH_SIZE"] * 1024 * 2 / 1e9
         d["WRITE_SIZE_GB"] = counters.get("WRITE_SIZE", 0.0) * 1024 / 1e9
         d["hbm_bytes_per_launch_corrected"] = counters["FETCH_SIZE"] * 1024 * 2 + counters.get("WRITE_SIZE", 0.0) * 1024
+        if mb and secs:     # HBM-bound kernels: achieved bandwidth against the 8 TB/s roof, measured bytes against the algorithmic ones
+            d["algorithmic_bytes"] = float(mb.group(1))
+            d["algorithmic_TBps_unprofiled_event"] = float(mb.group(1)) / secs / 1e12
+            d["measured_over_algorithmic_bytes"] = d["hbm_bytes_per_launch_corrected"] / float(mb.group(1))
+            d["frac_of_8TBps_roof"] = float(mb.group(1)) / secs / 8e12
     if counters.get("TCC_HIT_sum") is not None and counters.get("TCC_MISS_sum"):
         d["L2_hit_rate"] = counters["TCC_HIT_sum"] / (counters["TCC_HIT_sum"] + counters["TCC_MISS_sum"])
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
