@@ -29,34 +29,60 @@ F64 = hip.F64
 SLACK = 4096  # doubles of slack behind every buffer: compute tiles may overhang the valid region (reads only)
 
 
-def _omega(P):
-    rho = np.arange(P)
-    return np.where(rho <= P // 2, rho, rho - P // 2)
+def base_modes(n):
+    """Base rows b = 0 .. n-1 of the real eigenvector basis of symmetric circulants of size P = 2n, as (kind, omega):
+    cosines omega = 0 .. n/2-1, the middle pair (omega = n/2), sines omega = 1 .. n/2-1.  Every base row g_b comes with its
+    MIRROR row (-1)^z g_b, which is the eigenvector of frequency n - omega (cos) / minus that eigenvector (sin); for the middle
+    frequency the pair is (c + s, c - s) instead of (c, s) -- any rotation inside an eigenspace is as good a basis.
+    Spectral position 2b holds base row b, position 2b+1 its mirror: the two rows differ only in the sign of the odd inputs,
+    which is what the radix-2 (folded) transform kernels exploit -- per pair ONE even-input and ONE odd-input partial sum,
+    outputs E + O and E - O (half the multiply-adds of the plain matrix product)."""
+    h = n // 2
+    return [("cos", b) for b in range(h)] + [("mid", h)] + [("sin", b - h) for b in range(h + 1, n)]
+
+
+def _base_row(kind, om, n):
+    P = 2 * n
+    z = np.arange(n)
+    ang = 2.0 * np.pi * ((om * z) % P) / P                        # exact integer phase index
+    if kind == "cos":
+        return (1.0 if om == 0 else math.sqrt(2.0)) * np.cos(ang)
+    if kind == "sin":
+        return math.sqrt(2.0) * np.sin(ang)
+    return np.array([1.0, 1.0, -1.0, -1.0])[z % 4]                # cos(pi z / 2) + sin(pi z / 2), exactly
 
 
 def forward_matrix(n):
-    """G (P x n): real eigenvector basis of symmetric circulants of size P = 2n, restricted to the first n inputs."""
-    P = 2 * n
-    z = np.arange(n)
-    G = np.empty((P, n))
-    for rho in range(P):
-        m = (rho if rho <= P // 2 else rho - P // 2) * z % P          # exact integer phase index
-        ang = 2.0 * np.pi * m / P
-        if rho <= P // 2:
-            G[rho] = (1.0 if rho in (0, P // 2) else math.sqrt(2.0)) * np.cos(ang)
-        else:
-            G[rho] = math.sqrt(2.0) * np.sin(ang)
+    """G (P x n): real eigenvector basis of symmetric circulants of size P = 2n, restricted to the first n inputs, in the
+    pair-interleaved order of base_modes (row 2b = base row b, row 2b+1 = (-1)^z times it)."""
+    assert n % 4 == 0
+    G = np.empty((2 * n, n))
+    alt = 1.0 - 2.0 * (np.arange(n) % 2)
+    for b, (kind, om) in enumerate(base_modes(n)):
+        G[2 * b] = _base_row(kind, om, n)
+        G[2 * b + 1] = alt * G[2 * b]
     return G
 
 
 def eigen_matrix(n):
-    """E (P x n): Lambda' = E k for a half table k(d), d = 0..n-1, laid out on the same row index as G."""
+    """E (P x n): Lambda' = E k for a half table k(d), d = 0..n-1, laid out on the same row index as G: row 2b carries the
+    eigenvalue of frequency omega_b, row 2b+1 that of n - omega_b."""
     P = 2 * n
     d = np.arange(n)
-    om = _omega(P)
+    om = np.empty(P, dtype=np.int64)
+    for b, (kind, w) in enumerate(base_modes(n)):
+        om[2 * b], om[2 * b + 1] = w, n - w
     E = np.cos(2.0 * np.pi * ((om[:, None] * d[None, :]) % P) / P)
     E[:, 1:] *= 2.0
     return E
+
+
+def folded_matrices(n):
+    """(Fe, Fo), each n x n/2: even / odd input columns of the base rows, Fe[b][j] = g_b[2j], Fo[b][j] = g_b[2j+1].
+    forward:  out[2b] = E_b + O_b, out[2b+1] = E_b - O_b  with  E_b = sum_j Fe[b][j] x[2j], O_b = sum_j Fo[b][j] x[2j+1];
+    inverse:  x[2j] = sum_b Fe[b][j] (s[2b] + s[2b+1]),   x[2j+1] = sum_b Fo[b][j] (s[2b] - s[2b+1])."""
+    G = forward_matrix(n)
+    return G[0::2, 0::2].copy(), G[0::2, 1::2].copy()
 
 
 def _pad_rows(M, mult=128):
