@@ -1,0 +1,364 @@
+// xz2d_fold.hip -- radix-2 ("folded") form of the fused two-axis real-DFT passes of xz2d.hip: half the MFMAs.
+//
+// The spectral basis of geobo_amd/spectral.py is stored pair-interleaved: position 2b holds base row g_b, position 2b+1 its
+// mirror (-1)^i g_b (the eigenvector of the mirrored frequency).  The two rows of a pair differ only in the sign of the odd
+// inputs, so per pair ONE even-input and ONE odd-input partial sum is enough:
+//
+//   forward  (n -> 2n per axis):  E_b = sum_j Fe[b][j] x[2j],  O_b = sum_j Fo[b][j] x[2j+1];   out[2b] = E_b + O_b,  out[2b+1] = E_b - O_b
+//   inverse  (2n -> n per axis):  u_b = s[2b] + s[2b+1],  v_b = s[2b] - s[2b+1];   x[2j] = sum_b Fe[b][j] u_b,   x[2j+1] = sum_b Fo[b][j] v_b
+//
+// with Fe[b][j] = g_b[2j], Fo[b][j] = g_b[2j+1] (n x n/2 each; passed interleaved as F[b][j][2]).  Both axes of a plane are
+// folded: 768 v_mfma_f64_16x16x4 per 64 x 64 <-> 128 x 128 plane instead of 1536, plus ~200 fp64 VALU adds per wave for the
+// butterflies.  Everything else follows xz2d.hip: one persistent workgroup carries a plane through both contractions with
+// the intermediate in registers (the D fragments of step 1 are the B fragments of step 2), the input streams through an
+// LDS-DMA ring of 16-row chunks with hand-counted vmcnt waits, fragment reads are inline ds_read_b128.
+//
+// What makes the butterflies lane-local:
+//   * an MFMA k-step takes its four k values from the four 16-lane groups, and a ds_read_b128 delivers two ADJACENT inputs:
+//     the .x MFMA of a read contracts even inputs only, the .y MFMA odd inputs only -> E and O are separate accumulators of
+//     the same tile (forward), and a pair (s[2b], s[2b+1]) arrives in one read (inverse);
+//   * the rows of a chunk are permuted on their way into LDS (the DMA source row is free to choose) so that D register `reg`
+//     of a lane holds row 8 (reg >> 1) + 2 q + (reg & 1) of the chunk: even registers carry even rows, odd registers odd rows,
+//     and partner rows (2b, 2b+1) sit in registers (2h, 2h+1) of the same lane.  Step 2's k-step (chunk, reg) then contracts
+//     rows of one parity only.
+// 4 waves per workgroup (one per base tile of the first axis), 64 / 80 KiB of LDS: two workgroups per CU.
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <stdint.h>
+#include <type_traits>
+#include "geobo_hip.h"
+
+namespace {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+struct FoldArgs {
+  const double* in; int64_t in_row, in_plane;    // plane (r, p) at in + r*in_row + p*in_plane (row-major, dense)
+  double* out; int64_t out_row, out_plane;
+  const double* Fz;                              // [n][n/2][2]: (Fe, Fo) of the contiguous axis ("z")
+  const double* Fx;                              // the same for the row axis ("x")
+  int ppr; int64_t nplanes;
+};
+
+constexpr int vmcnt_imm(int v) { return (v & 15) | (7 << 4) | (15 << 8) | ((v >> 4) << 14); }
+
+int ensure_lds_attr(std::atomic<uint64_t>& done, const void* kern, size_t lds) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return GEOBO_E_LAUNCH;
+  if ((done.load(std::memory_order_acquire) >> dev) & 1) return GEOBO_OK;
+  if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GEOBO_E_LAUNCH;
+  done.fetch_or((uint64_t)1 << dev, std::memory_order_release);
+  return GEOBO_OK;
+}
+
+// row i of a chunk in LDS <- row rowperm(i) of the chunk in memory: D register reg = i >> 2 of lane group q = i & 3
+__device__ __forceinline__ int rowperm(int i) { return 8 * (i >> 3) + 2 * (i & 3) + ((i >> 2) & 1); }
+
+// ---- forward: X (N x N) -> O (2N x 2N) -------------------------------------------------------------------------------------
+// Register budget (two workgroups per CU = 256 VGPRs per wave): the 16 output accumulator tiles of step 2 (128 VGPRs) stay live for
+// the whole plane and every chunk is carried through BOTH steps before the next one is touched -- T never exists beyond one
+// chunk (16 VGPRs), the barrier of a chunk is amortised over 48 MFMAs.  All LDS addresses are (one per-lane VGPR) + (an
+// instruction immediate): ring slot = chunk index because RT % RING == 0, and the XOR swizzle only touches bits the immediates
+// leave alone.  (Left to itself the compiler hoists ~60 address registers out of the plane loop and spills them; a spill reload
+// is a vmcnt(0) wait in the middle of the DMA pipeline.)
+template <int I, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < E) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, E>(f);
+  }
+}
+
+template <int N, int RING>
+struct FwdCfg {
+  static constexpr int NW = 4, RT = N / 16, KP = N / 8, ROWB = N * 8, CHB = 16 * ROWB, ND = CHB / 1024 / NW;
+  static constexpr int LPR = ROWB / 16, RPI = 64 / LPR, MT = N / 16;
+  static constexpr size_t LDS = (size_t)RING * CHB + (size_t)N * N * 8;
+  static_assert(N == 64 && ND >= 1 && RT >= RING - 1 && RT % RING == 0 && N / 16 == NW, "shape");
+};
+
+template <int N>
+__global__ void __launch_bounds__(256, 2) xz_fold_fwd_kernel(FoldArgs g) {
+  constexpr int RING = 4;
+  using K = FwdCfg<N, RING>;
+  constexpr int RT = K::RT, KP = K::KP, MT = K::MT, H = N / 2;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  char* const ring = reinterpret_cast<char*>(smem);
+  double* const mxf = smem + RING * K::CHB / 8;               // [N base rows][N/2 slots of (Fe, Fo)], slots XOR-swizzled by row & 15
+  const unsigned ring_lds = (unsigned)(uintptr_t)(lds_ptr_t)ring;
+  const unsigned mxf_lds = ring_lds + RING * K::CHB;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, q = lane >> 4;
+
+  for (int idx = tid; idx < N * H; idx += 64 * K::NW) {
+    const int bx = idx / H, j = idx % H;
+    *reinterpret_cast<v2d*>(mxf + ((bx * H + (j ^ (bx & 15))) << 1)) = *reinterpret_cast<const v2d*>(g.Fx + ((int64_t)idx << 1));
+  }
+  double gE[KP], gO[KP];                                      // B[k = q][j = lr]: F?_z[b = 16 w + lr][j = 4 t + q]
+#pragma unroll
+  for (int t = 0; t < KP; ++t) {
+    const v2d f = *reinterpret_cast<const v2d*>(g.Fz + (((int64_t)(16 * w + lr) * H + 4 * t + q) << 1));
+    gE[t] = f.x;
+    gO[t] = f.y;
+  }
+  // per-lane LDS addresses.  Input fragment t of the chunk in ring slot c: raddr[t] + c*CHB.
+  unsigned raddr[KP];
+#pragma unroll
+  for (int t = 0; t < KP; ++t) raddr[t] = ring_lds + lr * K::ROWB + (((4 * t + q) ^ lr) << 4);
+  // Fx fragment (row tile m, k-step (rt, h)): row 16 m + lr, slot (8 rt + 4 h + q) ^ lr = 16 (rt >> 1) + [(8 (rt & 1) + 4 h + q) ^ lr]
+  //   -> faddr[rt & 1][h] + m * 16 * H * 16 + (rt >> 1) * 256
+  unsigned faddr[2][2];
+#pragma unroll
+  for (int r1 = 0; r1 < 2; ++r1)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) faddr[r1][h] = mxf_lds + lr * (H * 16) + (((8 * r1 + 4 * h + q) ^ lr) << 4);
+
+  const int64_t first = blockIdx.x, pstep = gridDim.x;
+  if (first >= g.nplanes) return;
+  const int drow = lane / K::LPR, dpos = lane % K::LPR;
+  unsigned doff[K::ND];                                       // per-lane byte offset of this lane's DMA source inside a chunk
+#pragma unroll
+  for (int j = 0; j < K::ND; ++j) {
+    const int row = (w + K::NW * j) * K::RPI + drow;          // LDS row of the chunk <- memory row rowperm(row)
+    doff[j] = rowperm(row) * K::ROWB + ((dpos ^ (row & 15)) << 4);
+  }
+  auto plane_ptr = [&](int64_t p) { return reinterpret_cast<const char*>(g.in + (p / g.ppr) * g.in_row + (p % g.ppr) * g.in_plane); };
+  auto stage = [&](const char* plane, int c, int slot) {
+#pragma unroll
+    for (int j = 0; j < K::ND; ++j)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(plane + c * K::CHB + doff[j]), (lds_ptr_t)(ring + slot * K::CHB + (w + K::NW * j) * 1024), 16, 0, 0);
+  };
+  const char* cur = plane_ptr(first);
+  __syncthreads();                                            // Fx image visible
+#pragma unroll
+  for (int c = 0; c < RING - 1; ++c) stage(cur, c, c);
+  const unsigned soff = (unsigned)(q * 2 * (2 * N) * 8 + 2 * (16 * w + lr) * 8);   // this lane's byte offset inside an output plane
+  bool warm = false;
+  for (int64_t p = first; p < g.nplanes; p += pstep) {
+    const int64_t pn = p + pstep < g.nplanes ? p + pstep : p;
+    const char* nxt = plane_ptr(pn);
+    v4d e2[MT][2], o2[MT][2];                                 // [base row tile][column 2b | 2b+1]: even-row / odd-row partial sums
+#pragma unroll
+    for (int m = 0; m < MT; ++m) e2[m][0] = e2[m][1] = o2[m][0] = o2[m][1] = (v4d){0., 0., 0., 0.};
+    static_for<0, RT>([&](auto cc) {
+      constexpr int c = decltype(cc)::value;                  // chunk index = ring slot (RT % RING == 0)
+      if (!(c <= RING - 2 && warm)) __builtin_amdgcn_s_waitcnt(vmcnt_imm((RING - 2) * K::ND));
+      __builtin_amdgcn_s_barrier();
+      {
+        constexpr int cn = c + RING - 1;
+        if constexpr (cn < RT) stage(cur, cn, cn % RING);
+        else stage(nxt, cn - RT, cn % RING);
+      }
+      // ---- step 1 on chunk c: E over even inputs, O over odd inputs, two chains each ----------------------------------------
+      v4d e[2], o[2];
+      e[0] = e[1] = o[0] = o[1] = (v4d){0., 0., 0., 0.};
+      static_for<0, 2>([&](auto hb) {                         // two batches of four fragment reads (16 VGPRs in flight)
+        constexpr int t0 = 4 * decltype(hb)::value;
+        v2d a[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(a[t]) : "v"(raddr[t0 + t]), "n"(c * K::CHB));
+        static_for<0, 4>([&](auto tt) {
+          constexpr int t = decltype(tt)::value;
+          asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a[t]) : "n"(3 - t));
+          e[t & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t].x, gE[t0 + t], e[t & 1], 0, 0, 0);
+          o[t & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t].y, gO[t0 + t], o[t & 1], 0, 0, 0);
+        });
+      });
+      const v4d es = e[0] + e[1], os = o[0] + o[1];
+      const v4d tp = es + os, tm = es - os;                   // T[rows of the chunk][column 2b], [column 2b+1]
+      // ---- step 2, k-steps (c, h): register 2h = even rows -> E2, register 2h+1 = odd rows -> O2 ------------------------------
+      static_for<0, 2>([&](auto hh) {
+        constexpr int h = decltype(hh)::value;
+        v2d f[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[m]) : "v"(faddr[c & 1][h]), "n"(m * 16 * H * 16 + (c >> 1) * 256));
+        static_for<0, MT>([&](auto mm) {
+          constexpr int m = decltype(mm)::value;
+          asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f[m]) : "n"(MT - 1 - m));
+          e2[m][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[m].x, tp[2 * h], e2[m][0], 0, 0, 0);
+          e2[m][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[m].x, tm[2 * h], e2[m][1], 0, 0, 0);
+          o2[m][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[m].y, tp[2 * h + 1], o2[m][0], 0, 0, 0);
+          o2[m][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[m].y, tm[2 * h + 1], o2[m][1], 0, 0, 0);
+        });
+      });
+    });
+    // the next plane's first RING-1 chunks were requested during the last chunks of this one: drain them here, so that no later
+    // wait has this plane's stores between itself and the chunk it waits for
+    __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+    char* const op = reinterpret_cast<char*>(g.out + (p / g.ppr) * g.out_row + (p % g.ppr) * g.out_plane) + soff;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        // base row bx = 16 m + 4 r + q: output rows 2 bx (E2 + O2) and 2 bx + 1 (E2 - O2), columns (2b, 2b+1)
+        const v2d plus = (v2d){e2[m][0][r] + o2[m][0][r], e2[m][1][r] + o2[m][1][r]};
+        const v2d minus = (v2d){e2[m][0][r] - o2[m][0][r], e2[m][1][r] - o2[m][1][r]};
+        char* const rowp = op + (size_t)(2 * (16 * m + 4 * r)) * (2 * N) * 8;
+        *reinterpret_cast<v2d*>(rowp) = plus;
+        *reinterpret_cast<v2d*>(rowp + (2 * N) * 8) = minus;
+      }
+    warm = true;
+    cur = nxt;
+  }
+}
+
+// ---- inverse: S (2N x 2N) -> X (N x N) -------------------------------------------------------------------------------------
+template <int KP, int T>
+__device__ __forceinline__ void inv_step1(v2d (&a)[KP], const double (&gz)[KP], double sgn, v4d (&d)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a[T]) : "n"(KP - 1 - T));
+  const double uv = __builtin_fma(sgn, a[T].y, a[T].x);       // u = s[2b] + s[2b+1] (even outputs) or v = s[2b] - s[2b+1] (odd)
+  d[T & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(uv, gz[T], d[T & 3], 0, 0, 0);
+  if constexpr (T + 1 < KP) inv_step1<KP, T + 1>(a, gz, sgn, d);
+}
+
+template <int N, int RING>
+struct InvCfg {
+  static constexpr int NW = 4, P = 2 * N, RT = P / 16, KP = N / 4, ROWB = P * 8, CHB = 16 * ROWB, ND = CHB / 1024 / NW;
+  static constexpr int LPR = ROWB / 16, RPI = 64 / LPR > 0 ? 64 / LPR : 1, MT = N / 32;
+  static constexpr size_t LDS = (size_t)RING * CHB + (size_t)N * N * 8;
+  static_assert(N == 64 && ND >= 1 && RT >= RING - 1 && N / 16 == NW && LPR == 64, "shape");
+};
+
+template <int N>
+__global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
+  constexpr int RING = 3;
+  using K = InvCfg<N, RING>;
+  constexpr int RT = K::RT, KP = K::KP, MT = K::MT, H = N / 2;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  char* const ring = reinterpret_cast<char*>(smem);
+  double* const mxf = smem + RING * K::CHB / 8;               // [N/2 output pairs j][N slots bx of (Fe, Fo)[bx][j]], slots XOR row & 15
+  const unsigned ring_lds = (unsigned)(uintptr_t)(lds_ptr_t)ring;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, q = lane >> 4;
+  const int par = w >> 1, jt = w & 1;                         // this wave: outputs z = 2 (16 jt + lane column) + par
+
+  for (int idx = tid; idx < N * H; idx += 64 * K::NW) {
+    const int bx = idx / H, j = idx % H;
+    *reinterpret_cast<v2d*>(mxf + ((j * N + (bx ^ (j & 15))) << 1)) = *reinterpret_cast<const v2d*>(g.Fx + ((int64_t)idx << 1));
+  }
+  double gz[KP];                                              // B[k = q][j = lr]: F{e|o}_z[b = 4 t + q][j = 16 jt + lr]
+#pragma unroll
+  for (int t = 0; t < KP; ++t) gz[t] = g.Fz[(((int64_t)(4 * t + q) * H + 16 * jt + lr) << 1) + par];
+  const double sgn = par ? -1.0 : 1.0;
+
+  const int64_t first = blockIdx.x, pstep = gridDim.x;
+  if (first >= g.nplanes) return;
+  auto plane_ptr = [&](int64_t p) { return g.in + (p / g.ppr) * g.in_row + (p % g.ppr) * g.in_plane; };
+  auto stage = [&](const double* plane, int c, int slot) {
+#pragma unroll
+    for (int j = 0; j < K::ND; ++j) {
+      const int row = w + K::NW * j;                          // one 1-KiB row per DMA instruction
+      const char* src = reinterpret_cast<const char*>(plane) + (int64_t)(16 * c + rowperm(row)) * K::ROWB + ((lane ^ (row & 15)) << 4);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(ring + slot * K::CHB + row * 1024), 16, 0, 0);
+    }
+  };
+  const double* cur = plane_ptr(first);
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < RING - 1; ++c) stage(cur, c, c);
+  int slot0 = 0;
+  bool warm = false;
+  for (int64_t p = first; p < g.nplanes; p += pstep) {
+    const int64_t pn = p + pstep < g.nplanes ? p + pstep : p;
+    const double* nxt = plane_ptr(pn);
+    v4d t1[RT];                                               // T[row position][this wave's 16 z outputs]
+#pragma unroll
+    for (int c = 0; c < RT; ++c) {
+      if (!(c <= RING - 2 && warm)) __builtin_amdgcn_s_waitcnt(vmcnt_imm((RING - 2) * K::ND));
+      __builtin_amdgcn_s_barrier();
+      {
+        const int cn = c + RING - 1;
+        if (cn < RT) stage(cur, cn, (slot0 + cn) % RING);
+        else stage(nxt, cn - RT, (slot0 + cn) % RING);
+      }
+      const unsigned xs = ring_lds + ((slot0 + c) % RING) * K::CHB + lr * K::ROWB;
+      v2d a[KP];
+#pragma unroll
+      for (int t = 0; t < KP; ++t) {
+        const unsigned addr = xs + (((4 * t + q) ^ lr) << 4);    // slot b = 4 t + q: the pair (s[2b], s[2b+1]) of row lr
+        asm volatile("ds_read_b128 %0, %1" : "=v"(a[t]) : "v"(addr));
+      }
+      v4d d[4];
+      d[0] = d[1] = d[2] = d[3] = (v4d){0., 0., 0., 0.};
+      inv_step1<KP, 0>(a, gz, sgn, d);
+      t1[c] = (d[0] + d[1]) + (d[2] + d[3]);
+    }
+    // ---- step 2: row pairs (2 bx, 2 bx+1) sit in registers (2h, 2h+1): U = sum, V = difference; even output rows from U with
+    //      Fe_x, odd output rows from V with Fo_x; A = (Fe_x, Fo_x)[bx = 8 rt + 4 h + q][j = 16 m + lr] from one b128 read ------
+    v4d xe[MT][2], xo[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) xe[m][0] = xe[m][1] = xo[m][0] = xo[m][1] = (v4d){0., 0., 0., 0.};
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const double u = t1[rt][2 * h] + t1[rt][2 * h + 1], v = t1[rt][2 * h] - t1[rt][2 * h + 1];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const v2d f = *reinterpret_cast<const v2d*>(mxf + (((16 * m + lr) * N + ((8 * rt + 4 * h + q) ^ lr)) << 1));
+          xe[m][h] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.x, u, xe[m][h], 0, 0, 0);
+          xo[m][h] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.y, v, xo[m][h], 0, 0, 0);
+        }
+      }
+    __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+    double* const op = g.out + (p / g.ppr) * g.out_row + (p % g.ppr) * g.out_plane + 2 * (16 * jt + lr) + par;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const v4d ev = xe[m][0] + xe[m][1], od = xo[m][0] + xo[m][1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 16 * m + q + 4 * r;                     // output rows 2j (even) and 2j+1 (odd)
+        op[(int64_t)(2 * j) * N] = ev[r];
+        op[(int64_t)(2 * j + 1) * N] = od[r];
+      }
+    }
+    warm = true;
+    slot0 = (slot0 + RT) % RING;
+    cur = nxt;
+  }
+}
+
+template <int N>
+int launch_fwd(const FoldArgs& g, hipStream_t st) {
+  using K = FwdCfg<N, 4>;
+  auto kern = xz_fold_fwd_kernel<N>;
+  static std::atomic<uint64_t> attr_done{0};
+  if (int rc = ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), K::LDS)) return rc;
+  const int64_t nwg = g.nplanes < 2048 ? g.nplanes : 2048;   // persistent, two workgroups per CU resident
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), K::LDS, st, g);
+  return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
+}
+
+template <int N>
+int launch_inv(const FoldArgs& g, hipStream_t st) {
+  using K = InvCfg<N, 3>;
+  auto kern = xz_fold_inv_kernel<N>;
+  static std::atomic<uint64_t> attr_done{0};
+  if (int rc = ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), K::LDS)) return rc;
+  const int64_t nwg = g.nplanes < 2048 ? g.nplanes : 2048;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), K::LDS, st, g);
+  return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" int geobo_xz2d_fold(int inverse, int n, int64_t rows, int planes_per_row, const double* in, int64_t in_row,
+                               int64_t in_plane, const double* Fx, const double* Fz, double* out, int64_t out_row,
+                               int64_t out_plane, void* stream) {
+  if (!in || !out || !Fx || !Fz) return GEOBO_E_ARG;
+  if (rows <= 0 || planes_per_row <= 0) return GEOBO_OK;
+  if ((in_row & 1) || (in_plane & 1) || (out_row & 1) || (out_plane & 1) || ((uintptr_t)in & 15) || ((uintptr_t)out & 15) ||
+      ((uintptr_t)Fx & 15) || ((uintptr_t)Fz & 15))
+    return GEOBO_E_ALIGN;
+  if (n != 64) return GEOBO_E_UNSUPPORTED;
+  FoldArgs g;
+  g.in = in; g.in_row = in_row; g.in_plane = in_plane; g.out = out; g.out_row = out_row; g.out_plane = out_plane;
+  g.Fz = Fz; g.Fx = Fx; g.ppr = planes_per_row; g.nplanes = rows * planes_per_row;
+  return inverse ? launch_inv<64>(g, (hipStream_t)stream) : launch_fwd<64>(g, (hipStream_t)stream);
+}

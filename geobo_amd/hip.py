@@ -305,6 +305,17 @@ def xz2d(inverse, nx, nz, rows, ppr, src, in_row, in_plane, Mx, Mz, out, out_row
                               _p(_chk(out, "out")), int(out_row), int(out_plane), _stream()), "geobo_xz2d")
 
 
+XZ2D_FOLD_N = (64,)      # extents the radix-2 kernels are instantiated for (both axes equal)
+
+
+def xz2d_fold(inverse, n, rows, ppr, src, in_row, in_plane, Fx, Fz, out, out_row, out_plane):
+    """Radix-2 form of xz2d on the pair-interleaved basis (geobo_xz2d_fold); Fx / Fz: (n, n/2, 2) folded matrices."""
+    lib = require_gpu()
+    _lib.check(lib.geobo_xz2d_fold(1 if inverse else 0, int(n), int(rows), int(ppr), _p(_chk(src, "src")), int(in_row), int(in_plane),
+                                   _p(_chk(Fx, "Fx")), _p(_chk(Fz, "Fz")), _p(_chk(out, "out")), int(out_row), int(out_plane), _stream()),
+               "geobo_xz2d_fold")
+
+
 def tile_rows(m, m_valid, tile=256, group=64):
     """Rows of each `tile`-row tile that take part in the contraction when rows >= m_valid are padding: whole `group`-row
     wavefront groups (flop accounting of the m_valid argument of geobo_gemm_nt / geobo_posterior_reduce)."""

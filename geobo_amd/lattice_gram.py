@@ -89,4 +89,7 @@ class LatticeGram:
             s = sp.buf("LG_S", R * Py * Px)
             hip.xcorr_reduce(nx, nz, R, Py, y1b, Py * plane, plane, sp.G["x"], lam, s, Py * Px, Px)
             # "x" of geobo_xz2d is this grid's y axis, its "z" this grid's x axis: S_r (Py x Px) -> Gy^T S_r Gx (ny x nx)
-            hip.xz2d(True, ny, nx, R, 1, s, Py * Px, Py * Px, sp.GT["y"], sp.GT["x"], out[r0:], out.stride(0), ny * nx)
+            if sp.fold and ny == nx and "y" in sp.F:
+                hip.xz2d_fold(True, ny, R, 1, s, Py * Px, Py * Px, sp.F["y"], sp.F["x"], out[r0:], out.stride(0), ny * nx)
+            else:
+                hip.xz2d(True, ny, nx, R, 1, s, Py * Px, Py * Px, sp.GT["y"], sp.GT["x"], out[r0:], out.stride(0), ny * nx)

@@ -111,6 +111,9 @@ class SpectralProduct:
         self.G = {a: dev(_pad_rows(forward_matrix(n))) for a, n in (("x", nx), ("y", ny), ("z", nz))}
         self.GT = {a: dev(_pad_rows(forward_matrix(n).T.copy())) for a, n in (("x", nx), ("y", ny), ("z", nz))}
         self.E = {a: dev(_pad_rows(eigen_matrix(n))) for a, n in (("x", nx), ("y", ny), ("z", nz))}
+        # folded (radix-2) matrices [n][n/2][(Fe, Fo)] for the axes the radix-2 kernels are instantiated for
+        self.F = {a: dev(np.stack(folded_matrices(n), axis=2)) for a, n in (("x", nx), ("y", ny), ("z", nz)) if n in hip.XZ2D_FOLD_N}
+        self.fold = os.environ.get("GEOBO_XZ_FOLD", "1") != "0"
         # y axis: applied as Toeplitz blocks per (x, z) mode (geobo_toeplitz_y) when the kernel has the extent, else carried
         # through the spectrum like x and z
         self.dense_y = ny in (16, 32, 48, 64) and os.environ.get("GEOBO_SPECTRAL_DENSE_Y", "1") != "0"
@@ -137,7 +140,10 @@ class SpectralProduct:
         lds = self.N if src_row_stride is None else int(src_row_stride)
         if self.fused_xz:
             t2 = self.buf(out_name, R * ny * Px * Pz)
-            hip.xz2d(False, nx, nz, R, ny, src, lds, nx * nz, M["x"], M["z"], t2, ny * Px * Pz, Px * Pz)
+            if self.fold and M is self.G and nx == nz and "x" in self.F:     # radix-2 kernels: half the MFMAs (xz2d_fold.hip)
+                hip.xz2d_fold(False, nx, R, ny, src, lds, nx * nz, self.F["x"], self.F["z"], t2, ny * Px * Pz, Px * Pz)
+            else:
+                hip.xz2d(False, nx, nz, R, ny, src, lds, nx * nz, M["x"], M["z"], t2, ny * Px * Pz, Px * Pz)
             return t2
         t1 = self.buf("T1", rows * Pz)
         hip.gemm_batched(False, hip.pad_n(ny * nx), hip.pad_n(Pz), nz, src, nz, lds, M["z"], nz, 0, t1, Pz, ny * nx * Pz, ny * nx, Pz, R)
@@ -170,8 +176,12 @@ class SpectralProduct:
         Ly = yhi - ylo
         if self.fused_xz:
             for ya, yb, out, ldo in targets:
-                hip.xz2d(True, nx, nz, R, yb - ya, u2[(ya - ylo) * Px * Pz:], Ly * Px * Pz, Px * Pz, self.GT["x"], self.GT["z"],
-                         out, ldo, nx * nz)
+                if self.fold and nx == nz and "x" in self.F:
+                    hip.xz2d_fold(True, nx, R, yb - ya, u2[(ya - ylo) * Px * Pz:], Ly * Px * Pz, Px * Pz, self.F["x"], self.F["z"],
+                                  out, ldo, nx * nz)
+                else:
+                    hip.xz2d(True, nx, nz, R, yb - ya, u2[(ya - ylo) * Px * Pz:], Ly * Px * Pz, Px * Pz, self.GT["x"], self.GT["z"],
+                             out, ldo, nx * nz)
             return
         u1 = self.buf("U1", R * Ly * nx * Pz)
         hip.gemm_batched(True, hip.pad_n(nx), hip.pad_n(Pz), Px, self.GT["x"], Px, 0, u2, Pz, Px * Pz, u1, Pz, nx * Pz, nx, Pz,

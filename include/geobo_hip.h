@@ -194,6 +194,14 @@ int geobo_xz2d(int inverse, int nx, int nz, int64_t rows, int planes_per_row, co
                int64_t in_plane, const double* Mx, int64_t ldmx, const double* Mz, int64_t ldmz, double* out,
                int64_t out_row, int64_t out_plane, void* stream);
 
+/* Radix-2 ("folded") form of geobo_xz2d for the pair-interleaved spectral basis (geobo_amd/spectral.py: position 2b = base
+ * row g_b, position 2b+1 = (-1)^i g_b): per pair one even-input and one odd-input partial sum, outputs E + O and E - O -- half
+ * the MFMAs of the plain matrix product on both axes.  Fx, Fz: [n][n/2][2] = (Fe[b][j], Fo[b][j]) = (g_b[2j], g_b[2j+1]) of the
+ * row axis and of the contiguous axis.  inverse = 0: planes n x n -> 2n x 2n; inverse = 1: 2n x 2n -> n x n (cropped).
+ * n = 64 (GEOBO_E_UNSUPPORTED otherwise: use geobo_xz2d); strides even, 16-byte aligned bases. */
+int geobo_xz2d_fold(int inverse, int n, int64_t rows, int planes_per_row, const double* in, int64_t in_row, int64_t in_plane,
+                    const double* Fx, const double* Fz, double* out, int64_t out_row, int64_t out_plane, void* stream);
+
 /* AkA = (A K) A^T (inversion.py:96) on a lattice survey ("lattice Gram"): the x step of a (y, x)
  * correlation of the rows of A K with the operator's stencil table, the z axis acting as a channel.  For plane (r, p), r < rows, p < planes, at in + r*in_row + p*in_plane (nx x nz, row-major):
  *     out[r*out_row + p*out_plane + o] = sum_z lamT[(p*nz + z)*2nx + o] * sum_x Mx[o][x] * in[x][z],   o < 2nx

@@ -262,6 +262,39 @@ def test_concurrent_factorisations_on_two_streams(hip):
             assert info == 0 and e1 < 1e-12 and e2 < 1e-10, (i, info, e1, e2)
 
 
+@pytest.mark.parametrize("rows,ppr", [(1, 1), (3, 5), (7, 64), (33, 17)])
+def test_xz2d_fold_matches_the_plain_transform(hip, rows, ppr):
+    """geobo_xz2d_fold (radix-2 kernels on the pair-interleaved basis) against G_x X G_z^T / G_x^T S G_z with torch, and against
+    geobo_xz2d with the full matrices."""
+    from geobo_amd.spectral import folded_matrices, forward_matrix
+    n, P = 64, 128
+    G = hip.to_dev(forward_matrix(n))
+    GT = G.t().contiguous()
+    F = hip.to_dev(np.stack(folded_matrices(n), axis=2))
+    for inverse in (False, True):
+        ix, ox = (P, n) if inverse else (n, P)
+        src = _rand((rows, ppr * ix * ix + 16), 60 + rows)
+        out = torch.full((rows, ppr * ox * ox), float("nan"), dtype=torch.float64, device="cuda")
+        hip.xz2d_fold(inverse, n, rows, ppr, src, src.stride(0), ix * ix, F, F, out, out.stride(0), ox * ox)
+        X = src[:, :ppr * ix * ix].reshape(rows, ppr, ix, ix)
+        M = GT if inverse else G
+        ref = torch.einsum("ai,rpik,bk->rpab", M, X, M)
+        e = (out.reshape(rows, ppr, ox, ox) - ref).abs().max().item() / ref.abs().max().item()
+        assert e < 1e-13, (inverse, e)
+        out2 = torch.empty_like(out)
+        hip.xz2d(inverse, n, n, rows, ppr, src, src.stride(0), ix * ix, M, M, out2, out2.stride(0), ox * ox)
+        assert (out - out2).abs().max().item() <= 1e-13 * ref.abs().max().item()
+    # different matrices on the two axes (asymmetric: catches a swapped Fx / Fz or a transposed fragment)
+    Gz = hip.to_dev(forward_matrix(n) * (1.0 + 0.01 * np.arange(n))[None, :])
+    Fz = hip.to_dev(np.stack([forward_matrix(n)[0::2, 0::2] * (1.0 + 0.01 * np.arange(n))[None, 0::2],
+                              forward_matrix(n)[0::2, 1::2] * (1.0 + 0.01 * np.arange(n))[None, 1::2]], axis=2))
+    src = _rand((2, 3 * n * n), 77)
+    out = torch.empty((2, 3 * P * P), dtype=torch.float64, device="cuda")
+    hip.xz2d_fold(False, n, 2, 3, src, src.stride(0), n * n, F, Fz, out, out.stride(0), P * P)
+    ref = torch.einsum("ai,rpik,bk->rpab", G, src.reshape(2, 3, n, n), Gz)
+    assert (out.reshape(2, 3, P, P) - ref).abs().max().item() <= 1e-13 * ref.abs().max().item()
+
+
 def test_soak_hand_synchronised_kernels():
     """Short form of tools/soak_kernels.py: randomised plane / row counts through geobo_xz2d (both directions), geobo_xcorr_reduce
     and geobo_toeplitz_y against torch einsum references -- the counted vmcnt waits of the LDS-DMA rings must never let a tile be

@@ -18,6 +18,10 @@ def soak(seed=0, seconds=None, iters=60, verbose=True):
     n, P = 64, 128
     rnd = lambda *shape: torch.rand(shape, dtype=torch.float64, device="cuda") * 2 - 1
     Gx, Gz, GxT, GzT = rnd(P, n), rnd(P, n), rnd(n, P), rnd(n, P)
+    from geobo_amd.spectral import folded_matrices, forward_matrix
+    Gf = hip.to_dev(forward_matrix(n))
+    GfT = Gf.t().contiguous()
+    Ff = hip.to_dev(np.stack(folded_matrices(n), axis=2))
     bad = 0
     t0 = time.time()
     it = 0
@@ -35,6 +39,14 @@ def soak(seed=0, seconds=None, iters=60, verbose=True):
             e = (out.reshape(rows, ppr, ox, oz) - ref).abs().max().item() / ref.abs().max().item()
             if not e < 1e-13:
                 bad += 1; print("xz2d inverse=%s rows=%d ppr=%d err %.3e" % (inverse, rows, ppr, e), flush=True)
+            # the radix-2 kernels on the same plane counts (pair-interleaved basis)
+            M = GfT if inverse else Gf
+            out = torch.empty((rows, ppr * ox * oz), dtype=torch.float64, device="cuda")
+            hip.xz2d_fold(inverse, n, rows, ppr, src, src.stride(0), ix * iz, Ff, Ff, out, out.stride(0), ox * oz)
+            ref = torch.einsum("ai,rpik,bk->rpab", M, src[:, :ppr * ix * iz].reshape(rows, ppr, ix, iz), M)
+            e = (out.reshape(rows, ppr, ox, oz) - ref).abs().max().item() / ref.abs().max().item()
+            if not e < 1e-13:
+                bad += 1; print("xz2d_fold inverse=%s rows=%d ppr=%d err %.3e" % (inverse, rows, ppr, e), flush=True)
         # xcorr
         planes = int(rng.integers(1, 129))
         src = rnd(rows, planes * n * n)
