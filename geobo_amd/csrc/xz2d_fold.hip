@@ -324,6 +324,132 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
   }
 }
 
+// ---- lattice Gram, x step + eigenvalue scaling + channel sum (radix-2 form of xcorr_kernel in xz2d.hip) -----------------------
+// For every (row r, y-mode p) plane X (N x N, x rows, z contiguous):   out[r][p][o] = sum_z lamT[p][z][o] * sum_x G_x[o][x] X[x][z].
+// The product is formed transposed (D[z][o]: the z sum then runs over accumulator registers and the four 16-lane groups), and
+// folded over the parity of x:  E[z][b] = sum_(x even) X[x][z] Fe[b][x/2],  O[z][b] = sum_(x odd) X[x][z] Fo[b][(x-1)/2],
+// D[z][2b] = E + O, D[z][2b+1] = E - O  -- half the MFMAs.  A k-step takes rows of ONE parity (rows 8s + 2q + parity of a chunk);
+// the pair (Fe, Fo)[b][j] is one 16-byte LDS read, and so is the eigenvalue pair lamT[p][z][2b .. 2b+1].
+struct XCFArgs {
+  const double* in; int64_t in_row, in_plane;   // plane (r, p) at in + r*in_row + p*in_plane
+  const double* F;                              // [N][N/2][2] folded x matrices
+  const double* lamT;                           // [planes][N][2N]
+  double* out; int64_t out_row, out_plane;      // out + r*out_row + p*out_plane + o
+  int64_t rows, nplanes;
+};
+
+// slot swizzle of the input chunks: a ds_read_b64 serves lanes 0-31 together = rows 8s + parity and 8s + 2 + parity, 16 z columns
+// each; bit 1 of the row goes to bit 3 of the slot XOR, so the two rows land in different 128-byte halves of the 256-byte bank row
+__device__ __forceinline__ int xfswz(int row) { return (((row >> 1) & 1) << 3) | ((row & 1) << 2) | ((row >> 2) & 3); }
+
+template <int N>
+__global__ void __launch_bounds__(512, 2) xcorr_fold_kernel(XCFArgs g) {
+  constexpr int RING = 4, NW = 8, PX = 2 * N, H = N / 2, NCH = N / 16, ROWB = N * 8, CHB = 16 * ROWB, LPR = ROWB / 16, RPI = 64 / LPR;
+  constexpr int ND = CHB / 1024 / NW, BT = N / 16 / 2, NL = BT * 4;   // base tiles per wave, eigenvalue loads per plane
+  static_assert(N == 64 && ND >= 1 && NCH >= RING - 1, "shape");
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  char* const ring = reinterpret_cast<char*>(smem);
+  double* const fx = smem + RING * CHB / 8;            // [N/2 rows j][N slots b of (Fe, Fo)[b][j]]
+  double* const red = fx + H * N * 2;                  // [2][4][PX]
+  const unsigned ring_lds = (unsigned)(uintptr_t)(lds_ptr_t)ring;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int w = wv & 3, bt0 = (wv >> 2) * BT;          // z tile, first base column tile of this wave
+  const int lr = lane & 15, q = lane >> 4;
+  for (int idx = tid; idx < N * H; idx += 64 * NW) {
+    const int b = idx / H, j = idx % H;
+    *reinterpret_cast<v2d*>(fx + ((j * N + b) << 1)) = *reinterpret_cast<const v2d*>(g.F + ((int64_t)idx << 1));
+  }
+  const int64_t first = blockIdx.x, pstep = gridDim.x;
+  if (first >= g.nplanes) return;
+  const int drow = lane / LPR, dpos = lane % LPR;
+  auto plane_ptr = [&](int64_t p) { return g.in + (p % g.rows) * g.in_row + (p / g.rows) * g.in_plane; };
+  auto stage = [&](const double* plane, int c, int slot) {
+#pragma unroll
+    for (int j = 0; j < ND; ++j) {
+      const int ii = wv + NW * j;
+      const int row = ii * RPI + drow;
+      const char* src = reinterpret_cast<const char*>(plane) + (int64_t)(16 * c + row) * ROWB + ((dpos ^ xfswz(row)) << 4);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(ring + slot * CHB + ii * 1024), 16, 0, 0);
+    }
+  };
+  const double* cur = plane_ptr(first);
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < RING - 1; ++c) stage(cur, c, c);
+  int slot0 = 0, it = 0;
+  const int col = 16 * w + lr;                         // this lane's z (row i of the transposed product)
+  for (int64_t p = first; p < g.nplanes; p += pstep, ++it) {
+    const int64_t pn = p + pstep < g.nplanes ? p + pstep : p;
+    const double* nxt = plane_ptr(pn);
+    v4d e[BT], o[BT];
+#pragma unroll
+    for (int b = 0; b < BT; ++b) e[b] = o[b] = (v4d){0., 0., 0., 0.};
+    // this plane's eigenvalue pairs: issued now, consumed after the MFMAs (their L2 latency hides under the chunk loop)
+    const int64_t pl = p / g.rows;
+    const double* lp = g.lamT + pl * (int64_t)(N * PX) + (int64_t)(16 * w + q) * PX + 2 * (16 * bt0 + lr);
+    v2d lam[BT][4];
+#pragma unroll
+    for (int b = 0; b < BT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lam[b][r] = *reinterpret_cast<const v2d*>(lp + 4 * r * PX + 32 * b);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      // chunk c has landed when at most the newer operations are in flight: RING-2 chunks, plus -- for the chunks that were
+      // requested during the previous plane -- the NL eigenvalue loads above (conservative for the <= 1 result store)
+      if (c <= RING - 2) __builtin_amdgcn_s_waitcnt(vmcnt_imm((RING - 2) * ND + NL));
+      else __builtin_amdgcn_s_waitcnt(vmcnt_imm((RING - 2) * ND));
+      __builtin_amdgcn_s_barrier();
+      {
+        const int cn = c + RING - 1;
+        if (cn < NCH) stage(cur, cn, (slot0 + cn) % RING);
+        else stage(nxt, cn - NCH, (slot0 + cn) % RING);
+      }
+      const unsigned xs = ring_lds + ((slot0 + c) % RING) * CHB;
+      double a[4];                                     // [2 s + parity]: X[x = 16 c + 8 s + 2 q + parity][z = col]
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp) {
+        const int row = 8 * (sp >> 1) + 2 * q + (sp & 1);
+        const unsigned addr = xs + row * ROWB + ((((col >> 1) ^ xfswz(row)) << 4) | ((col & 1) << 3));
+        asm volatile("ds_read_b64 %0, %1" : "=v"(a[sp]) : "v"(addr));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) {
+        const double* bp = fx + (((8 * c + 4 * s_ + q) * N + 16 * bt0 + lr) << 1);   // B[k = q][j = lr]: (Fe, Fo)[b][j = 8c + 4s + q]
+#pragma unroll
+        for (int b = 0; b < BT; ++b) {
+          const v2d f = *reinterpret_cast<const v2d*>(bp + 32 * b);
+          e[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2 * s_], f.x, e[b], 0, 0, 0);
+          o[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2 * s_ + 1], f.y, o[b], 0, 0, 0);
+        }
+      }
+    }
+    // ---- butterfly, scale by the eigenvalues and sum over z: registers (4 z per lane), the four 16-lane groups, the waves -----
+    double* const rp = red + (it & 1) * (4 * PX) + w * PX + 2 * (16 * bt0 + lr);
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+      double vp = 0., vm = 0.;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        vp = __builtin_fma(e[b][r] + o[b][r], lam[b][r].x, vp);
+        vm = __builtin_fma(e[b][r] - o[b][r], lam[b][r].y, vm);
+      }
+      vp += __shfl_xor(vp, 16); vp += __shfl_xor(vp, 32);
+      vm += __shfl_xor(vm, 16); vm += __shfl_xor(vm, 32);
+      if (q == 0) *reinterpret_cast<v2d*>(rp + 32 * b) = (v2d){vp, vm};
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (tid < PX) {
+      const double* r4 = red + (it & 1) * (4 * PX) + tid;
+      g.out[(p % g.rows) * g.out_row + pl * g.out_plane + tid] = (r4[0] + r4[PX]) + (r4[2 * PX] + r4[3 * PX]);
+    }
+    slot0 = (slot0 + NCH) % RING;
+    cur = nxt;
+  }
+}
+
 template <int N>
 int launch_fwd(const FoldArgs& g, hipStream_t st) {
   using K = FwdCfg<N, 4>;
@@ -347,6 +473,26 @@ int launch_inv(const FoldArgs& g, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" int geobo_xcorr_reduce_fold(int n, int64_t rows, int planes, const double* in, int64_t in_row, int64_t in_plane,
+                                       const double* F, const double* lamT, double* out, int64_t out_row, int64_t out_plane,
+                                       void* stream) {
+  if (!in || !out || !F || !lamT) return GEOBO_E_ARG;
+  if (rows <= 0 || planes <= 0) return GEOBO_OK;
+  if ((in_row & 1) || (in_plane & 1) || ((uintptr_t)in & 15) || ((uintptr_t)F & 15) || ((uintptr_t)lamT & 15)) return GEOBO_E_ALIGN;
+  if (n != 64) return GEOBO_E_UNSUPPORTED;
+  XCFArgs g;
+  g.in = in; g.in_row = in_row; g.in_plane = in_plane; g.F = F; g.lamT = lamT;
+  g.out = out; g.out_row = out_row; g.out_plane = out_plane; g.rows = rows; g.nplanes = rows * planes;
+  constexpr int N = 64;
+  constexpr size_t lds = (size_t)4 * 16 * N * 8 + (size_t)N * N * 8 + 2 * 4 * (2 * N) * 8;
+  auto kern = xcorr_fold_kernel<N>;
+  static std::atomic<uint64_t> attr_done{0};
+  if (int rc = ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), lds)) return rc;
+  const int64_t nwg = g.nplanes < 2048 ? g.nplanes : 2048;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(512), lds, (hipStream_t)stream, g);
+  return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
+}
 
 extern "C" int geobo_xz2d_fold(int inverse, int n, int64_t rows, int planes_per_row, const double* in, int64_t in_row,
                                int64_t in_plane, const double* Fx, const double* Fz, double* out, int64_t out_row,

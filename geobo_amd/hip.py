@@ -335,6 +335,14 @@ def xcorr_reduce(nx, nz, rows, planes, src, in_row, in_plane, Mx, lam, out, out_
                                       int(out_row), int(out_plane), _stream()), "geobo_xcorr_reduce")
 
 
+def xcorr_reduce_fold(n, rows, planes, src, in_row, in_plane, F, lam, out, out_row, out_plane):
+    """Radix-2 form of xcorr_reduce on the pair-interleaved basis (geobo_xcorr_reduce_fold); F: (n, n/2, 2) folded x matrices."""
+    lib = require_gpu()
+    _lib.check(lib.geobo_xcorr_reduce_fold(int(n), int(rows), int(planes), _p(_chk(src, "src")), int(in_row), int(in_plane),
+                                           _p(_chk(F, "F")), _p(_chk(lam, "lam")), _p(_chk(out, "out")), int(out_row), int(out_plane),
+                                           _stream()), "geobo_xcorr_reduce_fold")
+
+
 def a_sens_lattice_stencil(ws, nx, ny, nz):
     """View of the stencil table Q[(2ny-3)][(2nx-1)][nz] that geobo_a_sens_lattice left in its workspace."""
     np_ = (2 * ny - 2) * (2 * nx) * (nz + 1)

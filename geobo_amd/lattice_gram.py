@@ -87,7 +87,10 @@ class LatticeGram:
             hip.gemm_batched(True, hip.pad_n(Py), hip.pad_n(plane), Ly, gy, ny, 0, X[r0:], plane, X.stride(0), y1b, plane,
                              Py * plane, Py, plane, R)
             s = sp.buf("LG_S", R * Py * Px)
-            hip.xcorr_reduce(nx, nz, R, Py, y1b, Py * plane, plane, sp.G["x"], lam, s, Py * Px, Px)
+            if sp.fold and nx == nz and "x" in sp.F:
+                hip.xcorr_reduce_fold(nx, R, Py, y1b, Py * plane, plane, sp.F["x"], lam, s, Py * Px, Px)
+            else:
+                hip.xcorr_reduce(nx, nz, R, Py, y1b, Py * plane, plane, sp.G["x"], lam, s, Py * Px, Px)
             # "x" of geobo_xz2d is this grid's y axis, its "z" this grid's x axis: S_r (Py x Px) -> Gy^T S_r Gx (ny x nx)
             if sp.fold and ny == nx and "y" in sp.F:
                 hip.xz2d_fold(True, ny, R, 1, s, Py * Px, Py * Px, sp.F["y"], sp.F["x"], out[r0:], out.stride(0), ny * nx)

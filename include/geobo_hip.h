@@ -210,6 +210,11 @@ int geobo_xcorr_reduce(int nx, int nz, int64_t rows, int planes, const double* i
                        const double* Mx, int64_t ldmx, const double* lamT, double* out, int64_t out_row, int64_t out_plane,
                        void* stream);
 
+/* Radix-2 form of geobo_xcorr_reduce for the pair-interleaved basis: the x product folded over the parity of x (half the
+ * MFMAs), F = [n][n/2][2] folded matrices of the x axis; lamT and out in spectral position order as before.  n = 64. */
+int geobo_xcorr_reduce_fold(int n, int64_t rows, int planes, const double* in, int64_t in_row, int64_t in_plane,
+                            const double* F, const double* lamT, double* out, int64_t out_row, int64_t out_plane, void* stream);
+
 /* y-axis stage of the structured product on a regular grid: for every mode c < C (the (x, z)
  * spectral index, contiguous) and row r < R,   out_j[r][y - y0][c] = sum_{y'} tab_j[|y - y'|][c] * in[r][y'][c]
  * for y in [y0, y1) -- the symmetric Toeplitz blocks of create_cov's K_sj (kernels.py:158-195) applied directly.

@@ -58,6 +58,13 @@ def soak(seed=0, seconds=None, iters=60, verbose=True):
         e = (out.reshape(rows, planes, P) - ref).abs().max().item() / ref.abs().max().item()
         if not e < 1e-13:
             bad += 1; print("xcorr rows=%d planes=%d err %.3e" % (rows, planes, e), flush=True)
+        out = torch.empty((rows, planes * P), dtype=torch.float64, device="cuda")
+        hip.xcorr_reduce_fold(n, rows, planes, src, src.stride(0), n * n, Ff, lam, out, out.stride(0), P)
+        Z = torch.einsum("ox,rpxz->rpzo", Gf, src.reshape(rows, planes, n, n))
+        ref = (Z * lam.reshape(planes, n, P)[None]).sum(2)
+        e = (out.reshape(rows, planes, P) - ref).abs().max().item() / ref.abs().max().item()
+        if not e < 1e-13:
+            bad += 1; print("xcorr_fold rows=%d planes=%d err %.3e" % (rows, planes, e), flush=True)
         # toeplitz
         C, R = 64 * int(rng.integers(1, 9)), int(rng.integers(1, 30))
         srct = rnd(R, n, C)
