@@ -19,6 +19,9 @@ DRIVERS = {"posterior": ("run_posterior_once.py", "gemm_f64_kernel<4, 2, 2, 1", 
            "xz2d_bwd": ("run_spectral_kernels_once.py xz2d_bwd", "xz2d_kernel<128, 128, 64, 64>", "pmc_xz2d_bwd.json"),
            "toeplitz": ("run_spectral_kernels_once.py toeplitz", "toeplitz_y_kernel", "pmc_toeplitz_y.json"),
            "xcorr": ("run_spectral_kernels_once.py xcorr", "xcorr_kernel", "pmc_xcorr.json"),
+           "fold_fwd": ("run_spectral_kernels_once.py fold_fwd", "xz_fold_fwd_kernel", "pmc_xz2d_fold_fwd.json"),
+           "fold_bwd": ("run_spectral_kernels_once.py fold_bwd", "xz_fold_inv_kernel", "pmc_xz2d_fold_bwd.json"),
+           "xcorr_fold": ("run_spectral_kernels_once.py xcorr_fold", "xcorr_fold_kernel", "pmc_xcorr_fold.json"),
            "kblock_exp": ("run_k_block_once.py exp f64", "k_block_kernel", "pmc_k_block_exp_f64.json"),
            "kblock_matern": ("run_k_block_once.py matern32 f64", "k_block_kernel", "pmc_k_block_matern32_f64.json"),
            "kblock_exp_f32": ("run_k_block_once.py exp f32", "k_block_kernel", "pmc_k_block_exp_f32.json")}
@@ -44,7 +47,7 @@ def main():
             counters[c] /= len(ids)
     m = re.search(r"([0-9.]+) s, ([0-9.]+) T[FB]/s", text)
     secs = float(m.group(1)) if m else None
-    mb = re.search(r"algorithmic bytes ([0-9]+)", text)
+    mb = re.search(r"algorithmic bytes ([0-9][0-9.e+]*)", text)
     mf = re.search(r"flop ([0-9]+)", text)
     out = {"flop": float(mf.group(1)) if mf else (float(m.group(2)) * 1e12 * secs if m else None),"note": "rocprofv3 --pmc passes (separate runs, one launch each) of tools/%s: %s" % (script, text),
            "seconds_unprofiled_event": secs, "counters": counters, "derived": {}}

@@ -39,3 +39,24 @@ if which in ("all", "xcorr"):
     out = torch.empty((R, P * P), dtype=torch.float64, device=dev)
     timed("xcorr", R * P * 2.0 * P * n * n, R * P * (n * n + P) * 8.0,
           lambda: hip.xcorr_reduce(n, n, R, P, src, src.stride(0), n * n, Gx, lam, out, out.stride(0), P))
+# ---- radix-2 kernels (round 2): flop = what the folded kernels execute on the matrix pipe (half of the plain products) -------
+if which in ("all", "fold_fwd", "fold_bwd", "xcorr_fold"):
+    import numpy as np
+    from geobo_amd.spectral import folded_matrices
+    F = hip.to_dev(np.stack(folded_matrices(n), axis=2))
+if which in ("all", "fold_fwd"):
+    src, out = rnd(R, n * n * n), torch.empty((R, n * P * P), dtype=torch.float64, device=dev)
+    timed("xz2d_fold_fwd", R * n * 1.0 * (n * n * P + P * n * P), R * n * (n * n + P * P) * 8.0,
+          lambda: hip.xz2d_fold(False, n, R, n, src, src.stride(0), n * n, F, F, out, out.stride(0), P * P))
+    del src, out
+if which in ("all", "fold_bwd"):
+    src, out = rnd(R, n * P * P), torch.empty((R, n * n * n), dtype=torch.float64, device=dev)
+    timed("xz2d_fold_bwd", R * n * 1.0 * (P * P * n + n * P * n), R * n * (n * n + P * P) * 8.0,
+          lambda: hip.xz2d_fold(True, n, R, n, src, src.stride(0), P * P, F, F, out, out.stride(0), n * n))
+    del src, out
+if which in ("all", "xcorr_fold"):
+    src = rnd(R, P * n * n)
+    lam = rnd(P * n * P)
+    out = torch.empty((R, P * P), dtype=torch.float64, device=dev)
+    timed("xcorr_fold", R * P * 1.0 * P * n * n, R * P * (n * n + P) * 8.0,
+          lambda: hip.xcorr_reduce_fold(n, R, P, src, src.stride(0), n * n, F, lam, out, out.stride(0), P))
