@@ -30,7 +30,7 @@ import numpy as np
 import torch
 
 from . import geometry, hip
-from .sharding import allreduce_sum_, assemble_columns, exchange_blocks, gather_slices, shard_columns
+from .sharding import allreduce_sum_, assemble_columns, exchange_blocks, gather_rows, gather_slices, shard_columns
 
 F64 = hip.F64
 
@@ -161,7 +161,7 @@ class PosteriorEngine:
                          and xmode != "0" and (world >= 4 or xmode == "1") and not self.f32 and not self.streamed)
         if self.streamed and not self.use_spectral:
             raise ValueError("streamed operators feed the spectral product: needs the spectral method's grid conditions")
-        self._Arows = {}
+        self._Arows, self._Aedge, self._fullrows = {}, {}, {}
         self._potrf_ctx = None
         self.kernel_events = None  # set to [] to record (name, flops, start, stop) HIP events per fused launch
 
@@ -249,6 +249,15 @@ class PosteriorEngine:
             self._Arows[func] = Ar
             lam = self._gram_eigen(plan, lws) if plan is not None else None
             self._lam[func] = None if lam is None else (A, lam)
+            if lam is not None:
+                # row-sharded lattice Gram: the two 1e6-padded boundary slabs of the operator, every sensor (their part of AkA is a GEMM)
+                E2 = self._workspace2d("Aedge_" + func, self.Ms_pad, 2 * plane)
+                if self.Ms_pad > self.Ms:
+                    E2[self.Ms:].zero_()
+                for k, iy in enumerate((0, self.ny - 1)):
+                    hip.a_sens(func, Bv, locd, self.nx, self.ny, self.nz, xed, yed, zed, mul, div, E2[:, k * plane:(k + 1) * plane], iy, iy + 1,
+                               plan=plan, ws=lws, col_origin=iy * plane)
+                self._Aedge[func] = E2
         else:
             self._timed("a_sens_" + func, 0.0, lambda: hip.a_sens(func, Bv, locd, self.nx, self.ny, self.nz, xed, yed, zed, mul, div, A,
                                                                  plan=plan, ws=lws))
@@ -426,8 +435,29 @@ class PosteriorEngine:
         [dest][operator][block][row][col]; one all_to_all_single over xGMI; the received blocks are this rank's columns of
         every sensor row."""
         send = self._exchange_send(lengths, W, name, amp, props)
+        self._keep_full_rows(send, props)
         recv = self._timed("xgmi_all_to_all", 0.0, lambda: exchange_blocks(send, self.world, self.group))
         self._exchange_place(AK, recv, props)
+
+    def _row_gram(self):
+        """True when AkA is assembled from row blocks: row exchange + lattice Gram available for both operators."""
+        return self.exchange and all(self._lam.get(f) is not None for f in ("grav", "magn"))
+
+    def _keep_full_rows(self, send, props):
+        """This rank's own sensor rows of A K over ALL voxels (block columns 0 and 1), gathered from the per-destination slabs of
+        the send buffer: the input of the row-sharded lattice Gram."""
+        self._fullrows = {}
+        if not self._row_gram():
+            return
+        G, nc = self.world, self.nc
+        rows_r, P_c = self.Ms // G, len(props)
+        v = send.view(G, 2, P_c, rows_r, nc)
+        for s_ in (0, 1):
+            for sp_ in (0, 1):
+                full = self._workspace2d("fullrows_%d%d" % (s_, sp_), rows_r, G * nc)
+                for d in range(G):
+                    full[:, d * nc:(d + 1) * nc].copy_(v[d, s_, props.index(sp_)])
+                self._fullrows[(s_, sp_)] = full
 
     def _exchange_send(self, lengths, W, name, amp, props):
         sp, sset, nc, G = self._spectral, self.s, self.nc, self.world
@@ -466,9 +496,15 @@ class PosteriorEngine:
         # column-sharded runs: every rank correlates its own y-slab of the A K rows (the partial results add up in the all-reduce
         # of AkA); the x step and the back-transform are not divided, so from ~5 ranks the N-deep GEMM over N/G columns is cheaper
         # (with the row exchange -- 4 ranks and more -- the GEMM over N/G columns is within a few ms of it: not used there)
-        if (not self.use_spectral or not plan["rowmajor"] or self.Ms_pad != self.Ms or self.world > 4 or self.exchange
-                or (self.c1 - self.c0) % plane or Ly % 16 or self.c1 > self.N
+        if (not self.use_spectral or not plan["rowmajor"] or self.Ms_pad != self.Ms
                 or not LatticeGram.supported(self.nx, self.ny, self.nz) or os.environ.get("GEOBO_AKA_LATTICE", "1") == "0"):
+            return None
+        if self.exchange:
+            # row exchange (>= 4 ranks): every rank holds ALL voxels of its own sensor rows before the all-to-all, so it correlates
+            # those rows itself and AkA arrives as row blocks (all-gather) -- no N/G-deep GEMM, no all-reduce
+            if (self.Ms // self.world) % 128:
+                return None
+        elif self.world > 4 or (self.c1 - self.c0) % plane or Ly % 16 or self.c1 > self.N:
             return None
         if self._spectral is None:
             from .spectral import SpectralProduct
@@ -484,6 +520,8 @@ class PosteriorEngine:
         off_d = 2 * self.Ms_pad
         AkA = self._workspace("AkA", (M_pad, M_pad))
         AkA.zero_()
+        if self._row_gram() and self._fullrows:
+            return self._assemble_AkA_rows(AkA, M_pad, A_g, A_m, sel_t, lengths, name, amp, gp_sigma, props)
         # only the LOWER triangle of AkA is consumed (Cholesky, lower=True): block column s needs rows >= s*Ms_pad, and
         # tiles strictly above the diagonal are skipped inside the GEMM (47 % fewer tiles at 64^3)
         for s_, A in ((0, A_g), (1, A_m)):
@@ -553,6 +591,60 @@ class PosteriorEngine:
             else:
                 self._timed("aka_gemm_nt", fl, lambda: hip.gemm_nt(Xv, Yv, Cv, lower_only=True, m_valid=mv), alg=alg)
         allreduce_sum_(AkA, self.world, self.group)
+        return self._finish_AkA(AkA, M_pad, sel_t, lengths, name, amp, gp_sigma)
+
+    def _aka_local_rows(self, props, sel_t, lengths, W, name, amp):
+        """Row blocks of AkA this rank owns in the row-sharded form: (2, rows_r, 2 Ms_pad) for its gravity / magnetic sensor rows,
+        and the drill rows (every rank computes those 50 rows itself: cheaper than shipping them)."""
+        gram, pl, G = self._gram, self.nx * self.nz, self.world
+        rows_r, Md = self.Ms // G, 0 if sel_t is None else sel_t.numel()
+        loc = self._workspace("aka_rows_local", (2, rows_r, 2 * self.Ms_pad))
+        loc.zero_()
+        lam = {0: self._lam["grav"][1], 1: self._lam["magn"][1]}
+        edge = {0: self._Aedge["grav"], 1: self._Aedge["magn"]}
+
+        def rows_times_AT(X, nrows, sp_, out):
+            # out[:nrows, :Ms] = X[:nrows] . A_sp^T : interior y-slabs by the (y, x) correlation, the two padded slabs by a GEMM
+            gram.gram_rows(X, nrows, lam[sp_], out, 0, self.ny)
+            for k, iy in enumerate((0, self.ny - 1)):
+                hip.gemm_nt(X[:, iy * pl:(iy + 1) * pl], edge[sp_][:, k * pl:(k + 1) * pl], out, alpha=1.0, beta=1.0, m_valid=nrows)
+        for s_ in (0, 1):
+            for sp_ in (0, 1):
+                rows_times_AT(self._fullrows[(s_, sp_)], rows_r, sp_, loc[s_][:, sp_ * self.Ms_pad:(sp_ + 1) * self.Ms_pad])
+        drill = None
+        if Md:
+            xyz = self.grid_points()
+            rows = tuple(c[sel_t] for c in xyz)
+            Mdp = (Md + 127) // 128 * 128
+            drill = self._workspace("aka_rows_drill", (Mdp, 2 * self.Ms_pad))
+            drill.zero_()
+            Xd = self._workspace2d("fullrows_drill", Mdp, self.N_pad)
+            for sp_ in (0, 1):
+                Xd.zero_()
+                hip.k_block(hip.kernel_id(name, 2 != sp_), rows, xyz, lengths[sp_], lengths[2], W[2][sp_], amp, Xd[:Md])
+                rows_times_AT(Xd[:, :self.N], Md, sp_, drill[:, sp_ * self.Ms_pad:(sp_ + 1) * self.Ms_pad])
+        return loc, drill
+
+    def _assemble_AkA_rows(self, AkA, M_pad, A_g, A_m, sel_t, lengths, name, amp, gp_sigma, props):
+        """AkA from row blocks (row exchange + lattice Gram): local correlation of this rank's sensor rows, one all-gather."""
+        W = self._W
+        rows_r, Md, off_d = self.Ms // self.world, 0 if sel_t is None else sel_t.numel(), 2 * self.Ms_pad
+        fl = self._gram.flops(2 * rows_r + Md, self.ny) * 2
+        loc, drill = self._timed("aka_lattice", fl, lambda: self._aka_local_rows(props, sel_t, lengths, W, name, amp))
+        allrows = self._timed("xgmi_all_gather", 0.0, lambda: gather_rows(loc, self.world, self.group))
+        for src in range(self.world):
+            for s_ in (0, 1):
+                r0 = s_ * self.Ms_pad + src * rows_r
+                AkA[r0:r0 + rows_r, :off_d].copy_(allrows[src, s_])
+        if Md:
+            AkA[off_d:off_d + Md, :off_d].copy_(drill[:Md])
+        return self._finish_AkA(AkA, M_pad, sel_t, lengths, name, amp, gp_sigma)
+
+    def _finish_AkA(self, AkA, M_pad, sel_t, lengths, name, amp, gp_sigma):
+        """Drill columns by symmetry, the drill-drill block, the noise variances on the diagonal (identity on the padding)."""
+        xyz = self.grid_points()
+        Md = 0 if sel_t is None else sel_t.numel()
+        off_d = 2 * self.Ms_pad
         dvec = torch.ones(M_pad, dtype=F64, device=self.device)
         dvec[0:self.Ms] = float(gp_sigma[0]) ** 2
         dvec[self.Ms_pad:self.Ms_pad + self.Ms] = float(gp_sigma[1]) ** 2
@@ -580,7 +672,7 @@ class PosteriorEngine:
         Returns dict(mu (3N, NaN for skipped property blocks), var, logl, info)."""
         props = tuple(props)
         assert 0 in props and 1 in props, "gravity and magnetic blocks are needed for AkA"
-        W = weight_matrix(crossweights)
+        W = self._W = weight_matrix(crossweights)
         sel = np.asarray(sel, dtype=np.int64)
         sel_t = torch.as_tensor(sel, device=self.device) if sel.size else None
         t = self._tick("start")

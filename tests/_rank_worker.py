@@ -14,7 +14,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 def main():
     backend, out = sys.argv[1], sys.argv[2]
-    size = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+    dims = [int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else "32").split("x")]
+    dims = dims * 3 if len(dims) == 1 else dims
     local = int(os.environ["LOCAL_RANK"]) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dist.init_process_group(backend)
@@ -22,8 +23,8 @@ def main():
     from conftest import settings_for
     from geobo_amd.inversion import Inversion
     import bench
-    s = settings_for(size, size, size, kernelfunc="matern32")
-    inv = Inversion(settings=s, rank=rank, world=world, device="cuda:%d" % local)
+    s = settings_for(*dims, kernelfunc="matern32")
+    inv = Inversion(settings=s, props=(0, 1) if dims[0] >= 64 else (0, 1, 2), rank=rank, world=world, device="cuda:%d" % local)
     grav, mag, loc, drill0 = bench.synthetic_inputs(inv, 20)
     inv.engine.clear_operators()
     inv.gp_length = np.array([200.0, 202.0, 204.0])
@@ -31,7 +32,8 @@ def main():
     ones = torch.ones(1, device="cuda")
     dist.all_reduce(ones)
     if rank == 0:
-        np.savez(out, cubes=np.asarray(cubes), logl=inv.logl, world=int(ones.item()), exchange=bool(inv.engine.exchange))
+        np.savez(out, cubes=np.asarray(cubes), logl=inv.logl, world=int(ones.item()), exchange=bool(inv.engine.exchange),
+                 row_gram=bool(inv.engine._row_gram()))
     dist.barrier()
     dist.destroy_process_group()
 
