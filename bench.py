@@ -57,11 +57,20 @@ def synthetic_inputs(inv, md):
     eng = inv.engine
     # full operators on every rank for the synthetic data (the timed steps build only what each rank needs); in the
     # streamed-operator mode they are generated in row batches here as well (never resident)
-    full = not eng.streamed
-    A_g = eng.operator("grav", loc, B=s.magneticField * 0., full=full)
-    A_m = eng.operator("magn", loc, B=s.magneticField, full=full)
-    grav = eng.apply_operator(A_g, rho).cpu().numpy().astype(np.float32).astype(np.float64)
-    mag = eng.apply_operator(A_m, chi).cpu().numpy().astype(np.float32).astype(np.float64)
+    if eng.streamed or eng.world > 1:
+        # rows generated in batches (multi-rank runs: no rank holds a whole operator just to synthesise the survey)
+        was, eng.streamed = eng.streamed, True
+        A_g = eng.operator("grav", loc, B=s.magneticField * 0.)
+        A_m = eng.operator("magn", loc, B=s.magneticField)
+        grav = eng.apply_operator(A_g, rho).cpu().numpy().astype(np.float32).astype(np.float64)
+        mag = eng.apply_operator(A_m, chi).cpu().numpy().astype(np.float32).astype(np.float64)
+        eng.streamed = was
+        eng.clear_operators()
+    else:
+        A_g = eng.operator("grav", loc, B=s.magneticField * 0., full=True)
+        A_m = eng.operator("magn", loc, B=s.magneticField, full=True)
+        grav = eng.apply_operator(A_g, rho).cpu().numpy().astype(np.float32).astype(np.float64)
+        mag = eng.apply_operator(A_m, chi).cpu().numpy().astype(np.float32).astype(np.float64)
     drill0 = np.zeros_like(rho)
     if md > 0:
         sel = np.random.default_rng(2020).choice(rho.size, md, replace=False)

@@ -162,6 +162,7 @@ class PosteriorEngine:
         if self.streamed and not self.use_spectral:
             raise ValueError("streamed operators feed the spectral product: needs the spectral method's grid conditions")
         self._Arows, self._Aedge, self._fullrows = {}, {}, {}
+        self._slab_ops = set()      # data pointers of operators that hold only this rank's column slab
         self._potrf_ctx = None
         self.kernel_events = None  # set to [] to record (name, flops, start, stop) HIP events per fused launch
 
@@ -202,7 +203,14 @@ class PosteriorEngine:
             return self._A[key]
         xe, ye, ze = self.node_axes() if axes is None else axes
         stream_it = self.streamed and not full
-        if not stream_it:
+        if partial and not stream_it:
+            # row-exchange form: only this rank's y-slab of every sensor row is ever read (AkA operand of the N/G-deep GEMM):
+            # a compact (Ms_pad x nc) buffer, columns c0 .. c1 (the kernels address columns absolutely: col_origin)
+            A = self._workspace2d("Aslab_" + func, self.Ms_pad, self.nc)
+            if self.Ms_pad > self.Ms:
+                A[self.Ms:].zero_()
+            self._slab_ops.add(A.data_ptr())
+        elif not stream_it:
             A = self._workspace2d("A_" + func, self.Ms_pad, self.N_pad)
             if self.Ms_pad > self.Ms:
                 A[self.Ms:].zero_()
@@ -242,7 +250,7 @@ class PosteriorEngine:
 
             def build():
                 hip.a_sens(func, Bv, locd, self.nx, self.ny, self.nz, xed, yed, zed, mul, div, A, self.c0 // plane, self.c1 // plane,
-                           plan=plan, ws=lws)
+                           plan=plan, ws=lws, col_origin=self.c0)
                 hip.a_sens(func, Bv, loc_r, self.nx, self.ny, self.nz, xed, yed, zed, mul, div, Ar, plan=plan,
                            rows=slice(self.rank * rows_r, (self.rank + 1) * rows_r), ws=lws)
             self._timed("a_sens_" + func, 0.0, build)
@@ -537,7 +545,7 @@ class PosteriorEngine:
                     break
             streamed = isinstance(A, StreamedOperator)
             Xv, Cv = AK[r0:, jj * nc:(jj + 1) * nc], AkA[r0:, r0:r0 + self.Ms_pad]
-            Yv = None if streamed else A[:, self.c0:self.c1]
+            Yv = None if streamed else (A if A.data_ptr() in self._slab_ops else A[:, self.c0:self.c1])
             mv = off_d + Md - r0                       # rows behind the last drill row are padding: not contracted
             pl = self.nx * self.nz
             ya, yb = self.c0 // pl, self.c1 // pl      # this rank's y-slab (slab-aligned shards only where it is used)

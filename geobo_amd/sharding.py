@@ -90,9 +90,12 @@ def exchange_blocks(send, world, group=None):
     if dist.get_backend(group) == "nccl":
         dist.all_to_all_single(recv, send, group=group)
     else:
-        parts = [torch.empty_like(send) for _ in range(world)]
-        dist.all_gather(parts, send, group=group)
+        # emulation: one all-gather per destination (a buffer of one send size at a time instead of world of them)
         me = dist.get_rank(group)
-        for src in range(world):
-            recv[src].copy_(parts[src][me])
+        parts = [torch.empty_like(send[0]) for _ in range(world)]
+        for dest in range(world):
+            dist.all_gather(parts, send[dest].contiguous(), group=group)
+            if dest == me:
+                for src in range(world):
+                    recv[src].copy_(parts[src])
     return recv

@@ -660,7 +660,7 @@ def test_row_sharded_exchange_matches_dense_columns():
         # this rank's slab of every sensor row, and all voxels of its own sensor rows, are bit-identical to the full operator
         rows_r = e.Ms // world
         for k, A in (("grav", A_g), ("magn", A_m)):
-            assert torch.equal(A[:e.Ms, e.c0:e.c1], Af[k][:e.Ms, e.c0:e.c1])
+            assert A.shape == (e.Ms_pad, e.nc) and torch.equal(A[:e.Ms], Af[k][:e.Ms, e.c0:e.c1])     # compact slab buffer
             assert torch.equal(e._Arows[k][:, :e.N], Af[k][e.rank * rows_r:(e.rank + 1) * rows_r, :e.N])
         from geobo_amd.spectral import SpectralProduct
         e._spectral = SpectralProduct(e.nx, e.ny, e.nz, e.device)
