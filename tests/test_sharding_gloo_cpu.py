@@ -106,6 +106,11 @@ def _xchg_worker(rank, world, port, q):
     blk = 6
     send = torch.arange(world * blk, dtype=torch.float64).reshape(world, blk) + 1000.0 * rank   # row d -> rank d
     recv = exchange_blocks(send, world)
+    # row blocks of AkA (row-sharded lattice Gram): all-gather, every rank ends with the same (world, rows, cols) stack
+    from geobo_amd.sharding import gather_rows
+    rows = gather_rows(torch.full((2, 3), float(rank), dtype=torch.float64) + torch.arange(3, dtype=torch.float64), world)
+    assert rows.shape == (world, 2, 3) and all(torch.equal(rows[r], torch.full((2, 3), float(r), dtype=torch.float64) +
+                                                           torch.arange(3, dtype=torch.float64)) for r in range(world))
     q.put((rank, recv.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
