@@ -158,7 +158,7 @@ class PosteriorEngine:
         # more than the forward passes it saves; replicated forward passes + slab-cropped backward passes win there.
         xmode = os.environ.get("GEOBO_SPECTRAL_EXCHANGE", "auto")
         self.exchange = (self.use_spectral and world > 1 and self.Ms % world == 0 and len(ncs) == 1
-                         and xmode != "0" and (world >= 4 or xmode == "1") and not self.f32 and not self.streamed)
+                         and xmode != "0" and (world >= 4 or xmode == "1"))
         if self.streamed and not self.use_spectral:
             raise ValueError("streamed operators feed the spectral product: needs the spectral method's grid conditions")
         self._Arows, self._Aedge, self._fullrows = {}, {}, {}
@@ -442,10 +442,54 @@ class PosteriorEngine:
         operators for every voxel, cropping the backward passes once per destination y-slab straight into the send buffer
         [dest][operator][block][row][col]; one all_to_all_single over xGMI; the received blocks are this rank's columns of
         every sensor row."""
+        if self.f32 or self.streamed:
+            return self._exchange_chunked(AK, lengths, W, name, amp, props)
         send = self._exchange_send(lengths, W, name, amp, props)
         self._keep_full_rows(send, props)
         recv = self._timed("xgmi_all_to_all", 0.0, lambda: exchange_blocks(send, self.world, self.group))
         self._exchange_place(AK, recv, props)
+
+    def _exchange_chunked(self, AK, lengths, W, name, amp, props):
+        """The row exchange for the large-cube modes (fp32 assembly and / or streamed operators, BASELINE config 5): the rank's
+        sensor rows go through the transform in chunks of a few row batches; each chunk is cropped per destination into a send
+        buffer of ~1.5 GB (fp32 in the fp32 mode: converted from an fp64 scratch of one batch), exchanged by its own
+        all_to_all_single and written straight into the A K shard -- no rank-sized send / receive buffers (3 x 104 GB at 128^3)."""
+        sp, nc, G = self._spectral, self.nc, self.world
+        plane = self.nx * self.nz
+        rows_r, P_c, Rb = self.Ms // G, len(props), self._spectral.R
+        esize = 4 if self.f32 else 8
+        Rc = Rb * max(1, int((3 << 29) // (G * P_c * Rb * nc * esize)))
+        send = self._workspace("xchg_send_chunk", (G, P_c, Rc, nc), dtype=hip.F32 if self.f32 else F64)
+        scr = self._workspace("xchg_scratch64", (G, P_c, Rb, nc)) if self.f32 else None
+        slabs_of = [tuple(c // plane for c in shard_columns(self.N_pad, G, d)) for d in range(G)]
+        self._fullrows = {}
+        for s_, func in ((0, "grav"), (1, "magn")):
+            lams = [sp.eigenvalues(self._cov_table(hip.kernel_id(name, s_ != j), lengths[j], lengths[s_], W[s_][j], amp)) for j in props]
+            A = [v for k, v in self._A.items() if k[0] == func][0]
+            streamed = isinstance(A, StreamedOperator)
+            abuf = self._op_rows_buffer() if streamed else None
+            for r0 in range(0, rows_r, Rc):
+                R = min(Rc, rows_r - r0)
+
+                def transform():
+                    for rb in range(0, R, Rb):
+                        n = min(Rb, R - rb)
+                        g0 = self.rank * rows_r + r0 + rb                 # first sensor row of this batch
+                        src = A.rows_into(abuf, g0, n) if streamed else self._Arows[func][r0 + rb:r0 + rb + n]
+                        dst = scr if self.f32 else send[:, :, rb:rb + Rb]
+                        sp.product(src, n, lams, None, slabs=[(slabs_of[d][0], slabs_of[d][1], [dst[d, jj] for jj in range(P_c)])
+                                                              for d in range(G)])
+                        if self.f32:
+                            for d in range(G):
+                                for jj in range(P_c):
+                                    hip.convert(scr[d, jj, :n], send[d, jj, rb:rb + n])
+                self._timed("spectral_product", sp.flops(R, P_c, self.ny), transform, valu=sp.flops_valu(R, P_c))
+                recv = self._timed("xgmi_all_to_all", 0.0, lambda: exchange_blocks(send.view(G, -1), self.world, self.group))
+                for srcr in range(G):
+                    blk = recv[srcr].view(P_c, Rc, nc)
+                    a0 = s_ * self.Ms_pad + srcr * rows_r + r0
+                    for jj in range(P_c):
+                        AK[a0:a0 + R, jj * nc:(jj + 1) * nc].copy_(blk[jj, :R])
 
     def _row_gram(self):
         """True when AkA is assembled from row blocks: row exchange + lattice Gram available for both operators."""

@@ -24,7 +24,10 @@ def main():
     from geobo_amd.inversion import Inversion
     import bench
     s = settings_for(*dims, kernelfunc="matern32")
-    inv = Inversion(settings=s, props=(0, 1) if dims[0] >= 64 else (0, 1, 2), rank=rank, world=world, device="cuda:%d" % local)
+    assembly = sys.argv[4] if len(sys.argv) > 4 else "f64"
+    operators = sys.argv[5] if len(sys.argv) > 5 else "resident"
+    inv = Inversion(settings=s, props=(0, 1) if dims[0] >= 64 else (0, 1, 2), rank=rank, world=world, device="cuda:%d" % local,
+                    assembly=assembly, operators=operators)
     grav, mag, loc, drill0 = bench.synthetic_inputs(inv, 20)
     inv.engine.clear_operators()
     inv.gp_length = np.array([200.0, 202.0, 204.0])

@@ -15,14 +15,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run_ranks(n, backend, out, size="32"):
+def _run_ranks(n, backend, out, size="32", extra=()):
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "tests", "_rank_worker.py"), backend, out, str(size)]
+           "--master-port", str(port), os.path.join(ROOT, "tests", "_rank_worker.py"), backend, out, str(size), *extra]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     return dict(np.load(out))
@@ -77,3 +77,16 @@ def test_four_gloo_ranks_row_exchange_and_row_gram(tmp_path):
         else:
             assert normwise(a, b) <= 1e-10
     assert abs(float(four["logl"]) - float(one["logl"])) <= 1e-10 * abs(float(one["logl"]))
+
+
+@pytest.mark.parametrize("assembly,operators", [("f32", "streamed"), ("f64", "streamed"), ("f32", "resident")])
+def test_large_cube_modes_on_the_row_exchange_path(assembly, operators, tmp_path):
+    """BASELINE config 5's modes (fp32 assembly, streamed operators) with 4 ranks: chunked row exchange (each chunk of sensor rows
+    transformed, cropped per destination, exchanged by its own all-to-all and written straight into the A K shard), N/G-deep AkA
+    panels, sharded posterior -- against the 1-rank run of the same mode (32^3, gloo transport on this box's one device)."""
+    one = _run_ranks(1, "gloo", str(tmp_path / "m1.npz"), "32", (assembly, operators))
+    four = _run_ranks(4, "gloo", str(tmp_path / "m4.npz"), "32", (assembly, operators))
+    assert int(four["world"]) == 4 and bool(four["exchange"])
+    tol = 1e-10 if assembly == "f64" else 2e-6          # fp32 storage: the shards round different partial sums
+    for a, b in zip(four["cubes"], one["cubes"]):
+        assert normwise(a, b) <= tol
