@@ -25,6 +25,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# one process plays the ranks: the column-sharded form that needs no peer (forward passes replicated, backward passes cropped);
+# a real multi-rank run of these modes uses the chunked row exchange instead (engine._exchange_chunked)
+os.environ["GEOBO_SPECTRAL_EXCHANGE"] = "0"
 
 
 def sequential(a):
