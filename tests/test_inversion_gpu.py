@@ -366,6 +366,43 @@ def test_config5_sequential_shards_equal_the_single_rank_run(tmp_path):
     assert c["finite"] and 0.0 < c["var_min"] and c["var_max"] <= 1.0 + 1e-6 and c["rms_residual_grav"] < 0.1 and c["rms_residual_magn"] < 0.1
 
 
+@pytest.mark.parametrize("case", ["off_lattice", "inclined_field", "off_lattice_dense"])
+def test_irregular_surveys_against_the_oracle(case):
+    """Inputs the fast lattice forms must step aside for, end to end against the (pinned) oracle at 16^3: sensors that are NOT on the
+    cube's x-y lattice (A_sens by the direct kernel, AkA by the N-deep GEMM) and an inclined magnetic field (odd stencil table:
+    no lattice Gram for the magnetic block)."""
+    from oracle import geobo_oracle as O
+    from conftest import oracle_grid
+    kw = dict(kernelfunc="matern32")
+    if case == "inclined_field":
+        kw.update(XMAG=0.4, YMAG=-0.3, ZMAG=0.85)
+    s = settings_for(16, 16, 16, **kw)
+    G = oracle_grid(s)
+    loc = G.sensor_locations()
+    if case.startswith("off_lattice"):
+        rng = np.random.default_rng(4)
+        loc = loc + np.c_[rng.uniform(-30, 30, loc.shape[0]), rng.uniform(-30, 30, loc.shape[0]), rng.uniform(0, 40, loc.shape[0])]
+    e = G.edges()
+    A = (O.a_sens(G, G.B * 0., loc, e, "grav"), O.a_sens(G, G.B, loc, e, "magn"))
+    rho, chi = O.synthetic_truth(G)
+    grav, mag = A[0] @ rho.flatten(), A[1] @ chi.flatten()
+    d0 = np.zeros_like(rho)
+    sel = np.random.default_rng(2020).choice(rho.size, 12, replace=False)
+    d0.reshape(-1)[sel] = rho.reshape(-1)[sel]
+    gl = np.array([200.0, 202.0, 204.0])
+    ref = O.cubing(G, grav, mag, d0[d0 != 0], loc, d0, gp_length=gl.copy(), A=A)
+    inv = _inv(s, method="dense" if case.endswith("dense") else "auto")
+    inv.gp_length = gl.copy()
+    cubes = inv.cubing(grav, mag, d0[d0 != 0], loc, d0)
+    eng = inv.engine
+    if case.startswith("off_lattice"):
+        assert eng._lattice_plan[1] is None and not any(v is not None for v in eng._lam.values())
+    else:
+        assert eng._lattice_plan[1] is not None          # lattice form of A_sens also for an inclined field (it is exact for any B)
+    _check_cubes(cubes, ref["cubes"], TOL_T3, case)
+    assert abs(inv.logl - ref["logl"]) <= 1e-8 * abs(ref["logl"])
+
+
 def test_props_subset_and_errors():
     f = load_golden("tiny_exp.npz")
     s = settings_for(**TINY, kernelfunc="exp")
