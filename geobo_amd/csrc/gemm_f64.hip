@@ -67,6 +67,8 @@ struct GemmArgs {
   const double* table; int gnx, gny, gnz; int64_t gN;
   // reduce epilogue
   const double* u; double* part_mu; double* part_ss; int64_t ncols;
+  // row tiles start at bi * TM - row_shift (a multiple of 64): the under-filled tile of a ragged row count is the FIRST one
+  int64_t row_shift;
 };
 
 // Item order of memory-mode launches with few, long tiles (AkA, split-K slices, Cholesky trailing updates, L^-1 merges).
@@ -195,7 +197,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_f64_kernel(const GemmArg
   const double* const Yp = a.Y + (int64_t)batch_idx * a.sYb;
   double* const Cp = a.C + (int64_t)batch_idx * a.sCb;
   if ((a.tri & TRI_X_LOWER) && a.xcd_map != 3) bi = a.nbi - 1 - bi;  // triangular X: the longest contraction ranges are dispatched first
-  const int64_t row0 = (int64_t)bi * TM, col0 = (int64_t)bj * TN;
+  const int64_t row0 = (int64_t)bi * TM - a.row_shift, col0 = (int64_t)bj * TN;
   if ((a.tri & TRI_LOWER_ONLY) && col0 >= row0 + TM) return;
   int64_t kb = (a.tri & TRI_Y_LOWER) ? col0 : 0;
   int64_t ke = a.k;
@@ -219,12 +221,13 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_f64_kernel(const GemmArg
   };
   constexpr int RPI = NT / 8;  // tile rows covered by one pass of the whole workgroup (8 lanes per 128-byte row)
   const int srow = tid >> 3;   // this thread's row within a pass
-  const char* const Xgb = reinterpret_cast<const char*>(Xp + row0 * a.ldx);
+  const char* const Xgb = reinterpret_cast<const char*>(Xp);
   int64_t xsrc[XU];
 #pragma unroll
   for (int i = 0; i < XU; ++i) {
     const int row = i * RPI + srow;
-    xsrc[i] = ((int64_t)row * a.ldx + 2 * ((tid & 7) ^ swz(row))) * 8;
+    const int64_t grow = row0 + row < 0 ? 0 : row0 + row;   // rows in front of a shifted first tile: any valid row (their waves idle)
+    xsrc[i] = (grow * a.ldx + 2 * ((tid & 7) ^ swz(row))) * 8;
   }
   auto stage_x = [&](int64_t k0, int st) {
 #pragma unroll
@@ -414,7 +417,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_f64_kernel(const GemmArg
       int64_t kw = ke;
       if constexpr (YMODE != Y_GEN) {
         if ((a.tri & TRI_X_LOWER) && kw > row0 + 64 * (wm + 1)) kw = row0 + 64 * (wm + 1);
-        if (row0 + wm * 64 >= a.m_valid || kw < kb) kw = kb;
+        if (row0 + wm * 64 >= a.m_valid || row0 + wm * 64 < 0 || kw < kb) kw = kb;
       }
       if (kw > kb) {
       v2d a0[4], b0[4], a1[4], b1[4];
@@ -507,7 +510,8 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_f64_kernel(const GemmArg
     for (int m = 0; m < 4; ++m)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const double ur = a.u[row0 + wm * 64 + m * 16 + lg + 4 * r];
+        const int64_t ri = row0 + wm * 64 + m * 16 + lg + 4 * r;
+        const double ur = a.u[ri < 0 ? 0 : ri];             // rows in front of a shifted first tile: acc = 0
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
           const double v = acc[m][n][r];
@@ -740,11 +744,18 @@ extern "C" int geobo_posterior_reduce(int64_t m, int64_t ncols, const double* Li
   a.X = Linv; a.ldx = ldi; a.Y = AK; a.ldy = ldak; a.C = nullptr; a.ldc = 0; a.k = m;
   a.alpha = 1.0; a.beta = 0.0; a.tri = TRI_X_LOWER;
   a.u = u; a.ncols = ncols;
-  a.m_valid = m_valid;
+  a.m_valid = (m_valid > 0 && m_valid < m) ? m_valid : m;
   const int nbi_max = (int)((m + 127) / 128);
   a.part_mu = (double*)ws;
   a.part_ss = (double*)ws + (size_t)nbi_max * ncols;
-  int rc = launch_by_rows<Y_NN, EPI_REDUCE, COV_D2>(a, m, ncols, st);
+  // 256-row tiles of four 64-row wavefront groups, aligned to the END of the valid rows: a row count that does not fill its
+  // last tile would leave that tile -- the one with the LONGEST contraction -- to a quarter of the workgroup (64^3 with 50
+  // drill rows: 3 % of the launch for 0.6 % of the flop).  Shifted, the under-filled tile is the first one (contraction <= 192).
+  const int64_t groups = (a.m_valid + 63) / 64;
+  a.row_shift = 64 * ((4 - groups % 4) % 4);
+  a.nbi = (int)((groups * 64 + a.row_shift) / 256);
+  a.nbj = (int)(ncols / 128);
+  int rc = launch<4, 2, Y_NN, EPI_REDUCE, COV_D2>(a, st);
   if (rc) return rc;
   hipLaunchKernelGGL(posterior_finish_kernel, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, st, a.part_mu,
                      a.part_ss, a.nbi, ncols, prior_var, mu, var);

@@ -431,8 +431,9 @@ def test_gemm_nt_m_valid_skips_padding_rows(hip, m_valid):
     assert (C2[m_valid:] == 0.0).all()
 
 
-def test_posterior_reduce_m_valid(hip):
-    m, ncols, mv = 768, 256, 530
+@pytest.mark.parametrize("m,mv", [(768, 530), (768, 64), (768, 65), (512, 449), (1024, 1024), (128, 100), (896, 770)])
+def test_posterior_reduce_m_valid(hip, m, mv):
+    ncols = 256
     g = torch.Generator().manual_seed(5)
     Linv = torch.tril(torch.rand((m, m), generator=g, dtype=torch.float64)).cuda()
     Linv[mv:] = 0.0
@@ -446,7 +447,8 @@ def test_posterior_reduce_m_valid(hip):
     V = Linv @ AK
     assert normwise(mu1.cpu().numpy(), (V.t() @ u).cpu().numpy()) < 1e-13
     assert normwise(var1.cpu().numpy(), (1.5 - (V * V).sum(0)).cpu().numpy()) < 1e-13
-    assert torch.equal(mu0, mu1) and torch.equal(var0, var1)
+    # the 256-row tiles are aligned to the end of the valid rows, so the two calls sum their partial column sums in different groups
+    assert normwise(mu0.cpu().numpy(), mu1.cpu().numpy()) < 1e-14 and normwise(var0.cpu().numpy(), var1.cpu().numpy()) < 1e-14
 
 
 @pytest.mark.parametrize("func", ["grav", "magn"])
