@@ -24,6 +24,7 @@
 // row tile (they stream the same A rows through that XCD's L2) and different column tiles.
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <type_traits>
 #include <stdint.h>
 #include "covfun.h"
 #include "geobo_hip.h"
@@ -419,10 +420,16 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_f64_kernel(const GemmArg
         if ((a.tri & TRI_X_LOWER) && kw > row0 + 64 * (wm + 1)) kw = row0 + 64 * (wm + 1);
         if (row0 + wm * 64 >= a.m_valid || row0 + wm * 64 < 0 || kw < kb) kw = kb;
       }
+      // The wave's last 64 contraction indices under a triangular X are its own diagonal block: 16-row group m of the wave is
+      // zero beyond column 16 (m + 1) of that block, so chunk c of the four (kd + 16 c) only needs the groups m >= c.
+      int64_t kd = kw;                                   // first index of the peeled diagonal chunks (kw: none)
+      if constexpr (YMODE != Y_GEN) {
+        if ((a.tri & TRI_X_LOWER) && kw == row0 + 64 * (wm + 1) && kw - 64 >= kb) kd = kw - 64;
+      }
       if (kw > kb) {
       v2d a0[4], b0[4], a1[4], b1[4];
       read_half(0, 0, a0, b0);
-      for (int64_t k0 = kb; k0 < kw; k0 += BK) {
+      for (int64_t k0 = kb; k0 < kd; k0 += BK) {
         int64_t kn = k0 + 2 * BK;
         if (kn >= ke) kn = ke - BK;
         stage_x(kn, s2);
@@ -468,6 +475,39 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_f64_kernel(const GemmArg
         if constexpr (YMODE == Y_GEN) store_gen(s2);
         __syncthreads();
         const int ts = s0; s0 = s1; s1 = s2; s2 = ts;
+      }
+      if constexpr (YMODE != Y_GEN) {
+        if (kd < kw) {
+          auto diag_chunk = [&](auto mlo, int64_t k0) {
+            constexpr int MLO = decltype(mlo)::value;
+            int64_t kn = k0 + 2 * BK;
+            if (kn >= ke) kn = ke - BK;
+            stage_x(kn, s2);
+            stage_y(kn, s2);
+            read_half(s0, 1, a1, b1);
+  #pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              if (t == 2) read_half(s1, 0, a0, b0);
+  #pragma unroll
+              for (int m = MLO; m < 4; ++m)
+  #pragma unroll
+                for (int n = 0; n < 4; ++n)
+                  acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(t < 2 ? a0[m][t & 1] : a1[m][t & 1],
+                                                                   t < 2 ? b0[n][t & 1] : b1[n][t & 1], acc[m][n], 0, 0, 0);
+            }
+  #pragma unroll
+            for (int i = 0; i < 16 * (4 - MLO); ++i) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              __builtin_amdgcn_sched_group_barrier(0x126, 6, 0);
+            }
+            __syncthreads();
+            const int ts = s0; s0 = s1; s1 = s2; s2 = ts;
+          };
+          diag_chunk(std::integral_constant<int, 0>{}, kd);
+          diag_chunk(std::integral_constant<int, 1>{}, kd + BK);
+          diag_chunk(std::integral_constant<int, 2>{}, kd + 2 * BK);
+          diag_chunk(std::integral_constant<int, 3>{}, kd + 3 * BK);
+        }
       }
       }
       if constexpr (YMODE != Y_GEN) {

@@ -752,11 +752,10 @@ class PosteriorEngine:
         else:
             out["logl"] = 0.0
         if want_mean_var:
-            # executed flop: lower-triangular Linv in 256-row tiles; 64-row group g of a tile contracts 256 bi + 64 (g + 1)
-            # columns (whole groups of the valid rows only)
+            # executed flop: every 64-row wavefront group g of the valid rows contracts the 64 g columns in front of its diagonal
+            # block in full, and of the block itself the 16-row sub-groups' chunks at or below the diagonal (40 of 64 MFMA steps)
             Mv = 2 * self.Ms_pad + len(sel)
-            fl = 2.0 * AK.shape[1] * sum(64.0 * (256 * bi + 64 * (g + 1)) for bi, rv in enumerate(hip.tile_rows(M_pad, Mv))
-                                         for g in range(rv // 64))
+            fl = 2.0 * AK.shape[1] * sum(64.0 * 64 * g + 2560.0 for g in range((Mv + 63) // 64))
             Mu = 2 * self.Ms + len(sel)                                  # unpadded observation rows
             nv = len(props) * min(self.nc, max(self.N - self.c0, 0))     # this rank's voxel-property columns
             if AK.dtype == F64:
