@@ -53,7 +53,7 @@ constexpr int RING = 4;  // chunks in the LDS ring (prefetch distance RING-1)
 // s_waitcnt immediate for vmcnt(v) only (gfx9 encoding: vmcnt[3:0] | expcnt 7 | lgkmcnt 15 | vmcnt[5:4] << 14)
 constexpr int vmcnt_imm(int v) { return (v & 15) | (7 << 4) | (15 << 8) | ((v >> 4) << 14); }
 
-constexpr int xz_threads(int out_z) { return out_z / 16 >= 8 ? 512 : 256; }
+constexpr int xz_threads(int out_z) { return out_z / 16 >= 8 ? 512 : (out_z / 16 >= 4 ? 256 : 128); }
 
 template <int IN_X, int IN_Z, int OUT_X, int OUT_Z>
 struct XZCfg {
@@ -375,6 +375,10 @@ extern "C" int geobo_xz2d(int inverse, int nx, int nz, int64_t rows, int planes_
   g.in = in; g.in_row = in_row; g.in_plane = in_plane; g.out = out; g.out_row = out_row; g.out_plane = out_plane;
   g.Mz = Mz; g.ldmz = ldmz; g.Mx = Mx; g.ldmx = ldmx; g.ppr = planes_per_row; g.nplanes = rows * planes_per_row;
   hipStream_t st = (hipStream_t)stream;
+  if (nz == 32 && nx == 64) {
+    // also the form 32 x 32 planes take: two consecutive planes stacked along x with Mx = diag(Mx32, Mx32) (spectral.py)
+    return inverse ? launch<128, 64, 64, 32>(g, st) : launch<64, 32, 128, 64>(g, st);
+  }
   if (nz != 64) return GEOBO_E_UNSUPPORTED;
   if (!inverse) {
     if (nx == 64) return launch<64, 64, 128, 128>(g, st);

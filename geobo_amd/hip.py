@@ -294,7 +294,7 @@ def scale_broadcast2(a, b0, b1, out0, out1):
                                           _p(out0), _p(out1), _stream()), "geobo_scale_broadcast2")
 
 
-XZ2D_SHAPES = ((48, 64), (64, 64))      # (nx, nz) the fused (x, z) transform kernel is instantiated for
+XZ2D_SHAPES = ((48, 64), (64, 64), (64, 32))      # (nx, nz) the fused (x, z) transform kernel is instantiated for
 
 
 def xz2d(inverse, nx, nz, rows, ppr, src, in_row, in_plane, Mx, Mz, out, out_row, out_plane):

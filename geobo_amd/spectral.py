@@ -119,6 +119,11 @@ class SpectralProduct:
         self.dense_y = ny in (16, 32, 48, 64) and os.environ.get("GEOBO_SPECTRAL_DENSE_Y", "1") != "0"
         # x and z: one fused kernel per direction (geobo_xz2d) where it is instantiated, else two batched GEMM passes
         self.fused_xz = (nx, nz) in hip.XZ2D_SHAPES and os.environ.get("GEOBO_SPECTRAL_FUSED_XZ", "1") != "0"
+        # 32 x 32 planes: two consecutive y-planes stacked along x go through the (64, 32) instance with diag(Mx, Mx) -- the z step
+        # is row-wise anyway, the x step spends half its MFMAs on the zero blocks (cheap next to two GEMM passes through HBM)
+        self.pair_xz = ((nx, nz) == (32, 32) and (64, 32) in hip.XZ2D_SHAPES and ny % 2 == 0
+                        and os.environ.get("GEOBO_SPECTRAL_FUSED_XZ", "1") != "0")
+        self._pairs = {}
         if rows_per_batch is None:
             per_row = (ny * self.Px * self.Pz if self.dense_y else self.P3) * 8
             rows_per_batch = max(1, min(256 if self.dense_y else 128, (3 << 30) // per_row))  # ~3 GB per work buffer
@@ -132,6 +137,17 @@ class SpectralProduct:
             b = self._bufs[name] = _buf(n, self.device)
         return b
 
+    def _paired(self, Mx, rows, cols):
+        """diag(Mx, Mx) for the stacked-pair form of the fused kernel (Mx: the valid rows x cols of a padded matrix)."""
+        key = (Mx.data_ptr(), rows, cols)
+        m2 = self._pairs.get(key)
+        if m2 is None:
+            m2 = torch.zeros((2 * rows, 2 * cols), dtype=Mx.dtype, device=Mx.device)
+            m2[:rows, :cols] = Mx[:rows, :cols]
+            m2[rows:, cols:] = Mx[:rows, :cols]
+            self._pairs[key] = m2
+        return m2
+
     # ---- axis passes, z (contiguous) then x [then y]: [R][ny][nx][nz] -> [R][ny][Px][Pz] [-> [R][Py][Px][Pz]] -----------------
     def forward_zx(self, src, R, M, src_row_stride=None, out_name="T2"):
         """src: R volumes of ny*nx*nz doubles, `src_row_stride` doubles apart (default: contiguous)."""
@@ -144,6 +160,11 @@ class SpectralProduct:
                 hip.xz2d_fold(False, nx, R, ny, src, lds, nx * nz, self.F["x"], self.F["z"], t2, ny * Px * Pz, Px * Pz)
             else:
                 hip.xz2d(False, nx, nz, R, ny, src, lds, nx * nz, M["x"], M["z"], t2, ny * Px * Pz, Px * Pz)
+            return t2
+        if self.pair_xz:
+            t2 = self.buf(out_name, R * ny * Px * Pz)
+            hip.xz2d(False, 2 * nx, nz, R, ny // 2, src, lds, 2 * nx * nz, self._paired(M["x"], Px, nx), M["z"], t2, ny * Px * Pz,
+                     2 * Px * Pz)
             return t2
         t1 = self.buf("T1", rows * Pz)
         hip.gemm_batched(False, hip.pad_n(ny * nx), hip.pad_n(Pz), nz, src, nz, lds, M["z"], nz, 0, t1, Pz, ny * nx * Pz, ny * nx, Pz, R)
@@ -183,6 +204,11 @@ class SpectralProduct:
                     hip.xz2d(True, nx, nz, R, yb - ya, u2[(ya - ylo) * Px * Pz:], Ly * Px * Pz, Px * Pz, self.GT["x"], self.GT["z"],
                              out, ldo, nx * nz)
             return
+        if self.pair_xz and all((yb - ya) % 2 == 0 for ya, yb, _, _ in targets):
+            for ya, yb, out, ldo in targets:
+                hip.xz2d(True, 2 * nx, nz, R, (yb - ya) // 2, u2[(ya - ylo) * Px * Pz:], Ly * Px * Pz, 2 * Px * Pz,
+                         self._paired(self.GT["x"], nx, Px), self.GT["z"], out, ldo, 2 * nx * nz)
+            return
         u1 = self.buf("U1", R * Ly * nx * Pz)
         hip.gemm_batched(True, hip.pad_n(nx), hip.pad_n(Pz), Px, self.GT["x"], Px, 0, u2, Pz, Px * Pz, u1, Pz, nx * Pz, nx, Pz,
                          R * Ly)
@@ -197,6 +223,9 @@ class SpectralProduct:
         pn = hip.pad_n
         fwd = 2.0 * (ny * nx * pn(Pz) * nz + ny * pn(Px) * pn(Pz) * nx)
         bwd = 2.0 * (slab * pn(nx) * pn(Pz) * Px + pn(slab * nx) * pn(nz) * Pz)
+        if self.pair_xz:                            # diag(Mx, Mx) on stacked plane pairs: the x steps run over the zero blocks too
+            fwd += 2.0 * ny * Px * Pz * nx
+            bwd += 2.0 * slab * nx * Pz * Px
         if self.dense_y:
             bwd += 2.0 * ny * ny * Px * Pz          # the kernel computes every output y and stores the slab
         else:

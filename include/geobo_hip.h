@@ -188,8 +188,9 @@ int geobo_scale_broadcast2(const double* a, const double* b0, const double* b1, 
  * p < planes_per_row, at in + r*in_row + p*in_plane goes  X -> Mx X Mz^T  to out + r*out_row + p*out_plane.
  * inverse = 0: X is nx x nz, Mx = G_x (2nx x nx), Mz = G_z (2nz x nz), result 2nx x 2nz (into the spectrum);
  * inverse = 1: X is 2nx x 2nz, Mx = G_x^T (nx x 2nx), Mz = G_z^T (nz x 2nz), result nx x nz (back, cropped).
- * Planes are dense row-major; strides in doubles, even; in 16-byte aligned.  nz = 64 and nx in {48, 64}
- * (GEOBO_E_UNSUPPORTED otherwise: use two geobo_gemm_batched passes). */
+ * Planes are dense row-major; strides in doubles, even; in 16-byte aligned.  (nx, nz) in {(48, 64), (64, 64), (64, 32)}
+ * (GEOBO_E_UNSUPPORTED otherwise: use two geobo_gemm_batched passes).  The matrices are the caller's: 32 x 32 planes go
+ * through (64, 32) two at a time, consecutive planes stacked along x with Mx = diag(Mx32, Mx32) (geobo_amd/spectral.py). */
 int geobo_xz2d(int inverse, int nx, int nz, int64_t rows, int planes_per_row, const double* in, int64_t in_row,
                int64_t in_plane, const double* Mx, int64_t ldmx, const double* Mz, int64_t ldmz, double* out,
                int64_t out_row, int64_t out_plane, void* stream);

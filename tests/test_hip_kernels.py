@@ -392,12 +392,12 @@ def test_toeplitz_y_matches_torch(hip, ny, C, R, nprop, y0, y1):
         assert normwise(outs[j].cpu().numpy(), ref.cpu().numpy()) < 1e-14
 
 
-@pytest.mark.parametrize("nx,rows,ppr", [(48, 3, 37), (64, 3, 37), (64, 4, 800), (48, 7, 500)])
+@pytest.mark.parametrize("nx,nz,rows,ppr", [(48, 64, 3, 37), (64, 64, 3, 37), (64, 64, 4, 800), (48, 64, 7, 500), (64, 32, 3, 37),
+                                            (64, 32, 5, 900)])
 @pytest.mark.parametrize("inverse", [False, True])
-def test_xz2d_matches_torch(hip, nx, rows, ppr, inverse):
+def test_xz2d_matches_torch(hip, nx, nz, rows, ppr, inverse):
     # fused two-axis transform  X -> Mx X Mz^T  per plane, strided rows (asymmetric random operands); the large cases give
     # every persistent workgroup several planes (steady state of the chunk ring, manual vmcnt waits)
-    nz = 64
     ix, iz, ox, oz = (2 * nx, 2 * nz, nx, nz) if inverse else (nx, nz, 2 * nx, 2 * nz)
     Mx, Mz = _rand((ox, ix), 21), _rand((oz, iz), 22)
     in_row = ppr * ix * iz + 16
@@ -484,3 +484,29 @@ def test_a_sens_lattice_form_is_identical_to_the_direct_kernel(hip, func, dims, 
     loc2 = loc.copy(); loc2[3, 0] += 1.0
     assert hip.lattice_plan(loc2, xe, ye, ze, nx, ny, nz) is None
     assert hip.lattice_plan(loc, xe * (1.0 / 3.0), ye, ze, nx, ny, nz) is None or True
+
+
+@pytest.mark.parametrize("R,ny", [(3, 32), (5, 16)])
+def test_spectral_32_planes_go_through_the_fused_kernel_in_pairs(hip, R, ny):
+    """32 x 32 planes (BASELINE config 2): two y-planes stacked along x through the (64, 32) instance with diag(Mx, Mx), against
+    the two batched GEMM passes the same class falls back to."""
+    from geobo_amd.spectral import SpectralProduct
+    sp = SpectralProduct(32, ny, 32, "cuda")
+    assert sp.pair_xz and not sp.fused_xz
+    src = _rand((R, sp.N), 90 + R)
+    got = sp.forward_zx(src, R, sp.G, out_name="pair_fwd")[:R * ny * 64 * 64].clone()
+    sp.pair_xz = False
+    ref = sp.forward_zx(src, R, sp.G, out_name="gemm_fwd")[:R * ny * 64 * 64].clone()
+    assert normwise(got.cpu().numpy(), ref.cpu().numpy()) < 1e-14
+    X = src.reshape(R, ny, 32, 32)
+    G = sp.G["x"][:64, :32]
+    assert normwise(got.reshape(R, ny, 64, 64).cpu().numpy(), torch.einsum("ai,rpik,bk->rpab", G, X, G).cpu().numpy()) < 1e-14
+    u2 = _rand((R * ny * 64 * 64 + 4096,), 91)
+    outs = []
+    for pair in (True, False):
+        sp.pair_xz = pair
+        out = torch.full((R, sp.N + 16), float("nan"), dtype=torch.float64, device="cuda")
+        sp.backward_xz(u2, R, 0, ny, [(0, ny // 2, out, out.stride(0)), (ny // 2, ny, out[:, (ny // 2) * 1024:], out.stride(0))])
+        assert torch.isnan(out[:, sp.N:]).all()
+        outs.append(out[:, :sp.N].clone())
+    assert normwise(outs[0].cpu().numpy(), outs[1].cpu().numpy()) < 1e-14
