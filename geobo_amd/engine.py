@@ -728,6 +728,8 @@ class PosteriorEngine:
         sel = np.asarray(sel, dtype=np.int64)
         sel_t = torch.as_tensor(sel, device=self.device) if sel.size else None
         t = self._tick("start")
+        # the data vector goes up first: a pageable host-to-device copy blocks the host until the stream reaches it
+        y = self._pad_y(y_g, y_m, y_d, hip.pad_m(2 * self.Ms_pad + len(sel)))
         AK, M_pad = self._assemble_AK(A_g, A_m, sel_t, lengths, W, kernelfunc, gp_amp, props)
         t = self._tick("ak_fused", t)
         AkA = self._assemble_AkA(AK, M_pad, A_g, A_m, sel_t, lengths, kernelfunc, gp_amp, gp_sigma, props)
@@ -738,19 +740,24 @@ class PosteriorEngine:
             AkA, self._workspace("Linv", (M_pad, M_pad)), self._workspace("potrf_ws", (hip.potrf_ws_doubles(M_pad),)),
             ctx=self._potrf_ctx), alg=(2 * self.Ms + len(sel)) ** 3 * 2.0 / 3.0)  # AkA now holds L
         L = AkA
-        y = self._pad_y(y_g, y_m, y_d, M_pad)
         u, stats = hip.trmv_stats(Linv, y, L)
-        info_h = int(info.item())
         t = self._tick("cholesky", t)
-        if info_h != 0:
-            raise CholeskyError(info_h)
         out = dict(info=0, M_pad=M_pad, lengths=[float(v) for v in lengths])
-        if calclogl:
-            st = stats.cpu().numpy()
-            out["uu"], out["logdet"] = float(st[0]), float(st[1])
-            out["logl"] = -0.5 * (st[0] + st[1] + self.N * math.log(2 * math.pi))  # inversion.py:107-110
-        else:
-            out["logl"] = 0.0
+
+        def check_factor():
+            # the status word and the likelihood statistics come back in one host read, AFTER the reduction has been queued:
+            # a failed factorisation costs the wasted launch, a good one (every step of a survey) no idle gap in front of it
+            info_h = int(info.item())
+            if info_h != 0:
+                raise CholeskyError(info_h)
+            if calclogl:
+                st = stats.cpu().numpy()
+                out["uu"], out["logdet"] = float(st[0]), float(st[1])
+                out["logl"] = -0.5 * (st[0] + st[1] + self.N * math.log(2 * math.pi))  # inversion.py:107-110
+            else:
+                out["logl"] = 0.0
+        if not want_mean_var:
+            check_factor()
         if want_mean_var:
             # executed flop: every 64-row wavefront group g of the valid rows contracts the 64 g columns in front of its diagonal
             # block in full, and of the block itself the 16-row sub-groups' chunks at or below the diagonal (40 of 64 MFMA steps)
@@ -772,6 +779,7 @@ class PosteriorEngine:
                                                   gp_amp * 1.0, ws, m_valid=Mv) for cs in range(0, ncols, pw)]
                     return torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
                 mu_l, var_l = self._timed("posterior_reduce", fl, panels, alg=(1.0 * Mu * Mu + 4.0 * Mu) * nv)
+            check_factor()
             t = self._tick("posterior", t)
             mu = assemble_columns(gather_slices(mu_l, len(props), self.N_pad, self.world, self.group), props, self.N,
                                   self.N_pad, self.world)

@@ -106,7 +106,10 @@ class Inversion:
         eng = self.engine
         axes = None
         if hasattr(self, "Edges"):
-            axes = sm._edge_axes(self.Edges, eng.nx, eng.ny, eng.nz)
+            # the meshgrid check of the node tensor costs a millisecond at 64^3: once per Edges object
+            if getattr(self, "_axes_of", (None, None))[0] is not self.Edges:
+                self._axes_of = (self.Edges, sm._edge_axes(self.Edges, eng.nx, eng.ny, eng.nz))
+            axes = self._axes_of[1]
         A_g = eng.operator("grav", self.sensor_locations, B=self.settings.magneticField * 0., axes=axes)
         A_m = eng.operator("magn", self.sensor_locations, B=self.settings.magneticField, axes=axes)
         return A_g, A_m
@@ -213,7 +216,10 @@ class Inversion:
         gravfield_norm, grav_std = _zscore(self.gravfield)
         magfield_norm, magn_std = _zscore(self.magfield)
         drillfield_norm, drill_std = _zscore(self.drillfield)
-        self.points3D = kernel.calcGridPoints3D((s.xNcube, s.yNcube, s.zNcube), (s.xvoxsize, s.yvoxsize, s.zvoxsize))
+        gkey = (s.xNcube, s.yNcube, s.zNcube, s.xvoxsize, s.yvoxsize, s.zvoxsize)
+        if getattr(self, "_points_key", None) != gkey:
+            self._points_key, self._points3D = gkey, kernel.calcGridPoints3D(gkey[:3], gkey[3:])
+        self.points3D = self._points3D
         self._sel = self._drill_selection()
         if self._sel.size != self.drillfield.size:
             raise ValueError("drillfield must hold one value per non-zero voxel of drilldata0")
