@@ -209,6 +209,29 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_f64_kernel(const GemmArg
   for (int m = 0; m < 4; ++m)
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[m][n] = (v4d){0., 0., 0., 0.};
+  // C <- alpha X Y^T + beta C with |beta| = |alpha| (rank-k updates of the Cholesky trailing matrix, accumulating panels): the
+  // accumulators START as (beta / alpha) C -- exact -- so the loads of C fly together with the first operand chunks instead of
+  // sitting, latency exposed, between the last MFMA and the stores (K = 128 update at m = 8192: 378 -> 2xx us).
+  bool c_in_acc = false;
+  if constexpr (EPI == EPI_STORE && (YMODE == Y_NT || YMODE == Y_NN)) {
+    c_in_acc = a.beta != 0.0 && (a.beta == a.alpha || a.beta == -a.alpha);
+    if (c_in_acc) {
+      const double sgn = (a.beta == a.alpha) ? 1.0 : -1.0;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            // branch-free (clamped address + select): under a per-element branch the compiler waits for every load on its own
+            const int64_t row = row0 + wm * 64 + m * 16 + lg + 4 * r;
+            const int64_t col = col0 + wn * 64 + n * 16 + lr;
+            const bool ok = row < a.m_valid && col < a.n_valid;
+            const double c = Cp[(row < a.m_valid ? row : a.m_valid - 1) * a.ldc + (col < a.n_valid ? col : a.n_valid - 1)];
+            acc[m][n][r] = ok ? sgn * c : 0.0;
+          }
+    }
+  }
 
   // ---- staging: global -> LDS by LDS-DMA (global_load_lds_dwordx4) -------------------------------------------
   // No VGPR round trip and no ds_write: a wave instruction moves 64 x 16 B = 8 tile rows; the LDS image is lane-linear
@@ -537,7 +560,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_f64_kernel(const GemmArg
           if (row < a.m_valid && col < a.n_valid) {
             double v = a.alpha * acc[m][n][r];
             double* dst = Cp + row * a.ldc + col;
-            if (a.beta != 0.0) v += a.beta * (*dst);
+            if (a.beta != 0.0 && !c_in_acc) v += a.beta * (*dst);
             *dst = v;
           }
         }
@@ -656,10 +679,10 @@ int launch(GemmArgs& a, hipStream_t st) {
 }
 
 template <int YMODE, int EPI, int KID>
-int launch_by_rows(GemmArgs& a, int64_t m, int64_t n, hipStream_t st) {
+int launch_by_rows(GemmArgs& a, int64_t m, int64_t n, hipStream_t st, bool small_tiles = false) {
   if (n % 128) return GEOBO_E_ALIGN;
   a.nbj = (int)(n / 128);
-  if (m % 256 == 0) { a.nbi = (int)(m / 256); return launch<4, 2, YMODE, EPI, KID>(a, st); }
+  if (m % 256 == 0 && !small_tiles) { a.nbi = (int)(m / 256); return launch<4, 2, YMODE, EPI, KID>(a, st); }
   if (m % 128 == 0) { a.nbi = (int)(m / 128); return launch<2, 2, YMODE, EPI, KID>(a, st); }
   return GEOBO_E_ALIGN;
 }
@@ -719,9 +742,9 @@ extern "C" int geobo_gemm_nt(int64_t m, int64_t n, int64_t k, double alpha, cons
   if (k % BK || (ldx & 1) || (ldy & 1)) return GEOBO_E_ALIGN;
   GemmArgs a{};
   a.X = X; a.ldx = ldx; a.Y = Y; a.ldy = ldy; a.C = C; a.ldc = ldc; a.k = k;
-  a.alpha = alpha; a.beta = beta; a.tri = lower_only ? TRI_LOWER_ONLY : 0;
+  a.alpha = alpha; a.beta = beta; a.tri = (lower_only & GEOBO_GEMM_LOWER_ONLY) ? TRI_LOWER_ONLY : 0;
   a.m_valid = m_valid;
-  return launch_by_rows<Y_NT, EPI_STORE, COV_D2>(a, m, n, (hipStream_t)stream);
+  return launch_by_rows<Y_NT, EPI_STORE, COV_D2>(a, m, n, (hipStream_t)stream, (lower_only & GEOBO_GEMM_SMALL_TILES) != 0);
 }
 
 extern "C" int geobo_gemm_nt_splitk(int64_t m, int64_t n, int64_t k, int splits, const double* X, int64_t ldx, const double* Y,

@@ -267,7 +267,10 @@ extern "C" int geobo_potrf_inv(int64_t m, double* A, int64_t ld, double* Linv, i
     const int64_t rem = m - kb - NB;
     if (rem > 0) {
       double* P = A + (kb + NB) * ld + kb;
-      int rc = geobo_gemm_nt(rem, NB, NB, 1.0, P, ld, Linv + kb * ldi + kb, ldi, 0.0, P, ld, 0, 0, stream);
+      // panel and (a) are short and run next to (b) of the previous step: 128-row tiles find room as soon as HALF a CU drains
+      // (a 512-thread workgroup waits for a whole CU: behind 256-thread (b) tiles that only happens when (b) ends)
+      const int crit = pc ? GEOBO_GEMM_SMALL_TILES : 0;
+      int rc = geobo_gemm_nt(rem, NB, NB, 1.0, P, ld, Linv + kb * ldi + kb, ldi, 0.0, P, ld, crit, 0, stream);
       if (rc) return rc;
       if (!pc) {
         rc = geobo_gemm_nt(rem, rem, NB, -1.0, P, ld, P, ld, 1.0, A + (kb + NB) * ld + (kb + NB), ld, 1, 0, stream);
@@ -277,7 +280,7 @@ extern "C" int geobo_potrf_inv(int64_t m, double* A, int64_t ld, double* Linv, i
       if (hipEventRecord(Pev[step & 3], st) != hipSuccess) return GEOBO_E_LAUNCH;
       if (last_b >= 0 && hipStreamWaitEvent(st, Bev[last_b & 3], 0) != hipSuccess) return GEOBO_E_LAUNCH;
       // (a)_c: column block c+1, rows >= c+1
-      rc = geobo_gemm_nt(rem, NB, NB, -1.0, P, ld, P, ld, 1.0, A + (kb + NB) * ld + (kb + NB), ld, 0, 0, stream);
+      rc = geobo_gemm_nt(rem, NB, NB, -1.0, P, ld, P, ld, 1.0, A + (kb + NB) * ld + (kb + NB), ld, crit, 0, stream);
       if (rc) return rc;
       prev_b = last_b;
       if (rem > NB) {

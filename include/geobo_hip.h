@@ -139,9 +139,14 @@ int geobo_ak_fused_grid(const double* A, int64_t Ms_pad, int64_t N_pad, int64_t 
 
 /* C = alpha * X * Y^T + beta * C   (X: m x k, Y: n x k, both k-contiguous).  inversion.py:96 (AkA = (A K) A^T),
  * Cholesky panel/trailing updates.  m % 256 == 0, n % 128 == 0, k % 16 == 0.
- * lower_only != 0: tiles strictly above the diagonal are skipped (SYRK-style).
+ * lower_only: flag word.  GEOBO_GEMM_LOWER_ONLY (1): tiles strictly above the diagonal are skipped (SYRK-style).
+ * GEOBO_GEMM_SMALL_TILES (2): 128-row workgroup tiles (256 threads) even when m % 256 == 0 -- for short launches that must
+ * find room next to a concurrent kernel on another stream (two such workgroups share a CU; a 512-thread workgroup needs a
+ * whole CU to drain first).  The Cholesky panel solves use it.
  * m_valid > 0: rows >= m_valid of X are zero padding -- they are neither contracted (64-row groups that lie entirely in
  * the padding issue no MFMAs) nor stored (those rows of C are left untouched); 0 = all m rows. */
+#define GEOBO_GEMM_LOWER_ONLY 1
+#define GEOBO_GEMM_SMALL_TILES 2
 int geobo_gemm_nt(int64_t m, int64_t n, int64_t k, double alpha, const double* X, int64_t ldx,
                   const double* Y, int64_t ldy, double beta, double* C, int64_t ldc, int lower_only, int64_t m_valid,
                   void* stream);
