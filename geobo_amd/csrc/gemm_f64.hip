@@ -775,8 +775,8 @@ extern "C" int geobo_gemm_nn(int64_t m, int64_t n, int64_t k, double alpha, cons
   if (k % BK || (ldx & 1) || (ldy & 1)) return GEOBO_E_ALIGN;
   GemmArgs a{};
   a.X = X; a.ldx = ldx; a.Y = Y; a.ldy = ldy; a.C = C; a.ldc = ldc; a.k = k;
-  a.alpha = alpha; a.beta = beta; a.tri = (x_lower ? TRI_X_LOWER : 0) | (y_lower ? TRI_Y_LOWER : 0);
-  return launch_by_rows<Y_NN, EPI_STORE, COV_D2>(a, m, n, (hipStream_t)stream);
+  a.alpha = alpha; a.beta = beta; a.tri = ((x_lower & 1) ? TRI_X_LOWER : 0) | ((y_lower & 1) ? TRI_Y_LOWER : 0);
+  return launch_by_rows<Y_NN, EPI_STORE, COV_D2>(a, m, n, (hipStream_t)stream, ((x_lower | y_lower) & GEOBO_GEMM_SMALL_TILES) != 0);
 }
 
 extern "C" int geobo_gemm_batched(int y_is_kn, int64_t m, int64_t n, int64_t k, double alpha, const double* X, int64_t ldx,

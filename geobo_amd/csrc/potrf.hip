@@ -146,60 +146,97 @@ __global__ void __launch_bounds__(256) logl_stats_kernel(int64_t m, const double
   if (tid == 0) { stats[0] = s0[0]; stats[1] = s1[0]; }
 }
 
-// L^-1 by recursive halving.  The two halves of a node are independent until their merge, and the merges near the
-// leaves are a handful of tiles each (latency of ONE tile's k sweep, 0.2-0.5 ms, whatever the chip could do in
-// parallel): with a fork context (geobo_potrf_ctx_create) the top two levels of the tree fork onto the context's streams, so
-// four subtrees run concurrently, and join by events before their parent's merge.  Everything is ordered after / before
-// the caller's stream by the same events.  Without a context the whole tree runs on the caller's stream.
+// L^-1 by recursive halving, two MFMA GEMMs per merge:
+//   node [lo, hi) split at mid:   T = L[mid:hi, lo:mid] * Linv[lo:mid, lo:mid],   Linv[mid:hi, lo:mid] = -Linv[mid:hi, mid:hi] * T.
+// The merges near the leaves are a handful of tiles each (the latency of ONE tile's k sweep, whatever the chip could do in
+// parallel), so the tree is not built after the factorisation but UNDER it (with a fork context): along the right spine
+//   [0, nb) -> [mid_0, nb) -> [mid_1, nb) -> ...
+// the left child [lo_d, mid_d) of spine node d only needs columns < mid_d of L, which are final once the factorisation has
+// passed step mid_d - 1.  At that point a worker stream of the context inverts the left child (serial recursion: dozens of
+// launches of a few tiles each, which fit between the factorisation's own kernels).  What remains after the last panel is the
+// short last spine segment and the two GEMMs of every spine node's merge: T_d = L[mid_d:nb, lo_d:mid_d] * Linv[lo_d:mid_d, lo_d:mid_d]
+// on the workers, all spine nodes at once, and Linv[mid_d:nb, lo_d:mid_d] = -Linv[mid_d:nb, mid_d:nb] * T_d, deepest first.
 struct InvCtx {
-  const double* L; int64_t ld; double* Linv; int64_t ldi; double* ws; size_t ws_doubles;
-  hipStream_t s[4]; hipEvent_t ev[6]; int nev; bool fork;
+  const double* L; int64_t ld; double* Linv; int64_t ldi; double* T; hipStream_t st;
 };
 
-int build_inverse(InvCtx& c, int lo, int hi, int depth, int sidx) {
-  if (hi - lo <= 1) return GEOBO_OK;
+int split_point(int lo, int hi) {
   // split on a multiple of two 128-blocks where possible: the merge GEMMs then run on 256-row tiles
   int mid = (lo + hi) / 2;
   if (hi - lo > 2 && ((mid - lo) & 1)) ++mid;
-  int rc;
-  if (c.fork && depth < 2 && hi - lo >= 8) {
-    const int other = sidx + (depth == 0 ? 2 : 1);
-    hipEvent_t fork = c.ev[c.nev++], join = c.ev[c.nev++];
-    if (hipEventRecord(fork, c.s[sidx]) != hipSuccess || hipStreamWaitEvent(c.s[other], fork, 0) != hipSuccess) return GEOBO_E_LAUNCH;
-    rc = build_inverse(c, lo, mid, depth + 1, sidx);
-    if (rc) return rc;
-    rc = build_inverse(c, mid, hi, depth + 1, other);
-    if (rc) return rc;
-    if (hipEventRecord(join, c.s[other]) != hipSuccess || hipStreamWaitEvent(c.s[sidx], join, 0) != hipSuccess) return GEOBO_E_LAUNCH;
-  } else {
-    rc = build_inverse(c, lo, mid, depth + 1, sidx);
-    if (rc) return rc;
-    rc = build_inverse(c, mid, hi, depth + 1, sidx);
-    if (rc) return rc;
-  }
-  // scratch for T: the root owns the whole workspace, its children a half each, everything below a quarter per stream
-  double* T = depth == 0 ? c.ws : depth == 1 ? c.ws + (sidx / 2) * (c.ws_doubles / 2) : c.ws + sidx * (c.ws_doubles / 4);
-  void* st = c.s[sidx];
+  return mid;
+}
+
+// T (r x cc, leading dimension cc) = L[mid:hi, lo:mid] * Linv[lo:mid, lo:mid]   (Y lower triangular)
+int form_T(const InvCtx& c, int lo, int mid, int hi, double* T) {
   const int64_t r = (int64_t)(hi - mid) * NB, cc = (int64_t)(mid - lo) * NB;
   const int64_t o_lo = (int64_t)lo * NB, o_mid = (int64_t)mid * NB;
-  // T = L[mid:hi, lo:mid] * Linv[lo:mid, lo:mid]           (Y lower triangular)
-  rc = geobo_gemm_nn(r, cc, cc, 1.0, c.L + o_mid * c.ld + o_lo, c.ld, c.Linv + o_lo * c.ldi + o_lo, c.ldi, 0.0, T, cc, 0, 1, st);
+  return geobo_gemm_nn(r, cc, cc, 1.0, c.L + o_mid * c.ld + o_lo, c.ld, c.Linv + o_lo * c.ldi + o_lo, c.ldi, 0.0, T, cc, 0, 1, c.st);
+}
+
+// Linv[mid:hi, lo:mid] = -Linv[mid:hi, mid:hi] * T         (X lower triangular)
+int merge_T(const InvCtx& c, int lo, int mid, int hi, const double* T) {
+  const int64_t r = (int64_t)(hi - mid) * NB, cc = (int64_t)(mid - lo) * NB;
+  const int64_t o_lo = (int64_t)lo * NB, o_mid = (int64_t)mid * NB;
+  return geobo_gemm_nn(r, cc, r, -1.0, c.Linv + o_mid * c.ldi + o_mid, c.ldi, T, cc, 0.0, c.Linv + o_mid * c.ldi + o_lo, c.ldi, 1, 0,
+                       c.st);
+}
+
+// whole subtree [lo, hi) on c.st, scratch c.T (>= scratch_blocks(hi - lo) * NB^2 doubles: every T is consumed before the next)
+int build_inverse(const InvCtx& c, int lo, int hi) {
+  if (hi - lo <= 1) return GEOBO_OK;
+  const int mid = split_point(lo, hi);
+  int rc = build_inverse(c, lo, mid);
   if (rc) return rc;
-  // Linv[mid:hi, lo:mid] = -Linv[mid:hi, mid:hi] * T         (X lower triangular)
-  return geobo_gemm_nn(r, cc, r, -1.0, c.Linv + o_mid * c.ldi + o_mid, c.ldi, T, cc, 0.0, c.Linv + o_mid * c.ldi + o_lo, c.ldi, 1, 0, st);
+  rc = build_inverse(c, mid, hi);
+  if (rc) return rc;
+  rc = form_T(c, lo, mid, hi, c.T);
+  if (rc) return rc;
+  return merge_T(c, lo, mid, hi, c.T);
+}
+
+int64_t scratch_blocks(int n) {   // 128 x 128 blocks of T scratch a serial subtree of n blocks needs (its root's T is the largest)
+  if (n <= 1) return 0;
+  const int mid = split_point(0, n);
+  return (int64_t)(n - mid) * mid;
+}
+
+// right spine of the tree over nb blocks: nodes d < depth with (lo, mid); the last segment [lo[depth], nb) is a plain subtree
+constexpr int MAX_SPINE = 8, SPINE_LEAF = 8;
+struct Spine {
+  int depth; int lo[MAX_SPINE + 1], mid[MAX_SPINE];
+  int64_t t_off[MAX_SPINE], s_off[MAX_SPINE], leaf_off, total;   // offsets into the workspace, in doubles
+};
+Spine plan_spine(int nb) {
+  Spine sp;
+  sp.depth = 0;
+  int lo = 0;
+  int64_t off = 0;
+  while (nb - lo > SPINE_LEAF && sp.depth < MAX_SPINE) {
+    const int mid = split_point(lo, nb), d = sp.depth++;
+    sp.lo[d] = lo; sp.mid[d] = mid;
+    sp.t_off[d] = off; off += (int64_t)(nb - mid) * (mid - lo) * NB * NB;
+    sp.s_off[d] = off; off += scratch_blocks(mid - lo) * NB * NB;
+    lo = mid;
+  }
+  sp.lo[sp.depth] = lo;
+  sp.leaf_off = off; off += scratch_blocks(nb - lo) * NB * NB;
+  sp.total = off;
+  return sp;
 }
 
 // Fork context (geobo_potrf_ctx_create): three streams + a few events on the device that was current at creation, owned by
 // the caller.  Nothing here is process-global: two engines (or two devices, or two threads) each bring their own.
-constexpr int NEV = 14;   // 6 for the L^-1 tree, 2 x 4 for the look-ahead rings of the factorisation
+constexpr int NEV = 8 + 2 * MAX_SPINE;   // 2 x 4 for the look-ahead rings of the factorisation, 2 per spine node of the L^-1 tree
 struct PotrfCtx { int dev; hipStream_t s[3]; hipEvent_t ev[NEV]; };
 
 }  // namespace
 
 extern "C" size_t geobo_potrf_ws_bytes(int64_t m) {
   const int64_t nb = (m + NB - 1) / NB;
-  const int64_t half = ((nb + 1) / 2) * NB;
-  return (size_t)(half * half) * sizeof(double);
+  const Spine sp = plan_spine((int)nb);          // every spine node's T and its worker's scratch side by side (they overlap in time)
+  const int64_t serial = scratch_blocks((int)nb) * NB * NB;
+  return (size_t)(sp.total > serial ? sp.total : serial) * sizeof(double);
 }
 
 extern "C" int geobo_potrf_ctx_create(void** ctx) {
@@ -253,8 +290,16 @@ extern "C" int geobo_potrf_inv(int64_t m, double* A, int64_t ld, double* Linv, i
   // remains.  Every element still receives the same updates in the same order: bit-identical to the serial schedule.
   const PotrfCtx* pc = (const PotrfCtx*)ctx;
   hipStream_t side = pc ? pc->s[0] : st;
-  const hipEvent_t* Pev = pc ? pc->ev + 6 : nullptr;
-  const hipEvent_t* Bev = pc ? pc->ev + 10 : nullptr;
+  const hipEvent_t* Pev = pc ? pc->ev : nullptr;
+  const hipEvent_t* Bev = pc ? pc->ev + 4 : nullptr;
+  const hipEvent_t* Sev = pc ? pc->ev + 8 : nullptr;     // spine node d: [2d] factorisation passed mid_d, [2d+1] its T_d is ready
+  const int nb = (int)(m / NB);
+  Spine sp = plan_spine(nb);
+  if (!pc) { sp.depth = 0; sp.lo[0] = 0; sp.leaf_off = 0; }   // no workers: the whole tree after the factorisation, on the caller's stream
+  InvCtx ic;
+  ic.L = A; ic.ld = ld; ic.Linv = Linv; ic.ldi = ldi;
+  double* const wsd = (double*)ws;
+  int next_spine = 0;                                    // spine nodes are passed in order: mid_0 < mid_1 < ...
   int step = 0, last_b = -1, prev_b = -1;   // steps whose (b) was launched most recently
   if (pc) {   // the side stream starts after everything already queued on the caller's stream (the memsets above, the producer of A)
     if (hipEventRecord(Pev[3], st) != hipSuccess || hipStreamWaitEvent(side, Pev[3], 0) != hipSuccess) return GEOBO_E_LAUNCH;
@@ -272,6 +317,15 @@ extern "C" int geobo_potrf_inv(int64_t m, double* A, int64_t ld, double* Linv, i
       const int crit = pc ? GEOBO_GEMM_SMALL_TILES : 0;
       int rc = geobo_gemm_nt(rem, NB, NB, 1.0, P, ld, Linv + kb * ldi + kb, ldi, 0.0, P, ld, crit, 0, stream);
       if (rc) return rc;
+      if (next_spine < sp.depth && step + 1 == sp.mid[next_spine]) {
+        // columns < mid_d of L are final: a worker inverts the spine node's left child under the rest of the loop
+        const int d = next_spine++;
+        hipStream_t wk = pc->s[1 + (d & 1)];
+        if (hipEventRecord(Sev[2 * d], st) != hipSuccess || hipStreamWaitEvent(wk, Sev[2 * d], 0) != hipSuccess) return GEOBO_E_LAUNCH;
+        ic.st = wk; ic.T = wsd + sp.s_off[d];
+        rc = build_inverse(ic, sp.lo[d], sp.mid[d]);
+        if (rc) return rc;
+      }
       if (!pc) {
         rc = geobo_gemm_nt(rem, rem, NB, -1.0, P, ld, P, ld, 1.0, A + (kb + NB) * ld + (kb + NB), ld, 1, 0, stream);
         if (rc) return rc;
@@ -295,17 +349,26 @@ extern "C" int geobo_potrf_inv(int64_t m, double* A, int64_t ld, double* Linv, i
     }
   }
   if (pc && last_b >= 0 && hipStreamWaitEvent(st, Bev[last_b & 3], 0) != hipSuccess) return GEOBO_E_LAUNCH;
-  InvCtx c;
-  c.L = A; c.ld = ld; c.Linv = Linv; c.ldi = ldi; c.ws = (double*)ws; c.ws_doubles = geobo_potrf_ws_bytes(m) / sizeof(double);
-  c.s[0] = st;
-  c.nev = 0;
-  c.fork = ctx != nullptr;
-  if (c.fork) {
-    const PotrfCtx* pc = (const PotrfCtx*)ctx;
-    for (int i = 0; i < 3; ++i) c.s[i + 1] = pc->s[i];
-    for (int i = 0; i < 6; ++i) c.ev[i] = pc->ev[i];
+  // the T products (hundreds of long tiles) wait for the end of the loop: under it they cost the critical path more than they
+  // hide (measured 18.9 against 17.9 ms, also in chunks and on 128-row tiles) -- one worker per spine node, concurrently
+  for (int d = 0; d < sp.depth; ++d) {
+    ic.st = pc->s[1 + (d & 1)];
+    // not before the factorisation is through (the event of the node's start is free again: its wait was captured at the time)
+    if (hipEventRecord(Sev[2 * d], st) != hipSuccess || hipStreamWaitEvent(ic.st, Sev[2 * d], 0) != hipSuccess) return GEOBO_E_LAUNCH;
+    int rc = form_T(ic, sp.lo[d], sp.mid[d], nb, wsd + sp.t_off[d]);
+    if (rc) return rc;
+    if (hipEventRecord(Sev[2 * d + 1], ic.st) != hipSuccess) return GEOBO_E_LAUNCH;
   }
-  return build_inverse(c, 0, (int)(m / NB), 0, 0);
+  // what is left: the last spine segment, then the second GEMM of every spine node's merge, deepest first
+  ic.st = st; ic.T = wsd + sp.leaf_off;
+  int rc = build_inverse(ic, sp.lo[sp.depth], nb);
+  if (rc) return rc;
+  for (int d = sp.depth - 1; d >= 0; --d) {
+    if (hipStreamWaitEvent(st, Sev[2 * d + 1], 0) != hipSuccess) return GEOBO_E_LAUNCH;
+    rc = merge_T(ic, sp.lo[d], sp.mid[d], nb, wsd + sp.t_off[d]);
+    if (rc) return rc;
+  }
+  return GEOBO_OK;
 }
 
 extern "C" int geobo_trmv_stats(int64_t m, const double* Linv, int64_t ldi, const double* y, const double* L,

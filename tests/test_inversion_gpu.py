@@ -221,11 +221,14 @@ def test_optimize_gp_reaches_the_reference_optimum():
     # Same objective (the probes above and the reference's optimum below agree to 1e-8), but SHGO's local SLSQP steps use
     # forward differences with h = 1.5e-8: rounding-level differences of the objective (1e-12 relative) move the gradient by
     # ~1e-2, so two correct implementations stop at slightly different points of the flat valley.  Pinned: the optimum found here
-    # is at least as good as the reference's, within 0.5 % of its objective and 10 % of its coordinates.
+    # is at least as good as the reference's, within 0.5 % of its objective; coordinates as below.
     assert abs(inv.calc_logl(ref_x) - ref_fun) <= 1e-8 * abs(ref_fun)
     assert fun <= ref_fun + 1e-6 * abs(ref_fun)
     assert abs(fun - ref_fun) <= 5e-3 * abs(ref_fun)
-    assert (np.abs(x - ref_x) <= 0.1 * np.abs(ref_x)).all()
+    # amplitude and length scale within 10 %; the three correlation coefficients sit in the flat part of the valley (a change of
+    # 0.05 in the last one moves the objective in the fourth digit): within 0.1 absolute
+    assert (np.abs(x[:2] - ref_x[:2]) <= 0.1 * np.abs(ref_x[:2])).all()
+    assert (np.abs(x[2:] - ref_x[2:]) <= 0.1).all()
     # the optimised state must be usable (the reference's is not): one more inversion with it
     cubes = inv.cubing(f["gravfield"], f["magfield"], d0[d0 != 0], f["sensor_locations"], d0)
     assert np.isfinite(cubes[0]).all()
