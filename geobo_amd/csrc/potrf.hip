@@ -284,10 +284,9 @@ extern "C" int geobo_potrf_inv(int64_t m, double* A, int64_t ld, double* Linv, i
   // the caller's stream already factors the next diagonal block and solves the next panel, which need (a)_c and (b)_(c-2) only:
   //     caller's stream:  [wait (b)_(c-2)] potf2(c), panel(c) -> event P_c;  [wait (b)_(c-1): same column block] (a)_c
   //     side stream:      [wait P_c] (b)_c -> event B_c
-  // The two small latency-bound launches of a step (86 + 74 us at M = 8448) start while the previous step's (b) still runs.
-  // Measured gain is small (22.8 -> 22.3 ms): (b) occupies every CU with one workgroup, so the critical-path kernels wait for
-  // a tile of it to retire (~80 us; stream priorities do not change that) -- the chain potf2 + panel + (a) = 66 x ~200 us is what
-  // remains.  Every element still receives the same updates in the same order: bit-identical to the serial schedule.
+  // The first half of the loop is bound by (b) (250 us per step at M = 8448: a K = 128 rank update moves 16 flop per byte of C),
+  // the second half by the chain potf2 + panel + (a) = ~175 us per step.  Every element still receives the same updates in the
+  // same order: bit-identical to the serial schedule.
   const PotrfCtx* pc = (const PotrfCtx*)ctx;
   hipStream_t side = pc ? pc->s[0] : st;
   const hipEvent_t* Pev = pc ? pc->ev : nullptr;

@@ -46,7 +46,10 @@ def test_host_side_helpers(lib):
     assert lib.geobo_version() == 200
     assert lib.geobo_pad_m(8242) == 8448 and lib.geobo_pad_m(256) == 256 and lib.geobo_pad_m(1) == 256
     assert lib.geobo_pad_n(480) == 512 and lib.geobo_pad_n(262144) == 262144
-    assert lib.geobo_potrf_ws_bytes(8448) == (33 * 128) ** 2 * 8
+    # 66 blocks of 128: spine nodes (0, 34), (34, 50), (50, 58) and the last segment (58, 66); per node its T (rows behind mid x its
+    # left child) and the scratch of the worker that inverts the left child -- 1088 + 288, 256 + 64, 64 + 16, and 16 for the segment
+    assert lib.geobo_potrf_ws_bytes(8448) == 1792 * 128 * 128 * 8
+    assert lib.geobo_potrf_ws_bytes(1024) == 16 * 128 * 128 * 8      # 8 blocks: no spine, the serial tree's largest T (4 x 4 blocks)
 
 
 def test_argument_validation_without_gpu(lib):
