@@ -1,5 +1,7 @@
+"""Rank-k update  C <- C - P P^T  (lower tiles) at the shapes of the Cholesky trailing updates: time, flop rate and the traffic of C
+for k = 128 / 256 / 512, with and without the read of C (beta).  python tools/bench_rank_update.py"""
 import sys, os
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from geobo_amd import hip
 def t(f, n=5):
