@@ -355,6 +355,7 @@ def main():
                        "method": "spectral" if inv.engine.use_spectral else "dense", "assembly": a.assembly, "operators": a.operators,
                        "row_exchange": bool(inv.engine.exchange),
                        "ms_per_step_median": step_ms[len(step_ms) // 2], "ms_per_step_all_rank0": [round(v, 2) for v in step_ms],
+                       "ms_per_step_in_order_rank0": [round(1e3 * (b - a_), 2) for a_, b in zip(marks[:-1], marks[1:])],
                        "cube_checksums": [float(np.abs(cubes[i]).sum()) for i in ((0, 1, 3, 4) if p_out == 2 else range(6))],
                        "dense_algorithmic_flop_per_step": F,
                        "executed_mfma_flop_per_step_rank0": F_mfma, "executed_valu_flop_per_step_rank0": F_valu,

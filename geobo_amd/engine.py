@@ -138,6 +138,7 @@ class PosteriorEngine:
         self._xyz = None
         self._A = {}
         self._ws = {}   # persistent device workspaces keyed by name (re-used across calls: no per-step allocation)
+        self._host = {}  # pinned host staging buffers of the result read-back, keyed by slot
         self.use_grid = self.nz >= 16 and self.nz % 2 == 0  # lattice-table generator (geobo_ak_fused_grid); coordinates otherwise
         # spectral (real-DFT) product: regular grid with extents % 16 == 0, unpadded voxel columns, shards on y-slab boundaries
         plane = self.nx * self.nz
@@ -295,6 +296,18 @@ class PosteriorEngine:
             self._ws.pop(name, None)
             t = self._ws[name] = torch.empty(shape, dtype=dtype, device=self.device)
         return t
+
+    def _to_host(self, t, slot=0):
+        """Device vector -> host array through a persistent PINNED staging buffer (valid until the next call with the same slot).
+        A pageable device-to-host copy pins its destination on the fly; on a busy host that now and then took 20-30 ms for the
+        4 MB of a result vector (one 64^3 step in five came out 4 % slow)."""
+        n = t.numel()
+        buf = self._host.get(slot)
+        if buf is None or buf.numel() < n or buf.dtype != t.dtype:
+            buf = self._host[slot] = torch.empty(max(n, 1), dtype=t.dtype, pin_memory=True)
+        buf[:n].copy_(t.detach().reshape(-1), non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return buf[:n].numpy()
 
     def _workspace2d(self, name, rows, cols, pad=16, dtype=F64):
         """(rows x cols) view of a persistent buffer whose leading dimension is cols + pad.  Power-of-two row strides
@@ -747,11 +760,14 @@ class PosteriorEngine:
         def check_factor():
             # the status word and the likelihood statistics come back in one host read, AFTER the reduction has been queued:
             # a failed factorisation costs the wasted launch, a good one (every step of a survey) no idle gap in front of it
+            # the long wait of a step is spent HERE, in the stream's own synchronize: a pageable device-to-host copy that has to wait
+            # for a busy stream itself now and then returns 25-30 ms late (one step in five at 64^3)
+            torch.cuda.current_stream(self.device).synchronize()
             info_h = int(info.item())
             if info_h != 0:
                 raise CholeskyError(info_h)
             if calclogl:
-                st = stats.cpu().numpy()
+                st = self._to_host(stats, "stats")
                 out["uu"], out["logdet"] = float(st[0]), float(st[1])
                 out["logl"] = -0.5 * (st[0] + st[1] + self.N * math.log(2 * math.pi))  # inversion.py:107-110
             else:
@@ -782,9 +798,9 @@ class PosteriorEngine:
             check_factor()
             t = self._tick("posterior", t)
             mu = assemble_columns(gather_slices(mu_l, len(props), self.N_pad, self.world, self.group), props, self.N,
-                                  self.N_pad, self.world)
+                                  self.N_pad, self.world, to_host=self._to_host)
             var = assemble_columns(gather_slices(var_l, len(props), self.N_pad, self.world, self.group), props, self.N,
-                                   self.N_pad, self.world)
+                                   self.N_pad, self.world, to_host=self._to_host)
             out["mu"], out["var"] = mu, var
             self._tick("d2h", t)
         self.last = dict(L=L, Linv=Linv, u=u, AK=AK, props=props, sel=sel)

@@ -61,9 +61,10 @@ def gather_rows(local, world, group=None):
     return out
 
 
-def assemble_columns(parts, props, n, n_pad, world):
+def assemble_columns(parts, props, n, n_pad, world, to_host=None):
     """Per-rank [P_c x ncols_r] slices -> one (3n,) host vector in the reference's property-major order
-    (NaN for property blocks that were not computed)."""
+    (NaN for property blocks that were not computed).  to_host(tensor, slot) -> 1-D host array that stays valid until the next
+    call with the same slot (the engine's pinned staging buffers); default: a pageable copy per part."""
     out = np.full(3 * n, np.nan)
     for r, part in enumerate(parts):
         c0, c1 = shard_columns(n_pad, world, r)
@@ -71,7 +72,10 @@ def assemble_columns(parts, props, n, n_pad, world):
         hi = min(c1, n)
         if hi <= c0:
             continue
-        ph = part.detach().cpu().numpy() if isinstance(part, torch.Tensor) else np.asarray(part)
+        if isinstance(part, torch.Tensor):
+            ph = to_host(part, r) if (to_host is not None and part.is_cuda) else part.detach().cpu().numpy()
+        else:
+            ph = np.asarray(part)
         for jj, j in enumerate(props):
             out[j * n + c0:j * n + hi] = ph[jj * ncr:jj * ncr + (hi - c0)]
     return out
