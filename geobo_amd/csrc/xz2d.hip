@@ -363,6 +363,103 @@ __global__ void __launch_bounds__(64 * NW, 1) xcorr_kernel(XCArgs g) {
   }
 }
 
+// ---- lattice Gram, y step (geobo_ymul) ----------------------------------------------------------------------------------------
+// out[r][ky][c] = sum_y G[ky][y] in[r][y][c]   for every row r and column c < C: the same 128 x 64 matrix from the left of every
+// (64 x C) row.  As a batched GEMM (geobo_gemm_batched) every 128 x 128 tile restaged G through LDS and paid a prologue and an
+// epilogue for four 16-deep chunks (0.45 ms per 256 rows at 64^3, 3.4 TB/s).  Here G lives in registers as MFMA A fragments
+// (wave w owns the 32 output rows 32w .. 32w+31), a persistent workgroup streams (row, 64-column block) tiles of the input
+// through a two-stage LDS ring by LDS-DMA, and the only LDS traffic is the B fragments.
+struct YMulArgs {
+  const double* in; int64_t in_row;     // row r at in + r*in_row, [64][C]
+  const double* G; int64_t ldg;         // 128 x 64
+  double* out; int64_t out_row;         // row r at out + r*out_row, [128][C]
+  int64_t C, R, ntiles;                 // ntiles = R * (C / 64)
+};
+
+__global__ void __launch_bounds__(256, 2) ymul_kernel(YMulArgs g) {
+  constexpr int NY = 64, CB = 64, TILE = NY * CB;          // doubles per staged tile (32 KiB)
+  __shared__ __attribute__((aligned(16))) double xs[2][TILE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, q = lane >> 4;
+  // A fragments: A[i = lane & 15][k = lane >> 4] of M tile mt, k-step t  ->  G[32 w + 16 mt + lr][4 t + q]
+  double a[2][16];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int t = 0; t < 16; ++t) a[mt][t] = g.G[(int64_t)(32 * w + 16 * mt + lr) * g.ldg + 4 * t + q];
+  const int64_t cbs = g.C / CB;
+  int64_t tile = blockIdx.x;
+  if (tile >= g.ntiles) return;
+  // one DMA instruction = two y rows of the tile (lanes 0-31 row 2i, lanes 32-63 row 2i+1; 16 bytes per lane)
+  const int64_t dma_lane = (int64_t)(lane >> 5) * g.C + (lane & 31) * 2;
+  auto stage = [&](int64_t t_, int b) {
+    const double* src = g.in + (t_ / cbs) * g.in_row + (t_ % cbs) * CB + dma_lane;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int pr = w + 4 * i;                              // row pair
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + (int64_t)(2 * pr) * g.C), (lds_ptr_t)(&xs[b][2 * pr * CB]), 16, 0, 0);
+    }
+  };
+  stage(tile, 0);
+  int b = 0;
+  // The stores of a tile are issued one iteration LATE, right after the request for the tile after next: both are in flight
+  // under a whole tile of MFMAs, so the vmcnt(0) in front of the barrier (loads and stores share the counter and do not retire
+  // in order relative to each other: it has to be 0) never waits for a store that was issued a moment ago.
+  v4d prev[2][4];
+  int64_t prev_tile = -1;
+  auto store = [&](const v4d (&acc)[2][4], int64_t t_) {
+    double* op = g.out + (t_ / cbs) * g.out_row + (t_ % cbs) * CB + lr;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) op[(int64_t)(32 * w + 16 * mt + q + 4 * r) * g.C + 16 * nt] = acc[mt][nt][r];
+  };
+  for (; tile < g.ntiles; tile += gridDim.x) {
+    __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));              // this tile has landed
+    __builtin_amdgcn_s_barrier();                          // ... for every wave; every wave is done reading the other stage
+    const int64_t nxt = tile + gridDim.x;
+    if (nxt < g.ntiles) stage(nxt, b ^ 1);
+    if (prev_tile >= 0) store(prev, prev_tile);
+    v4d acc[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (v4d){0., 0., 0., 0.};
+    // B[k = q][n = lr] of k-step t, column tile nt: xs[b][(4 t + q) * CB + 16 nt + lr].  Inline reads: for LDS reads it can see,
+    // the compiler first waits for EVERY outstanding LDS-DMA (vmcnt(0)), i.e. for the tile that was requested a moment ago.
+    const unsigned xaddr = (unsigned)(uintptr_t)(lds_ptr_t)&xs[b][q * CB + lr];
+    double bv[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(bv[0][nt]) : "v"(xaddr), "n"(16 * nt * 8));
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      if (t + 1 < 16) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(bv[(t + 1) & 1][nt]) : "v"(xaddr), "n"((4 * (t + 1) * CB + 16 * nt) * 8));
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bv[t & 1][0]), "+v"(bv[t & 1][1]), "+v"(bv[t & 1][2]), "+v"(bv[t & 1][3]));
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[t & 1][0]), "+v"(bv[t & 1][1]), "+v"(bv[t & 1][2]), "+v"(bv[t & 1][3]));
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt][t], bv[t & 1][nt], acc[mt][nt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) prev[mt][nt] = acc[mt][nt];
+    prev_tile = tile;
+    b ^= 1;
+  }
+  if (prev_tile >= 0) store(prev, prev_tile);
+}
+
 }  // namespace
 
 extern "C" int geobo_xz2d(int inverse, int nx, int nz, int64_t rows, int planes_per_row, const double* in, int64_t in_row,
@@ -408,5 +505,19 @@ extern "C" int geobo_xcorr_reduce(int nx, int nz, int64_t rows, int planes, cons
   if (int rc = ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), lds)) return rc;
   const int64_t nwg = g.nplanes < 1024 ? g.nplanes : 1024;
   hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(64 * NW), lds, (hipStream_t)stream, g);
+  return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
+}
+
+extern "C" int geobo_ymul(int m, int k, int64_t C, int64_t rows, const double* G, int64_t ldg, const double* in, int64_t in_row,
+                          double* out, int64_t out_row, void* stream) {
+  if (!G || !in || !out) return GEOBO_E_ARG;
+  if (rows <= 0 || C <= 0) return GEOBO_OK;
+  if (m != 128 || k != 64) return GEOBO_E_UNSUPPORTED;
+  if (C % 64 || (in_row & 1) || ((uintptr_t)in & 15) || (C & 1)) return GEOBO_E_ALIGN;
+  YMulArgs g;
+  g.in = in; g.in_row = in_row; g.G = G; g.ldg = ldg; g.out = out; g.out_row = out_row; g.C = C; g.R = rows;
+  g.ntiles = rows * (C / 64);
+  const int64_t nwg = g.ntiles < 512 ? g.ntiles : 512;   // persistent: two workgroups per CU, 32 tiles each at 64^3
+  hipLaunchKernelGGL(ymul_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, g);
   return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
 }

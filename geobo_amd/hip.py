@@ -327,6 +327,16 @@ def tile_rows(m, m_valid, tile=256, group=64):
     return out
 
 
+YMUL_SHAPES = ((128, 64),)      # (m, k) geobo_ymul is instantiated for
+
+
+def ymul(m, k, C, rows, G, src, in_row, out, out_row):
+    """out[r] (m x C) = G (m x k) . src[r] (k x C) for every row (geobo_ymul)."""
+    lib = require_gpu()
+    _lib.check(lib.geobo_ymul(int(m), int(k), int(C), int(rows), _p(_chk(G, "G")), int(G.stride(0)), _p(_chk(src, "src")), int(in_row),
+                              _p(_chk(out, "out")), int(out_row), _stream()), "geobo_ymul")
+
+
 def xcorr_reduce(nx, nz, rows, planes, src, in_row, in_plane, Mx, lam, out, out_row, out_plane):
     """x step + eigenvalue scaling + channel sum of the lattice Gram (geobo_xcorr_reduce)."""
     lib = require_gpu()

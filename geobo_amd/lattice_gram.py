@@ -20,6 +20,8 @@ transforms G as the covariance (spectral.py), channel by channel:
 
 2 x 1.9e8 flop per row instead of 2.1e9, and no N-deep pass over A."""
 import numpy as np
+import os
+
 import torch
 
 from . import hip
@@ -87,8 +89,11 @@ class LatticeGram:
         for r0 in range(0, nrows, self.R):
             R = min(self.R, nrows - r0)
             y1b = sp.buf("LG_Y1", R * Py * plane)
-            hip.gemm_batched(True, hip.pad_n(Py), hip.pad_n(plane), Ly, gy, ny, 0, X[r0:], plane, X.stride(0), y1b, plane,
-                             Py * plane, Py, plane, R)
+            if (Py, Ly) in hip.YMUL_SHAPES and plane % 64 == 0 and os.environ.get("GEOBO_GRAM_YMUL", "1") != "0":
+                hip.ymul(Py, Ly, plane, R, gy, X[r0:], X.stride(0), y1b, Py * plane)      # G_y in registers, rows streamed once
+            else:
+                hip.gemm_batched(True, hip.pad_n(Py), hip.pad_n(plane), Ly, gy, ny, 0, X[r0:], plane, X.stride(0), y1b, plane,
+                                 Py * plane, Py, plane, R)
             s = sp.buf("LG_S", R * Py * Px)
             if sp.fold and nx == nz and "x" in sp.F:
                 hip.xcorr_reduce_fold(nx, R, Py, y1b, Py * plane, plane, sp.F["x"], lam, s, Py * Px, Px)

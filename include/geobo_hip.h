@@ -216,6 +216,12 @@ int geobo_xcorr_reduce(int nx, int nz, int64_t rows, int planes, const double* i
                        const double* Mx, int64_t ldmx, const double* lamT, double* out, int64_t out_row, int64_t out_plane,
                        void* stream);
 
+/* y step of the lattice Gram: the same (m x k) matrix G from the left of every row,  out[r][i][c] = sum_j G[i][j] in[r][j][c]
+ * for r < rows, c < C (in: rows of k x C at in + r*in_row, out: rows of m x C at out + r*out_row; strides in doubles).
+ * m = 128, k = 64 (GEOBO_E_UNSUPPORTED otherwise: geobo_gemm_batched does the same), C % 64 == 0, in 16-byte aligned. */
+int geobo_ymul(int m, int k, int64_t C, int64_t rows, const double* G, int64_t ldg, const double* in, int64_t in_row,
+               double* out, int64_t out_row, void* stream);
+
 /* Radix-2 form of geobo_xcorr_reduce for the pair-interleaved basis: the x product folded over the parity of x (half the
  * MFMAs), F = [n][n/2][2] folded matrices of the x axis; lamT and out in spectral position order as before.  n = 64. */
 int geobo_xcorr_reduce_fold(int n, int64_t rows, int planes, const double* in, int64_t in_row, int64_t in_plane,

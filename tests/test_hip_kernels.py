@@ -510,3 +510,18 @@ def test_spectral_32_planes_go_through_the_fused_kernel_in_pairs(hip, R, ny):
         assert torch.isnan(out[:, sp.N:]).all()
         outs.append(out[:, :sp.N].clone())
     assert normwise(outs[0].cpu().numpy(), outs[1].cpu().numpy()) < 1e-14
+
+
+@pytest.mark.parametrize("rows,C", [(1, 64), (3, 4096), (37, 192), (300, 4096)])
+def test_ymul_matches_torch(hip, rows, C):
+    # out[r] = G . in[r] with the same 128 x 64 matrix for every row; strided rows; persistent workgroups over many tiles
+    G = _rand((128, 64), 71)
+    in_row = 64 * C + 16
+    src = _rand((rows, in_row), 72)
+    out_row = 128 * C + 6
+    out = torch.full((rows, out_row), float("nan"), dtype=torch.float64, device="cuda")
+    hip.ymul(128, 64, C, rows, G, src, in_row, out, out_row)
+    torch.cuda.synchronize()
+    ref = torch.einsum("ij,rjc->ric", G, src[:, :64 * C].reshape(rows, 64, C))
+    assert normwise(out[:, :128 * C].reshape(rows, 128, C).cpu().numpy(), ref.cpu().numpy()) < 1e-14
+    assert torch.isnan(out[:, 128 * C:]).all()

@@ -60,3 +60,10 @@ if which in ("all", "xcorr_fold"):
     out = torch.empty((R, P * P), dtype=torch.float64, device=dev)
     timed("xcorr_fold", R * P * 1.0 * P * n * n, R * P * (n * n + P) * 8.0,
           lambda: hip.xcorr_reduce_fold(n, R, P, src, src.stride(0), n * n, F, lam, out, out.stride(0), P))
+if which in ("all", "ymul"):
+    # y step of the lattice Gram: the (128 x 64) matrix from the left of every (64 x 4096) row; flop = MFMA, bytes = in + out
+    G = rnd(128, 64)
+    src, out = rnd(R, 64 * n * n), torch.empty((R, 128 * n * n), dtype=torch.float64, device=dev)
+    timed("ymul", R * 2.0 * 128 * 64 * n * n, R * (64 + 128) * n * n * 8.0, lambda: hip.ymul(128, 64, n * n, R, G, src, src.stride(0), out, out.stride(0)))
+    timed("ymul_as_gemm_batched", R * 2.0 * 128 * 64 * n * n, R * (64 + 128) * n * n * 8.0,
+          lambda: hip.gemm_batched(True, 128, n * n, 64, G, 64, 0, src, n * n, src.stride(0), out, n * n, out.stride(0), 128, n * n, R))
