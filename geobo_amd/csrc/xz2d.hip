@@ -391,8 +391,12 @@ __global__ void __launch_bounds__(256, 2) ymul_kernel(YMulArgs g) {
   const int64_t cbs = g.C / CB;
   int64_t tile = blockIdx.x;
   if (tile >= g.ntiles) return;
-  // one DMA instruction = two y rows of the tile (lanes 0-31 row 2i, lanes 32-63 row 2i+1; 16 bytes per lane)
-  const int64_t dma_lane = (int64_t)(lane >> 5) * g.C + (lane & 31) * 2;
+  // one DMA instruction = two y rows of the tile (lanes 0-31 row 2i, lanes 32-63 row 2i+1; 16 bytes per lane).  The four
+  // 128-byte column groups of row y are stored at group ^ (y & 3) (the LDS image of a DMA is lane-linear, so the permutation is
+  // applied to the SOURCE slot): the four rows 4t .. 4t+3 a B-fragment read touches then sit in four different bank groups
+  // (unswizzled: SQ_LDS_BANK_CONFLICT = 50 % of the LDS-active cycles).  (2 pr + h) & 3 = (2 w + h) & 3 for every pr = w + 4 i.
+  const int dma_h = lane >> 5;
+  const int64_t dma_lane = (int64_t)dma_h * g.C + ((lane & 31) ^ (((2 * w + dma_h) & 3) << 3)) * 2;
   auto stage = [&](int64_t t_, int b) {
     const double* src = g.in + (t_ / cbs) * g.in_row + (t_ % cbs) * CB + dma_lane;
 #pragma unroll
@@ -428,18 +432,20 @@ __global__ void __launch_bounds__(256, 2) ymul_kernel(YMulArgs g) {
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (v4d){0., 0., 0., 0.};
-    // B[k = q][n = lr] of k-step t, column tile nt: xs[b][(4 t + q) * CB + 16 nt + lr].  Inline reads: for LDS reads it can see,
+    // B[k = q][n = lr] of k-step t, column tile nt: xs[b][(4 t + q) * CB + 16 (nt ^ q) + lr].  Inline reads: for LDS reads it can see,
     // the compiler first waits for EVERY outstanding LDS-DMA (vmcnt(0)), i.e. for the tile that was requested a moment ago.
-    const unsigned xaddr = (unsigned)(uintptr_t)(lds_ptr_t)&xs[b][q * CB + lr];
+    unsigned xaddr[4];                                     // row q of a k-step, column group nt (stored at group nt ^ q)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) xaddr[nt] = (unsigned)(uintptr_t)(lds_ptr_t)&xs[b][q * CB + 16 * (nt ^ q) + lr];
     double bv[2][4];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(bv[0][nt]) : "v"(xaddr), "n"(16 * nt * 8));
+    for (int nt = 0; nt < 4; ++nt) asm volatile("ds_read_b64 %0, %1" : "=v"(bv[0][nt]) : "v"(xaddr[nt]));
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
       if (t + 1 < 16) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
-          asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(bv[(t + 1) & 1][nt]) : "v"(xaddr), "n"((4 * (t + 1) * CB + 16 * nt) * 8));
+          asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(bv[(t + 1) & 1][nt]) : "v"(xaddr[nt]), "n"(4 * (t + 1) * CB * 8));
         asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bv[t & 1][0]), "+v"(bv[t & 1][1]), "+v"(bv[t & 1][2]), "+v"(bv[t & 1][3]));
       } else {
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bv[t & 1][0]), "+v"(bv[t & 1][1]), "+v"(bv[t & 1][2]), "+v"(bv[t & 1][3]));
