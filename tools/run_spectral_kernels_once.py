@@ -70,3 +70,17 @@ if which in ("all", "ymul_gemm"):   # the same product as a batched GEMM (what g
     src, out = rnd(R, 64 * n * n), torch.empty((R, 128 * n * n), dtype=torch.float64, device=dev)
     timed("ymul_as_gemm_batched", R * 2.0 * 128 * 64 * n * n, R * (64 + 128) * n * n * 8.0,
           lambda: hip.gemm_batched(True, 128, n * n, 64, G, 64, 0, src, n * n, src.stride(0), out, n * n, out.stride(0), 128, n * n, R))
+if which in ("all", "xz2d32_fwd", "xz2d32_bwd"):
+    # BASELINE config 2 (32^3): 32 x 32 planes through the (64, 32) instance of geobo_xz2d two at a time (M_x -> diag(M_x, M_x))
+    m, ny32 = 32, 32
+    Mx, Mz = rnd(2 * m, m), rnd(2 * m, m)
+    Mx2 = torch.zeros((4 * m, 2 * m), dtype=torch.float64, device=dev); Mx2[:2 * m, :m] = Mx; Mx2[2 * m:, m:] = Mx
+    MxT2 = Mx2.t().contiguous(); MzT = Mz.t().contiguous()
+if which in ("all", "xz2d32_fwd"):
+    src, out = rnd(R, ny32 * m * m), torch.empty((R, ny32 * 4 * m * m), dtype=torch.float64, device=dev)
+    timed("xz2d32_fwd", R * ny32 * 2.0 * (m * m * 2 * m + 2 * 2 * m * m * 2 * m), R * ny32 * 5 * m * m * 8.0,
+          lambda: hip.xz2d(False, 2 * m, m, R, ny32 // 2, src, src.stride(0), 2 * m * m, Mx2, Mz, out, out.stride(0), 8 * m * m))
+if which in ("all", "xz2d32_bwd"):
+    src, out = rnd(R, ny32 * 4 * m * m), torch.empty((R, ny32 * m * m), dtype=torch.float64, device=dev)
+    timed("xz2d32_bwd", R * ny32 * 2.0 * (2 * m * 2 * m * m + 2 * m * 2 * m * m), R * ny32 * 5 * m * m * 8.0,
+          lambda: hip.xz2d(True, 2 * m, m, R, ny32 // 2, src, src.stride(0), 8 * m * m, MxT2, MzT, out, out.stride(0), 2 * m * m))
