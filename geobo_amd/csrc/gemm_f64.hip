@@ -549,6 +549,17 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) gemm_f64_kernel(const GemmArg
 
   // ---- epilogue ------------------------------------------------------------------------------------------
   if constexpr (EPI == EPI_STORE) {
+    // tiles that lie inside the valid region (all but the last row / column of tiles): no per-element predicate
+    if (row0 + TM <= a.m_valid && col0 + TN <= a.n_valid && (a.beta == 0.0 || c_in_acc)) {
+      double* const cw = Cp + (row0 + wm * 64 + lg) * a.ldc + col0 + wn * 64 + lr;
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) cw[(int64_t)(m * 16 + 4 * r) * a.ldc + n * 16] = a.alpha * acc[m][n][r];
+      return;
+    }
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
