@@ -30,7 +30,8 @@ import numpy as np
 import torch
 
 from . import geometry, hip
-from .sharding import allreduce_sum_, assemble_columns, exchange_blocks, gather_rows, gather_slices, shard_columns
+from .sharding import (allreduce_sum_, assemble_columns, exchange_blocks, exchange_blocks_finish, exchange_blocks_start, gather_rows,
+                       gather_slices, shard_columns)
 
 F64 = hip.F64
 
@@ -452,15 +453,22 @@ class PosteriorEngine:
 
     def _assemble_AK_spectral_exchange(self, AK, lengths, W, name, amp, props):
         """Row-sharded spectral product + all-to-all (multi-GPU): rank r transforms sensor rows [r*Ms/G, (r+1)*Ms/G) of both
-        operators for every voxel, cropping the backward passes once per destination y-slab straight into the send buffer
-        [dest][operator][block][row][col]; one all_to_all_single over xGMI; the received blocks are this rank's columns of
-        every sensor row."""
+        operators for every voxel, cropping the backward passes once per destination y-slab straight into the send buffer of
+        the operator, [dest][block][row][col]; one all_to_all_single over xGMI per operator (the first one runs under the second
+        operator's transforms); the received blocks are this rank's columns of every sensor row."""
         if self.f32 or self.streamed:
             return self._exchange_chunked(AK, lengths, W, name, amp, props)
-        send = self._exchange_send(lengths, W, name, amp, props)
-        self._keep_full_rows(send, props)
-        recv = self._timed("xgmi_all_to_all", 0.0, lambda: exchange_blocks(send, self.world, self.group))
-        self._exchange_place(AK, recv, props)
+        # one exchange per operator: the gravity rows travel while the magnetic rows are being transformed
+        sends, pending = [], []
+        for s_, func in ((0, "grav"), (1, "magn")):
+            send = self._exchange_send(s_, func, lengths, W, name, amp, props)
+            sends.append(send)
+            out = self._workspace("xchg_recv_%d" % s_, tuple(send.shape)) if torch.distributed.get_backend(self.group) == "nccl" else None
+            pending.append(exchange_blocks_start(send, self.world, self.group, out=out))
+        self._keep_full_rows(sends, props)
+        for s_, (recv, work) in enumerate(pending):
+            self._timed("xgmi_all_to_all", 0.0, lambda: exchange_blocks_finish(work))
+            self._exchange_place(AK, recv, props, s_)
 
     def _exchange_chunked(self, AK, lengths, W, name, amp, props):
         """The row exchange for the large-cube modes (fp32 assembly and / or streamed operators, BASELINE config 5): the rank's
@@ -508,50 +516,48 @@ class PosteriorEngine:
         """True when AkA is assembled from row blocks: row exchange + lattice Gram available for both operators."""
         return self.exchange and all(self._lam.get(f) is not None for f in ("grav", "magn"))
 
-    def _keep_full_rows(self, send, props):
+    def _keep_full_rows(self, sends, props):
         """This rank's own sensor rows of A K over ALL voxels (block columns 0 and 1), gathered from the per-destination slabs of
-        the send buffer: the input of the row-sharded lattice Gram."""
+        the two send buffers: the input of the row-sharded lattice Gram."""
         self._fullrows = {}
         if not self._row_gram():
             return
         G, nc = self.world, self.nc
         rows_r, P_c = self.Ms // G, len(props)
-        v = send.view(G, 2, P_c, rows_r, nc)
         for s_ in (0, 1):
+            v = sends[s_].view(G, P_c, rows_r, nc)
             for sp_ in (0, 1):
                 full = self._workspace2d("fullrows_%d%d" % (s_, sp_), rows_r, G * nc)
                 for d in range(G):
-                    full[:, d * nc:(d + 1) * nc].copy_(v[d, s_, props.index(sp_)])
+                    full[:, d * nc:(d + 1) * nc].copy_(v[d, props.index(sp_)])
                 self._fullrows[(s_, sp_)] = full
 
-    def _exchange_send(self, lengths, W, name, amp, props):
-        sp, sset, nc, G = self._spectral, self.s, self.nc, self.world
+    def _exchange_send(self, s_, func, lengths, W, name, amp, props):
+        """Send buffer of one operator, (G, P_c * rows_r * nc): [destination][block][row][col] -- this rank's sensor rows of A_s K,
+        every voxel, cropped per destination y-slab by the backward passes themselves."""
+        sp, nc, G = self._spectral, self.nc, self.world
         plane = self.nx * self.nz
         rows_r, P_c = self.Ms // G, len(props)
-        blk = 2 * P_c * rows_r * nc
-        send = self._workspace("xchg_send", (G, blk))
+        send = self._workspace("xchg_send_%d" % s_, (G, P_c * rows_r * nc))
         slabs_of = [tuple(c // plane for c in shard_columns(self.N_pad, G, d)) for d in range(G)]
-        for s_, func in ((0, "grav"), (1, "magn")):
-            lams = []
-            for j in props:
-                tab = self._cov_table(hip.kernel_id(name, s_ != j), lengths[j], lengths[s_], W[s_][j], amp)
-                lams.append(sp.eigenvalues(tab))
-            slabs = [(slabs_of[d][0], slabs_of[d][1], [send[d].view(2, P_c, rows_r, nc)[s_, jj] for jj in range(P_c)])
-                     for d in range(G)]
-            Ar = self._Arows[func]
-            self._timed("spectral_product", sp.flops(rows_r, P_c, self.ny), lambda: sp.product(Ar, rows_r, lams, None, slabs=slabs),
-                        valu=sp.flops_valu(rows_r, P_c))
+        lams = []
+        for j in props:
+            tab = self._cov_table(hip.kernel_id(name, s_ != j), lengths[j], lengths[s_], W[s_][j], amp)
+            lams.append(sp.eigenvalues(tab))
+        slabs = [(slabs_of[d][0], slabs_of[d][1], [send[d].view(P_c, rows_r, nc)[jj] for jj in range(P_c)]) for d in range(G)]
+        Ar = self._Arows[func]
+        self._timed("spectral_product", sp.flops(rows_r, P_c, self.ny), lambda: sp.product(Ar, rows_r, lams, None, slabs=slabs),
+                    valu=sp.flops_valu(rows_r, P_c))
         return send
 
-    def _exchange_place(self, AK, recv, props):
+    def _exchange_place(self, AK, recv, props, s_):
         G, nc = self.world, self.nc
         rows_r, P_c = self.Ms // G, len(props)
         for src in range(G):
-            blocks = recv[src].view(2, P_c, rows_r, nc)
-            for s_ in (0, 1):
-                r0 = s_ * self.Ms_pad + src * rows_r
-                for jj in range(P_c):
-                    AK[r0:r0 + rows_r, jj * nc:(jj + 1) * nc].copy_(blocks[s_, jj])
+            blocks = recv[src].view(P_c, rows_r, nc)
+            r0 = s_ * self.Ms_pad + src * rows_r
+            for jj in range(P_c):
+                AK[r0:r0 + rows_r, jj * nc:(jj + 1) * nc].copy_(blocks[jj])
 
     def _gram_eigen(self, plan, lws):
         """Eigen-data of the operator's stencil table for the lattice Gram (lattice_gram.py); None -> AkA by the N-deep GEMM."""

@@ -103,3 +103,23 @@ def exchange_blocks(send, world, group=None):
                 for src in range(world):
                     recv[src].copy_(parts[src])
     return recv
+
+
+def exchange_blocks_start(send, world, group=None, out=None):
+    """exchange_blocks in two halves, so that a caller with more to compute can put that between them: on RCCL the all-to-all is
+    issued asynchronously (it runs on the communicator's stream, ordered after everything queued on the current stream so far) and
+    (recv, work) is returned -- `exchange_blocks_finish(work)` makes the current stream wait for it.  Other backends (gloo: CPU
+    tests, single-GPU dry runs) do the whole exchange here and return work = None."""
+    if world == 1:
+        return send, None
+    import torch.distributed as dist
+    if dist.get_backend(group) == "nccl":
+        assert send.dim() == 2 and send.shape[0] == world and send.is_contiguous()
+        recv = out if out is not None else torch.empty_like(send)
+        return recv, dist.all_to_all_single(recv, send, group=group, async_op=True)
+    return exchange_blocks(send, world, group), None
+
+
+def exchange_blocks_finish(work):
+    if work is not None:
+        work.wait()

@@ -704,12 +704,12 @@ def test_row_sharded_exchange_matches_dense_columns():
             assert torch.equal(e._Arows[k][:, :e.N], Af[k][e.rank * rows_r:(e.rank + 1) * rows_r, :e.N])
         from geobo_amd.spectral import SpectralProduct
         e._spectral = SpectralProduct(e.nx, e.ny, e.nz, e.device)
-        sends.append(e._exchange_send(lengths, W, "matern32", 1.0, props).clone())
+        sends.append([e._exchange_send(s_, func, lengths, W, "matern32", 1.0, props).clone() for s_, func in ((0, "grav"), (1, "magn"))])
     for r, e in enumerate(engs):
-        recv = torch.stack([sends[src][r] for src in range(world)])
         M_pad = E.hip.pad_m(2 * e.Ms_pad + f["sel"].size)
         AK = torch.zeros((M_pad, len(props) * e.nc), dtype=torch.float64, device="cuda")
-        e._exchange_place(AK, recv, props)
+        for s_ in (0, 1):               # what the all-to-all of operator s_ delivers to rank r: block r of every source's buffer
+            e._exchange_place(AK, torch.stack([sends[src][s_][r] for src in range(world)]), props, s_)
         d = E.PosteriorEngine(s, rank=r, world=world, method="dense")
         ref, _ = d._assemble_AK(Af["grav"], Af["magn"], sel_t, lengths, W, "matern32", 1.0, props)
         rows = np.r_[0:e.Ms, e.Ms_pad:e.Ms_pad + e.Ms]
@@ -750,7 +750,7 @@ def test_row_sharded_lattice_gram_matches_the_single_rank_AkA():
         e.operator("grav", loc), e.operator("magn", loc)
         assert e._row_gram()
         e._spectral = e._spectral or SpectralProduct(nx, ny, nz, e.device)
-        send = e._exchange_send(lengths, W, "matern32", 1.0, props)
+        send = [e._exchange_send(s_, func, lengths, W, "matern32", 1.0, props) for s_, func in ((0, "grav"), (1, "magn"))]
         e._keep_full_rows(send, props)
         lo, dr = e._aka_local_rows(props, sel_t, lengths, W, "matern32", 1.0)
         blocks.append(lo.clone())

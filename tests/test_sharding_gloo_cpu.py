@@ -106,6 +106,11 @@ def _xchg_worker(rank, world, port, q):
     blk = 6
     send = torch.arange(world * blk, dtype=torch.float64).reshape(world, blk) + 1000.0 * rank   # row d -> rank d
     recv = exchange_blocks(send, world)
+    # the two-phase form (asynchronous on RCCL, complete at start on gloo) delivers the same blocks
+    from geobo_amd.sharding import exchange_blocks_finish, exchange_blocks_start
+    recv2, work = exchange_blocks_start(send, world)
+    exchange_blocks_finish(work)
+    assert work is None and torch.equal(recv2, recv)
     # row blocks of AkA (row-sharded lattice Gram): all-gather, every rank ends with the same (world, rows, cols) stack
     from geobo_amd.sharding import gather_rows
     rows = gather_rows(torch.full((2, 3), float(rank), dtype=torch.float64) + torch.arange(3, dtype=torch.float64), world)
