@@ -228,15 +228,16 @@ def ak_fused_grid(A, nx, ny, nz, table, col0, ncols, out):
     return out
 
 
-def gemm_nt(X, Y, C_, alpha=1.0, beta=0.0, lower_only=False, m_valid=0):
-    """C = alpha X Y^T + beta C.  m_valid > 0: rows >= m_valid of X are zero padding (not contracted, not stored)."""
+def gemm_nt(X, Y, C_, alpha=1.0, beta=0.0, lower_only=False, m_valid=0, small_tiles=False):
+    """C = alpha X Y^T + beta C.  m_valid > 0: rows >= m_valid of X are zero padding (not contracted, not stored).
+    small_tiles: 128-row workgroup tiles even when 256-row tiles would fit (GEOBO_GEMM_SMALL_TILES)."""
     lib = require_gpu()
     ldx, ldy, ldc = _rowmajor(X, "X"), _rowmajor(Y, "Y"), _rowmajor(C_, "C")
     m, k = X.shape
     n = Y.shape[0]
     assert Y.shape[1] == k and C_.shape[0] >= m and C_.shape[1] >= n
     _lib.check(lib.geobo_gemm_nt(m, n, k, float(alpha), _p(X), ldx, _p(Y), ldy, float(beta), _p(C_), ldc,
-                                 1 if lower_only else 0, int(m_valid), _stream()), "geobo_gemm_nt")
+                                 (1 if lower_only else 0) | (2 if small_tiles else 0), int(m_valid), _stream()), "geobo_gemm_nt")
     return C_
 
 

@@ -525,3 +525,17 @@ def test_ymul_matches_torch(hip, rows, C):
     ref = torch.einsum("ij,rjc->ric", G, src[:, :64 * C].reshape(rows, 64, C))
     assert normwise(out[:, :128 * C].reshape(rows, 128, C).cpu().numpy(), ref.cpu().numpy()) < 1e-14
     assert torch.isnan(out[:, 128 * C:]).all()
+
+
+@pytest.mark.parametrize("alpha,beta", [(1.0, 1.0), (-1.0, 1.0), (2.0, -2.0), (1.0, -1.0), (0.5, 1.0)])
+@pytest.mark.parametrize("m,small", [(512, False), (512, True), (384, False)])
+def test_gemm_nt_accumulating_forms(hip, alpha, beta, m, small):
+    # |beta| = |alpha|: C is loaded into the accumulators before the loop (scaled by +-1); other ratios read it in the epilogue.
+    # Both tile sizes, a row count that leaves the last row tile partly outside m_valid, rows behind m_valid untouched.
+    n, k, mv = 256, 208, m - 70
+    X, Y, C0 = _rand((m, k), 51), _rand((n, k), 52), _rand((m, n), 53)
+    C = C0.clone()
+    hip.gemm_nt(X, Y, C, alpha=alpha, beta=beta, m_valid=mv, small_tiles=small)
+    ref = alpha * X @ Y.t() + beta * C0
+    assert (C[:mv] - ref[:mv]).abs().max().item() <= 1e-12 * k ** 0.5
+    assert torch.equal(C[mv:], C0[mv:])
