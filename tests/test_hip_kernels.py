@@ -203,7 +203,9 @@ def test_ak_fused_grid_matches_coordinate_path(hip, name, cross, dims):
 
 
 @pytest.mark.parametrize("fork", [False, True])
-@pytest.mark.parametrize("m", [256, 512, 1280, 2304, 4224])   # 2304 / 4224: both fork levels of the concurrent L^-1 build
+# 10, 18, 23, 33, 66 blocks of 128: L^-1 spines of depth 1, 1, 2, 3, 3 (odd and even splits) built under the factorisation;
+# 2, 4 blocks: the plain serial tree
+@pytest.mark.parametrize("m", [256, 512, 1280, 2304, 2944, 4224, 8448])
 def test_potrf_inv_matches_torch(hip, m, fork):
     B = _rand((m, m), 20)
     S = B @ B.t() / m + 0.05 * torch.eye(m, dtype=torch.float64, device="cuda")
