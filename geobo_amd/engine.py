@@ -140,6 +140,7 @@ class PosteriorEngine:
         self._A = {}
         self._ws = {}   # persistent device workspaces keyed by name (re-used across calls: no per-step allocation)
         self._host = {}  # pinned host staging buffers of the result read-back, keyed by slot
+        self._pending_exchange = None   # (A K, [(recv, work)], props) of a row exchange that has been started but not placed yet
         self.use_grid = self.nz >= 16 and self.nz % 2 == 0  # lattice-table generator (geobo_ak_fused_grid); coordinates otherwise
         # spectral (real-DFT) product: regular grid with extents % 16 == 0, unpadded voxel columns, shards on y-slab boundaries
         plane = self.nx * self.nz
@@ -458,6 +459,7 @@ class PosteriorEngine:
         operator's transforms); the received blocks are this rank's columns of every sensor row."""
         if self.f32 or self.streamed:
             return self._exchange_chunked(AK, lengths, W, name, amp, props)
+        self._finish_exchange()          # (an exchange left over by a call that failed between its start and its factorisation)
         # one exchange per operator: the gravity rows travel while the magnetic rows are being transformed
         sends, pending = [], []
         for s_, func in ((0, "grav"), (1, "magn")):
@@ -466,6 +468,18 @@ class PosteriorEngine:
             out = self._workspace("xchg_recv_%d" % s_, tuple(send.shape)) if torch.distributed.get_backend(self.group) == "nccl" else None
             pending.append(exchange_blocks_start(send, self.world, self.group, out=out))
         self._keep_full_rows(sends, props)
+        self._pending_exchange = (AK, pending, props)
+        if not self._row_gram():
+            self._finish_exchange()      # AkA by the GEMM reads the received columns of A K
+
+    def _finish_exchange(self):
+        """Wait for the row exchange and put the received blocks into A K.  With the row-sharded lattice Gram nothing reads those
+        columns before the posterior reduction (AkA comes from this rank's own rows, kept from the send buffers), so posterior()
+        calls this after the factorisation: the all-to-all runs under the Gram, the all-gather and the Cholesky."""
+        if self._pending_exchange is None:
+            return
+        AK, pending, props = self._pending_exchange
+        self._pending_exchange = None
         for s_, (recv, work) in enumerate(pending):
             self._timed("xgmi_all_to_all", 0.0, lambda: exchange_blocks_finish(work))
             self._exchange_place(AK, recv, props, s_)
@@ -759,6 +773,7 @@ class PosteriorEngine:
             AkA, self._workspace("Linv", (M_pad, M_pad)), self._workspace("potrf_ws", (hip.potrf_ws_doubles(M_pad),)),
             ctx=self._potrf_ctx), alg=(2 * self.Ms + len(sel)) ** 3 * 2.0 / 3.0)  # AkA now holds L
         L = AkA
+        self._finish_exchange()
         u, stats = hip.trmv_stats(Linv, y, L)
         t = self._tick("cholesky", t)
         out = dict(info=0, M_pad=M_pad, lengths=[float(v) for v in lengths])
