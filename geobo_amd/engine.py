@@ -164,6 +164,14 @@ class PosteriorEngine:
                          and xmode != "0" and (world >= 4 or xmode == "1"))
         if self.streamed and not self.use_spectral:
             raise ValueError("streamed operators feed the spectral product: needs the spectral method's grid conditions")
+        # The row exchange gets a communicator of its own: collectives of one communicator run in issue order on its stream, and
+        # the all-gather of the AkA row blocks (issued while the exchange is still in flight) must not queue up behind it.
+        # (Collective call: every rank builds its engine at the same point -- Inversion does on first use.)
+        self._xgroup = group
+        if self.exchange and torch.distributed.is_available() and torch.distributed.is_initialized():
+            ranks = torch.distributed.get_process_group_ranks(group) if group is not None else list(range(torch.distributed.get_world_size()))
+            if len(ranks) == world:
+                self._xgroup = torch.distributed.new_group(ranks=ranks, backend=torch.distributed.get_backend(group))
         self._Arows, self._Aedge, self._fullrows = {}, {}, {}
         self._slab_ops = set()      # data pointers of operators that hold only this rank's column slab
         self._potrf_ctx = None
@@ -465,8 +473,8 @@ class PosteriorEngine:
         for s_, func in ((0, "grav"), (1, "magn")):
             send = self._exchange_send(s_, func, lengths, W, name, amp, props)
             sends.append(send)
-            out = self._workspace("xchg_recv_%d" % s_, tuple(send.shape)) if torch.distributed.get_backend(self.group) == "nccl" else None
-            pending.append(exchange_blocks_start(send, self.world, self.group, out=out))
+            out = self._workspace("xchg_recv_%d" % s_, tuple(send.shape)) if torch.distributed.get_backend(self._xgroup) == "nccl" else None
+            pending.append(exchange_blocks_start(send, self.world, self._xgroup, out=out))
         self._keep_full_rows(sends, props)
         self._pending_exchange = (AK, pending, props)
         if not self._row_gram():
