@@ -1,7 +1,7 @@
 """BASELINE config 5 on ONE MI355X: rank r of an 8-rank column-sharded run of the 128^3 x 3-property inversion
 (fp32 kernel assembly + fp64 Cholesky), with independent CPU-oracle spot checks of what the rank produced.
 
-    python tools/dryrun_config5.py [--size 128] [--world 8] [--rank 0] [--no-oracle] > gpurun_out/config5_rank0.json
+    python tests/dryrun_config5.py [--size 128] [--world 8] [--rank 0] [--no-oracle] > gpurun_out/config5_rank0.json
 
 What runs is exactly the engine's per-rank step in the column-sharded form that needs no peer (forward passes of every sensor
 row replicated, backward passes cropped to the rank's y-slabs): streamed forward operators (A is 275 GB per type at 128^3 and is

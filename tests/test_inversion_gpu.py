@@ -351,14 +351,14 @@ def test_fp32_assembly_tracks_fp64_at_32_and_the_headline_shape():
 
 
 def test_config5_sequential_shards_equal_the_single_rank_run(tmp_path):
-    """tools/dryrun_config5.py --sequential (all column shards of an 8-rank fp32-assembly run executed on one device, partial AkA
+    """tests/dryrun_config5.py --sequential (all column shards of an 8-rank fp32-assembly run executed on one device, partial AkA
     summed where the all-reduce would be) against the same tool with one shard: same posterior checksums."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
     for world in (1, 4):
-        r = subprocess.run([sys.executable, os.path.join(root, "tools", "dryrun_config5.py"), "--size", "32", "--world", str(world),
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "dryrun_config5.py"), "--size", "32", "--world", str(world),
                             "--sequential"], cwd=root, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         res[world] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
