@@ -57,7 +57,7 @@ def synthetic_inputs(inv, md):
     eng = inv.engine
     # full operators on every rank for the synthetic data (the timed steps build only what each rank needs); in the
     # streamed-operator mode they are generated in row batches here as well (never resident)
-    if eng.streamed or eng.world > 1:
+    if eng.streamed or eng.auto_ops or eng.world > 1:
         # rows generated in batches (multi-rank runs: no rank holds a whole operator just to synthesise the survey)
         was, eng.streamed = eng.streamed, True
         A_g = eng.operator("grav", loc, B=s.magneticField * 0.)
@@ -224,7 +224,8 @@ def main():
                     help="A.K route: dense = fused in-kernel covariance generation; spectral = real-DFT on batched MFMA GEMMs")
     ap.add_argument("--assembly", default="f64", choices=["f64", "f32"], help="f32 = BASELINE config 5's fp32 kernel assembly (A K and the "
                     "covariance tables in fp32, fp64 accumulation and factorisation); NOT the headline configuration")
-    ap.add_argument("--operators", default="resident", choices=["resident", "streamed"])
+    ap.add_argument("--operators", default="auto", choices=["auto", "resident", "streamed"],
+                    help="auto (the library default): no materialised operators where the lattice forms make them unnecessary")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-forms", default="16", help="comma list of cube edges for the full matrix-free CPU oracle step "
                     "(SURVEY 8(d) form (b)); '16,32' adds the 32^3 run (minutes)")
@@ -353,6 +354,7 @@ def main():
                        "N_voxels": N, "M_rows": M, "props_out": p_out, "parallelism": "voxel-column shards x%d" % world,
                        "backend": a.backend if world > 1 else None, "ranks_reported_by_backend": ranks_reported,
                        "method": "spectral" if inv.engine.use_spectral else "dense", "assembly": a.assembly, "operators": a.operators,
+                       "operators_in_use": sorted({"streamed" if type(v).__name__ == "StreamedOperator" else "resident" for v in inv.engine._A.values()}),
                        "row_exchange": bool(inv.engine.exchange),
                        "ms_per_step_median": step_ms[len(step_ms) // 2], "ms_per_step_all_rank0": [round(v, 2) for v in step_ms],
                        "ms_per_step_in_order_rank0": [round(1e3 * (b - a_), 2) for a_, b in zip(marks[:-1], marks[1:])],

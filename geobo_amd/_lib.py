@@ -43,6 +43,7 @@ SIGNATURES = {
     "geobo_xz2d": (_int, [_int, _int, _int, _i64, _int, _dp, _i64, _i64, _dp, _i64, _dp, _i64, _dp, _i64, _i64, _dp]),
     "geobo_xz2d_fold": (_int, [_int, _int, _i64, _int, _dp, _i64, _i64, _dp, _dp, _dp, _i64, _i64, _dp]),
     "geobo_xcorr_reduce_fold": (_int, [_int, _i64, _int, _dp, _i64, _i64, _dp, _dp, _dp, _i64, _i64, _dp]),
+    "geobo_xz2d_fold_lattice": (_int, [_int, _i64, _int, _dp, _dp, _i64, _dp, _i64, _dp, _dp, _dp, _i64, _i64, _dp]),
     "geobo_ymul": (_int, [_int, _int, _i64, _i64, _dp, _i64, _dp, _i64, _dp, _i64, _dp]),
     "geobo_xcorr_reduce": (_int, [_int, _int, _i64, _int, _dp, _i64, _i64, _dp, _i64, _dp, _dp, _i64, _i64, _dp]),
     "geobo_toeplitz_y": (_int, [_int, _i64, _i64, _int, _dp, _dp, _dp, _dp, _dp, _int, _int, _dp]),

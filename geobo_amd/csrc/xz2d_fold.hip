@@ -41,6 +41,10 @@ struct FoldArgs {
   const double* Fz;                              // [n][n/2][2]: (Fe, Fo) of the contiguous axis ("z")
   const double* Fx;                              // the same for the row axis ("x")
   int ppr; int64_t nplanes;
+  // forward only, lattice survey (geobo_xz2d_fold_lattice): the planes of an operator row are windows of the stencil table --
+  // row r, plane y at in + row_off[r] + y*in_plane, except the first and the last plane of a row (the 1e6-padded boundary slabs),
+  // which come from edge + r*edge_row (+ one plane for the last one).  row_off == nullptr: dense rows as above.
+  const int64_t* row_off; const double* edge; int64_t edge_row;
 };
 
 constexpr int vmcnt_imm(int v) { return (v & 15) | (7 << 4) | (15 << 8) | ((v >> 4) << 14); }
@@ -126,7 +130,16 @@ __global__ void __launch_bounds__(256, 2) xz_fold_fwd_kernel(FoldArgs g) {
     const int row = (w + K::NW * j) * K::RPI + drow;          // LDS row of the chunk <- memory row rowperm(row)
     doff[j] = rowperm(row) * K::ROWB + ((dpos ^ (row & 15)) << 4);
   }
-  auto plane_ptr = [&](int64_t p) { return reinterpret_cast<const char*>(g.in + (p / g.ppr) * g.in_row + (p % g.ppr) * g.in_plane); };
+  auto plane_ptr = [&](int64_t p) {
+    const int64_t r = p / g.ppr;
+    const int y = (int)(p % g.ppr);
+    const double* q = g.in + r * g.in_row + y * g.in_plane;
+    if (g.row_off) {
+      q = g.in + g.row_off[r] + y * g.in_plane;
+      if (y == 0 || y == g.ppr - 1) q = g.edge + r * g.edge_row + (y ? N * N : 0);
+    }
+    return reinterpret_cast<const char*>(q);
+  };
   auto stage = [&](const char* plane, int c, int slot) {
 #pragma unroll
     for (int j = 0; j < K::ND; ++j)
@@ -506,5 +519,23 @@ extern "C" int geobo_xz2d_fold(int inverse, int n, int64_t rows, int planes_per_
   FoldArgs g;
   g.in = in; g.in_row = in_row; g.in_plane = in_plane; g.out = out; g.out_row = out_row; g.out_plane = out_plane;
   g.Fz = Fz; g.Fx = Fx; g.ppr = planes_per_row; g.nplanes = rows * planes_per_row;
+  g.row_off = nullptr; g.edge = nullptr; g.edge_row = 0;
   return inverse ? launch_inv<64>(g, (hipStream_t)stream) : launch_fwd<64>(g, (hipStream_t)stream);
+}
+
+extern "C" int geobo_xz2d_fold_lattice(int n, int64_t rows, int planes_per_row, const double* Q, const int64_t* row_off,
+                                       int64_t q_plane, const double* edge, int64_t edge_row, const double* Fx, const double* Fz,
+                                       double* out, int64_t out_row, int64_t out_plane, void* stream) {
+  if (!Q || !row_off || !edge || !out || !Fx || !Fz) return GEOBO_E_ARG;
+  if (rows <= 0 || planes_per_row <= 0) return GEOBO_OK;
+  if (planes_per_row < 3) return GEOBO_E_ARG;
+  if ((q_plane & 1) || (edge_row & 1) || (out_row & 1) || (out_plane & 1) || ((uintptr_t)Q & 15) || ((uintptr_t)edge & 15) ||
+      ((uintptr_t)out & 15) || ((uintptr_t)Fx & 15) || ((uintptr_t)Fz & 15))
+    return GEOBO_E_ALIGN;
+  if (n != 64) return GEOBO_E_UNSUPPORTED;
+  FoldArgs g;
+  g.in = Q; g.in_row = 0; g.in_plane = q_plane; g.out = out; g.out_row = out_row; g.out_plane = out_plane;
+  g.Fz = Fz; g.Fx = Fx; g.ppr = planes_per_row; g.nplanes = rows * planes_per_row;
+  g.row_off = row_off; g.edge = edge; g.edge_row = edge_row;
+  return launch_fwd<64>(g, (hipStream_t)stream);
 }

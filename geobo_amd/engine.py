@@ -83,6 +83,28 @@ class StreamedOperator:
     def __init__(self, eng, func, Bv, mul, div, locd, axes_dev, plan, lws):
         self.eng, self.func, self.Bv, self.mul, self.div = eng, func, Bv, mul, div
         self.locd, self.axes_dev, self.plan, self.lws = locd, axes_dev, plan, lws
+        self.lattice = None     # spectral.LatticeRows: the transform reads the rows as windows of the stencil table (keep_stencil)
+
+    def keep_stencil(self, name):
+        """Lattice survey: keep this operator's stencil table Q (63 MB at 64^3; the lattice workspace is shared between the
+        operators) and its two 1e6-padded boundary slabs for every sensor, and describe the rows as windows of Q -- the forward
+        transform then reads the table, which stays in cache, and no operator row is ever written or read."""
+        from .spectral import LatticeRows
+        e = self.eng
+        nx, ny, nz, plane = e.nx, e.ny, e.nz, e.nx * e.nz
+        nqx = 2 * nx - 1
+        Q = e._workspace("lattice_Q_" + name, (2 * ny - 3, nqx, nz))
+        Q.copy_(hip.a_sens_lattice_stencil(self.lws, nx, ny, nz))
+        row_off = (((ny - 2 - self.plan["jy"].to(torch.int64)) * nqx + (nx - 1 - self.plan["jx"].to(torch.int64))) * nz).contiguous()
+        E2 = e._workspace2d("Aedge_" + name, e.Ms_pad, 2 * plane)
+        if e.Ms_pad > e.Ms:
+            E2[e.Ms:].zero_()
+        xed, yed, zed = self.axes_dev
+        for k, iy in enumerate((0, ny - 1)):
+            hip.a_sens(self.func, self.Bv, self.locd, nx, ny, nz, xed, yed, zed, self.mul, self.div, E2[:, k * plane:(k + 1) * plane], iy, iy + 1,
+                       plan=self.plan, ws=self.lws, col_origin=iy * plane)
+        self.edge = E2
+        self.lattice = LatticeRows(Q.view(-1), row_off, nqx * nz, E2)
 
     def rows_into(self, buf, r0, R):
         """buf[:R, :N_pad] <- operator rows r0 .. r0+R-1 (voxel padding columns zero)."""
@@ -115,10 +137,13 @@ class PosteriorEngine:
         assembly + fp64 Cholesky"); every contraction still accumulates in fp64 on fp64 panels converted on the fly.
         operators "streamed": A_g / A_m are generated in row batches / column slabs when needed instead of being resident."""
         hip.require_gpu()
-        if assembly not in ("f64", "f32") or operators not in ("resident", "streamed"):
-            raise ValueError("assembly must be 'f64' or 'f32', operators 'resident' or 'streamed'")
+        if assembly not in ("f64", "f32") or operators not in ("resident", "streamed", "auto"):
+            raise ValueError("assembly must be 'f64' or 'f32', operators 'resident', 'streamed' or 'auto'")
         self.f32 = assembly == "f32"
         self.streamed = operators == "streamed"
+        # "auto": streamed where that costs nothing -- a lattice survey on one device, whose transform reads the operator rows as
+        # windows of the stencil table and whose AkA comes from the lattice Gram (no operator is ever materialised) -- else resident
+        self.auto_ops = operators == "auto"
         self.s = settings
         self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
         if self.device.type != "cuda":
@@ -140,6 +165,7 @@ class PosteriorEngine:
         self._A = {}
         self._ws = {}   # persistent device workspaces keyed by name (re-used across calls: no per-step allocation)
         self._host = {}  # pinned host staging buffers of the result read-back, keyed by slot
+        self._auto_denied = set()       # operators="auto": (func, B) whose stencil turned out not to be even -> resident
         self._pending_exchange = None   # (A K, [(recv, work)], props) of a row exchange that has been started but not placed yet
         self.use_grid = self.nz >= 16 and self.nz % 2 == 0  # lattice-table generator (geobo_ak_fused_grid); coordinates otherwise
         # spectral (real-DFT) product: regular grid with extents % 16 == 0, unpadded voxel columns, shards on y-slab boundaries
@@ -209,11 +235,19 @@ class PosteriorEngine:
         loc = np.ascontiguousarray(sensor_locations, dtype=np.float64)
         assert loc.shape == (self.Ms, 3), "A_sens handles exactly xNcube*yNcube sensors (sensormodel.py:54,58)"
         partial = self.exchange and not full
-        key = (func, loc.tobytes(), None if B is None else tuple(np.asarray(B, dtype=float)), partial, self.streamed and not full)
+        xe, ye, ze = self.node_axes() if axes is None else axes
+        # survey on the cube's own x-y lattice (the reference's workflow): translation-invariant stencil, ~2000x fewer potentials
+        plan = None
+        if os.environ.get("GEOBO_A_SENS_LATTICE", "1") != "0":
+            pkey = (loc.tobytes(), xe.tobytes(), ye.tobytes(), ze.tobytes())
+            if self._lattice_plan is None or self._lattice_plan[0] != pkey:
+                self._lattice_plan = (pkey, hip.lattice_plan(loc, xe, ye, ze, self.nx, self.ny, self.nz, self.device))
+            plan = self._lattice_plan[1]
+        Bkey = None if B is None else tuple(np.asarray(B, dtype=float))
+        stream_it = (self.streamed or (self.auto_ops and (func, Bkey) not in self._auto_denied and self._implicit_operators_pay(plan))) and not full
+        key = (func, loc.tobytes(), Bkey, partial, stream_it)
         if key in self._A:
             return self._A[key]
-        xe, ye, ze = self.node_axes() if axes is None else axes
-        stream_it = self.streamed and not full
         if partial and not stream_it:
             # row-exchange form: only this rank's y-slab of every sensor row is ever read (AkA operand of the N/G-deep GEMM):
             # a compact (Ms_pad x nc) buffer, columns c0 .. c1 (the kernels address columns absolutely: col_origin)
@@ -234,13 +268,6 @@ class PosteriorEngine:
             Bv = s.magneticField if B is None else np.asarray(B, dtype=float)
             mul, div = 1.0, s.fcor_mag
         locd, xed, yed, zed = (hip.to_dev(v, self.device) for v in (loc, xe, ye, ze))
-        # survey on the cube's own x-y lattice (the reference's workflow): translation-invariant stencil, ~2000x fewer potentials
-        plan = None
-        if os.environ.get("GEOBO_A_SENS_LATTICE", "1") != "0":
-            pkey = (loc.tobytes(), xe.tobytes(), ye.tobytes(), ze.tobytes())
-            if self._lattice_plan is None or self._lattice_plan[0] != pkey:
-                self._lattice_plan = (pkey, hip.lattice_plan(loc, xe, ye, ze, self.nx, self.ny, self.nz, self.device))
-            plan = self._lattice_plan[1]
         lws = None
         if plan is not None:
             lws = self._workspace("a_sens_lattice_ws", (hip.a_sens_lattice_ws_doubles(self.nx, self.ny, self.nz),))
@@ -252,6 +279,16 @@ class PosteriorEngine:
                 tmp = self._op_rows_buffer()
                 self._timed("a_sens_" + func, 0.0, lambda: A.rows_into(tmp, 0, 2))
                 lam = self._gram_eigen(plan, lws)
+                if lam is None and not self.streamed:
+                    # "auto" and the stencil is not even (no lattice Gram): AkA is an N-deep GEMM against the operator -- resident
+                    self._auto_denied.add((func, Bkey))
+                    return self.operator(func, sensor_locations, B=B, axes=axes, full=full)
+                from .spectral import SpectralProduct
+                if self._spectral is None and self.use_spectral:
+                    self._spectral = SpectralProduct(self.nx, self.ny, self.nz, self.device)
+                if (self.use_spectral and self._spectral.lattice_feed and not self.f32
+                        and os.environ.get("GEOBO_LATTICE_FEED", "1") != "0"):
+                    self._timed("a_sens_" + func, 0.0, lambda: A.keep_stencil(func))
             self._lam[func] = None if lam is None else (A, lam)
         elif partial:
             plane = self.nx * self.nz
@@ -285,6 +322,20 @@ class PosteriorEngine:
         self._A = {k: v for k, v in self._A.items() if k[0] != func}  # one operator per type stays resident
         self._A[key] = A
         return A
+
+    def _implicit_operators_pay(self, plan):
+        """operators="auto": True when neither the transforms nor AkA need a materialised operator."""
+        if plan is None or self.world != 1 or self.f32 or not self.use_spectral or not plan["rowmajor"]:
+            return False
+        if os.environ.get("GEOBO_LATTICE_FEED", "1") == "0" or os.environ.get("GEOBO_AKA_LATTICE", "1") == "0":
+            return False
+        from .lattice_gram import LatticeGram
+        from .spectral import SpectralProduct
+        if not LatticeGram.supported(self.nx, self.ny, self.nz) or self.Ms_pad != self.Ms:
+            return False
+        if self._spectral is None:
+            self._spectral = SpectralProduct(self.nx, self.ny, self.nz, self.device)
+        return self._spectral.lattice_feed
 
     def _timed(self, name, flops, fn, alg=0.0, valu=0.0):
         """Run fn(); when kernel_events is a list, bracket it with HIP events on the launch stream (torch's current one).
@@ -452,7 +503,10 @@ class PosteriorEngine:
                 scr = [self._workspace2d("ak_rows64_%d" % jj, Rb, nc) for jj in range(len(props))] if self.f32 else None
                 for r0 in range(0, self.Ms, Rb):
                     R = min(Rb, self.Ms - r0)
-                    src = A.rows_into(abuf, r0, R) if abuf is not None else A[r0:r0 + R]
+                    if abuf is not None and A.lattice is not None:
+                        src = A.lattice.rows(r0)              # no rows at all: the forward transform reads the stencil table
+                    else:
+                        src = A.rows_into(abuf, r0, R) if abuf is not None else A[r0:r0 + R]
                     dst = [b[:R] for b in scr] if scr is not None else [o[r0:r0 + R] for o in outs]
                     sp.product(src, R, lams, dst, y0, y1)
                     if scr is not None:
@@ -658,7 +712,12 @@ class PosteriorEngine:
                             R = min(gram.R, mv - rb)
                             gram.gram_rows(self._panel64("gram_rows64", Xv[rb:rb + R], rows=gram.R), R, lam, Cv[rb:], ya, yb)
                     for c0 in edges:
-                        hip.gemm_nt(self._panel64("aka_panel64", Xv[:, c0:c0 + pl]), operand_cols(c0, c0 + pl), Cv, alpha=1.0,
+                        if streamed and A.lattice is not None:      # the two boundary slabs are kept with the stencil table
+                            k = 0 if ya + c0 // pl == 0 else 1
+                            ycols = A.edge[:, k * pl:(k + 1) * pl]
+                        else:
+                            ycols = operand_cols(c0, c0 + pl)
+                        hip.gemm_nt(self._panel64("aka_panel64", Xv[:, c0:c0 + pl]), ycols, Cv, alpha=1.0,
                                     beta=1.0, lower_only=True, m_valid=mv)
                 self._timed("aka_lattice", fl, lattice)
                 continue

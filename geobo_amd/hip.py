@@ -328,6 +328,15 @@ def tile_rows(m, m_valid, tile=256, group=64):
     return out
 
 
+def xz2d_fold_lattice(n, rows, ppr, Q, row_off, q_plane, edge, edge_row, Fx, Fz, out, out_row, out_plane):
+    """Forward radix-2 transform of operator rows read as windows of the lattice stencil table (geobo_xz2d_fold_lattice)."""
+    lib = require_gpu()
+    assert row_off.dtype == torch.int64 and row_off.is_contiguous() and row_off.numel() >= rows
+    _lib.check(lib.geobo_xz2d_fold_lattice(int(n), int(rows), int(ppr), _p(_chk(Q, "Q")), row_off.data_ptr(), int(q_plane),
+                                           _p(_chk(edge, "edge")), int(edge_row), _p(_chk(Fx, "Fx")), _p(_chk(Fz, "Fz")),
+                                           _p(_chk(out, "out")), int(out_row), int(out_plane), _stream()), "geobo_xz2d_fold_lattice")
+
+
 YMUL_SHAPES = ((128, 64),)      # (m, k) geobo_ymul is instantiated for
 
 

@@ -11,7 +11,7 @@ Same constructor-less usage, attributes and method signatures as the reference:
 kernel (any grid), "spectral" = real-DFT route on batched MFMA GEMMs (regular grids with extents % 16 == 0, ~40x
 faster at 64^3, same results to ~1e-13), "auto" (default) = spectral when applicable.  `assembly="f32"` keeps the covariance
 tables and A K in fp32 (BASELINE config 5: fp32 kernel assembly + fp64 Cholesky; results at fp32-storage accuracy, ~1e-5),
-`operators="streamed"` generates the forward operators in batches instead of keeping them resident.
+`operators="streamed"` generates the forward operators in batches instead of keeping them resident; "auto" (default) does so where it costs nothing (lattice survey on one device: the transforms read the stencil table, AkA is the lattice Gram), "resident" never.
 
 `cubing`/`predict3`/`calc_logl` run matrix-free on the GPU (engine.PosteriorEngine): D2, the 3N x 3N prior
 and the 3N x 3N posterior covariance of the reference (inversion.py:92,117) are never formed -- only the
@@ -72,7 +72,7 @@ class Inversion:
     """Class for inversion and reconstruction of 3D cubes from 2D sensor data (inversion.py:23-248)."""
 
     def __init__(self, settings=None, props=(0, 1, 2), rank=0, world=1, group=None, device=None, profile=False,
-                 method="auto", assembly="f64", operators="resident"):
+                 method="auto", assembly="f64", operators="auto"):
         self.settings = s = settings or config_loader.active()
         # inversion.py:46-51 -- NB x voxel size for all three length scales
         self.gp_length = s.gp_lengthscale * np.asarray([s.xvoxsize, s.xvoxsize, s.xvoxsize])

@@ -96,6 +96,18 @@ def _buf(n, device):
     return torch.empty(int(n) + SLACK, dtype=F64, device=device)
 
 
+class LatticeRows:
+    """Operator rows of a lattice survey that are never materialised: plane y of row r is a window of the stencil table Q
+    (hip.a_sens_lattice_stencil) at row_off[r] + y * q_plane, the two boundary planes come from `edge` ([rows][2][nx*nz]).
+    forward_zx feeds the radix-2 forward kernel from this directly (geobo_xz2d_fold_lattice)."""
+
+    def __init__(self, Q, row_off, q_plane, edge, r0=0):
+        self.Q, self.row_off, self.q_plane, self.edge, self.r0 = Q, row_off, int(q_plane), edge, int(r0)
+
+    def rows(self, r0):
+        return LatticeRows(self.Q, self.row_off, self.q_plane, self.edge, self.r0 + r0)
+
+
 class SpectralProduct:
     """AK rows by the real-DFT route for one grid; holds the transform matrices and the work buffers."""
 
@@ -124,6 +136,8 @@ class SpectralProduct:
         self.pair_xz = ((nx, nz) == (32, 32) and (64, 32) in hip.XZ2D_SHAPES and ny % 2 == 0
                         and os.environ.get("GEOBO_SPECTRAL_FUSED_XZ", "1") != "0")
         self._pairs = {}
+        # operator rows fed straight from a lattice survey's stencil table (LatticeRows): needs the radix-2 forward kernel
+        self.lattice_feed = self.fused_xz and self.fold and nx == nz and "x" in self.F and ny >= 3 and self.dense_y
         if rows_per_batch is None:
             per_row = (ny * self.Px * self.Pz if self.dense_y else self.P3) * 8
             rows_per_batch = max(1, min(256 if self.dense_y else 128, (3 << 30) // per_row))  # ~3 GB per work buffer
@@ -154,6 +168,12 @@ class SpectralProduct:
         nx, ny, nz, Px, Pz = self.nx, self.ny, self.nz, self.Px, self.Pz
         rows = R * ny * nx
         lds = self.N if src_row_stride is None else int(src_row_stride)
+        if isinstance(src, LatticeRows):
+            assert self.lattice_feed and M is self.G
+            t2 = self.buf(out_name, R * ny * Px * Pz)
+            hip.xz2d_fold_lattice(nx, R, ny, src.Q, src.row_off[src.r0:], src.q_plane, src.edge[src.r0:], src.edge.stride(0),
+                                  self.F["x"], self.F["z"], t2, ny * Px * Pz, Px * Pz)
+            return t2
         if self.fused_xz:
             t2 = self.buf(out_name, R * ny * Px * Pz)
             if self.fold and M is self.G and nx == nz and "x" in self.F:     # radix-2 kernels: half the MFMAs (xz2d_fold.hip)
@@ -263,7 +283,10 @@ class SpectralProduct:
         if slabs is None:
             slabs = [(y0, y1, outs)]
         N = self.N
-        assert A.stride(1) == 1 and A.stride(0) >= N and A.stride(0) % 2 == 0
+        if isinstance(A, LatticeRows):
+            assert self.lattice_feed
+        else:
+            assert A.stride(1) == 1 and A.stride(0) >= N and A.stride(0) % 2 == 0
         if self.dense_y:
             return self._product_dense_y(A, Ms, lam_list, slabs)
         for r0 in range(0, Ms, self.R):
@@ -293,7 +316,10 @@ class SpectralProduct:
         n_out = (yhi - ylo) * C
         for r0 in range(0, Ms, self.R):
             R = min(self.R, Ms - r0)
-            t2 = self.forward_zx(A[r0:], R, self.G, src_row_stride=A.stride(0))
+            if isinstance(A, LatticeRows):
+                t2 = self.forward_zx(A.rows(r0), R, self.G)
+            else:
+                t2 = self.forward_zx(A[r0:], R, self.G, src_row_stride=A.stride(0))
             for j in range(0, len(gens), 2):
                 js = list(range(j, min(j + 2, len(gens))))
                 u2 = [self.buf(("S", "S1")[i], R * n_out) for i in range(len(js))]

@@ -216,6 +216,15 @@ int geobo_xcorr_reduce(int nx, int nz, int64_t rows, int planes, const double* i
                        const double* Mx, int64_t ldmx, const double* lamT, double* out, int64_t out_row, int64_t out_plane,
                        void* stream);
 
+/* Forward form of geobo_xz2d_fold fed straight from the stencil table of a lattice survey (geobo_a_sens_lattice): plane y of
+ * operator row r is the contiguous window  Q + row_off[r] + y*q_plane  (n*n doubles) of the table, except the first and the last
+ * plane of a row -- the 1e6-padded boundary slabs -- which are read from  edge + r*edge_row  and  edge + r*edge_row + n*n.  The
+ * operator rows themselves (8.6 GB per operator at 64^3) are neither written nor read; the table (63 MB) stays in cache.
+ * row_off: device array of `rows` offsets in doubles (even).  n = 64, planes_per_row >= 3. */
+int geobo_xz2d_fold_lattice(int n, int64_t rows, int planes_per_row, const double* Q, const int64_t* row_off, int64_t q_plane,
+                            const double* edge, int64_t edge_row, const double* Fx, const double* Fz, double* out,
+                            int64_t out_row, int64_t out_plane, void* stream);
+
 /* y step of the lattice Gram: the same (m x k) matrix G from the left of every row,  out[r][i][c] = sum_j G[i][j] in[r][j][c]
  * for r < rows, c < C (in: rows of k x C at in + r*in_row, out: rows of m x C at out + r*out_row; strides in doubles).
  * m = 128, k = 64 (GEOBO_E_UNSUPPORTED otherwise: geobo_gemm_batched does the same), C % 64 == 0, in 16-byte aligned. */
