@@ -862,6 +862,14 @@ def test_lattice_gram_needs_an_even_stencil():
     eng2 = E.PosteriorEngine(s)
     eng2.operator("grav", loc2)
     assert eng2._lam.get("grav") is None
+    # operators="auto": no operator is materialised where the stencil is even; the inclined field falls back to a resident one
+    eng3 = E.PosteriorEngine(s, operators="auto")
+    assert isinstance(eng3.operator("grav", loc), E.StreamedOperator)
+    Am = eng3.operator("magn", loc, B=(0.4, -0.3, 0.85))
+    assert isinstance(Am, torch.Tensor) and eng3._lam["magn"] is None
+    assert torch.equal(Am, eng.operator("magn", loc, B=(0.4, -0.3, 0.85)))
+    assert isinstance(eng3.operator("magn", loc, B=(0.0, 0.0, 1.0)), E.StreamedOperator)
+    assert isinstance(eng3.operator("grav", loc, full=True), torch.Tensor)          # an explicit request for the matrix
 
 
 @pytest.mark.parametrize("world", [2, 4])
