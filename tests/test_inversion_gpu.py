@@ -965,3 +965,29 @@ def test_streamed_operator_rows_are_windows_of_the_stencil_table():
     for g, r in zip(got, ref):      # (ny = 16 has no lattice Gram: AkA panels accumulate in another order than the resident split-K)
         if np.isfinite(r).any():
             assert normwise(g, r) < 1e-10
+
+
+def test_auto_operators_with_an_inclined_field_match_resident_operators():
+    """operators="auto" with an inclined magnetic field: the gravity operator is never materialised (even stencil), the magnetic
+    one is resident (odd stencil: AkA by the GEMM); the cubes equal the all-resident run's."""
+    from geobo_amd.inversion import Inversion
+    nx, ny, nz = 64, 48, 64
+    s = settings_for(nx, ny, nz, kernelfunc="matern32", XMAG=0.4, YMAG=-0.3, ZMAG=0.85)
+    out = {}
+    rng = np.random.default_rng(11)
+    grav, mag = rng.standard_normal(nx * ny), rng.standard_normal(nx * ny)
+    d0 = np.zeros((ny, nx, nz)); d0[3, 5, 7] = 1.0; d0[40, 40, 20] = 2.0
+    for mode in ("auto", "resident"):
+        inv = Inversion(settings=s, props=(0, 1), operators=mode)
+        inv.create_cubegeometry()
+        xe, ye, ze = inv.engine.node_axes()
+        X, Y = np.meshgrid(0.5 * (xe[:-1] + xe[1:]), 0.5 * (ye[:-1] + ye[1:]))
+        loc = np.c_[X.ravel(), Y.ravel(), np.full(nx * ny, 1.0)]
+        inv.gp_length = np.array([200.0, 202.0, 204.0])
+        out[mode] = inv.cubing(grav, mag, d0[d0 != 0], loc, d0)
+        kinds = sorted(type(v).__name__ for v in inv.engine._A.values())
+        assert kinds == (["StreamedOperator", "Tensor"] if mode == "auto" else ["Tensor", "Tensor"]), kinds
+        del inv
+        torch.cuda.empty_cache()
+    for a, b in zip(out["auto"], out["resident"]):
+        assert np.isnan(b).all() if np.isnan(a).all() else normwise(a, b) <= 1e-11
