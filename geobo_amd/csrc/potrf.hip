@@ -299,6 +299,8 @@ extern "C" int geobo_potrf_inv(int64_t m, double* A, int64_t ld, double* Linv, i
   ic.L = A; ic.ld = ld; ic.Linv = Linv; ic.ldi = ldi;
   double* const wsd = (double*)ws;
   int next_spine = 0;                                    // spine nodes are passed in order: mid_0 < mid_1 < ...
+  bool t0_early = false;
+  constexpr int T0_LEAD = 4;
   int step = 0, last_b = -1, prev_b = -1;   // steps whose (b) was launched most recently
   if (pc) {   // the side stream starts after everything already queued on the caller's stream (the memsets above, the producer of A)
     if (hipEventRecord(Pev[3], st) != hipSuccess || hipStreamWaitEvent(side, Pev[3], 0) != hipSuccess) return GEOBO_E_LAUNCH;
@@ -325,6 +327,16 @@ extern "C" int geobo_potrf_inv(int64_t m, double* A, int64_t ld, double* Linv, i
         rc = build_inverse(ic, sp.lo[d], sp.mid[d]);
         if (rc) return rc;
       }
+      if (next_spine > 0 && !t0_early && step + 1 >= nb - T0_LEAD) {
+        // the root's T product starts under the LAST few steps (their bulk updates are a handful of tiles): 18.1 -> 17.5 ms;
+        // any earlier and its long tiles cost the critical path more than they hide (see below)
+        ic.st = pc->s[1];
+        if (hipEventRecord(Sev[0], st) != hipSuccess || hipStreamWaitEvent(ic.st, Sev[0], 0) != hipSuccess) return GEOBO_E_LAUNCH;
+        rc = form_T(ic, sp.lo[0], sp.mid[0], nb, wsd + sp.t_off[0]);
+        if (rc) return rc;
+        if (hipEventRecord(Sev[1], ic.st) != hipSuccess) return GEOBO_E_LAUNCH;
+        t0_early = true;
+      }
       if (!pc) {
         rc = geobo_gemm_nt(rem, rem, NB, -1.0, P, ld, P, ld, 1.0, A + (kb + NB) * ld + (kb + NB), ld, 1, 0, stream);
         if (rc) return rc;
@@ -348,9 +360,9 @@ extern "C" int geobo_potrf_inv(int64_t m, double* A, int64_t ld, double* Linv, i
     }
   }
   if (pc && last_b >= 0 && hipStreamWaitEvent(st, Bev[last_b & 3], 0) != hipSuccess) return GEOBO_E_LAUNCH;
-  // the T products (hundreds of long tiles) wait for the end of the loop: under it they cost the critical path more than they
-  // hide (measured 18.9 against 17.9 ms, also in chunks and on 128-row tiles) -- one worker per spine node, concurrently
-  for (int d = 0; d < sp.depth; ++d) {
+  // the other T products (hundreds of long tiles) wait for the end of the loop: under it they cost the critical path more than
+  // they hide (measured 18.9 against 17.9 ms, also in chunks and on 128-row tiles) -- one worker per spine node, concurrently
+  for (int d = t0_early ? 1 : 0; d < sp.depth; ++d) {
     ic.st = pc->s[1 + (d & 1)];
     // not before the factorisation is through (the event of the node's start is free again: its wait was captured at the time)
     if (hipEventRecord(Sev[2 * d], st) != hipSuccess || hipStreamWaitEvent(ic.st, Sev[2 * d], 0) != hipSuccess) return GEOBO_E_LAUNCH;
