@@ -26,28 +26,51 @@ def _hipcc():
     raise RuntimeError("hipcc not found: the HIP extension cannot be built on this machine")
 
 
+def _deps(src):
+    return [os.path.join(CSRC, src)] + HEADERS
+
+
+def _obj(src):
+    return os.path.join(LIBDIR, "obj", os.path.splitext(src)[0] + ".o")
+
+
 def up_to_date():
     if not os.path.exists(LIB):
         return False
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
-    return all(os.path.getmtime(d) <= t for d in deps)
+    return all(os.path.getmtime(d) <= t for s in SOURCES for d in _deps(s))
 
 
 def build(force=False, verbose=False, extra_flags=()):
-    """Compile every HIP source of the package into one shared library for gfx950."""
-    if not force and up_to_date():
+    """Compile every HIP source of the package for gfx950 (one object per source, stale ones only, in parallel) and link them
+    into one shared library."""
+    if not force and not extra_flags and up_to_date():
         return LIB
-    os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, *extra_flags,
-           *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB + ".tmp"]
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(os.path.join(LIBDIR, "obj"), exist_ok=True)
+    base = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, *extra_flags]
+
+    def compile_one(src):
+        obj = _obj(src)
+        if not force and not extra_flags and os.path.exists(obj) and all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in _deps(src)):
+            return None
+        cmd = base + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        return subprocess.run(cmd, capture_output=True, text=True)
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        results = list(ex.map(compile_one, SOURCES))
+    for r in results:
+        if r is not None and r.returncode != 0:
+            sys.stderr.write(r.stdout + r.stderr)
+            raise RuntimeError("hipcc failed building libgeobo_hip.so")
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *[_obj(s) for s in SOURCES], "-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stdout + r.stderr)
-        raise RuntimeError("hipcc failed building libgeobo_hip.so")
+        raise RuntimeError("hipcc failed linking libgeobo_hip.so")
     os.replace(LIB + ".tmp", LIB)
     return LIB
 

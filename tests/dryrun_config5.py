@@ -209,7 +209,12 @@ def main():
         t0 = time.perf_counter()
         Ao = {0: O.a_sens(G, G.B * 0., loc, edges, "grav", rows=sens), 1: O.a_sens(G, G.B, loc, edges, "magn", rows=sens)}
         c0, c1 = eng.c0, eng.c1
-        errs_ak, errs_aka = [], []
+        errs_ak, errs_aka, errs_a = [], [], []
+        abuf = eng._op_rows_buffer()
+        for s_, op in ((0, A_g), (1, A_m)):                                   # forward-operator rows as the streamed operator generates them
+            for k, r in enumerate(sens):
+                got = op.rows_into(abuf, r, 1)[0, :eng.N].cpu().numpy()
+                errs_a.append(float(np.abs(got - Ao[s_][k]).max() / np.abs(Ao[s_][k]).max()))
         AkA_l = torch.tril(AkA)
         for s_ in (0, 1):
             for k, r in enumerate(sens):
@@ -228,7 +233,7 @@ def main():
                         want = float(w[t_][c0:c1] @ Aot[k2][c0:c1])
                         got = float(AkA_l[row, col].item()) - (0.1 ** 2 if col == row else 0.0)
                         errs_aka.append(abs(got - want) / max(abs(want), 1e-300))
-        checks = dict(sensors=sens, ak_rows_vs_oracle_fp32_rounded=max(errs_ak), partial_aka_entries_rel=max(errs_aka),
+        checks = dict(sensors=sens, a_sens_rows_vs_oracle=max(errs_a), ak_rows_vs_oracle_fp32_rounded=max(errs_ak), partial_aka_entries_rel=max(errs_aka),
                       oracle_seconds=time.perf_counter() - t0,
                       note="A K rows: device fp32 shard vs the oracle's exact row rounded to fp32 (normwise); AkA: this rank's partial sum "
                            "vs oracle operator rows x oracle A K rows on the rank's columns (fp32-storage accuracy expected)")
@@ -251,6 +256,7 @@ def main():
         return [hip.posterior_reduce(Linv, eng._panel64("post_panel64", AK[:, cs:min(ncols, cs + pw)], cols=pw), u, 1.0, ws, m_valid=Mv)
                 for cs in range(0, ncols, pw)]
     parts = stage("posterior (panels)", post)
+    post_finite = bool(all(torch.isfinite(p[0]).all().item() and torch.isfinite(p[1]).all().item() for p in parts))
     Mu = 2 * eng.Ms + sel.size
     alg = (1.0 * Mu * Mu + 4.0 * Mu) * ncols
     stages = {}
@@ -269,7 +275,7 @@ def main():
                kernel_stage_seconds={k: round(v["seconds"], 3) for k, v in stages.items()},
                kernel_stage_tflops_executed={k: round(v["flop"] / v["seconds"] / 1e12, 2) for k, v in stages.items() if v["flop"] > 0},
                memory_map_GB=dict(sorted(ws_gb.items(), key=lambda kv: -kv[1])), max_memory_allocated_GB=torch.cuda.max_memory_allocated() / 1e9,
-               oracle_checks=checks,
+               oracle_checks=checks, posterior_finite=post_finite,
                missing="the all-reduce of AkA (identity here: the factorised matrix is a stand-in of the right size) and the all-gather of "
                        "the mu / var slices; with the row exchange (>= 4 ranks, all_to_all of A K block-columns) a rank transforms 1/8 of "
                        "the sensor rows instead of all of them: the 'A K' stage divides by ~8 there")

@@ -369,6 +369,35 @@ def test_config5_sequential_shards_equal_the_single_rank_run(tmp_path):
     assert c["finite"] and 0.0 < c["var_min"] and c["var_max"] <= 1.0 + 1e-6 and c["rms_residual_grav"] < 0.1 and c["rms_residual_magn"] < 0.1
 
 
+def test_config5_rank0_of_8_at_full_size(tmp_path):
+    """BASELINE config 5 at its own size: rank 0 of an 8-rank column-sharded run of the 128^3 x 3-property inversion (fp32 kernel
+    assembly, streamed operators, fp64 Cholesky at M_pad = 33024) on this one device, with the oracle contacts of
+    tests/dryrun_config5.py asserted: forward-operator rows, fp32-rounded rows of A K on the rank's columns (oracle FFT form), entries
+    of the rank's partial AkA; finite posterior columns; the rank's footprint stays far inside one MI355X (288 GB)."""
+    import subprocess
+    import sys
+    import gc
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gc.collect()
+    torch.cuda.empty_cache()          # the child needs 153 GB of the device this process has been caching allocations on
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "dryrun_config5.py"), "--size", "128", "--world", "8", "--rank", "0"],
+                       cwd=root, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    c = out["oracle_checks"]
+    print("config 5 rank 0 of 8: step %.1f s, peak %.0f GB, stages %s, checks %s" % (
+        out["rank_step_seconds"], out["max_memory_allocated_GB"], out["wall_seconds"], c))
+    assert out["N_voxels"] == 128 ** 3 and out["M_pad"] == 33024 and out["ak_dtype"] == "float32"
+    assert c["a_sens_rows_vs_oracle"] <= 1e-10
+    assert c["ak_rows_vs_oracle_fp32_rounded"] <= 3e-7                       # fp32 storage of the exact row (observed 1.0e-7)
+    assert c["partial_aka_entries_rel"] <= 2e-7                              # observed 4.6e-8
+    assert out["posterior_finite"]
+    assert out["max_memory_allocated_GB"] < 200.0
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", "config5_rank0_of_8_from_test.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 @pytest.mark.parametrize("case", ["off_lattice", "inclined_field", "off_lattice_dense"])
 def test_irregular_surveys_against_the_oracle(case):
     """Inputs the fast lattice forms must step aside for, end to end against the (pinned) oracle at 16^3: sensors that are NOT on the
@@ -588,7 +617,33 @@ def test_full_size_64cube_properties():
     e_m = np.abs(Am_d - Am_o).max() / np.abs(Am_o).max()
     print("64^3 A_sens rows vs oracle: grav %.2e magn %.2e" % (e_g, e_m))
     assert e_g <= 1e-10 and e_m <= 1e-12                                     # the T2 tier
-    # (b) rows of A K and entries of AkA: oracle operator rows through the oracle's FFT form of the covariance product
+    # (b), (c): rows of A K, entries of AkA and the factor -- on the resident-operator engine and then, again, on the engine the
+    # benchmark times: the default operators="auto" (no operator materialised; the forward transform reads windows of the stencil
+    # table, AkA from the lattice Gram).  Its cubes must equal the resident run's bit for bit.
+    _independent_checks_64(inv, s, G, Ag_o, Am_o, sens, lengths, W, "resident")
+    res_mu, res_var = inv.mu_rec.copy(), var.copy()
+    del A_g, A_m
+    inv_auto = Inversion(settings=s, props=(0, 1))
+    assert inv_auto.engine.auto_ops and inv_auto.engine.use_spectral
+    inv_auto.gp_length = np.array([200.0, 202.0, 204.0])
+    cubes_auto = inv_auto.cubing(grav, mag, drill0[drill0 != 0], loc, drill0)
+    from geobo_amd.engine import StreamedOperator
+    ops = inv_auto._operators()
+    assert all(isinstance(o, StreamedOperator) and o.lattice is not None for o in ops), "auto did not choose implicit operators at 64^3"
+    assert not any(k.startswith("A_") for k in inv_auto.engine._ws), "an operator was materialised on the auto path"
+    for i in (0, 1, 3, 4):
+        assert np.array_equal(cubes_auto[i], cubes[i]), "cube %d: operators='auto' differs from operators='resident'" % i
+    assert np.array_equal(inv_auto.mu_rec[:2 * N], res_mu[:2 * N]) and np.array_equal(inv_auto.cov_rec.diagonal()[:2 * N], res_var[:2 * N])
+    assert inv_auto.logl == inv.logl
+    _independent_checks_64(inv_auto, s, G, Ag_o, Am_o, sens, lengths, W, "auto")
+
+
+def _independent_checks_64(inv, s, G, Ag_o, Am_o, sens, lengths, W, what):
+    """Oracle contact that needs no operator tensor: rows of A K through the oracle's FFT form, entries of AkA as (L L^T) of the device
+    against oracle operator rows x oracle A K rows, and || L L^T - AkA || with AkA re-assembled by the engine's own route."""
+    from oracle import geobo_oracle as O
+    eng = inv.engine
+    N = eng.N
     L = eng.last["L"]
     Lt = torch.tril(L)
     sel = inv._sel
@@ -601,24 +656,25 @@ def test_full_size_64cube_properties():
             for jj, j in enumerate((0, 1)):                                  # rows of A K (the spectral product, P_c = 2)
                 got = AK[off[s_] + r, jj * N:(jj + 1) * N].cpu().numpy()
                 e = np.abs(got - w[j]).max() / np.abs(w[j]).max()
-                print("64^3 A K row %d block (%d,%d) vs oracle: %.2e" % (r, s_, j, e))
+                print("64^3 [%s] A K row %d block (%d,%d) vs oracle: %.2e" % (what, r, s_, j, e))
                 assert e <= 1e-10, (s_, r, j)      # observed 3e-12 (gravity rows: the operator's own 1.5e-11) / 5e-15 (magnetic)
             want = np.r_[Ag_o @ w[0], Am_o @ w[1], w[2][sel]]
             cols = np.r_[np.array(sens), eng.Ms_pad + np.array(sens), 2 * eng.Ms_pad + np.arange(sel.size)]
             got = (Lt[off[s_] + r] @ Lt[cols].t()).cpu().numpy()            # (L L^T)[row, cols]
             want[(cols == off[s_] + r)] += gs ** 2                           # sigma^2 on the diagonal
             e = np.abs(got - want).max() / np.abs(want).max()
-            print("64^3 AkA row %d block %d vs oracle: %.2e" % (r, s_, e))
+            print("64^3 [%s] AkA row %d block %d vs oracle: %.2e" % (what, r, s_, e))
             assert e <= 1e-11                                                # observed <= 8e-14
-    # (c) the factor itself: || tril(L) tril(L)^T - AkA || / || AkA || on the device (AkA re-assembled from the resident A K)
+    # the factor itself: || tril(L) tril(L)^T - AkA || / || AkA || on the device (AkA re-assembled from the resident A K)
     Lc = Lt.clone()
     M_pad = L.shape[0]
     sel_t = torch.as_tensor(sel, device="cuda")
+    A_g, A_m = inv._operators()
     AkA2 = eng._assemble_AkA(AK, M_pad, A_g, A_m, sel_t, [float(x) for x in lengths], "matern32", 1.0, s.gp_err, (0, 1))
     AkA2 = torch.tril(AkA2)
     R = torch.tril(Lc @ Lc.t()) - AkA2
     e = (torch.linalg.matrix_norm(R) / torch.linalg.matrix_norm(AkA2)).item()
-    print("64^3 ||L L^T - AkA||_F / ||AkA||_F = %.2e" % e)
+    print("64^3 [%s] ||L L^T - AkA||_F / ||AkA||_F = %.2e" % (what, e))
     assert e <= 1e-13
 
 

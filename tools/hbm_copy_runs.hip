@@ -1,28 +1,90 @@
-// Stand-alone probe, not part of the library: what a read + write stream reaches on this device when every workgroup touches
-// runs of RUN doubles, one run per (row, y), 128 KiB apart -- the access pattern of toeplitz_y / ymul / the transform kernels.
+// Stand-alone probe, not part of the library: what a stream reaches on this device when every workgroup touches runs of RUN
+// doubles, one run per (row, y), a "plane stride" apart -- the access pattern of toeplitz_y / ymul / the transform kernels, whose
+// work buffers are [row][y][Px*Pz = 16384 doubles] (plane stride 128 KiB, a power of two).
 //     hipcc --offload-arch=gfx950 -O3 tools/hbm_copy_runs.hip -o /tmp/hbm_copy_runs && /tmp/hbm_copy_runs
-// MI355X, 2 x 1.07 GB per launch: 4.4 - 5.0 TB/s for runs of 512 B to 8 KiB (run length does not matter; too few workgroups do:
-// 2.9 TB/s with 8 row groups).  That -- not the 8 TB/s of the data sheet -- is the ceiling the HBM-bound kernels are held against
-// in DESIGN.md section 4.
+// Round 2 measured only the power-of-two stride with 8-byte lane accesses (4.4 - 5.0 TB/s read + write).  Round 3 (VERDICT r02,
+// item 3) adds: padded plane strides (+32 / +256 doubles), 16-byte lane accesses, read-only and write-only streams, and a plain
+// contiguous copy as the control.  Output is committed as profiles/r03_hbm_copy_runs.txt.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
-template <int RUN>   // doubles per run; blockDim = RUN threads... each thread 8 B
-__global__ void copyk(const double* in, double* out, long C, int NY, long R) {
-  const long c0 = (long)blockIdx.x * RUN;
+
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+// MODE 0: copy (read + write), 1: read only (the sum is stored once per thread), 2: write only.  T = double (8 B) or v2d (16 B).
+// Every thread owns one column position of the run and walks y inside a row, rows strided over gridDim.y.
+template <class T, int MODE>
+__global__ void runk(const T* in, T* out, long CS, long C, int NY, long R) {   // CS = plane stride, C = valid width (in units of T)
+  const long c0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c0 >= C) return;
+  T acc = {};
   for (long r = blockIdx.y; r < R; r += gridDim.y)
     for (int y = 0; y < NY; ++y) {
-      const long o = (r * NY + y) * C + c0 + threadIdx.x;
-      out[o] = in[o] * 1.0000001;
+      const long o = (r * NY + y) * CS + c0;
+      if (MODE == 0) out[o] = in[o] * 1.0000001;
+      if (MODE == 1) acc += in[o];
+      if (MODE == 2) out[o] = acc + (double)y;
     }
+  if (MODE == 1) out[c0 + (long)blockIdx.y * CS] = acc;
 }
+
+template <class T>
+__global__ void lineark(const T* in, T* out, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = in[i] * 1.0000001;
+}
+
+template <class T, int MODE>
+static void run(const char* what, double* a, double* b, long Cd, long padd, int NY, long R, int run_threads, int gy) {
+  const int W = sizeof(T) / 8;
+  const long C = Cd / W, CS = (Cd + padd) / W;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float best = 1e30f;
+  for (int rep = 0; rep < 3; ++rep) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((runk<T, MODE>), dim3((unsigned)((C + run_threads - 1) / run_threads), gy), dim3(run_threads), 0, 0,
+                       (const T*)a, (T*)b, CS, C, NY, R);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best) best = ms;
+  }
+  const double bytes = (MODE == 0 ? 2.0 : 1.0) * (double)R * NY * Cd * 8;
+  printf("%-10s lane %2zu B  plane stride %6ld+%-4ld doubles  run %5d B  gridy %3d : %7.3f ms  %5.2f TB/s\n", what, sizeof(T), Cd, padd,
+         run_threads * (int)sizeof(T), gy, best, bytes / best / 1e9);
+  hipEventDestroy(e0); hipEventDestroy(e1);
+}
+
 int main() {
   const long C = 16384, R = 128; const int NY = 64;
-  size_t n = (size_t)R * NY * C;
-  double *a, *b; hipMalloc(&a, n * 8); hipMalloc(&b, n * 8); hipMemset(a, 0, n * 8);
-  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int rep = 0; rep < 2; ++rep) {
-#define RUNK(RUN, GY) { hipEventRecord(e0); hipLaunchKernelGGL(copyk<RUN>, dim3(C / RUN, GY), dim3(RUN), 0, 0, a, b, C, NY, R); hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); printf("run %4d B x gridy %3d: %.3f ms  %.2f TB/s\n", RUN * 8, GY, ms, 2.0 * n * 8 / ms / 1e9); }
-    RUNK(64, 8) RUNK(64, 32) RUNK(128, 16) RUNK(128, 64) RUNK(256, 32) RUNK(256, 128) RUNK(512, 64) RUNK(512, 128) RUNK(1024, 128)
+  const size_t n = (size_t)R * NY * (C + 256) + 4096;
+  double *a, *b; hipMalloc(&a, n * 8); hipMalloc(&b, n * 8); hipMemset(a, 0, n * 8); hipMemset(b, 0, n * 8);
+  {   // control: contiguous grid-stride copy of the same volume
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const long nn = (long)R * NY * C;
+    for (int w = 0; w < 2; ++w) {
+      float best = 1e30f;
+      for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        if (w == 0) hipLaunchKernelGGL(lineark<double>, dim3(8192), dim3(256), 0, 0, a, b, nn);
+        else hipLaunchKernelGGL(lineark<v2d>, dim3(8192), dim3(256), 0, 0, (const v2d*)a, (v2d*)b, nn / 2);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
+      }
+      printf("contiguous copy, lane %2d B: %7.3f ms  %5.2f TB/s (read + write)\n", w ? 16 : 8, best, 2.0 * nn * 8 / best / 1e9);
+    }
+  }
+  const long pads[3] = {0, 32, 256};
+  for (int pi = 0; pi < 3; ++pi) {
+    const long pad = pads[pi];
+    printf("---- plane stride %ld + %ld doubles (%ld B) ----\n", C, pad, (C + pad) * 8);
+    run<double, 0>("copy", a, b, C, pad, NY, R, 64, 32);
+    run<double, 0>("copy", a, b, C, pad, NY, R, 256, 128);
+    run<double, 0>("copy", a, b, C, pad, NY, R, 1024, 128);
+    run<v2d, 0>("copy", a, b, C, pad, NY, R, 64, 64);
+    run<v2d, 0>("copy", a, b, C, pad, NY, R, 256, 128);
+    run<v2d, 0>("copy", a, b, C, pad, NY, R, 512, 128);
+    run<double, 1>("read", a, b, C, pad, NY, R, 256, 128);
+    run<v2d, 1>("read", a, b, C, pad, NY, R, 256, 128);
+    run<double, 2>("write", a, b, C, pad, NY, R, 256, 128);
+    run<v2d, 2>("write", a, b, C, pad, NY, R, 256, 128);
   }
   return 0;
 }
