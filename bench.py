@@ -4,18 +4,24 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--size 64] [--no-cpu]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one full pass of the hot path over one synthetic survey: forward operators A_g/A_m built on the
-device, fused covariance assembly x operator product (AK), AkA, Cholesky, posterior mean + variance, D2H of the
-cubes.  Workload = BASELINE config 3/4: 64^3 voxels of 100 m, gravity + magnetics joint inversion (density and
-magnetic-susceptibility cubes, P_out = 2), Matern-3/2 kernel with lengths (2.00, 2.02, 2.04) x 100 m, 50
-drill-core constraints, M = 4096 + 4096 + 50 observation rows.  With N > 1 the SAME problem is sharded by voxel
-columns over the ranks (strong scaling): one all-reduce of the partial AkA + one all-gather of the mu/var slices.
+A "step" is one full pass of the hot path over one synthetic survey: everything about the forward operators A_g/A_m that the
+route needs built on the device (stencil tables + boundary slabs on a lattice survey -- no operator is materialised there --, incl.
+the host analysis of the survey geometry and its uploads), A K by the spectral route (radix-2 real-DFT transforms over x and z,
+Toeplitz blocks over y), AkA (lattice Gram), Cholesky + L^-1, posterior mean + variance, D2H of the cubes.  Workload = BASELINE
+config 3/4: 64^3 voxels of 100 m, gravity + magnetics joint inversion (density and magnetic-susceptibility cubes, P_out = 2),
+Matern-3/2 kernel with lengths (2.00, 2.02, 2.04) x 100 m, 50 drill-core constraints, M = 4096 + 4096 + 50 observation rows.
+With N > 1 the SAME problem is sharded over the ranks (strong scaling): 1-2 ranks one all-reduce of the
+partial AkA, from 4 ranks one all-to-all of A K block-columns per operator + one all-gather of AkA row blocks; always one all-gather
+of the mu/var slices.
 
 Prints ONE JSON line on rank 0 (see the driver contract); extra objects:
-  roofline      dominant kernel = geobo_ak_fused (fp64 MFMA): algorithmic flops per launch / mean launch duration
-                measured with HIP events on the launch stream, against the 78.6 TFLOP/s fp64 matrix peak
+  roofline      dominant kernel = geobo_posterior_reduce on the default route (fp64 MFMA; geobo_ak_fused_grid with --method dense):
+                ALGORITHMIC flops per launch / mean launch duration measured with HIP events on the launch stream,
+                against the 78.6 TFLOP/s fp64 matrix peak
+  roofline_assembly  the HBM-bound regime of SURVEY 8(d): one materialised covariance block (geobo_k_block), bytes written per
+                launch / HIP-event duration against 8 TB/s (outside the timed steps)
   cpu_baseline  the NumPy/OpenBLAS oracle (kind "port") timed on this box's host cores on a bounded column sample of
-                the same workload
+                the same workload, plus the whole matrix-free oracle step at 16^3 and 32^3 (64^3 extrapolated from 32^3, labelled)
 """
 import argparse
 import json
@@ -227,8 +233,8 @@ def main():
     ap.add_argument("--operators", default="auto", choices=["auto", "resident", "streamed"],
                     help="auto (the library default): no materialised operators where the lattice forms make them unnecessary")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--cpu-forms", default="16", help="comma list of cube edges for the full matrix-free CPU oracle step "
-                    "(SURVEY 8(d) form (b)); '16,32' adds the 32^3 run (minutes)")
+    ap.add_argument("--cpu-forms", default="16,32", help="comma list of cube edges for the full matrix-free CPU oracle step "
+                    "(SURVEY 8(d) form (b)); the 64^3 figure is extrapolated from the LARGEST one (32^3: ~1 min on the box's 128 threads)")
     ap.add_argument("--cpu-dense-forms", default="", help="cube edges for the reference-shaped CPU form (a), e.g. '16' (~30 s) or '16,20'")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU dry runs)")
     ap.add_argument("--oversubscribe", action="store_true", help="dry runs: allow several ranks per device (gloo backend)")
@@ -270,7 +276,8 @@ def main():
     gp_length = np.array([2.00, 2.02, 2.04]) * s.xvoxsize if a.kernel == "matern32" else None
 
     def step():
-        inv.engine.clear_operators()          # A_g / A_m are rebuilt inside every step
+        inv.engine.clear_operators()          # operators, stencil tables, survey-geometry plan: rebuilt inside every step
+        inv._axes_of = (None, None)           # ... and the node-axis check of the Edges tensor
         if gp_length is not None:
             inv.gp_length = gp_length.copy()
         else:

@@ -25,7 +25,7 @@ SIGNATURES = {
     "geobo_round_f32": (_int, [_dp, _i64, _dp]),
     "geobo_k_eval": (_int, [_int, _dp, _i64, _f64, _f64, _f64, _f64, _dp, _dp]),
     "geobo_a_sens": (_int, [_int, C.POINTER(_f64), _dp, _i64, _int, _int, _int, _dp, _dp, _dp, _f64, _f64, _dp, _i64, _dp]),
-    "geobo_a_sens_slab": (_int, [_int, C.POINTER(_f64), _dp, _i64, _int, _int, _int, _dp, _dp, _dp, _f64, _f64, _int, _int, _dp, _i64, _dp]),
+    "geobo_a_sens_slab": (_int, [_int, C.POINTER(_f64), _dp, _i64, _int, _int, _int, _dp, _dp, _dp, _f64, _f64, _int, _int, _dp, _i64, _i64, _dp]),
     "geobo_potential": (_int, [_int, C.POINTER(_f64), _dp, _dp, _dp, _i64, _dp, _dp]),
     "geobo_ak_fused": (_int, [_int, _dp, _i64, _i64, _i64, _dp, _dp, _dp, _i64, _i64, _f64, _f64, _f64, _f64, _dp, _i64, _dp]),
     "geobo_cov_table": (_int, [_int, _int, _int, _int, _f64, _f64, _f64, _f64, _f64, _f64, _f64, _dp, _dp]),
@@ -39,7 +39,7 @@ SIGNATURES = {
     "geobo_scale_broadcast2": (_int, [_dp, _dp, _dp, _i64, _i64, _dp, _dp, _dp]),
     "geobo_a_sens_lattice_ws_bytes": (_sz, [_int, _int, _int]),
     "geobo_a_sens_lattice": (_int, [_int, C.POINTER(_f64), _i64, _int, _int, _int, _dp, _dp, _dp, _dp, _dp, _f64, _f64, _int, _int, _dp, _i64,
-                                    _dp, _sz, _dp]),
+                                    _i64, _dp, _sz, _dp]),
     "geobo_xz2d": (_int, [_int, _int, _int, _i64, _int, _dp, _i64, _i64, _dp, _i64, _dp, _i64, _dp, _i64, _i64, _dp]),
     "geobo_xz2d_fold": (_int, [_int, _int, _i64, _int, _dp, _i64, _i64, _dp, _dp, _dp, _i64, _i64, _dp]),
     "geobo_xcorr_reduce_fold": (_int, [_int, _i64, _int, _dp, _i64, _i64, _dp, _dp, _dp, _i64, _i64, _dp]),

@@ -403,7 +403,15 @@ extern "C" int geobo_k_eval(int kernel_id, const double* d2, int64_t n, double l
 
 extern "C" int geobo_a_sens_slab(int func_id, const double* B3_host, const double* loc, int64_t Ms, int nx, int ny, int nz,
                                  const double* xe, const double* ye, const double* ze, double scale_mul, double scale_div,
-                                 int iy0, int iy1, double* A, int64_t ld, void* stream);
+                                 int iy0, int iy1, double* A, int64_t ld, int64_t col_origin, void* stream);
+
+// A[n, 0] stands for voxel column col_origin; the requested slab's columns [iy0*nx*nz, iy1*nx*nz) must lie inside one row of the
+// buffer, [col_origin, col_origin + ld): nothing outside the caller's rows is ever addressed
+static bool slab_origin_ok(int nx, int ny, int nz, int iy0, int iy1, int64_t ld, int64_t col_origin) {
+  const int64_t plane = (int64_t)nx * nz;
+  (void)ny;
+  return col_origin >= 0 && col_origin <= plane * iy0 && plane * iy1 - col_origin <= ld;
+}
 
 extern "C" size_t geobo_a_sens_lattice_ws_bytes(int nx, int ny, int nz) {
   if (nx <= 0 || ny < 3 || nz <= 0) return 0;
@@ -413,12 +421,12 @@ extern "C" size_t geobo_a_sens_lattice_ws_bytes(int nx, int ny, int nz) {
 
 extern "C" int geobo_a_sens_lattice(int func_id, const double* B3_host, int64_t Ms, int nx, int ny, int nz, const double* dxv,
                                     const double* dyv, const double* dzv, const int* jxs, const int* jys, double scale_mul,
-                                    double scale_div, int iy0, int iy1, double* A, int64_t ld, void* ws, size_t ws_bytes,
-                                    void* stream) {
+                                    double scale_div, int iy0, int iy1, double* A, int64_t ld, int64_t col_origin, void* ws,
+                                    size_t ws_bytes, void* stream) {
   if (!B3_host || !dxv || !dyv || !dzv || !jxs || !jys || !A || !ws) return GEOBO_E_ARG;
   if (iy0 < 0 || iy1 > ny || iy0 >= iy1) return GEOBO_E_ARG;
-  // ld covers at least the requested slab (a caller holding only that slab passes A moved back by iy0*nx*nz elements)
-  if (Ms <= 0 || nx <= 0 || ny < 3 || nz <= 0 || (nz & 1) || (ld & 1) || ld < (int64_t)(iy1 - iy0) * nx * nz) return GEOBO_E_ARG;
+  if (Ms <= 0 || nx <= 0 || ny < 3 || nz <= 0 || (nz & 1) || (ld & 1) || !slab_origin_ok(nx, ny, nz, iy0, iy1, ld, col_origin)) return GEOBO_E_ARG;
+  A -= col_origin;                    // the kernels address columns absolutely and touch the requested slab only
   if (func_id != GEOBO_F_GRAV && func_id != GEOBO_F_MAGN) return GEOBO_E_UNSUPPORTED;
   if (ws_bytes < geobo_a_sens_lattice_ws_bytes(nx, ny, nz)) return GEOBO_E_ARG;
   const int ia = iy0 > 1 ? iy0 : 1, ib = iy1 < ny - 1 ? iy1 : ny - 1;   // interior slabs of the request
@@ -445,15 +453,16 @@ extern "C" int geobo_a_sens_lattice(int func_id, const double* B3_host, int64_t 
 extern "C" int geobo_a_sens(int func_id, const double* B3_host, const double* loc, int64_t Ms, int nx, int ny, int nz,
                             const double* xe, const double* ye, const double* ze, double scale_mul, double scale_div,
                             double* A, int64_t ld, void* stream) {
-  return geobo_a_sens_slab(func_id, B3_host, loc, Ms, nx, ny, nz, xe, ye, ze, scale_mul, scale_div, 0, ny, A, ld, stream);
+  return geobo_a_sens_slab(func_id, B3_host, loc, Ms, nx, ny, nz, xe, ye, ze, scale_mul, scale_div, 0, ny, A, ld, 0, stream);
 }
 
 extern "C" int geobo_a_sens_slab(int func_id, const double* B3_host, const double* loc, int64_t Ms, int nx, int ny, int nz,
                                  const double* xe, const double* ye, const double* ze, double scale_mul, double scale_div,
-                                 int iy0, int iy1, double* A, int64_t ld, void* stream) {
+                                 int iy0, int iy1, double* A, int64_t ld, int64_t col_origin, void* stream) {
   if (!B3_host || !loc || !xe || !ye || !ze || !A) return GEOBO_E_ARG;
   if (iy0 < 0 || iy1 > ny || iy0 >= iy1) return GEOBO_E_ARG;
-  if (Ms <= 0 || nx <= 0 || ny <= 0 || nz <= 0 || ld < (int64_t)(iy1 - iy0) * nx * nz) return GEOBO_E_ARG;
+  if (Ms <= 0 || nx <= 0 || ny <= 0 || nz <= 0 || !slab_origin_ok(nx, ny, nz, iy0, iy1, ld, col_origin)) return GEOBO_E_ARG;
+  A -= col_origin;
   if (func_id != GEOBO_F_GRAV && func_id != GEOBO_F_MAGN) return GEOBO_E_UNSUPPORTED;
   SensArgs a;
   a.loc = loc; a.Ms = Ms; a.nx = nx; a.ny = ny; a.nz = nz;

@@ -18,9 +18,11 @@ HBM layout (all fp64, row-major, zero padded -- include/geobo_hip.h "PADDING CON
     AkA/L      M_pad x M_pad             M_pad = pad256(2*Ms_pad + M_d); padding rows carry identity
     Linv       M_pad x M_pad
 
-Multi-GPU (one process per GPU, torch.distributed/RCCL): voxel COLUMNS are sharded across ranks in units of
-128; A_g/A_m are rebuilt on every rank (milliseconds, no traffic); the only data-path collectives are one
-all-reduce of the M_pad x M_pad partial AkA and one all-gather of the mu/var slices.
+Multi-GPU (one process per GPU, torch.distributed/RCCL): voxel COLUMNS of A K / V are sharded across ranks in units of 128
+(= y-slabs of the cube).  1-2 ranks: forward transforms replicated, AkA partial sums by one all-reduce, mu/var slices by one
+all-gather.  From 4 ranks: sensor ROWS are sharded through the transforms, one all-to-all per operator hands every peer the
+block-columns it owns, AkA arrives as row blocks (row-sharded lattice Gram + all-gather), mu/var slices by one all-gather.
+DESIGN.md section 7.
 """
 import math
 import os
@@ -60,6 +62,36 @@ def weight_matrix(crossweights):
     """kernels.py:166-169,181 -- w1: 0<->2, w2: 1<->2, w3: 0<->1."""
     w1, w2, w3 = [float(v) for v in np.asarray(crossweights)]
     return [[1.0, w3, w1], [w3, 1.0, w2], [w1, w2, 1.0]]
+
+
+_XGROUPS = {}
+
+
+def _exchange_group(ranks, backend):
+    """One extra communicator per rank tuple for the whole process (engines come and go; an RCCL communicator per engine would leak)."""
+    key = (ranks, backend)
+    if key not in _XGROUPS:
+        _XGROUPS[key] = torch.distributed.new_group(ranks=list(ranks), backend=backend)
+    return _XGROUPS[key]
+
+
+def lattice_gram_form(exchange, chunked, world, Ms, c0, c1, plane, N):
+    """Which form of the lattice Gram (AkA on a lattice survey) a rank can use -- pure shard arithmetic, tested on the CPU:
+      "rows"     row exchange with rank-sized send buffers (>= 4 ranks, fp64, resident operators): before the all-to-all a rank holds
+                 ALL voxels of its own Ms/world sensor rows, correlates those itself and AkA arrives as row blocks (all-gather);
+      "columns"  every rank correlates its own y-slab of the A K rows (partial block columns add up in the all-reduce of AkA); the x
+                 step and the back-transform are not divided, so from ~5 ranks the N/G-deep GEMM is cheaper; needs whole y-slabs in
+                 multiples of 16;
+      None       AkA by the N/G-deep GEMM.
+    The CHUNKED exchange of the large-cube modes (fp32 assembly / streamed operators) keeps no full rows: it falls under the
+    column rules (round-2 advisory: it used to get eigen-data under the row rule and then died in gram_rows' Ly % 16 assertion,
+    e.g. 64^3 on 8 ranks with assembly="f32")."""
+    if exchange and not chunked:
+        return "rows" if (Ms // world) % 128 == 0 else None
+    Ly = (c1 - c0) // plane
+    if world > 4 or (c1 - c0) % plane or Ly % 16 or c1 > N or Ly <= 0:
+        return None
+    return "columns"
 
 
 def _on_device(fn):
@@ -190,14 +222,22 @@ class PosteriorEngine:
                          and xmode != "0" and (world >= 4 or xmode == "1"))
         if self.streamed and not self.use_spectral:
             raise ValueError("streamed operators feed the spectral product: needs the spectral method's grid conditions")
-        # The row exchange gets a communicator of its own: collectives of one communicator run in issue order on its stream, and
-        # the all-gather of the AkA row blocks (issued while the exchange is still in flight) must not queue up behind it.
-        # (Collective call: every rank builds its engine at the same point -- Inversion does on first use.)
+        # Communicator of the row exchange.  Default: the caller's own group -- collectives of one communicator run in issue order on
+        # its stream, so the asynchronous all-to-all still overlaps with this rank's COMPUTE (second operator's transforms, row Gram)
+        # and only the all-gather of the AkA row blocks queues up behind it; nothing about that can deadlock.
+        # GEOBO_EXCHANGE_COMM=own gives the exchange a second communicator so that the all-gather overtakes it (the all-to-all then
+        # also runs under the factorisation).  Two communicators with collectives in flight on one device are deadlock-prone unless
+        # every rank issues them in the same order (they do) -- but that mode has never run on RCCL hardware (no multi-GPU box was
+        # available to the builder), so it is opt-in.  GEOBO_ASYNC_EXCHANGE=0: blocking exchange on the caller's group.
+        # (own: torch.distributed.new_group is a collective over the DEFAULT group -- every rank must build its engine at the same
+        # point; the communicator is cached per rank tuple and shared by all engines of the process.)
         self._xgroup = group
-        if self.exchange and torch.distributed.is_available() and torch.distributed.is_initialized():
+        self.async_exchange = os.environ.get("GEOBO_ASYNC_EXCHANGE", "1") != "0"
+        if (self.exchange and os.environ.get("GEOBO_EXCHANGE_COMM", "shared") == "own" and self.async_exchange
+                and torch.distributed.is_available() and torch.distributed.is_initialized()):
             ranks = torch.distributed.get_process_group_ranks(group) if group is not None else list(range(torch.distributed.get_world_size()))
             if len(ranks) == world:
-                self._xgroup = torch.distributed.new_group(ranks=ranks, backend=torch.distributed.get_backend(group))
+                self._xgroup = _exchange_group(tuple(ranks), torch.distributed.get_backend(group))
         self._Arows, self._Aedge, self._fullrows = {}, {}, {}
         self._slab_ops = set()      # data pointers of operators that hold only this rank's column slab
         self._potrf_ctx = None
@@ -244,7 +284,8 @@ class PosteriorEngine:
                 self._lattice_plan = (pkey, hip.lattice_plan(loc, xe, ye, ze, self.nx, self.ny, self.nz, self.device))
             plan = self._lattice_plan[1]
         Bkey = None if B is None else tuple(np.asarray(B, dtype=float))
-        stream_it = (self.streamed or (self.auto_ops and (func, Bkey) not in self._auto_denied and self._implicit_operators_pay(plan))) and not full
+        dkey = (func, Bkey, None if plan is None else self._lattice_plan[0])      # a stencil's evenness belongs to (field, survey geometry)
+        stream_it = (self.streamed or (self.auto_ops and dkey not in self._auto_denied and self._implicit_operators_pay(plan))) and not full
         key = (func, loc.tobytes(), Bkey, partial, stream_it)
         if key in self._A:
             return self._A[key]
@@ -276,12 +317,12 @@ class PosteriorEngine:
             lam = None
             if plan is not None:
                 # one two-sensor call leaves the stencil table Q in the lattice workspace (the Gram's eigen-data come from it)
-                tmp = self._op_rows_buffer()
+                tmp = self._workspace2d("op_rows2", 2, self.N_pad)
                 self._timed("a_sens_" + func, 0.0, lambda: A.rows_into(tmp, 0, 2))
                 lam = self._gram_eigen(plan, lws)
                 if lam is None and not self.streamed:
                     # "auto" and the stencil is not even (no lattice Gram): AkA is an N-deep GEMM against the operator -- resident
-                    self._auto_denied.add((func, Bkey))
+                    self._auto_denied.add(dkey)
                     return self.operator(func, sensor_locations, B=B, axes=axes, full=full)
                 from .spectral import SpectralProduct
                 if self._spectral is None and self.use_spectral:
@@ -418,6 +459,7 @@ class PosteriorEngine:
         """Drop the resident forward operators (the benchmark rebuilds them inside every timed step)."""
         self._A = {}
         self._lam = {}
+        self._lattice_plan = None      # host analysis of the survey geometry + its device copies: part of the operator build
 
     # ---- stages ------------------------------------------------------------------------------------------------
     def _tick(self, name, t0=None):
@@ -528,7 +570,10 @@ class PosteriorEngine:
             send = self._exchange_send(s_, func, lengths, W, name, amp, props)
             sends.append(send)
             out = self._workspace("xchg_recv_%d" % s_, tuple(send.shape)) if torch.distributed.get_backend(self._xgroup) == "nccl" else None
-            pending.append(exchange_blocks_start(send, self.world, self._xgroup, out=out))
+            if self.async_exchange:
+                pending.append(exchange_blocks_start(send, self.world, self._xgroup, out=out))
+            else:
+                pending.append((self._timed("xgmi_all_to_all", 0.0, lambda: exchange_blocks(send, self.world, self._xgroup)), None))
         self._keep_full_rows(sends, props)
         self._pending_exchange = (AK, pending, props)
         if not self._row_gram():
@@ -646,12 +691,8 @@ class PosteriorEngine:
         if (not self.use_spectral or not plan["rowmajor"] or self.Ms_pad != self.Ms
                 or not LatticeGram.supported(self.nx, self.ny, self.nz) or os.environ.get("GEOBO_AKA_LATTICE", "1") == "0"):
             return None
-        if self.exchange:
-            # row exchange (>= 4 ranks): every rank holds ALL voxels of its own sensor rows before the all-to-all, so it correlates
-            # those rows itself and AkA arrives as row blocks (all-gather) -- no N/G-deep GEMM, no all-reduce
-            if (self.Ms // self.world) % 128:
-                return None
-        elif self.world > 4 or (self.c1 - self.c0) % plane or Ly % 16 or self.c1 > self.N:
+        form = lattice_gram_form(self.exchange, self.f32 or self.streamed, self.world, self.Ms, self.c0, self.c1, plane, self.N)
+        if form is None:
             return None
         if self._spectral is None:
             from .spectral import SpectralProduct

@@ -128,17 +128,14 @@ def lattice_plan(loc, xe, ye, ze, nx, ny, nz, device="cuda"):
         return None
     X = xe[:, None] - ux[None, :]                 # (nx+1, nx): offset of node j from lattice column t
     Y = ye[1:ny, None] - uy[None, :]              # (ny-1, ny): planes 1 .. ny-1 (planes 0 and ny carry the 1e6 padding)
+    # every offset must depend on the index difference only, bit for bit: scatter by difference, then compare the whole matrix
+    dix = np.arange(nx + 1)[:, None] - np.arange(nx)[None, :] + nx - 1            # d = j - t        -> 0 .. 2nx-1
+    diy = np.arange(1, ny)[:, None] - np.arange(ny)[None, :] + ny - 2             # d = i - t, i>=1  -> 0 .. 2ny-3
     dxv, dyv = np.empty(2 * nx), np.empty(2 * ny - 2)
-    for d in range(-(nx - 1), nx + 1):            # d = j - t
-        v = np.diagonal(X, offset=-d)
-        if not (v == v[0]).all():
-            return None
-        dxv[d + nx - 1] = v[0]
-    for d in range(2 - ny, ny):                   # d = i - t with i = 1 .. ny-1  ->  row index i - 1
-        v = np.diagonal(Y, offset=-(d - 1))
-        if not (v == v[0]).all():
-            return None
-        dyv[d + ny - 2] = v[0]
+    dxv[dix.ravel()] = X.ravel()
+    dyv[diy.ravel()] = Y.ravel()
+    if not ((dxv[dix] == X).all() and (dyv[diy] == Y).all()):
+        return None
     dev = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a, dtype=dt)).to(device)
     return dict(dxv=dev(dxv, np.float64), dyv=dev(dyv, np.float64), dzv=dev(ze - loc[0, 2], np.float64),
                 jx=dev(jx, np.int32), jy=dev(jy, np.int32), rowmajor=bool((jy * nx + jx == np.arange(nx * ny)).all()))
@@ -149,14 +146,12 @@ def a_sens(func, B, loc, nx, ny, nz, xe, ye, ze, scale_mul, scale_div, out, iy0=
     """Forward operator rows for the sensors in `loc`; optionally only the voxel slab iy0 <= iy < iy1.
     plan (lattice_plan) + rows (slice of the plan's sensors that `loc` holds): interior slabs by the lattice kernels, the
     two 1e6-padded boundary slabs by the direct kernel.
-    col_origin: voxel column that out[:, 0] stands for (a compact slab buffer holds columns col_origin .. only; the kernels
-    address columns absolutely, so the base pointer is moved back by col_origin elements -- they never touch anything outside
-    the requested slab)."""
+    col_origin: voxel column that out[:, 0] stands for: 0 (full-width operator) or the first column of a compact buffer that holds
+    only a slab; the library checks that the requested columns lie inside a buffer row and applies the offset itself."""
     lib = require_gpu()
     ld = _rowmajor(out, "A")
     col_origin = int(col_origin)
-    assert col_origin == 0 or (col_origin == int(iy0) * nx * nz and out.shape[1] >= (int(ny if iy1 is None else iy1) - int(iy0)) * nx * nz)
-    base = C.c_void_p(out.data_ptr() - 8 * col_origin)
+    base = _p(out)
     loc = _chk(loc, "loc").contiguous()
     Bh = (C.c_double * 3)(*[float(b) for b in B])
     iy1 = int(ny if iy1 is None else iy1)
@@ -164,7 +159,7 @@ def a_sens(func, B, loc, nx, ny, nz, xe, ye, ze, scale_mul, scale_div, out, iy0=
     def direct(a, b):
         _lib.check(lib.geobo_a_sens_slab(FUNC_IDS[func], Bh, _p(loc), loc.shape[0], int(nx), int(ny), int(nz), _p(_chk(xe, "xe")),
                                          _p(_chk(ye, "ye")), _p(_chk(ze, "ze")), float(scale_mul), float(scale_div), int(a),
-                                         int(b), base, ld, _stream()), "geobo_a_sens_slab")
+                                         int(b), base, ld, col_origin, _stream()), "geobo_a_sens_slab")
     if plan is None:
         direct(iy0, iy1)
         return out
@@ -176,7 +171,7 @@ def a_sens(func, B, loc, nx, ny, nz, xe, ye, ze, scale_mul, scale_div, out, iy0=
         ws = torch.empty(nbytes // 8, dtype=F64, device=out.device)
     _lib.check(lib.geobo_a_sens_lattice(FUNC_IDS[func], Bh, loc.shape[0], int(nx), int(ny), int(nz), _p(plan["dxv"]), _p(plan["dyv"]),
                                         _p(plan["dzv"]), C.c_void_p(jx.data_ptr()), C.c_void_p(jy.data_ptr()), float(scale_mul),
-                                        float(scale_div), int(iy0), iy1, base, ld, _p(ws), nbytes, _stream()),
+                                        float(scale_div), int(iy0), iy1, base, ld, col_origin, _p(ws), nbytes, _stream()),
                "geobo_a_sens_lattice")
     if iy0 == 0:
         direct(0, 1)

@@ -12,6 +12,10 @@
  *     leading dimensions in elements; `stream` is a hipStream_t passed as void*;
  *   - functions are stream-ordered, never allocate, never synchronise, never throw; the return value
  *     is 0 on success or a negative GEOBO_E_* code (argument validation / launch failure);
+ *   - process-global state: ONE exception to "none" -- kernels that need more than 64 KiB of dynamic LDS record, in a
+ *     per-kernel atomic bit mask indexed by device (`attr_done` in gemm_f64.hip, xz2d.hip, xz2d_fold.hip), that
+ *     hipFuncSetAttribute(MaxDynamicSharedMemorySize) has been issued for that device.  The flag is idempotent, lock free,
+ *     never cleared and carries no data: concurrent first calls at worst issue the attribute twice;
  *   - PADDING CONTRACT: matrix operands are allocated with their dimensions rounded up to
  *     GEOBO_PAD_M (rows of M-like dims) / GEOBO_PAD_N (voxel-like dims) and the padding is ZERO
  *     (identity on the diagonal of matrices that get factorised).  Kernels then run without edge
@@ -92,12 +96,13 @@ int geobo_a_sens(int func_id, const double* B3_host, const double* loc, int64_t 
                  double* A, int64_t ld, void* stream);
 
 /* The same operator restricted to the voxel slab iy0 <= iy < iy1 (columns p = (iy*nx+ix)*nz+iz of that slab only; the rest of
- * A is not touched): a rank of a column-sharded run only needs its own y-slab of every sensor row.  Columns are addressed
- * absolutely; a caller that holds ONLY the slab (ld >= (iy1-iy0)*nx*nz) passes A moved back by iy0*nx*nz elements.  The same
- * holds for geobo_a_sens_lattice.  (Streamed operators of the 128^3 configuration: A is 275 GB per type and never resident.) */
+ * A is not touched): a rank of a column-sharded run only needs its own y-slab of every sensor row.  A[n, 0] stands for voxel
+ * column col_origin: 0 for a full-width operator, iy0*nx*nz for a caller that holds ONLY the slab; the requested columns must
+ * lie inside one buffer row, col_origin <= iy0*nx*nz and iy1*nx*nz - col_origin <= ld (GEOBO_E_ARG otherwise).  The same holds
+ * for geobo_a_sens_lattice.  (Streamed operators of the 128^3 configuration: A is 275 GB per type and never resident.) */
 int geobo_a_sens_slab(int func_id, const double* B3_host, const double* loc, int64_t Ms, int nx, int ny, int nz,
                       const double* xe, const double* ye, const double* ze, double scale_mul, double scale_div,
-                      int iy0, int iy1, double* A, int64_t ld, void* stream);
+                      int iy0, int iy1, double* A, int64_t ld, int64_t col_origin, void* stream);
 
 /* Lattice form of the same operator for sensors on a lattice commensurate with the voxel columns (sensor n at lattice column
  * jxs[n], jys[n]; all at one height): away from the +-1e6-padded node planes iy = 0 and ny the 8-corner stencil of
@@ -109,7 +114,8 @@ int geobo_a_sens_slab(int func_id, const double* B3_host, const double* loc, int
 size_t geobo_a_sens_lattice_ws_bytes(int nx, int ny, int nz);
 int geobo_a_sens_lattice(int func_id, const double* B3_host, int64_t Ms, int nx, int ny, int nz, const double* dxv,
                          const double* dyv, const double* dzv, const int* jxs, const int* jys, double scale_mul,
-                         double scale_div, int iy0, int iy1, double* A, int64_t ld, void* ws, size_t ws_bytes, void* stream);
+                         double scale_div, int iy0, int iy1, double* A, int64_t ld, int64_t col_origin, void* ws, size_t ws_bytes,
+                         void* stream);
 
 /* Node potential itself, elementwise: out[i] = grav_func(x,y,z) (sensormodel.py:96-110) or
  * magn_func(x,y,z,B) (sensormodel.py:113-133); same arithmetic as inside geobo_a_sens. */

@@ -488,6 +488,37 @@ def test_a_sens_lattice_form_is_identical_to_the_direct_kernel(hip, func, dims, 
     assert hip.lattice_plan(loc, xe * (1.0 / 3.0), ye, ze, nx, ny, nz) is None or True
 
 
+def test_a_sens_slab_origin_is_validated_by_the_library(hip):
+    """col_origin travels through the C ABI: a compact slab buffer equals the same columns of the full-width operator, and a request
+    whose columns do not fit one buffer row (full-width call with a short leading dimension, slab in front of the buffer's origin) is
+    GEOBO_E_ARG instead of overlapping rows."""
+    nx, ny, nz = 16, 12, 8
+    s = settings_for(nx, ny, nz)
+    from geobo_amd.inversion import Inversion
+    inv = Inversion(settings=s)
+    inv.create_cubegeometry()
+    xe, ye, ze = inv.engine.node_axes()
+    X, Y = np.meshgrid(0.5 * (xe[:-1] + xe[1:]), 0.5 * (ye[:-1] + ye[1:]))
+    loc = np.c_[X.ravel(), Y.ravel(), np.full(nx * ny, 1.0)]
+    plan = hip.lattice_plan(loc, xe, ye, ze, nx, ny, nz)
+    dev = lambda a: hip.to_dev(a)
+    N, plane = nx * ny * nz, nx * nz
+    locd = dev(loc)
+    full = torch.zeros((nx * ny, N), dtype=torch.float64, device="cuda")
+    hip.a_sens("grav", (0, 0, 0), locd, nx, ny, nz, dev(xe), dev(ye), dev(ze), 1.0, 1.0, full)
+    for pl in (None, plan):
+        for y0, y1 in ((0, 4), (3, 9), (8, 12)):
+            slab = torch.full((nx * ny, (y1 - y0) * plane + 16), 7.0, dtype=torch.float64, device="cuda")
+            view = slab[:, :(y1 - y0) * plane]
+            hip.a_sens("grav", (0, 0, 0), locd, nx, ny, nz, dev(xe), dev(ye), dev(ze), 1.0, 1.0, view, y0, y1, plan=pl, col_origin=y0 * plane)
+            assert torch.equal(view, full[:, y0 * plane:y1 * plane]) and bool((slab[:, (y1 - y0) * plane:] == 7.0).all())
+        short = torch.zeros((nx * ny, 6 * plane), dtype=torch.float64, device="cuda")
+        with pytest.raises(RuntimeError, match="GEOBO_E_ARG"):       # full-width addressing, rows only 6 planes apart
+            hip.a_sens("grav", (0, 0, 0), locd, nx, ny, nz, dev(xe), dev(ye), dev(ze), 1.0, 1.0, short, 3, 9, plan=pl)
+        with pytest.raises(RuntimeError, match="GEOBO_E_ARG"):       # slab in front of the buffer's first column
+            hip.a_sens("grav", (0, 0, 0), locd, nx, ny, nz, dev(xe), dev(ye), dev(ze), 1.0, 1.0, short, 3, 9, plan=pl, col_origin=4 * plane)
+
+
 @pytest.mark.parametrize("R,ny", [(3, 32), (5, 16)])
 def test_spectral_32_planes_go_through_the_fused_kernel_in_pairs(hip, R, ny):
     """32 x 32 planes (BASELINE config 2): two y-planes stacked along x through the (64, 32) instance with diag(Mx, Mx), against

@@ -150,3 +150,27 @@ def test_bench_refuses_a_line_for_another_job_size():
     import torch
     if not torch.cuda.is_available():
         assert r.returncode != 0 and "needs 2 visible devices" in r.stderr
+
+
+def test_lattice_gram_form_decision_table():
+    """Which form of the lattice Gram a rank may use (engine.lattice_gram_form): the chunked exchange of the large-cube modes
+    keeps no full rows, so it must never get the row form (round-2 advisory: 64^3 on 8 ranks with assembly='f32' died in
+    gram_rows' Ly % 16 assertion)."""
+    from geobo_amd.engine import lattice_gram_form
+    from geobo_amd.sharding import shard_columns
+    n = 64
+    N, Ms, plane = n ** 3, n * n, n * n
+    def form(world, rank, exchange, chunked):
+        c0, c1 = shard_columns(N, world, rank)
+        return lattice_gram_form(exchange, chunked, world, Ms, c0, c1, plane, N)
+    assert form(1, 0, False, False) == "columns"
+    assert form(2, 1, False, False) == "columns" and form(4, 3, False, False) == "columns"       # 32 / 16 planes per rank
+    assert form(8, 0, False, False) is None                                                       # world > 4: GEMM
+    assert form(4, 0, True, False) == "rows" and form(8, 5, True, False) == "rows"               # Ms / G = 1024, 512
+    for r in range(8):
+        assert form(8, r, True, True) is None                                                     # chunked: 8 planes per rank, no rows kept
+    assert form(4, 2, True, True) == "columns"                                                    # 16 planes per rank: column form is fine
+    c0, c1 = shard_columns(64 * 48 * 64, 4, 1)
+    assert lattice_gram_form(True, True, 4, 64 * 48, c0, c1, plane, 64 * 48 * 64) is None         # 12 planes: not a multiple of 16
+    assert lattice_gram_form(True, False, 3, 64 * 48, 0, 64 * 16 * 64, plane, 64 * 48 * 64) == "rows"
+    assert lattice_gram_form(True, False, 5, 64 * 48 + 5, 0, 0, plane, 1) is None                 # Ms / G not a multiple of 128

@@ -46,8 +46,9 @@ def _check_cubes(cubes, ref, tol, what, tol_elem=None):
     print(what, "normwise", " ".join("%.2e" % e for e in errs), "| element-wise rel (|ref| > 1e-3 max)", " ".join("%.2e" % e for e in elem))
     assert max(errs) <= tol, (what, errs)
     # north_star says "1e-8 relative": besides the normwise bound, the element-wise relative error on every voxel that is not
-    # near a zero crossing is bounded as well (100 x the normwise tolerance; observed ~1e-9 on the shipped fixtures)
-    assert max(elem) <= (100 * tol if tol_elem is None else tol_elem), (what, elem)
+    # near a zero crossing is bounded as well: 10 x the normwise tolerance = 1e-7 for the T3 tier (observed <= 4e-9 on every fixture;
+    # the reference's own A_sens cancellation noise, SURVEY section 7 hard part 1, is what an element-wise figure sees first)
+    assert max(elem) <= (10 * tol if tol_elem is None else tol_elem), (what, elem)
 
 
 @pytest.mark.parametrize("name", ["tiny_exp", "tiny_sparse", "tiny_matern32", "tiny_exp_nodrill"])
@@ -158,7 +159,7 @@ def test_ill_conditioned_regime_end_to_end(name, dims, kern, ls):
     d0 = f["drilldata0"]
     cubes = inv.cubing(f["gravfield"], f["magfield"], d0[d0 != 0], f["sensor_locations"], d0)
     print("cond(AkA) = %.2e" % float(f["cond_AkA"]))
-    _check_cubes(cubes, f["cubes"], TOL_T3, name + " T3", tol_elem=1e-5)
+    _check_cubes(cubes, f["cubes"], TOL_T3, name + " T3", tol_elem=1e-6)
     assert abs(inv.logl - float(f["logl"])) <= 1e-8 * abs(float(f["logl"]))
     eng = inv.engine
     Md = f["sel"].size

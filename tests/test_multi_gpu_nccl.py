@@ -79,14 +79,20 @@ def test_four_gloo_ranks_row_exchange_and_row_gram(tmp_path):
     assert abs(float(four["logl"]) - float(one["logl"])) <= 1e-10 * abs(float(one["logl"]))
 
 
-@pytest.mark.parametrize("assembly,operators", [("f32", "streamed"), ("f64", "streamed"), ("f32", "resident")])
-def test_large_cube_modes_on_the_row_exchange_path(assembly, operators, tmp_path):
+@pytest.mark.parametrize("assembly,operators,size", [("f32", "streamed", "32"), ("f64", "streamed", "32"), ("f32", "resident", "32"),
+                                                     ("f32", "resident", "64x48x64")])
+def test_large_cube_modes_on_the_row_exchange_path(assembly, operators, size, tmp_path):
     """BASELINE config 5's modes (fp32 assembly, streamed operators) with 4 ranks: chunked row exchange (each chunk of sensor rows
     transformed, cropped per destination, exchanged by its own all-to-all and written straight into the A K shard), N/G-deep AkA
-    panels, sharded posterior -- against the 1-rank run of the same mode (32^3, gloo transport on this box's one device)."""
-    one = _run_ranks(1, "gloo", str(tmp_path / "m1.npz"), "32", (assembly, operators))
-    four = _run_ranks(4, "gloo", str(tmp_path / "m4.npz"), "32", (assembly, operators))
+    panels, sharded posterior -- against the 1-rank run of the same mode (gloo transport on this box's one device)."""
+    # 64 x 48 x 64: the lattice Gram is instantiated there but a rank's slab (12 planes) is no multiple of 16 and the chunked exchange
+    # keeps no full rows -- AkA must fall back to the N/G-deep panels (round-2 advisory: it died in gram_rows' assertion)
+    one = _run_ranks(1, "gloo", str(tmp_path / "m1.npz"), size, (assembly, operators))
+    four = _run_ranks(4, "gloo", str(tmp_path / "m4.npz"), size, (assembly, operators))
     assert int(four["world"]) == 4 and bool(four["exchange"])
     tol = 1e-10 if assembly == "f64" else 2e-6          # fp32 storage: the shards round different partial sums
     for a, b in zip(four["cubes"], one["cubes"]):
-        assert normwise(a, b) <= tol
+        if np.isnan(b).all():
+            assert np.isnan(a).all()
+        else:
+            assert normwise(a, b) <= tol
