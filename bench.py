@@ -84,7 +84,8 @@ def synthetic_inputs(inv, md):
     return grav, mag, loc, drill0
 
 
-PMC_FILES = {"ak_fused_grid": "r01_pmc_ak_fused_grid_v2.json", "posterior_reduce": "r02_pmc_posterior_reduce.json"}
+PMC_FILES = {"ak_fused_grid": "r01_pmc_ak_fused_grid_v2.json", "posterior_reduce": "r02_pmc_posterior_reduce.json",
+             "k_block_grid": "r03_pmc_k_block_grid_f64.json"}
 GPU_DENSE_ROUTE = "profiles/r01_bench64_dense.json"   # builder-run bench line of `--method dense` (same algorithm as the CPU sample)
 
 
@@ -100,6 +101,54 @@ def pmc_traffic(kernel, executed_flop_per_launch):
         except Exception:
             continue
     return None, None
+
+
+def assembly_roofline(inv, lengths, rows=8192, launches=5):
+    """SURVEY 8(d) regime (i), materialised kernel assembly: one block of create_cov (kernels.py:183-195) written to HBM -- here
+    the (density, magsus) cross block of the headline workload for `rows` row voxels x all N column voxels, on the regular grid
+    gathered from the block's difference-lattice table (geobo_k_block_grid).  Algorithmic bytes per launch = the block written
+    (8 B per element) + the table and the row indices read once; HIP events on the launch stream; outside the timed steps."""
+    from geobo_amd import hip
+    from geobo_amd.engine import weight_matrix
+    eng, s = inv.engine, inv.settings
+    if not eng.use_grid:
+        return None
+    N = eng.N
+    rows = int(min(rows, N))
+    W = weight_matrix(s.gp_coeff)
+    with torch.cuda.device(eng.device):
+        tab = eng._cov_table(hip.kernel_id(s.kernelfunc, True), lengths[1], lengths[0], W[0][1], 1.0)
+        ridx = torch.arange(0, N, max(N // rows, 1), device=eng.device, dtype=torch.int64)[:rows].contiguous()
+        out = torch.empty((rows, N + 16), dtype=torch.float64, device=eng.device)[:, :N]
+        hip.k_block_grid(tab, eng.nx, eng.ny, eng.nz, ridx, 0, out)
+        torch.cuda.synchronize()
+        evs = []
+        for _ in range(launches):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            hip.k_block_grid(tab, eng.nx, eng.ny, eng.nz, ridx, 0, out)
+            e1.record()
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        durs = sorted(e0.elapsed_time(e1) * 1e-3 for e0, e1 in evs)
+        del out
+    mean_s = sum(durs) / len(durs)
+    by = 8.0 * rows * N + 8.0 * tab.numel() + 8.0 * rows
+    traffic, tsrc = None, None
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", PMC_FILES["k_block_grid"])))
+        traffic = d["derived"]["hbm_bytes_per_launch_corrected"] * by / d["derived"]["algorithmic_bytes"]
+        tsrc = "profiles/" + PMC_FILES["k_block_grid"]
+    except Exception:
+        pass
+    return {"bound": "hbm", "kernel": "geobo_k_block_grid (k_block_grid_kernel<double>)", "achieved": by / mean_s / 1e9, "peak": 8000.0,
+            "unit": "GB/s", "frac": by / mean_s / 8e12, "traffic": traffic,
+            "traffic_source": None if tsrc is None else tsrc + " (committed rocprofv3 --pmc passes of the same kernel: FETCH_SIZE x2 + WRITE_SIZE, "
+            "scaled by the algorithmic bytes; not collected in this run)",
+            "launches_timed": launches, "bytes_per_launch": by, "bytes_per_launch_is": "algorithmic: 8 B per element of the %d x %d block written "
+            "+ the 2N-entry lattice table and the row indices read once" % (rows, N), "mean_launch_s": mean_s, "median_launch_s": durs[len(durs) // 2],
+            "what": "materialised assembly of one covariance block (block (0,1) of create_cov, %s cross kernel) on the 64^3 grid: SURVEY 8(d) "
+                    "regime (i); not part of the timed step (the matrix-free path never materialises K)" % s.kernelfunc}
 
 
 def host_threads():
@@ -373,6 +422,8 @@ def main():
                        "kernel_tflops_executed_rank0": {k: round(v["flop"] / v["seconds"] / 1e12, 2) for k, v in stages.items() if v["flop"] > 0}},
             "roofline": roof,
         }
+        if world == 1 and a.assembly == "f64":
+            out["roofline_assembly"] = assembly_roofline(inv, [float(v) for v in inv.gp_length])
         if not a.no_cpu and world == 1:   # CPU baseline: rank 0 at N = 1 only
             lengths = inv.gp_length
             cb, (c0, b, smp) = cpu_baseline(inv, [float(v) for v in lengths])

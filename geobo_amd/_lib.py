@@ -21,6 +21,7 @@ SIGNATURES = {
     "geobo_pad_n": (_i64, [_i64]),
     "geobo_k_block": (_int, [_int, _dp, _dp, _dp, _i64, _dp, _dp, _dp, _i64, _f64, _f64, _f64, _f64, _dp, _i64, _dp]),
     "geobo_k_block_f32": (_int, [_int, _dp, _dp, _dp, _i64, _dp, _dp, _dp, _i64, _f64, _f64, _f64, _f64, _dp, _i64, _dp]),
+    "geobo_k_block_grid": (_int, [_int, _int, _int, _dp, _dp, _i64, _i64, _i64, _i64, _int, _dp, _i64, _dp]),
     "geobo_convert": (_int, [_int, _dp, _i64, _dp, _i64, _i64, _i64, _dp]),
     "geobo_round_f32": (_int, [_dp, _i64, _dp]),
     "geobo_k_eval": (_int, [_int, _dp, _i64, _f64, _f64, _f64, _f64, _dp, _dp]),
@@ -46,7 +47,7 @@ SIGNATURES = {
     "geobo_xz2d_fold_lattice": (_int, [_int, _i64, _int, _dp, _dp, _i64, _dp, _i64, _dp, _dp, _dp, _i64, _i64, _dp]),
     "geobo_ymul": (_int, [_int, _int, _i64, _i64, _dp, _i64, _dp, _i64, _dp, _i64, _dp]),
     "geobo_xcorr_reduce": (_int, [_int, _int, _i64, _int, _dp, _i64, _i64, _dp, _i64, _dp, _dp, _i64, _i64, _dp]),
-    "geobo_toeplitz_y": (_int, [_int, _i64, _i64, _int, _dp, _dp, _dp, _dp, _dp, _int, _int, _dp]),
+    "geobo_toeplitz_y": (_int, [_int, _i64, _i64, _i64, _int, _dp, _dp, _dp, _dp, _dp, _int, _int, _dp]),
     "geobo_potrf_ws_bytes": (_sz, [_i64]),
     "geobo_potrf_ctx_create": (_int, [C.POINTER(C.c_void_p)]),
     "geobo_potrf_ctx_destroy": (_int, [_dp]),

@@ -73,6 +73,50 @@ __global__ void __launch_bounds__(256) cov_table_kernel(int nx, int ny, int nz, 
   }
 }
 
+// ---- k_block on the regular grid: a gather from the difference-lattice table ------------------------------------------
+// out[r, c] = table[(|iy_r - iy_c| nx + |ix_r - ix_c|) 2nz + (iz_c - iz_r + nz - 1)]  for row voxel rows[r] (or row0 + r) and column
+// voxel col0 + c, voxel index p = (iy nx + ix) nz + iz.  No exp / sqrt / coordinates: integer index arithmetic and one 8-byte read
+// of a table that lives in L2 (4 MB at 64^3) per element, so the launch is bound by the HBM store of the block -- the
+// "materialised kernel assembly" regime of SURVEY.md section 8(d).  Along a row, consecutive columns of one (iy, ix) voxel column are
+// consecutive table entries: the gather is a sequence of nz-long contiguous copies.
+// grid: (ceil(ncols / 512), ceil(nr / KB_ROWS)); 256 threads, two adjacent columns per thread (nz even, col0 even: both in the
+// same voxel column), KB_ROWS rows per workgroup with wave-uniform row decoding on the scalar unit.
+template <typename OUT>
+__global__ void __launch_bounds__(256) k_block_grid_kernel(const double* __restrict__ table, int nx, int ny, int nz,
+                                                           const int64_t* __restrict__ rows, int64_t row0, int64_t nr, int64_t col0,
+                                                           int64_t ncols, OUT* __restrict__ out, int64_t ld) {
+  const int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+  const int64_t r0 = (int64_t)blockIdx.y * KB_ROWS;
+  if (c0 >= ncols) return;
+  const bool two = (c0 + 1) < ncols;
+  const int64_t pc = col0 + c0;
+  const int izc = (int)(pc % nz);
+  const int64_t tc = pc / nz;
+  const int ixc = (int)(tc % nx), iyc = (int)(tc / nx);
+  const int nz2 = 2 * nz;
+  typedef OUT pair_t __attribute__((ext_vector_type(2)));
+  const bool vec = two && ((ld & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & (2 * sizeof(OUT) - 1)) == 0);
+  const int nrow = (int)((nr - r0) < KB_ROWS ? (nr - r0) : KB_ROWS);
+  for (int i = 0; i < nrow; ++i) {
+    const int64_t r = r0 + i;
+    const int64_t pr = rows ? rows[r] : row0 + r;            // uniform -> scalar load and scalar decode
+    const int izr = (int)(pr % nz);
+    const int64_t tr = pr / nz;
+    const int ixr = (int)(tr % nx), iyr = (int)(tr / nx);
+    const int dy = iyc > iyr ? iyc - iyr : iyr - iyc, dx = ixc > ixr ? ixc - ixr : ixr - ixc;
+    const double* tp = table + ((int64_t)(dy * nx + dx) * nz2 + (izc - izr + nz - 1));
+    const double v0 = tp[0];
+    const double v1 = two ? tp[1] : v0;
+    OUT* dst = out + r * ld + c0;
+    if (vec) {
+      *reinterpret_cast<pair_t*>(dst) = (pair_t){(OUT)v0, (OUT)v1};
+    } else {
+      dst[0] = (OUT)v0;
+      if (two) dst[1] = (OUT)v1;
+    }
+  }
+}
+
 // 2-D strided precision conversion (rows x cols, cols even): the fp32-assembly mode keeps A K in fp32 in HBM and hands the fp64
 // MFMA kernels fp64 panels.  Pure streaming: 12 B per element.
 template <typename SRC, typename DST>
@@ -344,6 +388,22 @@ extern "C" int geobo_k_block_f32(int kernel_id, const double* rx, const double* 
 #define GEOBO_KB(ID) hipLaunchKernelGGL((k_block_kernel<ID, float>), grid, dim3(256), 0, st, rx, ry, rz, nr, cx, cy, cz, nc, p, out, ld)
   COV_DISPATCH(kernel_id, GEOBO_KB);
 #undef GEOBO_KB
+  return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
+}
+
+extern "C" int geobo_k_block_grid(int nx, int ny, int nz, const double* table, const int64_t* rows, int64_t row0, int64_t nr,
+                                  int64_t col0, int64_t ncols, int out_f32, void* out, int64_t ld, void* stream) {
+  if (!table || !out) return GEOBO_E_ARG;
+  if (nr <= 0 || ncols <= 0) return GEOBO_OK;
+  const int64_t N = (int64_t)nx * ny * nz;
+  if (nx <= 0 || ny <= 0 || nz <= 0 || (nz & 1) || (col0 & 1) || col0 < 0 || col0 + ncols > N || ld < ncols) return GEOBO_E_ARG;
+  if (!rows && (row0 < 0 || row0 + nr > N)) return GEOBO_E_ARG;
+  const dim3 grid((unsigned)((ncols + 511) / 512), (unsigned)((nr + KB_ROWS - 1) / KB_ROWS));
+  hipStream_t st = (hipStream_t)stream;
+  if (out_f32)
+    hipLaunchKernelGGL((k_block_grid_kernel<float>), grid, dim3(256), 0, st, table, nx, ny, nz, rows, row0, nr, col0, ncols, (float*)out, ld);
+  else
+    hipLaunchKernelGGL((k_block_grid_kernel<double>), grid, dim3(256), 0, st, table, nx, ny, nz, rows, row0, nr, col0, ncols, (double*)out, ld);
   return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
 }
 

@@ -20,10 +20,12 @@
 namespace {
 
 struct ToeplitzArgs {
-  const double* in;       // [R][NY][C]
+  const double* in;       // [R][NY][S]: C valid modes per plane, planes S >= C doubles apart
   const double* tab[2];   // [NY][C] per property block
-  double* out[2];         // [R][y1-y0][C] per property block
-  int64_t C, R;
+  double* out[2];         // [R][y1-y0][S] per property block
+  int64_t C, S, R;        // S: plane stride of in and out.  A power-of-two stride (C = 16384 doubles = 128 KiB at 64^3) puts the ny
+                          // planes a lane walks on the same HBM channels: 3.95 TB/s for a copy with this access pattern against
+                          // 5.2 TB/s with S = C + 256 (profiles/r03_hbm_copy_runs.txt)
   int nprop, y0, y1;
 };
 
@@ -92,13 +94,14 @@ __global__ void __launch_bounds__(256, 2) toeplitz_y_kernel(ToeplitzArgs g) {
   const int nw = 2 * g.nprop;
   const unsigned lane8 = (unsigned)lane * 8u;
   const int prop = w >> 1, half = w & 1;
-  const int64_t C = g.C, c0 = (int64_t)blockIdx.x * 64;
-  const int C8 = (int)(C * 8), in_bytes = NY * C8, out_bytes = (g.y1 - g.y0) * C8;
+  const int64_t C = g.S, c0 = (int64_t)blockIdx.x * 64;     // C: plane stride of the data from here on (the table's is g.C)
+  const int C8 = (int)(C * 8), out_bytes = (g.y1 - g.y0) * C8;
   double t[NY];
   {
-    const rsrc_t tr = make_rsrc(g.tab[prop] + c0, in_bytes);
+    const int T8 = (int)(g.C * 8);
+    const rsrc_t tr = make_rsrc(g.tab[prop] + c0, NY * T8);
 #pragma unroll
-    for (int d = 0; d < NY; ++d) t[d] = ld_lane(tr, lane8, d * C8);
+    for (int d = 0; d < NY; ++d) t[d] = ld_lane(tr, lane8, d * T8);
   }
   int64_t r = blockIdx.y;
   if (r >= g.R) return;
@@ -161,14 +164,14 @@ int launch(const ToeplitzArgs& g, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int geobo_toeplitz_y(int ny, int64_t C, int64_t R, int nprop, const double* in, const double* tab0,
+extern "C" int geobo_toeplitz_y(int ny, int64_t C, int64_t plane, int64_t R, int nprop, const double* in, const double* tab0,
                                 const double* tab1, double* out0, double* out1, int y0, int y1, void* stream) {
   if (!in || !tab0 || !out0 || (nprop == 2 && (!tab1 || !out1))) return GEOBO_E_ARG;
-  if (nprop < 1 || nprop > 2 || R <= 0 || y0 < 0 || y1 > ny || y1 <= y0) return GEOBO_E_ARG;
-  if (C <= 0 || C % 64 || (int64_t)ny * C * 8 >= (1ll << 31)) return GEOBO_E_ALIGN;
+  if (nprop < 1 || nprop > 2 || R <= 0 || y0 < 0 || y1 > ny || y1 <= y0 || plane < C) return GEOBO_E_ARG;
+  if (C <= 0 || C % 64 || (plane & 1) || (int64_t)ny * plane * 8 >= (1ll << 31)) return GEOBO_E_ALIGN;
   ToeplitzArgs g;
   g.in = in; g.tab[0] = tab0; g.tab[1] = nprop == 2 ? tab1 : tab0; g.out[0] = out0; g.out[1] = nprop == 2 ? out1 : out0;
-  g.C = C; g.R = R; g.nprop = nprop; g.y0 = y0; g.y1 = y1;
+  g.C = C; g.S = plane; g.R = R; g.nprop = nprop; g.y0 = y0; g.y1 = y1;
   hipStream_t st = (hipStream_t)stream;
   switch (ny) {
     case 16: return launch<16>(g, st);

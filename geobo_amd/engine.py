@@ -32,8 +32,8 @@ import numpy as np
 import torch
 
 from . import geometry, hip
-from .sharding import (allreduce_sum_, assemble_columns, exchange_blocks, exchange_blocks_finish, exchange_blocks_start, gather_rows,
-                       gather_slices, shard_columns)
+from .sharding import (EmulatedGroup, allreduce_sum_, assemble_columns, backend_of, exchange_blocks, exchange_blocks_finish,
+                       exchange_blocks_start, gather_rows, gather_slices, shard_columns)
 
 F64 = hip.F64
 
@@ -234,7 +234,7 @@ class PosteriorEngine:
         self._xgroup = group
         self.async_exchange = os.environ.get("GEOBO_ASYNC_EXCHANGE", "1") != "0"
         if (self.exchange and os.environ.get("GEOBO_EXCHANGE_COMM", "shared") == "own" and self.async_exchange
-                and torch.distributed.is_available() and torch.distributed.is_initialized()):
+                and not isinstance(group, EmulatedGroup) and torch.distributed.is_available() and torch.distributed.is_initialized()):
             ranks = torch.distributed.get_process_group_ranks(group) if group is not None else list(range(torch.distributed.get_world_size()))
             if len(ranks) == world:
                 self._xgroup = _exchange_group(tuple(ranks), torch.distributed.get_backend(group))
@@ -242,6 +242,7 @@ class PosteriorEngine:
         self._slab_ops = set()      # data pointers of operators that hold only this rank's column slab
         self._potrf_ctx = None
         self.kernel_events = None  # set to [] to record (name, flops, start, stop) HIP events per fused launch
+        self.aka_hook = None       # callable(AkA) run between the assembly of AkA and its factorisation (emulation tool only)
 
     # ---- geometry --------------------------------------------------------------------------------------------
     def grid_points(self):
@@ -510,11 +511,25 @@ class PosteriorEngine:
                 if self.f32:
                     hip.convert(out64, out)
             if Md:
-                rows = tuple(c[sel_t] for c in xyz)
-                colc = tuple(c[self.c0:self.c1] for c in xyz)
-                hip.k_block(hip.kernel_id(name, 2 != j), rows, colc, lengths[j], lengths[2], W[2][j], amp,
-                            AK[off_d:off_d + Md, cols])
+                self._cov_rows(name, 2, j, lengths, W, amp, sel_t, self.c0, AK[off_d:off_d + Md, cols])
         return AK, M_pad
+
+    def _cov_rows(self, name, i, j, lengths, W, amp, rows_t, col0, out):
+        """out[r, c] = block (i, j) of create_cov (kernels.py:183-195: w_ij k2(l_j, l_i)) for the row voxels rows_t (flat indices,
+        int64 device tensor) and the voxel columns col0 .. col0 + out.shape[1]: materialised covariance assembly.  On the regular
+        grid a gather from the block's difference-lattice table (geobo_k_block_grid: bound by the HBM store), otherwise evaluated
+        from coordinates (geobo_k_block)."""
+        kid = hip.kernel_id(name, i != j)
+        ncv = min(out.shape[1], max(self.N - col0, 0))       # columns behind N are voxel padding (zeroed by the caller)
+        if ncv <= 0:
+            return out
+        if self.use_grid and col0 % 2 == 0:
+            tab = self._cov_table(kid, lengths[j], lengths[i], W[i][j], amp)
+            return hip.k_block_grid(tab, self.nx, self.ny, self.nz, rows_t, col0, out[:, :ncv])
+        xyz = self.grid_points()
+        rows = tuple(c[rows_t] for c in xyz)
+        colc = tuple(c[col0:col0 + out.shape[1]] for c in xyz)
+        return hip.k_block(kid, rows, colc, lengths[j], lengths[i], W[i][j], amp, out)
 
     def _assemble_AK_spectral(self, AK, A_g, A_m, lengths, W, name, amp, props):
         """Sensor rows of AK through the real-DFT route (geobo_amd/spectral.py): same product, ~200x fewer flops."""
@@ -569,7 +584,7 @@ class PosteriorEngine:
         for s_, func in ((0, "grav"), (1, "magn")):
             send = self._exchange_send(s_, func, lengths, W, name, amp, props)
             sends.append(send)
-            out = self._workspace("xchg_recv_%d" % s_, tuple(send.shape)) if torch.distributed.get_backend(self._xgroup) == "nccl" else None
+            out = self._workspace("xchg_recv_%d" % s_, tuple(send.shape)) if backend_of(self._xgroup) == "nccl" else None
             if self.async_exchange:
                 pending.append(exchange_blocks_start(send, self.world, self._xgroup, out=out))
             else:
@@ -806,15 +821,13 @@ class PosteriorEngine:
                 rows_times_AT(self._fullrows[(s_, sp_)], rows_r, sp_, loc[s_][:, sp_ * self.Ms_pad:(sp_ + 1) * self.Ms_pad])
         drill = None
         if Md:
-            xyz = self.grid_points()
-            rows = tuple(c[sel_t] for c in xyz)
             Mdp = (Md + 127) // 128 * 128
             drill = self._workspace("aka_rows_drill", (Mdp, 2 * self.Ms_pad))
             drill.zero_()
             Xd = self._workspace2d("fullrows_drill", Mdp, self.N_pad)
             for sp_ in (0, 1):
                 Xd.zero_()
-                hip.k_block(hip.kernel_id(name, 2 != sp_), rows, xyz, lengths[sp_], lengths[2], W[2][sp_], amp, Xd[:Md])
+                self._cov_rows(name, 2, sp_, lengths, W, amp, sel_t, 0, Xd[:Md, :self.N])
                 rows_times_AT(Xd[:, :self.N], Md, sp_, drill[:, sp_ * self.Ms_pad:(sp_ + 1) * self.Ms_pad])
         return loc, drill
 
@@ -874,6 +887,8 @@ class PosteriorEngine:
         AK, M_pad = self._assemble_AK(A_g, A_m, sel_t, lengths, W, kernelfunc, gp_amp, props)
         t = self._tick("ak_fused", t)
         AkA = self._assemble_AkA(AK, M_pad, A_g, A_m, sel_t, lengths, kernelfunc, gp_amp, gp_sigma, props)
+        if self.aka_hook is not None:          # tools/emulate_rank.py: keep the assembled matrix (1 rank) / put the true one in place
+            self.aka_hook(AkA)                 # of what an emulated all-gather produced (a lone rank of G)
         t = self._tick("aka", t)
         if self._potrf_ctx is None:
             self._potrf_ctx = hip.PotrfContext()       # fork streams of the L^-1 build: per engine, on this engine's device

@@ -84,6 +84,23 @@ def k_block(kid, rows_xyz, cols_xyz, l1, l2, w, amp, out):
     return out
 
 
+def k_block_grid(table, nx, ny, nz, rows, col0, out, row0=0, nr=None):
+    """Covariance block on the regular grid gathered from the lattice table of cov_table: out[r, c] for row voxels `rows` (int64
+    device tensor of flat voxel indices, or None for the range row0 .. row0 + nr) and column voxels col0 .. col0 + out.shape[1]."""
+    lib = require_gpu()
+    if not (isinstance(out, torch.Tensor) and out.is_cuda and out.dtype in (F64, F32) and out.dim() == 2 and out.stride(1) == 1):
+        raise TypeError("out must be a 2-D CUDA float64 / float32 tensor with unit column stride")
+    if rows is not None:
+        assert rows.dtype == torch.int64 and rows.is_cuda and rows.is_contiguous()
+        nr = rows.numel()
+    nr = out.shape[0] if nr is None else int(nr)
+    assert out.shape[0] >= nr and _chk(table, "table").numel() >= 2 * nx * ny * nz
+    _lib.check(lib.geobo_k_block_grid(int(nx), int(ny), int(nz), _p(table), C.c_void_p(rows.data_ptr()) if rows is not None else None,
+                                      int(row0), nr, int(col0), out.shape[1], 1 if out.dtype == F32 else 0, _p(out), out.stride(0),
+                                      _stream()), "geobo_k_block_grid")
+    return out
+
+
 def convert(src, dst):
     """dst[r, c] = src[r, c] across fp64 <-> fp32 (2-D views, unit column stride, even widths and leading dimensions)."""
     lib = require_gpu()
@@ -364,16 +381,18 @@ def a_sens_lattice_stencil(ws, nx, ny, nz):
     return ws[np_:np_ + (2 * ny - 3) * (2 * nx - 1) * nz].view(2 * ny - 3, 2 * nx - 1, nz)
 
 
-def toeplitz_y(ny, C, R, src, tabs, outs, y0=0, y1=None):
-    """outs[j][r, y - y0, c] = sum_y' tabs[j][|y - y'|, c] * src[r, y', c]  (geobo_toeplitz_y); 1 or 2 property blocks."""
+def toeplitz_y(ny, C, R, src, tabs, outs, y0=0, y1=None, plane=None):
+    """outs[j][r, y - y0, c] = sum_y' tabs[j][|y - y'|, c] * src[r, y', c]  (geobo_toeplitz_y); 1 or 2 property blocks.
+    plane: stride in doubles between the y-planes of src and outs (default C: dense; the spectral product pads it)."""
     lib = require_gpu()
     y1 = ny if y1 is None else y1
     n = len(tabs)
     assert n in (1, 2) and len(outs) == n
     t1 = tabs[1] if n == 2 else tabs[0]
     o1 = outs[1] if n == 2 else outs[0]
-    _lib.check(lib.geobo_toeplitz_y(int(ny), int(C), int(R), n, _p(_chk(src, "src")), _p(_chk(tabs[0], "tab0")), _p(_chk(t1, "tab1")),
-                                    _p(outs[0]), _p(o1), int(y0), int(y1), _stream()), "geobo_toeplitz_y")
+    _lib.check(lib.geobo_toeplitz_y(int(ny), int(C), int(C if plane is None else plane), int(R), n, _p(_chk(src, "src")),
+                                    _p(_chk(tabs[0], "tab0")), _p(_chk(t1, "tab1")), _p(outs[0]), _p(o1), int(y0), int(y1), _stream()),
+               "geobo_toeplitz_y")
 
 
 class PotrfContext:

@@ -13,6 +13,25 @@ import torch
 PAD_N = 128
 
 
+class EmulatedGroup:
+    """Stand-in for a process group: ONE process plays rank `rank` of `world` alone on its device (tools/emulate_rank.py: what
+    does a rank's compute of the sharded step cost, measured where no multi-GPU node is available).  Every collective below becomes
+    its local part only: an all-reduce is the identity, an all-gather / all-to-all returns this rank's own contribution in every
+    slot (right sizes, finite values, wrong numbers for the peers' parts -- the caller injects what it needs to stay well posed)."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world = int(rank), int(world)
+
+
+def backend_of(group):
+    """'emulate' for an EmulatedGroup, else the torch.distributed backend name of the group (None: not initialised)."""
+    if isinstance(group, EmulatedGroup):
+        return "emulate"
+    if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        return None
+    return torch.distributed.get_backend(group)
+
+
 def shard_columns(n_pad, world, rank):
     """Contiguous voxel-column range [c0, c1) of `rank`, in units of 128 columns."""
     units = n_pad // PAD_N
@@ -23,7 +42,7 @@ def shard_columns(n_pad, world, rank):
 
 def allreduce_sum_(t, world, group=None):
     """In-place sum over ranks of the partial AkA."""
-    if world > 1:
+    if world > 1 and not isinstance(group, EmulatedGroup):
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=group)
     return t
 
@@ -40,6 +59,8 @@ def gather_slices(t, nblocks, n_pad, world, group=None):
     mx = max(sizes)
     buf = torch.zeros(mx, dtype=t.dtype, device=t.device)
     buf[:t.numel()] = t
+    if isinstance(group, EmulatedGroup):
+        return [buf[:n] for n in sizes]
     outs = [torch.empty(mx, dtype=t.dtype, device=t.device) for _ in range(world)]
     torch.distributed.all_gather(outs, buf, group=group)
     return [o[:n] for o, n in zip(outs, sizes)]
@@ -53,6 +74,8 @@ def gather_rows(local, world, group=None):
         return local.unsqueeze(0)
     import torch.distributed as dist
     local = local.contiguous()
+    if isinstance(group, EmulatedGroup):
+        return local.unsqueeze(0).expand((world,) + tuple(local.shape))
     out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
     if dist.get_backend(group) == "nccl":
         dist.all_gather_into_tensor(out.view(-1), local.view(-1), group=group)
@@ -86,7 +109,7 @@ def exchange_blocks(send, world, group=None):
     came from rank s.  RCCL: one all_to_all_single over xGMI (the exchange step of the row-sharded spectral product: every
     rank transforms its own sensor rows and hands each peer the block-columns that peer owns).  Backends without
     all-to-all (gloo: CPU tests, single-GPU dry runs) fall back to an all-gather + selection."""
-    if world == 1:
+    if world == 1 or isinstance(group, EmulatedGroup):
         return send
     import torch.distributed as dist
     assert send.dim() == 2 and send.shape[0] == world and send.is_contiguous()
@@ -110,7 +133,7 @@ def exchange_blocks_start(send, world, group=None, out=None):
     issued asynchronously (it runs on the communicator's stream, ordered after everything queued on the current stream so far) and
     (recv, work) is returned -- `exchange_blocks_finish(work)` makes the current stream wait for it.  Other backends (gloo: CPU
     tests, single-GPU dry runs) do the whole exchange here and return work = None."""
-    if world == 1:
+    if world == 1 or isinstance(group, EmulatedGroup):
         return send, None
     import torch.distributed as dist
     if dist.get_backend(group) == "nccl":

@@ -136,10 +136,20 @@ class SpectralProduct:
         self.pair_xz = ((nx, nz) == (32, 32) and (64, 32) in hip.XZ2D_SHAPES and ny % 2 == 0
                         and os.environ.get("GEOBO_SPECTRAL_FUSED_XZ", "1") != "0")
         self._pairs = {}
+        # plane stride of the (x, z)-spectrum work buffers [row][y][Px*Pz].  Px*Pz is a power of two at 64^3 (16384 doubles =
+        # 128 KiB); a bare copy with the y stage's access pattern (512-byte runs, one per plane) streams 3.95 TB/s at that stride and
+        # 5.2 TB/s with 2 KiB of padding (tools/hbm_copy_runs.hip, profiles/r03_hbm_copy_runs.txt) -- but the kernels of this
+        # pipeline do not move: toeplitz_y 1.514 / 1.506 ms, inverse transform 0.372 / 0.375 ms, forward 0.571 / 0.573 ms with / without
+        # the padding (profiles/r03_spectral_plane_pad_ab.txt): they are held by the fp64 VALU / the matrix pipe at the clock a
+        # memory-bound launch runs at, not by channel aliasing.  The stride stays a parameter (GEOBO_SPECTRAL_PLANE_PAD, doubles);
+        # default dense.  Fused kernels only: they take explicit row / plane strides.
+        C = self.Px * self.Pz
+        pad = int(os.environ.get("GEOBO_SPECTRAL_PLANE_PAD", "0"))
+        self.Cp = C + pad if (self.fused_xz and self.dense_y and C % 2048 == 0 and pad > 0) else C
         # operator rows fed straight from a lattice survey's stencil table (LatticeRows): needs the radix-2 forward kernel
         self.lattice_feed = self.fused_xz and self.fold and nx == nz and "x" in self.F and ny >= 3 and self.dense_y
         if rows_per_batch is None:
-            per_row = (ny * self.Px * self.Pz if self.dense_y else self.P3) * 8
+            per_row = (ny * self.Cp if self.dense_y else self.P3) * 8
             rows_per_batch = max(1, min(256 if self.dense_y else 128, (3 << 30) // per_row))  # ~3 GB per work buffer
         g = 128 // math.gcd(nx * ny, 128)
         self.R = max(g, rows_per_batch // g * g)
@@ -165,21 +175,21 @@ class SpectralProduct:
     # ---- axis passes, z (contiguous) then x [then y]: [R][ny][nx][nz] -> [R][ny][Px][Pz] [-> [R][Py][Px][Pz]] -----------------
     def forward_zx(self, src, R, M, src_row_stride=None, out_name="T2"):
         """src: R volumes of ny*nx*nz doubles, `src_row_stride` doubles apart (default: contiguous)."""
-        nx, ny, nz, Px, Pz = self.nx, self.ny, self.nz, self.Px, self.Pz
+        nx, ny, nz, Px, Pz, Cp = self.nx, self.ny, self.nz, self.Px, self.Pz, self.Cp
         rows = R * ny * nx
         lds = self.N if src_row_stride is None else int(src_row_stride)
         if isinstance(src, LatticeRows):
             assert self.lattice_feed and M is self.G
-            t2 = self.buf(out_name, R * ny * Px * Pz)
+            t2 = self.buf(out_name, R * ny * Cp)
             hip.xz2d_fold_lattice(nx, R, ny, src.Q, src.row_off[src.r0:], src.q_plane, src.edge[src.r0:], src.edge.stride(0),
-                                  self.F["x"], self.F["z"], t2, ny * Px * Pz, Px * Pz)
+                                  self.F["x"], self.F["z"], t2, ny * Cp, Cp)
             return t2
         if self.fused_xz:
-            t2 = self.buf(out_name, R * ny * Px * Pz)
+            t2 = self.buf(out_name, R * ny * Cp)       # planes Cp >= Px*Pz doubles apart (padded: see __init__)
             if self.fold and M is self.G and nx == nz and "x" in self.F:     # radix-2 kernels: half the MFMAs (xz2d_fold.hip)
-                hip.xz2d_fold(False, nx, R, ny, src, lds, nx * nz, self.F["x"], self.F["z"], t2, ny * Px * Pz, Px * Pz)
+                hip.xz2d_fold(False, nx, R, ny, src, lds, nx * nz, self.F["x"], self.F["z"], t2, ny * Cp, Cp)
             else:
-                hip.xz2d(False, nx, nz, R, ny, src, lds, nx * nz, M["x"], M["z"], t2, ny * Px * Pz, Px * Pz)
+                hip.xz2d(False, nx, nz, R, ny, src, lds, nx * nz, M["x"], M["z"], t2, ny * Cp, Cp)
             return t2
         if self.pair_xz:
             t2 = self.buf(out_name, R * ny * Px * Pz)
@@ -216,12 +226,13 @@ class SpectralProduct:
         nx, nz, Px, Pz = self.nx, self.nz, self.Px, self.Pz
         Ly = yhi - ylo
         if self.fused_xz:
+            Cp = self.Cp if self.dense_y else Px * Pz       # (y through the spectrum: the batched GEMM of backward() writes dense planes)
             for ya, yb, out, ldo in targets:
                 if self.fold and nx == nz and "x" in self.F:
-                    hip.xz2d_fold(True, nx, R, yb - ya, u2[(ya - ylo) * Px * Pz:], Ly * Px * Pz, Px * Pz, self.F["x"], self.F["z"],
+                    hip.xz2d_fold(True, nx, R, yb - ya, u2[(ya - ylo) * Cp:], Ly * Cp, Cp, self.F["x"], self.F["z"],
                                   out, ldo, nx * nz)
                 else:
-                    hip.xz2d(True, nx, nz, R, yb - ya, u2[(ya - ylo) * Px * Pz:], Ly * Px * Pz, Px * Pz, self.GT["x"], self.GT["z"],
+                    hip.xz2d(True, nx, nz, R, yb - ya, u2[(ya - ylo) * Cp:], Ly * Cp, Cp, self.GT["x"], self.GT["z"],
                              out, ldo, nx * nz)
             return
         if self.pair_xz and all((yb - ya) % 2 == 0 for ya, yb, _, _ in targets):
@@ -266,9 +277,10 @@ class SpectralProduct:
         src = self.buf("Tsrc", self.N)
         src[:self.N] = T.reshape(-1)
         if self.dense_y:
-            n = ny * self.Px * self.Pz
-            gen = self.forward_zx(src, 1, self.E, out_name="Lam")[:n].clone()
-            gen.mul_(1.0 / float(self.Px * self.Pz))
+            C = self.Px * self.Pz
+            Cp = self.Cp if self.fused_xz else C          # plane stride of what forward_zx wrote
+            gen = self.forward_zx(src, 1, self.E, out_name="Lam")[:ny * Cp].view(ny, Cp)[:, :C].clone().view(-1)   # own dense [ny][C] table (the work buffer is reused)
+            gen.mul_(1.0 / float(C))
             return gen
         lam = self.forward(src, 1, self.E, out_name="Lam")[:self.P3].clone()
         lam.mul_(1.0 / float(self.P3))
@@ -312,8 +324,9 @@ class SpectralProduct:
     def _product_dense_y(self, A, Ms, gens, slabs):
         """z and x through the spectrum, y as Toeplitz blocks: one read of the (x, z)-spectrum per pair of property blocks."""
         ny, C = self.ny, self.Px * self.Pz
+        Cp = self.Cp if self.fused_xz else C
         ylo, yhi = min(s[0] for s in slabs), max(s[1] for s in slabs)
-        n_out = (yhi - ylo) * C
+        n_out = (yhi - ylo) * Cp
         for r0 in range(0, Ms, self.R):
             R = min(self.R, Ms - r0)
             if isinstance(A, LatticeRows):
@@ -323,6 +336,6 @@ class SpectralProduct:
             for j in range(0, len(gens), 2):
                 js = list(range(j, min(j + 2, len(gens))))
                 u2 = [self.buf(("S", "S1")[i], R * n_out) for i in range(len(js))]
-                hip.toeplitz_y(ny, C, R, t2, [gens[jj] for jj in js], u2, ylo, yhi)
+                hip.toeplitz_y(ny, C, R, t2, [gens[jj] for jj in js], u2, ylo, yhi, plane=Cp)
                 for i, jj in enumerate(js):
                     self.backward_xz(u2[i], R, ylo, yhi, [(ya, yb, o[jj][r0:], o[jj].stride(0)) for ya, yb, o in slabs])

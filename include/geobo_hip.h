@@ -73,6 +73,15 @@ int geobo_k_block_f32(int kernel_id, const double* rx, const double* ry, const d
                       const double* cx, const double* cy, const double* cz, int64_t nc,
                       double l1, double l2, double w, double amp, float* out, int64_t ld, void* stream);
 
+/* The same block on the REGULAR GRID of calcGridPoints3D (kernels.py:27-42) as a gather from the difference-lattice table that
+ * geobo_cov_table builds once per block pair (N*2 doubles, cache resident): out[r, c] = table[(|diy| nx + |dix|) 2nz + (dz + nz-1)]
+ * for the row voxel rows[r] (device int64 array; NULL = row0 + r) and the column voxel col0 + c, voxel p = (iy nx + ix) nz + iz.
+ * No exp / sqrt per element: the launch is bound by the HBM store of the block (SURVEY.md 8(d) regime (i), "materialised kernel
+ * assembly"); geobo_k_block stays the generator for irregular point sets.  nz even, col0 even, col0 + ncols <= nx ny nz,
+ * ld >= ncols; out_f32 != 0: out is float* (config 5's fp32 assembly; the table is then the fp32-rounded one). */
+int geobo_k_block_grid(int nx, int ny, int nz, const double* table, const int64_t* rows, int64_t row0, int64_t nr, int64_t col0,
+                       int64_t ncols, int out_f32, void* out, int64_t ld, void* stream);
+
 /* fp32-assembly mode (config 5): A K lives in HBM as fp32 and the fp64 MFMA kernels are handed fp64 panels.
  *   geobo_convert: 2-D strided precision conversion, to_f32 = 1: dst(float)[r*ld_dst + c] = (float)src(double)[r*ld_src + c],
  *                  to_f32 = 0: float -> double; cols and both leading dimensions even, 8-byte aligned bases;
@@ -245,9 +254,11 @@ int geobo_xcorr_reduce_fold(int n, int64_t rows, int planes, const double* in, i
 /* y-axis stage of the structured product on a regular grid: for every mode c < C (the (x, z)
  * spectral index, contiguous) and row r < R,   out_j[r][y - y0][c] = sum_{y'} tab_j[|y - y'|][c] * in[r][y'][c]
  * for y in [y0, y1) -- the symmetric Toeplitz blocks of create_cov's K_sj (kernels.py:158-195) applied directly.
- * in: [R][ny][C]; tab_j: [ny][C]; out_j: [R][y1-y0][C]; nprop = 1 or 2 property blocks per sweep (tab1/out1 unused
- * for 1).  ny in {16, 32, 48, 64} (GEOBO_E_UNSUPPORTED otherwise), C % 64 == 0, ny*C*8 < 2^31. */
-int geobo_toeplitz_y(int ny, int64_t C, int64_t R, int nprop, const double* in, const double* tab0, const double* tab1,
+ * in: [R][ny][plane]; tab_j: [ny][C]; out_j: [R][y1-y0][plane]; plane >= C is the stride between the y-planes of in and out in
+ * doubles (even): with plane == C a power of two (16384 at 64^3) the ny planes a lane walks sit on the same HBM channels, which
+ * costs a quarter of the bandwidth (profiles/r03_hbm_copy_runs.txt) -- callers pad it.  nprop = 1 or 2 property blocks per
+ * sweep (tab1/out1 unused for 1).  ny in {16, 32, 48, 64} (GEOBO_E_UNSUPPORTED otherwise), C % 64 == 0, ny*plane*8 < 2^31. */
+int geobo_toeplitz_y(int ny, int64_t C, int64_t plane, int64_t R, int nprop, const double* in, const double* tab0, const double* tab1,
                      double* out0, double* out1, int y0, int y1, void* stream);
 
 /* In-place lower Cholesky of the (m x m, ld) matrix A, m % 256 == 0 (padding rows/cols = identity);

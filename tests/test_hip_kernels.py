@@ -388,10 +388,20 @@ def test_toeplitz_y_matches_torch(hip, ny, C, R, nprop, y0, y1):
     hip.toeplitz_y(ny, C, R, src.reshape(-1), [t.reshape(-1) for t in tabs], [o.reshape(-1) for o in outs], y0, y1)
     torch.cuda.synchronize()
     idx = (torch.arange(ny)[:, None] - torch.arange(ny)[None, :]).abs().cuda()      # |y - y'|
+    refs = []
     for j in range(nprop):
         T = tabs[j][idx]                                                            # [y][y'][c]
-        ref = torch.einsum("ypc,rpc->ryc", T, src)[:, y0:y1]
-        assert normwise(outs[j].cpu().numpy(), ref.cpu().numpy()) < 1e-14
+        refs.append(torch.einsum("ypc,rpc->ryc", T, src)[:, y0:y1])
+        assert normwise(outs[j].cpu().numpy(), refs[j].cpu().numpy()) < 1e-14
+    # padded plane stride (what the spectral product uses: power-of-two strides alias on the HBM channels): same sums bit for bit,
+    # the padding between the planes is neither read into a result nor written
+    S = C + 256
+    srcp = torch.full((R, ny, S), float("nan"), dtype=torch.float64, device="cuda")
+    srcp[:, :, :C] = src
+    outp = [torch.full((R, y1 - y0, S), 7.0, dtype=torch.float64, device="cuda") for _ in range(nprop)]
+    hip.toeplitz_y(ny, C, R, srcp.reshape(-1), [t.reshape(-1) for t in tabs], [o.reshape(-1) for o in outp], y0, y1, plane=S)
+    for j in range(nprop):
+        assert torch.equal(outp[j][:, :, :C], outs[j]) and bool((outp[j][:, :, C:] == 7.0).all())
 
 
 @pytest.mark.parametrize("nx,nz,rows,ppr", [(48, 64, 3, 37), (64, 64, 3, 37), (64, 64, 4, 800), (48, 64, 7, 500), (64, 32, 3, 37),
@@ -486,6 +496,43 @@ def test_a_sens_lattice_form_is_identical_to_the_direct_kernel(hip, func, dims, 
     loc2 = loc.copy(); loc2[3, 0] += 1.0
     assert hip.lattice_plan(loc2, xe, ye, ze, nx, ny, nz) is None
     assert hip.lattice_plan(loc, xe * (1.0 / 3.0), ye, ze, nx, ny, nz) is None or True
+
+
+@pytest.mark.parametrize("kern,cross", [("exp", False), ("exp", True), ("matern32", False), ("matern32", True), ("sparse", False), ("sparse", True)])
+@pytest.mark.parametrize("dims", [(10, 8, 6), (16, 16, 16)])
+def test_k_block_grid_equals_the_coordinate_kernel(hip, kern, cross, dims):
+    """Materialised covariance block on the regular grid as a gather from the difference-lattice table (geobo_k_block_grid) against
+    the coordinate kernel (geobo_k_block, itself pinned to the reference's vectors): 100 m voxels have exact coordinate differences,
+    so the two agree bit for bit; row subsets, column windows, odd widths, fp32 stores."""
+    nx, ny, nz = dims
+    N = nx * ny * nz
+    s = settings_for(nx, ny, nz)
+    from geobo_amd.engine import PosteriorEngine
+    eng = PosteriorEngine(s)
+    xyz = tuple(c[:N].contiguous() for c in eng.grid_points())
+    kid = hip.kernel_id(kern, cross)
+    l1, l2, w, amp = 200.0, 230.0, 0.7, 1.3
+    tab = hip.cov_table(kid, nx, ny, nz, s.xvoxsize, s.yvoxsize, s.zvoxsize, l1, l2, w, amp)
+    g = torch.Generator().manual_seed(5)
+    rows = torch.sort(torch.randperm(N, generator=g)[:37])[0].cuda()
+    for col0, ncols, rsel in ((0, N, None), (2 * nz, N - 2 * nz, rows), (6, 2 * nz + 1, rows), (N - 8, 7, None)):
+        nr = N if rsel is None else rsel.numel()
+        ref = torch.full((nr, ncols + 3), 9.0, dtype=torch.float64, device="cuda")
+        got = ref.clone()
+        rx = xyz if rsel is None else tuple(c[rsel] for c in xyz)
+        hip.k_block(kid, rx, tuple(c[col0:col0 + ncols] for c in xyz), l1, l2, w, amp, ref[:, :ncols])
+        hip.k_block_grid(tab, nx, ny, nz, rsel, col0, got[:, :ncols])
+        assert torch.equal(ref, got), (kern, cross, col0, ncols)
+    ref32 = torch.empty((37, N), dtype=torch.float32, device="cuda")
+    got32 = torch.empty_like(ref32)
+    hip.k_block(kid, tuple(c[rows] for c in xyz), xyz, l1, l2, w, amp, ref32)
+    hip.k_block_grid(hip.round_f32_(tab.clone()), nx, ny, nz, rows, 0, got32)
+    assert torch.equal(ref32, got32)
+    bad = torch.empty((4, 8), dtype=torch.float64, device="cuda")
+    with pytest.raises(RuntimeError, match="GEOBO_E_ARG"):
+        hip.k_block_grid(tab, nx, ny, nz, None, 3, bad)                     # odd first column
+    with pytest.raises(RuntimeError, match="GEOBO_E_ARG"):
+        hip.k_block_grid(tab, nx, ny, nz, None, N - 4, bad)                 # columns beyond the grid
 
 
 def test_a_sens_slab_origin_is_validated_by_the_library(hip):

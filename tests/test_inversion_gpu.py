@@ -120,7 +120,9 @@ def test_shipped_examples(name):
     assert np.array_equal(inv.gp_length, f["gp_length_in"])
     cubes = inv.cubing(f["gravfield"], f["magfield"], f["drillfield"], f["sensor_locations"], f["drilldata0"])
     _check_cubes(cubes, f["cubes"], TOL_T3, name + " vs reference re-run")
-    _check_cubes(cubes, f["vtk_cubes"], 5e-8, name + " vs committed VTK")   # the re-run itself differs by <= 3.7e-8
+    # the committed VTKs come from the reference on ITS NumPy / BLAS of years ago: the reference re-run here differs from them by
+    # <= 3.7e-8 normwise and 2e-6 element-wise, so this comparison cannot be tighter than the reference is with itself
+    _check_cubes(cubes, f["vtk_cubes"], 5e-8, name + " vs committed VTK", tol_elem=5e-6)
 
 
 @pytest.mark.parametrize("method", ["dense", "spectral"])
@@ -1008,8 +1010,9 @@ def test_streamed_operator_rows_are_windows_of_the_stencil_table():
         buf = eng._op_rows_buffer()
         for r0, R in ((0, 7), (300, 64), (eng.Ms - 5, 5)):
             rows = A.rows_into(buf, r0, R)
-            ref = sp.forward_zx(rows, R, sp.G, src_row_stride=rows.stride(0), out_name="feed_ref")[:R * ny * 4 * nx * nz].clone()
-            got = sp.forward_zx(A.lattice.rows(r0), R, sp.G, out_name="feed_got")[:R * ny * 4 * nx * nz]
+            planes = lambda t: t[:R * ny * sp.Cp].view(R * ny, sp.Cp)[:, :4 * nx * nz]     # (the planes sit sp.Cp doubles apart: padded)
+            ref = planes(sp.forward_zx(rows, R, sp.G, src_row_stride=rows.stride(0), out_name="feed_ref")).clone()
+            got = planes(sp.forward_zx(A.lattice.rows(r0), R, sp.G, out_name="feed_got"))
             assert torch.equal(got, ref), (func, r0)
     rng = np.random.default_rng(3)
     grav, mag = rng.standard_normal(nx * ny), rng.standard_normal(nx * ny)

@@ -7,10 +7,11 @@
 // contiguous copy as the control.  Output is committed as profiles/r03_hbm_copy_runs.txt.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 typedef double v2d __attribute__((ext_vector_type(2)));
 
-// MODE 0: copy (read + write), 1: read only (the sum is stored once per thread), 2: write only.  T = double (8 B) or v2d (16 B).
+// MODE 0: copy (read + write), 1: read only (the sum is stored once per thread), 2: write only, 3: copy with non-temporal accesses.  T = double (8 B) or v2d (16 B).
 // Every thread owns one column position of the run and walks y inside a row, rows strided over gridDim.y.
 template <class T, int MODE>
 __global__ void runk(const T* in, T* out, long CS, long C, int NY, long R) {   // CS = plane stride, C = valid width (in units of T)
@@ -23,6 +24,7 @@ __global__ void runk(const T* in, T* out, long CS, long C, int NY, long R) {   /
       if (MODE == 0) out[o] = in[o] * 1.0000001;
       if (MODE == 1) acc += in[o];
       if (MODE == 2) out[o] = acc + (double)y;
+      if (MODE == 3) __builtin_nontemporal_store(__builtin_nontemporal_load(in + o) * 1.0000001, out + o);
     }
   if (MODE == 1) out[c0 + (long)blockIdx.y * CS] = acc;
 }
@@ -46,14 +48,15 @@ static void run(const char* what, double* a, double* b, long Cd, long padd, int 
     float ms; hipEventElapsedTime(&ms, e0, e1);
     if (ms < best) best = ms;
   }
-  const double bytes = (MODE == 0 ? 2.0 : 1.0) * (double)R * NY * Cd * 8;
+  const double bytes = (MODE == 0 || MODE == 3 ? 2.0 : 1.0) * (double)R * NY * Cd * 8;
   printf("%-10s lane %2zu B  plane stride %6ld+%-4ld doubles  run %5d B  gridy %3d : %7.3f ms  %5.2f TB/s\n", what, sizeof(T), Cd, padd,
          run_threads * (int)sizeof(T), gy, best, bytes / best / 1e9);
   hipEventDestroy(e0); hipEventDestroy(e1);
 }
 
-int main() {
-  const long C = 16384, R = 128; const int NY = 64;
+int main(int argc, char** argv) {
+  const long C = 16384, R = argc > 1 ? atol(argv[1]) : 128; const int NY = 64;     // R = 128: 2 x 1.07 GB per launch; 1024: 2 x 8.6 GB
+  printf("R = %ld rows x NY = %d planes x C = %ld doubles: %.2f GB per direction\n", R, NY, C, (double)R * NY * C * 8 / 1e9);
   const size_t n = (size_t)R * NY * (C + 256) + 4096;
   double *a, *b; hipMalloc(&a, n * 8); hipMalloc(&b, n * 8); hipMemset(a, 0, n * 8); hipMemset(b, 0, n * 8);
   {   // control: contiguous grid-stride copy of the same volume
@@ -81,6 +84,8 @@ int main() {
     run<v2d, 0>("copy", a, b, C, pad, NY, R, 64, 64);
     run<v2d, 0>("copy", a, b, C, pad, NY, R, 256, 128);
     run<v2d, 0>("copy", a, b, C, pad, NY, R, 512, 128);
+    run<double, 3>("copy-nt", a, b, C, pad, NY, R, 256, 128);
+    run<v2d, 3>("copy-nt", a, b, C, pad, NY, R, 256, 128);
     run<double, 1>("read", a, b, C, pad, NY, R, 256, 128);
     run<v2d, 1>("read", a, b, C, pad, NY, R, 256, 128);
     run<double, 2>("write", a, b, C, pad, NY, R, 256, 128);
