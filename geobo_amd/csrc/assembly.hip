@@ -81,21 +81,23 @@ __global__ void __launch_bounds__(256) cov_table_kernel(int nx, int ny, int nz, 
 // consecutive table entries: the gather is a sequence of nz-long contiguous copies.
 // grid: (ceil(ncols / 512), ceil(nr / KB_ROWS)); 256 threads, two adjacent columns per thread (nz even, col0 even: both in the
 // same voxel column), KB_ROWS rows per workgroup with wave-uniform row decoding on the scalar unit.
-template <typename OUT>
+template <typename OUT, int CPT>
 __global__ void __launch_bounds__(256) k_block_grid_kernel(const double* __restrict__ table, int nx, int ny, int nz,
                                                            const int64_t* __restrict__ rows, int64_t row0, int64_t nr, int64_t col0,
                                                            int64_t ncols, OUT* __restrict__ out, int64_t ld) {
-  const int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+  // CPT adjacent columns per thread, all in one voxel column (nz % CPT == 0, col0 % CPT == 0): one 16-byte store per thread and row
+  // for fp64 (CPT = 2) and for fp32 (CPT = 4) alike -- with 8-byte stores the fp32 block went no faster than the fp64 one
+  const int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * CPT;
   const int64_t r0 = (int64_t)blockIdx.y * KB_ROWS;
   if (c0 >= ncols) return;
-  const bool two = (c0 + 1) < ncols;
+  const int nv = (int)((ncols - c0) < CPT ? (ncols - c0) : CPT);
   const int64_t pc = col0 + c0;
   const int izc = (int)(pc % nz);
   const int64_t tc = pc / nz;
   const int ixc = (int)(tc % nx), iyc = (int)(tc / nx);
   const int nz2 = 2 * nz;
-  typedef OUT pair_t __attribute__((ext_vector_type(2)));
-  const bool vec = two && ((ld & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & (2 * sizeof(OUT) - 1)) == 0);
+  typedef OUT vec_t __attribute__((ext_vector_type(CPT)));
+  const bool vec = nv == CPT && (ld % CPT == 0) && ((reinterpret_cast<uintptr_t>(out) & (CPT * sizeof(OUT) - 1)) == 0);
   const int nrow = (int)((nr - r0) < KB_ROWS ? (nr - r0) : KB_ROWS);
   for (int i = 0; i < nrow; ++i) {
     const int64_t r = r0 + i;
@@ -105,14 +107,19 @@ __global__ void __launch_bounds__(256) k_block_grid_kernel(const double* __restr
     const int ixr = (int)(tr % nx), iyr = (int)(tr / nx);
     const int dy = iyc > iyr ? iyc - iyr : iyr - iyc, dx = ixc > ixr ? ixc - ixr : ixr - ixc;
     const double* tp = table + ((int64_t)(dy * nx + dx) * nz2 + (izc - izr + nz - 1));
-    const double v0 = tp[0];
-    const double v1 = two ? tp[1] : v0;
+    double v[CPT];
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) v[k] = tp[k < nv ? k : 0];
     OUT* dst = out + r * ld + c0;
     if (vec) {
-      *reinterpret_cast<pair_t*>(dst) = (pair_t){(OUT)v0, (OUT)v1};
+      vec_t o;
+#pragma unroll
+      for (int k = 0; k < CPT; ++k) o[k] = (OUT)v[k];
+      *reinterpret_cast<vec_t*>(dst) = o;
     } else {
-      dst[0] = (OUT)v0;
-      if (two) dst[1] = (OUT)v1;
+#pragma unroll
+      for (int k = 0; k < CPT; ++k)
+        if (k < nv) dst[k] = (OUT)v[k];
     }
   }
 }
@@ -398,12 +405,17 @@ extern "C" int geobo_k_block_grid(int nx, int ny, int nz, const double* table, c
   const int64_t N = (int64_t)nx * ny * nz;
   if (nx <= 0 || ny <= 0 || nz <= 0 || (nz & 1) || (col0 & 1) || col0 < 0 || col0 + ncols > N || ld < ncols) return GEOBO_E_ARG;
   if (!rows && (row0 < 0 || row0 + nr > N)) return GEOBO_E_ARG;
-  const dim3 grid((unsigned)((ncols + 511) / 512), (unsigned)((nr + KB_ROWS - 1) / KB_ROWS));
   hipStream_t st = (hipStream_t)stream;
-  if (out_f32)
-    hipLaunchKernelGGL((k_block_grid_kernel<float>), grid, dim3(256), 0, st, table, nx, ny, nz, rows, row0, nr, col0, ncols, (float*)out, ld);
+  const unsigned gy = (unsigned)((nr + KB_ROWS - 1) / KB_ROWS);
+  if (out_f32 && nz % 4 == 0 && col0 % 4 == 0)
+    hipLaunchKernelGGL((k_block_grid_kernel<float, 4>), dim3((unsigned)((ncols + 1023) / 1024), gy), dim3(256), 0, st, table, nx, ny, nz, rows,
+                       row0, nr, col0, ncols, (float*)out, ld);
+  else if (out_f32)
+    hipLaunchKernelGGL((k_block_grid_kernel<float, 2>), dim3((unsigned)((ncols + 511) / 512), gy), dim3(256), 0, st, table, nx, ny, nz, rows,
+                       row0, nr, col0, ncols, (float*)out, ld);
   else
-    hipLaunchKernelGGL((k_block_grid_kernel<double>), grid, dim3(256), 0, st, table, nx, ny, nz, rows, row0, nr, col0, ncols, (double*)out, ld);
+    hipLaunchKernelGGL((k_block_grid_kernel<double, 2>), dim3((unsigned)((ncols + 511) / 512), gy), dim3(256), 0, st, table, nx, ny, nz, rows,
+                       row0, nr, col0, ncols, (double*)out, ld);
   return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
 }
 

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <new>
 #include <stdint.h>
+#include <stdlib.h>
 #include "geobo_hip.h"
 
 namespace {
@@ -301,21 +302,35 @@ extern "C" int geobo_potrf_inv(int64_t m, double* A, int64_t ld, double* Linv, i
   int next_spine = 0;                                    // spine nodes are passed in order: mid_0 < mid_1 < ...
   bool t0_early = false;
   constexpr int T0_LEAD = 4;
-  int step = 0, last_b = -1, prev_b = -1;   // steps whose (b) was launched most recently
+  // TWO-LEVEL blocking (round 3): outer panels of OB x 128 columns.  A panel is factorised by the 128-block steps above restricted
+  // to the panel's own columns (diagonal block, panel solve, update of the panel columns to the right of it: tall and narrow, a
+  // few tens of microseconds), and the trailing matrix receives ONE rank-(OB x 128) update per panel instead of OB rank-128 ones:
+  // a rank-128 update moves 16 flop per byte of C and ran at 34 TF/s (the first half of the loop was bound by it, 250 us per
+  // 128 columns at M = 8448); at rank 512 it is a matrix-pipe-bound GEMM again.  The look-ahead is the same, one level up:
+  //     caller's stream:  [wait (b)_(K-2)] factorise panel K -> event P_K;  [wait (b)_(K-1)] (a)_K = the next panel's columns
+  //     side stream:      [wait P_K] (b)_K = everything right of the next panel -> event B_K
+  // OB = 1 is the round-2 schedule exactly (GEOBO_POTRF_OB, for A/B runs).  Fixed summation orders for a given OB: ranks that
+  // factorise the same matrix get the same bits.  Measured (tools/run_potrf_once.py): M = 33024 (128^3 x 3 properties) 547 -> 408 ms
+  // with OB = 4; M = 8448 17.5 -> 18.2 ms -- there the loop is bound by the chain potf2 (98 us) -> panel solve -> panel update of
+  // every 128 columns, not by the trailing update, and the longer (a) of a 512-wide panel sits on that chain.  Hence by size:
+  int OB = nb >= 96 ? 4 : 1;
+  if (const char* e = getenv("GEOBO_POTRF_OB")) { const int v = atoi(e); if (v >= 1 && v <= 16) OB = v; }
+  int step = 0, ostep = 0, last_b = -1, prev_b = -1;   // step: global 128-block index; outer steps whose (b) was launched most recently
   if (pc) {   // the side stream starts after everything already queued on the caller's stream (the memsets above, the producer of A)
     if (hipEventRecord(Pev[3], st) != hipSuccess || hipStreamWaitEvent(side, Pev[3], 0) != hipSuccess) return GEOBO_E_LAUNCH;
   }
-  for (int64_t kb = 0; kb < m; kb += NB, ++step) {
+  // panel and (a) are short and run next to (b) of the previous step: 128-row tiles find room as soon as HALF a CU drains
+  // (a 512-thread workgroup waits for a whole CU: behind 256-thread (b) tiles that only happens when (b) ends)
+  const int crit = pc ? GEOBO_GEMM_SMALL_TILES : 0;
+  for (int64_t k0 = 0; k0 < m; ++ostep) {
+    const int64_t W = (m - k0) < (int64_t)OB * NB ? (m - k0) : (int64_t)OB * NB;
     if (pc && prev_b >= 0 && hipStreamWaitEvent(st, Bev[prev_b & 3], 0) != hipSuccess) return GEOBO_E_LAUNCH;
-    hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(256), 0, st, A + kb * ld + kb, ld, Linv + kb * ldi + kb, ldi,
-                       (int)kb, info);
-    if (hipGetLastError() != hipSuccess) return GEOBO_E_LAUNCH;
-    const int64_t rem = m - kb - NB;
-    if (rem > 0) {
+    for (int64_t kb = k0; kb < k0 + W; kb += NB, ++step) {
+      hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(256), 0, st, A + kb * ld + kb, ld, Linv + kb * ldi + kb, ldi, (int)kb, info);
+      if (hipGetLastError() != hipSuccess) return GEOBO_E_LAUNCH;
+      const int64_t rem = m - kb - NB;
+      if (rem <= 0) continue;
       double* P = A + (kb + NB) * ld + kb;
-      // panel and (a) are short and run next to (b) of the previous step: 128-row tiles find room as soon as HALF a CU drains
-      // (a 512-thread workgroup waits for a whole CU: behind 256-thread (b) tiles that only happens when (b) ends)
-      const int crit = pc ? GEOBO_GEMM_SMALL_TILES : 0;
       int rc = geobo_gemm_nt(rem, NB, NB, 1.0, P, ld, Linv + kb * ldi + kb, ldi, 0.0, P, ld, crit, 0, stream);
       if (rc) return rc;
       if (next_spine < sp.depth && step + 1 == sp.mid[next_spine]) {
@@ -337,27 +352,39 @@ extern "C" int geobo_potrf_inv(int64_t m, double* A, int64_t ld, double* Linv, i
         if (hipEventRecord(Sev[1], ic.st) != hipSuccess) return GEOBO_E_LAUNCH;
         t0_early = true;
       }
-      if (!pc) {
-        rc = geobo_gemm_nt(rem, rem, NB, -1.0, P, ld, P, ld, 1.0, A + (kb + NB) * ld + (kb + NB), ld, 1, 0, stream);
+      const int64_t cols_left = k0 + W - (kb + NB);
+      if (cols_left > 0) {   // the panel's own columns to the right of this block: rows >= kb + NB, lower tiles from the diagonal on
+        rc = geobo_gemm_nt(rem, cols_left, NB, -1.0, P, ld, P, ld, 1.0, A + (kb + NB) * ld + (kb + NB), ld, GEOBO_GEMM_LOWER_ONLY | crit, 0, stream);
         if (rc) return rc;
-        continue;
-      }
-      if (hipEventRecord(Pev[step & 3], st) != hipSuccess) return GEOBO_E_LAUNCH;
-      if (last_b >= 0 && hipStreamWaitEvent(st, Bev[last_b & 3], 0) != hipSuccess) return GEOBO_E_LAUNCH;
-      // (a)_c: column block c+1, rows >= c+1
-      rc = geobo_gemm_nt(rem, NB, NB, -1.0, P, ld, P, ld, 1.0, A + (kb + NB) * ld + (kb + NB), ld, crit, 0, stream);
-      if (rc) return rc;
-      prev_b = last_b;
-      if (rem > NB) {
-        // (b)_c: columns >= c+2, lower tiles
-        if (hipStreamWaitEvent(side, Pev[step & 3], 0) != hipSuccess) return GEOBO_E_LAUNCH;
-        double* P2 = P + NB * ld;
-        rc = geobo_gemm_nt(rem - NB, rem - NB, NB, -1.0, P2, ld, P2, ld, 1.0, A + (kb + 2 * NB) * ld + (kb + 2 * NB), ld, 1, 0, side);
-        if (rc) return rc;
-        if (hipEventRecord(Bev[step & 3], side) != hipSuccess) return GEOBO_E_LAUNCH;
-        last_b = step;
       }
     }
+    const int64_t remo = m - k0 - W;   // rows / columns behind the panel
+    if (remo > 0) {
+      double* Pp = A + (k0 + W) * ld + k0;   // the panel below its diagonal part: remo x W
+      double* C0 = A + (k0 + W) * ld + (k0 + W);
+      if (!pc) {
+        int rc = geobo_gemm_nt(remo, remo, W, -1.0, Pp, ld, Pp, ld, 1.0, C0, ld, GEOBO_GEMM_LOWER_ONLY, 0, stream);
+        if (rc) return rc;
+      } else {
+        if (hipEventRecord(Pev[ostep & 3], st) != hipSuccess) return GEOBO_E_LAUNCH;
+        if (last_b >= 0 && hipStreamWaitEvent(st, Bev[last_b & 3], 0) != hipSuccess) return GEOBO_E_LAUNCH;
+        const int64_t Wn = remo < (int64_t)OB * NB ? remo : (int64_t)OB * NB;
+        // (a)_K: the next panel's columns, rows >= its diagonal
+        int rc = geobo_gemm_nt(remo, Wn, W, -1.0, Pp, ld, Pp, ld, 1.0, C0, ld, (OB > 1 ? GEOBO_GEMM_LOWER_ONLY : 0) | crit, 0, stream);
+        if (rc) return rc;
+        prev_b = last_b;
+        if (remo > Wn) {
+          // (b)_K: columns behind the next panel, lower tiles
+          if (hipStreamWaitEvent(side, Pev[ostep & 3], 0) != hipSuccess) return GEOBO_E_LAUNCH;
+          double* P2 = Pp + Wn * ld;
+          rc = geobo_gemm_nt(remo - Wn, remo - Wn, W, -1.0, P2, ld, P2, ld, 1.0, C0 + Wn * ld + Wn, ld, GEOBO_GEMM_LOWER_ONLY, 0, side);
+          if (rc) return rc;
+          if (hipEventRecord(Bev[ostep & 3], side) != hipSuccess) return GEOBO_E_LAUNCH;
+          last_b = ostep;
+        }
+      }
+    }
+    k0 += W;
   }
   if (pc && last_b >= 0 && hipStreamWaitEvent(st, Bev[last_b & 3], 0) != hipSuccess) return GEOBO_E_LAUNCH;
   // the other T products (hundreds of long tiles) wait for the end of the loop: under it they cost the critical path more than
