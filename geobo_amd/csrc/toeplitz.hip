@@ -14,6 +14,7 @@
 // values of the lane held in registers for all the rows the wave sweeps, NY*OC fused multiply-adds per chunk of OC
 // outputs with every index static.  8 flop per byte of traffic; VALU-bound at ~NY^2 * 4 cycles per wave-row.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include "geobo_hip.h"
 
@@ -154,6 +155,137 @@ __global__ void __launch_bounds__(256, 2) toeplitz_y_kernel(ToeplitzArgs g) {
   }
 }
 
+// ---- long y axes (NY = 128: the 128^3 configuration): the NY table values of a lane no longer fit its registers ---------------
+// A lane owns ONE mode and ONE HALF of the inputs (lanes 0-31: y' < NY/2, lanes 32-63 the same 32 modes with y' >= NY/2) and a chunk of
+// OC consecutive outputs o = ob .. ob+OC-1.  The distances d = o - y' it meets form a window of NY/2 + OC - 1 consecutive values, so
+//     acc[oo] += t[oo - i + NY/2 - 1] * x[i]        (i: input inside the half, oo: output inside the chunk)
+// has static register indices into a window of 79 table values (NY = 128, OC = 16) loaded once per workgroup with |d| folded in at
+// load time; the two halves of a mode meet in one __shfl_xor(.., 32) per output -- no second LDS buffer, no second barrier.
+// Workgroup = 2 * nprop waves (property block, 32-mode group) sharing one input row at a time through the same LDS-DMA ring as above
+// (2 x NY x 512 B = 128 KiB: one workgroup per CU); grid = (64-mode blocks, output chunks, row groups).  Each output chunk re-reads
+// the input row: one chunk for a rank's 16-plane slab of the 8-rank run, NY / OC for a full-height product.
+struct ToeplitzWinArgs {
+  const double* in;       // [R][NY][S]
+  const double* tab[3];   // [NY][C] per property block
+  double* out[3];         // [R][y1-y0][S] per property block
+  int64_t C, S, R;
+  int nprop, y0, y1;
+};
+
+template <int NH, int OC, int G>
+__device__ __forceinline__ void toeplitz_win_group(const double (&t)[NH + OC - 1], double (&acc)[OC], double (&xb)[2][GX], unsigned xaddr) {
+  constexpr int NGX = NH / GX;
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (G + 1 < NGX) {
+#pragma unroll
+    for (int i = 0; i < GX; ++i)
+      asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xb[(G + 1) & 1][i]) : "v"(xaddr), "n"(((G + 1) * GX + i) * 512));
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(xb[G & 1][0]), "+v"(xb[G & 1][1]), "+v"(xb[G & 1][2]), "+v"(xb[G & 1][3]) : "n"(GX));
+  } else {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xb[G & 1][0]), "+v"(xb[G & 1][1]), "+v"(xb[G & 1][2]), "+v"(xb[G & 1][3]));
+  }
+#pragma unroll
+  for (int i = 0; i < GX; ++i) {
+    const int yi = G * GX + i;
+    const double x = xb[G & 1][i];
+#pragma unroll
+    for (int o = 0; o < OC; ++o) acc[o] = (yi == 0) ? t[o - yi + NH - 1] * x : __builtin_fma(t[o - yi + NH - 1], x, acc[o]);
+  }
+  if constexpr (G + 1 < NGX) toeplitz_win_group<NH, OC, G + 1>(t, acc, xb, xaddr);
+}
+
+template <int NY, int OC>
+__global__ void __launch_bounds__(384, 1) toeplitz_y_win_kernel(ToeplitzWinArgs g) {
+  constexpr int NH = NY / 2, WIN = NH + OC - 1;
+  static_assert(GX == 4 && NH % GX == 0 && NH * 512 < 65536, "shape");
+  extern __shared__ __attribute__((aligned(16))) double xs_dyn[];      // [2][NY][64]
+  double (*xs)[NY][64] = reinterpret_cast<double (*)[NY][64]>(xs_dyn);
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nw = 2 * g.nprop;
+  const int prop = w >> 1, mg = w & 1, h = lane >> 5;
+  const int mode = 32 * mg + (lane & 31);                                // this lane's mode inside the 64-mode block
+  const int64_t S = g.S, c0 = (int64_t)blockIdx.x * 64;
+  const int S8 = (int)(S * 8), out_bytes = (g.y1 - g.y0) * S8;
+  const int ob = g.y0 + OC * (int)blockIdx.y;                            // first output of this workgroup's chunk
+  double t[WIN];
+  {
+    const int dmin = ob - (NH * h + NH - 1);
+    const double* tp = g.tab[prop] + c0 + mode;
+#pragma unroll
+    for (int k = 0; k < WIN; ++k) {
+      int d = dmin + k;
+      d = d < 0 ? -d : d;
+      d = d > NY - 1 ? NY - 1 : d;                                       // (outputs behind the last plane: never stored)
+      t[k] = tp[(int64_t)d * g.C];
+    }
+  }
+  int64_t r = blockIdx.z;
+  if (r >= g.R) return;
+  const int64_t rstep = gridDim.z;
+  const int64_t ostep = (int64_t)(g.y1 - g.y0) * S;
+  double* po = g.out[prop] + c0 + r * ostep + (int64_t)(ob - g.y0) * S;
+  const double* ps = g.in + r * NY * S + c0;
+  const int64_t dma_lane = (int64_t)(lane >> 5) * S + (lane & 31) * 2;   // one DMA instruction moves two y-planes of 64 modes
+  auto stage = [&](const double* row, int b) {
+    for (int i = w; i < NY / 2; i += nw)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(row + (int64_t)(2 * i) * S + dma_lane), (lds_ptr_t)&xs[b][2 * i][0], 16, 0, 0);
+  };
+  stage(ps, 0);
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  const unsigned lane8 = (unsigned)(lane & 31) * 8u + (unsigned)(32 * mg) * 8u;
+  int nout = g.y1 - ob;
+  nout = nout > OC ? OC : nout;
+  int b = 0;
+  for (; r < g.R; r += rstep) {
+    const bool more = r + rstep < g.R;
+    if (more) {
+      ps += rstep * NY * S;
+      stage(ps, b ^ 1);
+    }
+    double acc[OC], xb[2][GX];
+    const unsigned xaddr = (unsigned)(uintptr_t)(lds_ptr_t)&xs[b][NH * h][mode];
+#pragma unroll
+    for (int i = 0; i < GX; ++i) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xb[0][i]) : "v"(xaddr), "n"(i * 512));
+    toeplitz_win_group<NH, OC, 0>(t, acc, xb, xaddr);
+#pragma unroll
+    for (int o = 0; o < OC; ++o) acc[o] += __shfl_xor(acc[o], 32);      // the other half of the inputs of the same mode
+#pragma unroll
+    for (int o = 0; o < OC; ++o) asm volatile("" : "+v"(acc[o]));
+    __builtin_amdgcn_s_waitcnt(vmcnt_only(0));                           // the next row has landed (free here), then the stores
+    if (h == 0) {
+      const rsrc_t dst = make_rsrc(po, out_bytes);
+      int n = nout, pitch = S8;
+      asm volatile("" : "+s"(n), "+s"(pitch));
+#pragma unroll
+      for (int o = 0; o < OC; ++o)
+        if (o < n) st_lane(dst, lane8, o * pitch, acc[o]);
+    }
+    po += rstep * ostep;
+    __builtin_amdgcn_s_barrier();
+    b ^= 1;
+  }
+}
+
+template <int NY, int OC>
+int launch_win(const ToeplitzWinArgs& g, hipStream_t st) {
+  constexpr size_t lds = (size_t)2 * NY * 64 * sizeof(double);
+  auto kern = toeplitz_y_win_kernel<NY, OC>;
+  static std::atomic<uint64_t> attr_done{0};      // per-device "large-LDS attribute set" bits (include/geobo_hip.h, conventions)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return GEOBO_E_LAUNCH;
+  if (!((attr_done.load(std::memory_order_acquire) >> dev) & 1)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return GEOBO_E_LAUNCH;
+    attr_done.fetch_or((uint64_t)1 << dev, std::memory_order_release);
+  }
+  const int nchunks = (g.y1 - g.y0 + OC - 1) / OC;
+  int64_t gz = 1;                                   // one workgroup per CU: a few waves of workgroups, each sweeping R / gz rows
+  while ((g.C / 64) * nchunks * gz < 1024 && gz < g.R) ++gz;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(g.C / 64), (unsigned)nchunks, (unsigned)gz), dim3(128 * g.nprop), lds, st, g);
+  return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
+}
+
 template <int NY>
 int launch(const ToeplitzArgs& g, hipStream_t st) {
   int64_t gy = g.R < 4 ? g.R : 4;  // 256 column blocks x 4 at 64^3: every workgroup sweeps R/4 rows with one table load
@@ -169,15 +301,43 @@ extern "C" int geobo_toeplitz_y(int ny, int64_t C, int64_t plane, int64_t R, int
   if (!in || !tab0 || !out0 || (nprop == 2 && (!tab1 || !out1))) return GEOBO_E_ARG;
   if (nprop < 1 || nprop > 2 || R <= 0 || y0 < 0 || y1 > ny || y1 <= y0 || plane < C) return GEOBO_E_ARG;
   if (C <= 0 || C % 64 || (plane & 1) || (int64_t)ny * plane * 8 >= (1ll << 31)) return GEOBO_E_ALIGN;
+  hipStream_t st = (hipStream_t)stream;
+  if (ny == 128) {
+    const double* tabs[3] = {tab0, nprop == 2 ? tab1 : nullptr, nullptr};
+    double* outs[3] = {out0, nprop == 2 ? out1 : nullptr, nullptr};
+    return geobo_toeplitz_y3(ny, C, plane, R, nprop, in, tabs, outs, y0, y1, stream);
+  }
   ToeplitzArgs g;
   g.in = in; g.tab[0] = tab0; g.tab[1] = nprop == 2 ? tab1 : tab0; g.out[0] = out0; g.out[1] = nprop == 2 ? out1 : out0;
   g.C = C; g.S = plane; g.R = R; g.nprop = nprop; g.y0 = y0; g.y1 = y1;
-  hipStream_t st = (hipStream_t)stream;
   switch (ny) {
     case 16: return launch<16>(g, st);
     case 32: return launch<32>(g, st);
     case 48: return launch<48>(g, st);
     case 64: return launch<64>(g, st);
-    default: return GEOBO_E_UNSUPPORTED;  // longer y axes: carry y through the spectrum instead (spectral.py)
+    default: return GEOBO_E_UNSUPPORTED;  // other y extents: carry y through the spectrum instead (spectral.py)
   }
+}
+
+extern "C" int geobo_toeplitz_y3(int ny, int64_t C, int64_t plane, int64_t R, int nprop, const double* in, const double* const* tabs,
+                                 double* const* outs, int y0, int y1, void* stream) {
+  if (!in || !tabs || !outs || nprop < 1 || nprop > 3) return GEOBO_E_ARG;
+  for (int j = 0; j < nprop; ++j)
+    if (!tabs[j] || !outs[j]) return GEOBO_E_ARG;
+  if (R <= 0 || y0 < 0 || y1 > ny || y1 <= y0 || plane < C) return GEOBO_E_ARG;
+  if (C <= 0 || C % 64 || (plane & 1) || (int64_t)ny * plane * 8 >= (1ll << 31)) return GEOBO_E_ALIGN;
+  if (ny != 128) {
+    // shorter axes: the register-table kernel, two property blocks per sweep
+    for (int j = 0; j < nprop; j += 2) {
+      const int n = nprop - j >= 2 ? 2 : 1;
+      const int rc = geobo_toeplitz_y(ny, C, plane, R, n, in, tabs[j], n == 2 ? tabs[j + 1] : nullptr, outs[j], n == 2 ? outs[j + 1] : nullptr,
+                                      y0, y1, stream);
+      if (rc) return rc;
+    }
+    return GEOBO_OK;
+  }
+  ToeplitzWinArgs g;
+  g.in = in; g.C = C; g.S = plane; g.R = R; g.nprop = nprop; g.y0 = y0; g.y1 = y1;
+  for (int j = 0; j < 3; ++j) { g.tab[j] = tabs[j < nprop ? j : 0]; g.out[j] = outs[j < nprop ? j : 0]; }
+  return launch_win<128, 16>(g, (hipStream_t)stream);
 }

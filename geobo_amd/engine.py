@@ -547,7 +547,7 @@ class PosteriorEngine:
                 tab = self._cov_table(hip.kernel_id(name, s_ != j), lengths[j], lengths[s_], W[s_][j], amp)
                 lams.append(sp.eigenvalues(tab))
                 outs.append(AK[s_ * self.Ms_pad:s_ * self.Ms_pad + self.Ms, jj * nc:(jj + 1) * nc])
-            fl, fv = sp.flops(self.Ms, len(props), y1 - y0), sp.flops_valu(self.Ms, len(props))
+            fl, fv = sp.flops(self.Ms, len(props), y1 - y0), sp.flops_valu(self.Ms, len(props), y1 - y0)
             if not self.f32 and not isinstance(A, StreamedOperator):
                 self._timed("spectral_product", fl, lambda: sp.product(A, self.Ms, lams, outs, y0, y1), valu=fv)
                 continue

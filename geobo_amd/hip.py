@@ -381,18 +381,21 @@ def a_sens_lattice_stencil(ws, nx, ny, nz):
     return ws[np_:np_ + (2 * ny - 3) * (2 * nx - 1) * nz].view(2 * ny - 3, 2 * nx - 1, nz)
 
 
+TOEPLITZ_NY = (16, 32, 48, 64, 128)      # y extents geobo_toeplitz_y / _y3 are instantiated for
+
+
 def toeplitz_y(ny, C, R, src, tabs, outs, y0=0, y1=None, plane=None):
-    """outs[j][r, y - y0, c] = sum_y' tabs[j][|y - y'|, c] * src[r, y', c]  (geobo_toeplitz_y); 1 or 2 property blocks.
-    plane: stride in doubles between the y-planes of src and outs (default C: dense; the spectral product pads it)."""
+    """outs[j][r, y - y0, c] = sum_y' tabs[j][|y - y'|, c] * src[r, y', c]  (geobo_toeplitz_y3); 1 to 3 property blocks per sweep.
+    plane: stride in doubles between the y-planes of src and outs (default C: dense)."""
     lib = require_gpu()
     y1 = ny if y1 is None else y1
     n = len(tabs)
-    assert n in (1, 2) and len(outs) == n
-    t1 = tabs[1] if n == 2 else tabs[0]
-    o1 = outs[1] if n == 2 else outs[0]
-    _lib.check(lib.geobo_toeplitz_y(int(ny), int(C), int(C if plane is None else plane), int(R), n, _p(_chk(src, "src")),
-                                    _p(_chk(tabs[0], "tab0")), _p(_chk(t1, "tab1")), _p(outs[0]), _p(o1), int(y0), int(y1), _stream()),
-               "geobo_toeplitz_y")
+    assert 1 <= n <= 3 and len(outs) == n
+    import ctypes                    # (the argument C -- modes per plane -- shadows the module alias here)
+    tp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in (_chk(t, "tab") for t in tabs)])
+    op = (ctypes.c_void_p * n)(*[o.data_ptr() for o in (_chk(o, "out") for o in outs)])
+    _lib.check(lib.geobo_toeplitz_y3(int(ny), int(C), int(C if plane is None else plane), int(R), n, _p(_chk(src, "src")), tp, op,
+                                     int(y0), int(y1), _stream()), "geobo_toeplitz_y3")
 
 
 class PotrfContext:

@@ -128,7 +128,7 @@ class SpectralProduct:
         self.fold = os.environ.get("GEOBO_XZ_FOLD", "1") != "0"
         # y axis: applied as Toeplitz blocks per (x, z) mode (geobo_toeplitz_y) when the kernel has the extent, else carried
         # through the spectrum like x and z
-        self.dense_y = ny in (16, 32, 48, 64) and os.environ.get("GEOBO_SPECTRAL_DENSE_Y", "1") != "0"
+        self.dense_y = ny in hip.TOEPLITZ_NY and os.environ.get("GEOBO_SPECTRAL_DENSE_Y", "1") != "0"
         # x and z: one fused kernel per direction (geobo_xz2d) where it is instantiated, else two batched GEMM passes
         self.fused_xz = (nx, nz) in hip.XZ2D_SHAPES and os.environ.get("GEOBO_SPECTRAL_FUSED_XZ", "1") != "0"
         # 32 x 32 planes: two consecutive y-planes stacked along x go through the (64, 32) instance with diag(Mx, Mx) -- the z step
@@ -258,15 +258,18 @@ class SpectralProduct:
             fwd += 2.0 * ny * Px * Pz * nx
             bwd += 2.0 * slab * nx * Pz * Px
         if self.dense_y:
-            bwd += 2.0 * ny * ny * Px * Pz          # the kernel computes every output y and stores the slab
+            # ny <= 64: the kernel computes every output y and stores the slab; ny = 128: chunks of 16 outputs covering the slab
+            bwd += 2.0 * ny * (ny if ny <= 64 else (slab + 15) // 16 * 16) * Px * Pz
         else:
             fwd += 2.0 * pn(Py) * Px * Pz * ny
             bwd += 2.0 * pn(slab) * Px * Pz * Py
         return rows * (fwd + nblocks * bwd)
 
-    def flops_valu(self, rows, nblocks):
+    def flops_valu(self, rows, nblocks, slab=None):
         """The part of flops() executed on the fp64 VALU (the Toeplitz y stage); everything else is MFMA."""
-        return rows * nblocks * 2.0 * self.ny * self.ny * self.Px * self.Pz if self.dense_y else 0.0
+        ny = self.ny
+        outs = ny if (ny <= 64 or slab is None) else (slab + 15) // 16 * 16
+        return rows * nblocks * 2.0 * ny * outs * self.Px * self.Pz if self.dense_y else 0.0
 
     def eigenvalues(self, table_mirrored):
         """What product() needs of one covariance block, from the (z-mirrored) lattice table of geobo_cov_table:
@@ -333,9 +336,9 @@ class SpectralProduct:
                 t2 = self.forward_zx(A.rows(r0), R, self.G)
             else:
                 t2 = self.forward_zx(A[r0:], R, self.G, src_row_stride=A.stride(0))
-            for j in range(0, len(gens), 2):
-                js = list(range(j, min(j + 2, len(gens))))
-                u2 = [self.buf(("S", "S1")[i], R * n_out) for i in range(len(js))]
+            for j in range(0, len(gens), 3):              # up to three property blocks per read of the (x, z)-spectrum
+                js = list(range(j, min(j + 3, len(gens))))
+                u2 = [self.buf(("S", "S1", "S2")[i], R * n_out) for i in range(len(js))]
                 hip.toeplitz_y(ny, C, R, t2, [gens[jj] for jj in js], u2, ylo, yhi, plane=Cp)
                 for i, jj in enumerate(js):
                     self.backward_xz(u2[i], R, ylo, yhi, [(ya, yb, o[jj][r0:], o[jj].stride(0)) for ya, yb, o in slabs])

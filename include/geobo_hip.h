@@ -261,6 +261,14 @@ int geobo_xcorr_reduce_fold(int n, int64_t rows, int planes, const double* in, i
 int geobo_toeplitz_y(int ny, int64_t C, int64_t plane, int64_t R, int nprop, const double* in, const double* tab0, const double* tab1,
                      double* out0, double* out1, int y0, int y1, void* stream);
 
+/* The same stage for up to THREE property blocks per sweep of the input (tabs / outs: HOST arrays of nprop device pointers) and
+ * for ny = 128 (BASELINE config 5, 128^3 x 3 properties): there the ny table values of a mode no longer fit a lane's registers; a
+ * lane owns one mode, one half of the inputs and a chunk of 16 outputs, whose distances form a window of 79 table values with
+ * static register indices; the input row is re-read once per 16-output chunk (one chunk for the 16-plane slab of an 8-rank shard).
+ * ny in {16, 32, 48, 64} is forwarded to geobo_toeplitz_y two blocks at a time. */
+int geobo_toeplitz_y3(int ny, int64_t C, int64_t plane, int64_t R, int nprop, const double* in, const double* const* tabs,
+                      double* const* outs, int y0, int y1, void* stream);
+
 /* In-place lower Cholesky of the (m x m, ld) matrix A, m % 256 == 0 (padding rows/cols = identity);
  * scipy.linalg.cholesky(AkA, lower=True), inversion.py:100.  Also writes Linv = L^-1 (m x m, ldi; lower,
  * upper part zeroed), used instead of the two solve_triangular calls (inversion.py:105,114).

@@ -379,7 +379,9 @@ def test_gemm_nt_splitk_matches_torch(hip):
 
 
 @pytest.mark.parametrize("ny,C,R,nprop,y0,y1", [(16, 64, 3, 1, 0, 16), (32, 128, 5, 2, 0, 32), (48, 64, 4, 2, 16, 32),
-                                                 (64, 256, 9, 2, 0, 64), (64, 128, 2, 1, 32, 64)])
+                                                 (64, 256, 9, 2, 0, 64), (64, 128, 2, 1, 32, 64), (64, 64, 3, 3, 0, 64),
+                                                 (128, 64, 3, 3, 0, 16), (128, 128, 5, 3, 16, 32), (128, 64, 2, 1, 100, 128),
+                                                 (128, 64, 4, 2, 0, 128), (128, 192, 3, 3, 40, 70), (128, 64, 7, 3, 112, 128)])
 def test_toeplitz_y_matches_torch(hip, ny, C, R, nprop, y0, y1):
     # out_j[r, y - y0, c] = sum_y' tab_j[|y - y'|, c] in[r, y', c]: the per-mode symmetric Toeplitz blocks of K_sj
     src = _rand((R, ny, C), 11)
