@@ -148,9 +148,14 @@ class SpectralProduct:
         self.Cp = C + pad if (self.fused_xz and self.dense_y and C % 2048 == 0 and pad > 0) else C
         # operator rows fed straight from a lattice survey's stencil table (LatticeRows): needs the radix-2 forward kernel
         self.lattice_feed = self.fused_xz and self.fold and nx == nz and "x" in self.F and ny >= 3 and self.dense_y
+        if rows_per_batch is None and os.environ.get("GEOBO_SPECTRAL_ROWS"):
+            rows_per_batch = int(os.environ["GEOBO_SPECTRAL_ROWS"])
         if rows_per_batch is None:
             per_row = (ny * self.Cp if self.dense_y else self.P3) * 8
-            rows_per_batch = max(1, min(256 if self.dense_y else 128, (3 << 30) // per_row))  # ~3 GB per work buffer
+            # ~3 GB per work buffer; ny = 128 (67 MB of spectrum per row): 24 rows -- measured on the 128^3 rank step: 12 rows 10.3 s
+            # (launch bound), 24: 6.1 s, 48: 6.3 s, 96: 6.7 s, 192: 8.3 s (the batch's intermediates fall out of the caches)
+            cap = (3 << 30) if ny <= 64 else (13 << 27)
+            rows_per_batch = max(1, min(256 if self.dense_y else 128, cap // per_row))
         g = 128 // math.gcd(nx * ny, 128)
         self.R = max(g, rows_per_batch // g * g)
         self._bufs = {}
