@@ -211,7 +211,7 @@ class PosteriorEngine:
             raise ValueError("spectral method needs grid extents % 16 == 0 and column shards on y-slab boundaries")
         self._spectral = None
         self._lattice_plan = None
-        self._gram, self._lam = None, {}
+        self._gram, self._lam, self._edgeV = None, {}, {}
         # row-sharded spectral product (N > 1): every rank transforms Ms/world sensor rows of each operator for ALL voxels
         # and one all-to-all hands each peer the block-columns it owns; needs equal shards
         ncs = {shard_columns(self.N_pad, world, r)[1] - shard_columns(self.N_pad, world, r)[0] for r in range(world)}
@@ -362,6 +362,7 @@ class PosteriorEngine:
             lam = self._gram_eigen(plan, lws) if plan is not None else None
             self._lam[func] = None if lam is None else (A, lam)      # valid for exactly this operator tensor
         self._A = {k: v for k, v in self._A.items() if k[0] != func}  # one operator per type stays resident
+        self._edgeV = {k: v for k, v in self._edgeV.items() if k[0] != func}   # (spectra of the previous operator's boundary slabs)
         self._A[key] = A
         return A
 
@@ -460,6 +461,7 @@ class PosteriorEngine:
         """Drop the resident forward operators (the benchmark rebuilds them inside every timed step)."""
         self._A = {}
         self._lam = {}
+        self._edgeV = {}
         self._lattice_plan = None      # host analysis of the survey geometry + its device copies: part of the operator build
 
     # ---- stages ------------------------------------------------------------------------------------------------
@@ -695,6 +697,15 @@ class PosteriorEngine:
             for jj in range(P_c):
                 AK[r0:r0 + rows_r, jj * nc:(jj + 1) * nc].copy_(blocks[jj])
 
+    def _edge_spectrum(self, func, k, ycols):
+        """Spectrum of boundary slab k (0: iy = 0, 1: iy = ny - 1) of operator `func` for the lattice Gram's x-correlation; built once
+        per operator build (clear_operators drops it) from the slab's columns of the operator."""
+        key = (func, k)
+        hit = self._edgeV.get(key)
+        if hit is None or hit[0] != ycols.data_ptr():
+            hit = self._edgeV[key] = (ycols.data_ptr(), self._gram.edge_eigen(ycols))
+        return hit[1]
+
     def _gram_eigen(self, plan, lws):
         """Eigen-data of the operator's stencil table for the lattice Gram (lattice_gram.py); None -> AkA by the N-deep GEMM."""
         from .lattice_gram import LatticeGram
@@ -768,13 +779,17 @@ class PosteriorEngine:
                             R = min(gram.R, mv - rb)
                             gram.gram_rows(self._panel64("gram_rows64", Xv[rb:rb + R], rows=gram.R), R, lam, Cv[rb:], ya, yb)
                     for c0 in edges:
+                        k = 0 if ya + c0 // pl == 0 else 1
                         if streamed and A.lattice is not None:      # the two boundary slabs are kept with the stencil table
-                            k = 0 if ya + c0 // pl == 0 else 1
                             ycols = A.edge[:, k * pl:(k + 1) * pl]
                         else:
                             ycols = operand_cols(c0, c0 + pl)
-                        hip.gemm_nt(self._panel64("aka_panel64", Xv[:, c0:c0 + pl]), ycols, Cv, alpha=1.0,
-                                    beta=1.0, lower_only=True, m_valid=mv)
+                        if gram.edge_supported() and Xv.dtype == F64:
+                            # x-Toeplitz slab: correlation through the full real DFT (three batched GEMMs) instead of a 4096-deep GEMM
+                            gram.edge_rows(Xv[:, c0:], mv, self._edge_spectrum(("grav", "magn")[s_], k, ycols), Cv)
+                        else:
+                            hip.gemm_nt(self._panel64("aka_panel64", Xv[:, c0:c0 + pl]), ycols, Cv, alpha=1.0,
+                                        beta=1.0, lower_only=True, m_valid=mv)
                 self._timed("aka_lattice", fl, lattice)
                 continue
             # executed flop: lower-only tiles, whole 64-row wavefront groups of the last row tile
@@ -815,7 +830,11 @@ class PosteriorEngine:
             # out[:nrows, :Ms] = X[:nrows] . A_sp^T : interior y-slabs by the (y, x) correlation, the two padded slabs by a GEMM
             gram.gram_rows(X, nrows, lam[sp_], out, 0, self.ny)
             for k, iy in enumerate((0, self.ny - 1)):
-                hip.gemm_nt(X[:, iy * pl:(iy + 1) * pl], edge[sp_][:, k * pl:(k + 1) * pl], out, alpha=1.0, beta=1.0, m_valid=nrows)
+                ycols = edge[sp_][:, k * pl:(k + 1) * pl]
+                if gram.edge_supported():
+                    gram.edge_rows(X[:, iy * pl:], nrows, self._edge_spectrum(("grav", "magn")[sp_], k, ycols), out)
+                else:
+                    hip.gemm_nt(X[:, iy * pl:(iy + 1) * pl], ycols, out, alpha=1.0, beta=1.0, m_valid=nrows)
         for s_ in (0, 1):
             for sp_ in (0, 1):
                 rows_times_AT(self._fullrows[(s_, sp_)], rows_r, sp_, loc[s_][:, sp_ * self.Ms_pad:(sp_ + 1) * self.Ms_pad])

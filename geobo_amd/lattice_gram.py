@@ -16,7 +16,15 @@ transforms G as the covariance (spectral.py), channel by channel:
                                            boundary slabs zeroed
   2. x step + scaling + channel sum        geobo_xcorr_reduce (fused MFMA kernel, one (row, y-mode) plane per workgroup step)
   3. back       C_r = Gy^T S_r Gx          geobo_xz2d (inverse), written straight into the AkA row segment
-  4. the two 1e6-padded boundary slabs     ordinary geobo_gemm_nt over their 2 nx nz columns (3 % of the contraction)
+  4. the two 1e6-padded boundary slabs     (3 % of the contraction, 20 % of the time as plain GEMMs over their 2 nx nz columns)
+     The padding shifts node x AND y offsets of the plane by 1e6 m (sensormodel.py:63-68): the slab's stencil is no longer even
+     in x -- no real-cosine diagonalisation -- and differs from sensor row to sensor row in y, but it is still a function of
+     (jy, ix - jx, iz): for every jy a one-level Toeplitz matrix in x with the z axis as a channel.  Round 3: cross-correlation
+     along x through the full real DFT (cosine AND sine parts, P = 2 nx points, nothing assumed about symmetry),
+         out[r, jy, jx] = 1/P sum_w c_w [ C_w cos(2 pi w jx / P) + S_w sin(2 pi w jx / P) ],
+         C_w = sum_iz (Xc Kc + Xs Ks),   S_w = sum_iz (Xs Kc - Xc Ks)
+     as three batched MFMA GEMMs (edge_rows): x-DFT of the slab planes, per-frequency contraction over (cos / sin, iz) against
+     the stencil's spectrum, inverse DFT; 4.3e6 instead of 3.4e7 flop per row and slab.
 
 2 x 1.9e8 flop per row instead of 2.1e9, and no N-deep pass over A."""
 import numpy as np
@@ -40,6 +48,78 @@ class LatticeGram:
         gy0[:, self.ny - 1] = 0.0
         self.Gy0 = gy0
         self.R = 256
+
+    # ---- boundary slabs: x-correlation through the full real DFT (module docstring, item 4) -----------------------------------
+    EDGE_ROWS = 1024     # rows per batch: 64 frequency slots x 8 column tiles = 512 tiles per batched GEMM (two per CU)
+
+    def _edge_consts(self):
+        """F2 [2 nx comps][nx]: slot 0 = (cos_0, cos_nx) -- the two frequencies without a sine part --, slot w = (cos_w, sin_w);
+        FiT [nx (padded to 128 rows)][2 nx]: the inverse with the weights c_w / P folded in."""
+        if getattr(self, "_edge_c", None) is None:
+            nx = self.nx
+            P = 2 * nx
+            i = np.arange(nx)
+            F2 = np.zeros((nx, 2, nx))
+            F2[0, 0], F2[0, 1] = 1.0, (-1.0) ** i
+            Fi = np.zeros((128, nx, 2))
+            Fi[:nx, 0, 0], Fi[:nx, 0, 1] = 1.0 / P, ((-1.0) ** i) / P
+            for w in range(1, nx):
+                ang = 2.0 * np.pi * ((w * i) % P) / P
+                F2[w, 0], F2[w, 1] = np.cos(ang), np.sin(ang)
+                Fi[:nx, w, 0], Fi[:nx, w, 1] = 2.0 / P * np.cos(ang), 2.0 / P * np.sin(ang)
+            self._edge_c = (hip.to_dev(F2.reshape(2 * nx, nx), self.device), hip.to_dev(Fi.reshape(128, 2 * nx), self.device))
+        return self._edge_c
+
+    def edge_supported(self):
+        return self.nx == 64 and self.nz == 64 and self.ny <= 64 and os.environ.get("GEOBO_GRAM_EDGE_SPECTRAL", "1") != "0"
+
+    def edge_eigen(self, E):
+        """Spectrum of one boundary slab of an operator.  E: (>= ny*nx rows) x (nx*nz) view of the slab's columns, row (jy, jx),
+        column (ix, iz), with E[(jy, jx), (ix, iz)] = kappa_jy(ix - jx, iz) exactly (lattice survey: the node offsets are bit-identical
+        for equal index differences, hip.lattice_plan).  Returns V [nx slots][2 x 64 (C / S, jy)][2 x nz (cos / sin, iz)]."""
+        nx, ny, nz = self.nx, self.ny, self.nz
+        F2, _ = self._edge_consts()
+        Ev = E[:ny * nx]
+        kap = torch.zeros((2, ny, nx, 2 * nz), dtype=F64, device=self.device)      # [+ / -][jy][d][iz | compute-extent padding]
+        kap[0, :, :, :nz] = Ev[0::nx].reshape(ny, nx, nz)                          # d = ix >= 0   (sensor column jx = 0)
+        kap[1, :, 1:, :nz] = Ev[:, :nz].reshape(ny, nx, nz)[:, 1:]                 # d = -jx < 0   (voxel column ix = 0)
+        T = torch.empty((2, ny, 2 * nx, nz), dtype=F64, device=self.device)        # [+ / -][jy][(slot, cs)][iz]
+        hip.gemm_batched(True, 2 * nx, 2 * nz, nx, F2, nx, 0, kap, 2 * nz, nx * 2 * nz, T, nz, 2 * nx * nz, 2 * nx, nz, 2 * ny)
+        T = T.view(2, ny, nx, 2, nz)
+        even = T[0] + T[1]                                                          # cosine parts: kappa(d) and kappa(-d) add
+        Ks = (T[0] - T[1])[:, :, 1]                                                 # sine parts: they subtract
+        Kc = even[:, :, 0]
+        V = torch.zeros((nx, 2, 64, 2, nz), dtype=F64, device=self.device)          # [slot][C | S][jy (64 slots)][cos | sin][iz]
+        Kc_s, Ks_s = Kc.permute(1, 0, 2), Ks.permute(1, 0, 2)                       # [slot][jy][iz]
+        V[1:, 0, :ny, 0], V[1:, 0, :ny, 1] = Kc_s[1:], Ks_s[1:]
+        V[1:, 1, :ny, 0], V[1:, 1, :ny, 1] = -Ks_s[1:], Kc_s[1:]
+        V[0, 0, :ny, 0] = Kc_s[0]                                                   # frequency 0
+        V[0, 1, :ny, 1] = even[:, 0, 1]                                             # frequency nx (a cosine, stored in the slot's second place)
+        return V.view(nx, 128, 2 * nz)
+
+    def edge_rows(self, X, nrows, V, out):
+        """out[r, :ny*nx] += X[r, :nx*nz] . E^T for r < nrows, E given by its spectrum V (edge_eigen).  X: view starting at the slab's
+        first column (unit column stride, even row stride); 64 doubles behind the last row's slab must be readable (compute extents
+        of the first GEMM overhang the plane: inside the next slab / the next row everywhere but at the end of the buffer)."""
+        nx, ny, nz, sp = self.nx, self.ny, self.nz, self.sp
+        pl, RB = nx * nz, self.EDGE_ROWS
+        F2, FiT = self._edge_consts()
+        assert X.stride(1) == 1 and X.stride(0) % 2 == 0 and out.stride(1) == 1
+        end = X.storage_offset() + (nrows - 1) * X.stride(0) + pl + nz
+        if end > X.untyped_storage().nbytes() // 8:                                 # no slack behind the last row: stage the rows
+            Xc = sp.buf("LG_EX", nrows * pl + 64)[:nrows * pl].view(nrows, pl)
+            Xc.copy_(X[:nrows, :pl])
+            X = Xc
+        for r0 in range(0, nrows, RB):
+            R = min(RB, nrows - r0)
+            Rp = (R + 127) // 128 * 128
+            Xh = sp.buf("LG_EXh", RB * 2 * nx * nz)                                  # [row][(slot, cs)][iz]
+            hip.gemm_batched(True, 2 * nx, 2 * nz, nx, F2, nx, 0, X[r0:], nz, X.stride(0), Xh, nz, 2 * nx * nz, 2 * nx, nz, R)
+            o2 = sp.buf("LG_EO2", nx * 128 * RB)                                     # [slot][(C | S, jy)][row]
+            hip.gemm_batched(False, 128, Rp, 2 * nz, V, 2 * nz, 128 * 2 * nz, Xh, 2 * nx * nz, 2 * nz, o2, Rp, 128 * Rp, 128, R, nx)
+            oT = sp.buf("LG_EOT", 64 * nx * RB)                                      # [jy][jx][row]
+            hip.gemm_batched(True, 128, Rp, 2 * nx, FiT, 2 * nx, 0, o2, 64 * Rp, Rp, oT, Rp, nx * Rp, nx, R, ny)
+            out[r0:r0 + R, :ny * nx] += oT[:ny * nx * Rp].view(ny * nx, Rp)[:, :R].t()
 
     @staticmethod
     def supported(nx, ny, nz):
