@@ -537,6 +537,33 @@ def test_k_block_grid_equals_the_coordinate_kernel(hip, kern, cross, dims):
         hip.k_block_grid(tab, nx, ny, nz, None, N - 4, bad)                 # columns beyond the grid
 
 
+@pytest.mark.parametrize("ny,nrows", [(64, 300), (48, 1100)])
+def test_lattice_gram_boundary_slab_correlation(hip, ny, nrows):
+    """The lattice Gram's boundary slabs: out[r, (jy, jx)] += sum_(ix, iz) X[r, ix, iz] kappa_jy(ix - jx, iz) through the full real
+    DFT along x (LatticeGram.edge_eigen / edge_rows: three batched MFMA GEMMs) against the plain GEMM with the materialised slab, on a
+    random NON-even x-Toeplitz stencil; ragged row counts, rows with and without readable slack behind the last one."""
+    from geobo_amd.lattice_gram import LatticeGram
+    from geobo_amd.spectral import SpectralProduct
+    nx = nz = 64
+    sp = SpectralProduct(nx, ny, nz, "cuda")
+    gram = LatticeGram(sp, "cuda")
+    assert gram.edge_supported()
+    kap = _rand((ny, 2 * nx - 1, nz), 71)                                   # kappa_jy(d, iz), d = -(nx-1) .. nx-1
+    idx = (torch.arange(nx)[None, :] - torch.arange(nx)[:, None] + nx - 1).cuda()      # [jx][ix] -> d index
+    E = kap[:, idx, :].reshape(ny * nx, nx * nz)                             # row (jy, jx), column (ix, iz)
+    Epad = torch.zeros((ny * nx + 256, nx * nz + 16), dtype=torch.float64, device="cuda")
+    Epad[:ny * nx, :nx * nz] = E
+    V = gram.edge_eigen(Epad[:, :nx * nz])
+    for slack in (True, False):
+        Xb = _rand((nrows + (1 if slack else 0), 3 * nx * nz), 72)
+        X = Xb[:nrows, nx * nz:] if slack else Xb[:, 2 * nx * nz:]          # without slack: the slab is the last thing in the buffer
+        out = _rand((nrows, ny * nx + 6), 73)
+        ref = out.clone()
+        ref[:, :ny * nx] += X[:nrows, :nx * nz] @ E.t()
+        gram.edge_rows(X, nrows, V, out)
+        assert (out - ref).abs().max().item() <= 1e-12 * ref.abs().max().item()
+
+
 def test_a_sens_slab_origin_is_validated_by_the_library(hip):
     """col_origin travels through the C ABI: a compact slab buffer equals the same columns of the full-width operator, and a request
     whose columns do not fit one buffer row (full-width call with a short leading dimension, slab in front of the buffer's origin) is
