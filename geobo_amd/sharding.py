@@ -89,6 +89,12 @@ def assemble_columns(parts, props, n, n_pad, world, to_host=None):
     (NaN for property blocks that were not computed).  to_host(tensor, slot) -> 1-D host array that stays valid until the next
     call with the same slot (the engine's pinned staging buffers); default: a pageable copy per part."""
     out = np.full(3 * n, np.nan)
+    if to_host is not None and len(parts) > 1 and all(isinstance(p, torch.Tensor) and p.is_cuda for p in parts):
+        # one device-to-host copy for all ranks' slices (8 per-part copies, each with its own stream sync, cost 2 ms at 8 ranks)
+        sizes = [int(p.numel()) for p in parts]
+        flat = to_host(torch.cat([p.reshape(-1) for p in parts]), 0)
+        offs = np.cumsum([0] + sizes)
+        parts = [flat[offs[i]:offs[i + 1]] for i in range(len(sizes))]
     for r, part in enumerate(parts):
         c0, c1 = shard_columns(n_pad, world, r)
         ncr = c1 - c0
