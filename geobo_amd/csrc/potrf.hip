@@ -45,19 +45,31 @@ __device__ __forceinline__ void potf2_group(double (&a)[8][8], double (&x)[8][8]
     }
     __syncthreads();
     const double d = colbuf[buf][j];
+    // every LDS read of the step is issued HERE, unconditionally, so that their latency runs under the pivot's reciprocal square
+    // root instead of behind it (they used to sit under the predicates below: the compiler placed them after the sqrt / division
+    // chain); -19 us per 128 x 128 block
+    double cv[8], cc[8], xr[8];
+#pragma unroll
+    for (int p = JB; p < 8; ++p) cv[p] = colbuf[buf][ti + 16 * p];
+#pragma unroll
+    for (int q = JB; q < 8; ++q) cc[q] = colbuf[buf][tj + 16 * q];
+#pragma unroll
+    for (int q = 0; q <= JB; ++q) xr[q] = rowbuf[buf][tj + 16 * q];
     if (!(d > 0.0) && !bad_seen) {  // non-positive or NaN pivot: LAPACK dpotrf's info = j (1-based)
       bad_seen = true;
       if (tid == 0 && *info == 0) *info = kb_global + j + 1;
     }
+    // (IEEE sqrt and division kept: a v_rsq_f64 + Newton form saves another 3 us per block, but its last-bit differences move
+    //  optimize_gp's SHGO / SLSQP iterates -- forward differences with h = 1.5e-8 -- to a different point of the flat valley)
     const double r = sqrt(d);
     const double rinv = 1.0 / r;
     double li[8], lc[8], xj[8];
 #pragma unroll
-    for (int p = JB; p < 8; ++p) li[p] = (ti + 16 * p > j) ? colbuf[buf][ti + 16 * p] * rinv : 0.0;
+    for (int p = JB; p < 8; ++p) li[p] = (ti + 16 * p > j) ? cv[p] * rinv : 0.0;
 #pragma unroll
-    for (int q = JB; q < 8; ++q) lc[q] = (tj + 16 * q > j) ? colbuf[buf][tj + 16 * q] * rinv : 0.0;
+    for (int q = JB; q < 8; ++q) lc[q] = (tj + 16 * q > j) ? cc[q] * rinv : 0.0;
 #pragma unroll
-    for (int q = 0; q <= JB; ++q) xj[q] = (tj + 16 * q <= j) ? rowbuf[buf][tj + 16 * q] * rinv : 0.0;
+    for (int q = 0; q <= JB; ++q) xj[q] = (tj + 16 * q <= j) ? xr[q] * rinv : 0.0;
     if (tj == jj) {  // column j of L: scaled sub-diagonal, sqrt on the diagonal
 #pragma unroll
       for (int p = JB; p < 8; ++p) {
