@@ -96,3 +96,21 @@ def test_large_cube_modes_on_the_row_exchange_path(assembly, operators, size, tm
             assert np.isnan(a).all()
         else:
             assert normwise(a, b) <= tol
+
+
+def test_emulated_rank_runs_the_sharded_path_alone():
+    """tools/emulate_rank.py (per-rank compute measured on one device, step times predicted): rank 0 of 4 of the
+    64^3 step through the real engine path with an EmulatedGroup -- row exchange, row-sharded lattice Gram, the true AkA put in
+    place for the replicated factorisation -- must run, report the forms it used, and cost less than the 1-rank step."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "emulate_rank.py"), "--of", "4", "--steps", "1", "--warmup", "1"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "PREDICTED, NOT MEASURED" in out["what"]
+    four = out["ranks"]["4"]
+    assert four["row_exchange"] and four["row_gram"]
+    assert 0.0 < four["compute_ms_per_step_measured"] < 0.5 * out["one_rank"]["ms_per_step"]
+    assert four["stage_ms_measured"]["posterior_reduce"] < 0.3 * out["one_rank"]["stage_ms"]["posterior_reduce"]
+    for v in four["predicted"].values():
+        assert v["step_ms_no_overlap"] >= v["step_ms_all_to_all_under_compute"] >= four["compute_ms_per_step_measured"]
