@@ -30,6 +30,7 @@ DRIVERS = {"posterior": ("run_posterior_once.py", "gemm_f64_kernel<4, 2, 2, 1", 
            "kblock_exp": ("run_k_block_once.py exp f64", "k_block_kernel", "pmc_k_block_exp_f64.json"),
            "kblock_matern": ("run_k_block_once.py matern32 f64", "k_block_kernel", "pmc_k_block_matern32_f64.json"),
            "kblock_exp_f32": ("run_k_block_once.py exp f32", "k_block_kernel", "pmc_k_block_exp_f32.json"),
+           "toeplitz128": ("run_spectral_kernels_once.py toeplitz128", "toeplitz_y_win_kernel", "pmc_toeplitz_y_win128.json"),
            "kblock_grid": ("run_k_block_once.py matern32_x f64 grid", "k_block_grid_kernel", "pmc_k_block_grid_f64.json"),
            "kblock_grid_f32": ("run_k_block_once.py matern32_x f32 grid", "k_block_grid_kernel", "pmc_k_block_grid_f32.json")}
 

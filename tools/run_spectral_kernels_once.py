@@ -84,3 +84,21 @@ if which in ("all", "xz2d32_bwd"):
     src, out = rnd(R, ny32 * 4 * m * m), torch.empty((R, ny32 * m * m), dtype=torch.float64, device=dev)
     timed("xz2d32_bwd", R * ny32 * 2.0 * (2 * m * 2 * m * m + 2 * m * 2 * m * m), R * ny32 * 5 * m * m * 8.0,
           lambda: hip.xz2d(True, 2 * m, m, R, ny32 // 2, src, src.stride(0), 8 * m * m, MxT2, MzT, out, out.stride(0), 2 * m * m))
+if which in ("all", "toeplitz128"):
+    # BASELINE config 5 (128^3 x 3 properties), the rank-0-of-8 batch: 26 sensor rows, all 128 planes in, the rank's 16 planes out,
+    # three property blocks per read of the (x, z)-spectrum (geobo_toeplitz_y3, windowed register table)
+    ny, C, Rb = 128, 256 * 256, 26
+    src = rnd(Rb * ny * C)
+    tabs = [rnd(ny * C) for _ in range(3)]
+    outs = [torch.empty(Rb * 16 * C, dtype=torch.float64, device=dev) for _ in range(3)]
+    timed("toeplitz_y_win", Rb * C * 2.0 * ny * 16 * 3, Rb * C * 8.0 * (ny + 3 * 16), lambda: hip.toeplitz_y(ny, C, Rb, src, tabs, outs, 0, 16))
+    del src, tabs, outs
+if which in ("all", "edge_rows"):
+    # lattice Gram, one boundary slab for 1024 rows: x-DFT, per-frequency contraction, inverse DFT (three batched GEMMs)
+    from geobo_amd.lattice_gram import LatticeGram
+    from geobo_amd.spectral import SpectralProduct
+    gram = LatticeGram(SpectralProduct(n, n, n, dev), dev)
+    E = rnd(n * n + 256, n * n)
+    V = gram.edge_eigen(E)
+    X, out = rnd(1025, 2 * n * n), torch.zeros((1024, n * n), dtype=torch.float64, device=dev)
+    timed("edge_rows", 1024 * 3 * 2.0 * 128 * 128 * 64, 1024 * (n * n + n * n) * 8.0, lambda: gram.edge_rows(X[:, :n * n + 64], 1024, V, out))
