@@ -22,6 +22,8 @@ SIGNATURES = {
     "geobo_k_block": (_int, [_int, _dp, _dp, _dp, _i64, _dp, _dp, _dp, _i64, _f64, _f64, _f64, _f64, _dp, _i64, _dp]),
     "geobo_k_block_f32": (_int, [_int, _dp, _dp, _dp, _i64, _dp, _dp, _dp, _i64, _f64, _f64, _f64, _f64, _dp, _i64, _dp]),
     "geobo_k_block_grid": (_int, [_int, _int, _int, _dp, _dp, _i64, _i64, _i64, _i64, _int, _dp, _i64, _dp]),
+    "geobo_colgemv_ws_bytes": (_sz, [_i64, _i64]),
+    "geobo_colgemv": (_int, [_i64, _i64, _dp, _i64, _dp, _dp, _dp, _sz, _dp]),
     "geobo_convert": (_int, [_int, _dp, _i64, _dp, _i64, _i64, _i64, _dp]),
     "geobo_round_f32": (_int, [_dp, _i64, _dp]),
     "geobo_k_eval": (_int, [_int, _dp, _i64, _f64, _f64, _f64, _f64, _dp, _dp]),
@@ -45,6 +47,8 @@ SIGNATURES = {
     "geobo_xz2d_fold": (_int, [_int, _int, _i64, _int, _dp, _i64, _i64, _dp, _dp, _dp, _i64, _i64, _dp]),
     "geobo_xcorr_reduce_fold": (_int, [_int, _i64, _int, _dp, _i64, _i64, _dp, _dp, _dp, _i64, _i64, _dp]),
     "geobo_xz2d_fold_lattice": (_int, [_int, _i64, _int, _dp, _dp, _i64, _dp, _i64, _dp, _dp, _dp, _i64, _i64, _dp]),
+    "geobo_xz2d_fold_inv_ss_slots": (_int, [_int, _i64, _int]),
+    "geobo_xz2d_fold_inv_ss": (_int, [_int, _i64, _int, _dp, _i64, _i64, _dp, _i64, _i64, _dp, _dp, _dp, _dp]),
     "geobo_ymul": (_int, [_int, _int, _i64, _i64, _dp, _i64, _dp, _i64, _dp, _i64, _dp]),
     "geobo_xcorr_reduce": (_int, [_int, _int, _i64, _int, _dp, _i64, _i64, _dp, _i64, _dp, _dp, _i64, _i64, _dp]),
     "geobo_toeplitz_y": (_int, [_int, _i64, _i64, _i64, _int, _dp, _dp, _dp, _dp, _dp, _int, _int, _dp]),

@@ -124,6 +124,44 @@ __global__ void __launch_bounds__(256) k_block_grid_kernel(const double* __restr
   }
 }
 
+// ---- weighted column sums: out[c] = sum_r X[r, c] v[r] ---------------------------------------------------------------------
+// w = Linv^T u and mu = (A K)^T w of the posterior mean (inversion.py:114-116: mu = V^T u = (A K)^T L^-T L^-1 y): a pure stream over
+// X.  grid (ceil(n / 512), RS): block (bx, rs) sums its slice of the rows into part[rs][c] (two adjacent columns per thread, v[r]
+// wave-uniform), colsum_finish adds the RS slices in a fixed order.
+__global__ void __launch_bounds__(256) colgemv_kernel(const double* __restrict__ X, int64_t ld, int64_t m, int64_t n,
+                                                      const double* __restrict__ v, int64_t rows_per, double* __restrict__ part) {
+  const int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+  if (c0 >= n) return;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per;
+  const int64_t r1 = r0 + rows_per < m ? r0 + rows_per : m;
+  v2d a0 = (v2d){0., 0.}, a1 = (v2d){0., 0.}, a2 = (v2d){0., 0.}, a3 = (v2d){0., 0.};
+  const double* p = X + r0 * ld + c0;
+  int64_t r = r0;
+  for (; r + 4 <= r1; r += 4, p += 4 * ld) {
+    const v2d x0 = *reinterpret_cast<const v2d*>(p), x1 = *reinterpret_cast<const v2d*>(p + ld);
+    const v2d x2 = *reinterpret_cast<const v2d*>(p + 2 * ld), x3 = *reinterpret_cast<const v2d*>(p + 3 * ld);
+    a0 += x0 * v[r]; a1 += x1 * v[r + 1]; a2 += x2 * v[r + 2]; a3 += x3 * v[r + 3];
+  }
+  for (; r < r1; ++r, p += ld) a0 += *reinterpret_cast<const v2d*>(p) * v[r];
+  *reinterpret_cast<v2d*>(part + (int64_t)blockIdx.y * n + c0) = (a0 + a1) + (a2 + a3);
+}
+
+__global__ void __launch_bounds__(256) colsum_finish_kernel(const double* __restrict__ part, int rs, int64_t n, double* __restrict__ out) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= n) return;
+  double a = 0.;
+  for (int s = 0; s < rs; ++s) a += part[(int64_t)s * n + c];
+  out[c] = a;
+}
+
+int colgemv_splits(int64_t m, int64_t n) {
+  const int64_t bx = (n + 511) / 512;
+  int64_t rs = (2048 + bx - 1) / bx;           // ~8 workgroups per CU in flight
+  if (rs > 64) rs = 64;
+  if (rs > m / 64) rs = m / 64 > 0 ? m / 64 : 1;
+  return (int)(rs < 1 ? 1 : rs);
+}
+
 // 2-D strided precision conversion (rows x cols, cols even): the fp32-assembly mode keeps A K in fp32 in HBM and hands the fp64
 // MFMA kernels fp64 panels.  Pure streaming: 12 B per element.
 template <typename SRC, typename DST>
@@ -416,6 +454,25 @@ extern "C" int geobo_k_block_grid(int nx, int ny, int nz, const double* table, c
   else
     hipLaunchKernelGGL((k_block_grid_kernel<double, 2>), dim3((unsigned)((ncols + 511) / 512), gy), dim3(256), 0, st, table, nx, ny, nz, rows,
                        row0, nr, col0, ncols, (double*)out, ld);
+  return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
+}
+
+extern "C" size_t geobo_colgemv_ws_bytes(int64_t m, int64_t n) {
+  if (m <= 0 || n <= 0) return 0;
+  return (size_t)colgemv_splits(m, n) * (size_t)n * sizeof(double);
+}
+
+extern "C" int geobo_colgemv(int64_t m, int64_t n, const double* X, int64_t ld, const double* v, double* out, void* ws,
+                             size_t ws_bytes, void* stream) {
+  if (!X || !v || !out || !ws) return GEOBO_E_ARG;
+  if (m <= 0 || n <= 0) return GEOBO_OK;
+  if ((n & 1) || (ld & 1) || ld < n || ((uintptr_t)X & 15) || ((uintptr_t)ws & 15)) return GEOBO_E_ALIGN;
+  if (ws_bytes < geobo_colgemv_ws_bytes(m, n)) return GEOBO_E_ARG;
+  const int rs = colgemv_splits(m, n);
+  const int64_t rows_per = (m + rs - 1) / rs;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(colgemv_kernel, dim3((unsigned)((n + 511) / 512), (unsigned)rs), dim3(256), 0, st, X, ld, m, n, v, rows_per, (double*)ws);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)ws, rs, n, out);
   return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
 }
 

@@ -45,6 +45,11 @@ struct FoldArgs {
   // row r, plane y at in + row_off[r] + y*in_plane, except the first and the last plane of a row (the 1e6-padded boundary slabs),
   // which come from edge + r*edge_row (+ one plane for the last one).  row_off == nullptr: dense rows as above.
   const int64_t* row_off; const double* edge; int64_t edge_row;
+  // inverse with the sum-of-squares reduction (geobo_xz2d_fold_inv_ss): rows r >= r2_first are the SUM of two spectra, plane (r, y)
+  // of the second one at in2 + (r - r2_first)*in2_row + y*in_plane (both contractions are linear: the first step accumulates over
+  // the terms, the second runs once); nothing is stored per plane -- every workgroup keeps sum_r X_r[y]^2 for its fixed y in
+  // registers and adds it to ss + (slot*ppr + y)*n*n at the end (slot = blockIdx.x / ppr; the grid is a multiple of ppr)
+  const double* in2; int64_t in2_row, r2_first; double* ss;
 };
 
 constexpr int vmcnt_imm(int v) { return (v & 15) | (7 << 4) | (15 << 8) | ((v >> 4) << 14); }
@@ -237,7 +242,7 @@ struct InvCfg {
   static_assert(N == 64 && ND >= 1 && RT >= RING - 1 && N / 16 == NW && LPR == 64, "shape");
 };
 
-template <int N>
+template <int N, bool RED>
 __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
   constexpr int RING = 3;
   using K = InvCfg<N, RING>;
@@ -262,7 +267,13 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
 
   const int64_t first = blockIdx.x, pstep = gridDim.x;
   if (first >= g.nplanes) return;
-  auto plane_ptr = [&](int64_t p) { return g.in + (p / g.ppr) * g.in_row + (p % g.ppr) * g.in_plane; };
+  // source planes: (output plane p, term); rows r >= r2_first of the reduction form have a second term
+  auto nterms = [&](int64_t p) { return (RED && g.in2 && p / g.ppr >= g.r2_first) ? 2 : 1; };
+  auto plane_ptr = [&](int64_t p, int term) {
+    const int64_t r = p / g.ppr;
+    if (RED && term == 1) return g.in2 + (r - g.r2_first) * g.in2_row + (p % g.ppr) * g.in_plane;
+    return g.in + r * g.in_row + (p % g.ppr) * g.in_plane;
+  };
   auto stage = [&](const double* plane, int c, int slot) {
 #pragma unroll
     for (int j = 0; j < K::ND; ++j) {
@@ -271,19 +282,26 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
       __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(ring + slot * K::CHB + row * 1024), 16, 0, 0);
     }
   };
-  const double* cur = plane_ptr(first);
+  const double* cur = plane_ptr(first, 0);
   __syncthreads();
 #pragma unroll
   for (int c = 0; c < RING - 1; ++c) stage(cur, c, c);
   int slot0 = 0;
   bool warm = false;
+  v4d sse[MT], sso[MT];                                       // RED: sum over this workgroup's planes of the squared outputs
+#pragma unroll
+  for (int m = 0; m < MT; ++m) sse[m] = sso[m] = (v4d){0., 0., 0., 0.};
   for (int64_t p = first; p < g.nplanes; p += pstep) {
-    const int64_t pn = p + pstep < g.nplanes ? p + pstep : p;
-    const double* nxt = plane_ptr(pn);
-    v4d t1[RT];                                               // T[row position][this wave's 16 z outputs]
+    const int nt = nterms(p);
+    v4d t1[RT];                                               // T[row position][this wave's 16 z outputs], summed over the terms
+    for (int term = 0; term < nt; ++term) {
+    const bool last_term = term + 1 == nt;
+    const int64_t pn = last_term ? (p + pstep < g.nplanes ? p + pstep : p) : p;
+    const double* nxt = plane_ptr(pn, last_term ? 0 : term + 1);
 #pragma unroll
     for (int c = 0; c < RT; ++c) {
-      if (!(c <= RING - 2 && warm)) __builtin_amdgcn_s_waitcnt(vmcnt_imm((RING - 2) * K::ND));
+      // (reduction form: no stores inside the loop, hence no drain before them -- every chunk takes the counted wait)
+      if (RED || !(c <= RING - 2 && warm)) __builtin_amdgcn_s_waitcnt(vmcnt_imm((RING - 2) * K::ND));
       __builtin_amdgcn_s_barrier();
       {
         const int cn = c + RING - 1;
@@ -300,8 +318,13 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
       v4d d[4];
       d[0] = d[1] = d[2] = d[3] = (v4d){0., 0., 0., 0.};
       inv_step1<KP, 0>(a, gz, sgn, d);
-      t1[c] = (d[0] + d[1]) + (d[2] + d[3]);
+      const v4d tc = (d[0] + d[1]) + (d[2] + d[3]);
+      t1[c] = (RED && term > 0) ? t1[c] + tc : tc;
     }
+    warm = true;
+    slot0 = (slot0 + RT) % RING;
+    cur = nxt;
+    }   // terms
     // ---- step 2: row pairs (2 bx, 2 bx+1) sit in registers (2h, 2h+1): U = sum, V = difference; even output rows from U with
     //      Fe_x, odd output rows from V with Fo_x; A = (Fe_x, Fo_x)[bx = 8 rt + 4 h + q][j = 16 m + lr] from one b128 read ------
     v4d xe[MT][2], xo[MT][2];
@@ -319,21 +342,40 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
           xo[m][h] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.y, v, xo[m][h], 0, 0, 0);
         }
       }
-    __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
-    double* const op = g.out + (p / g.ppr) * g.out_row + (p % g.ppr) * g.out_plane + 2 * (16 * jt + lr) + par;
+    if constexpr (RED) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const v4d ev = xe[m][0] + xe[m][1], od = xo[m][0] + xo[m][1];
+      for (int m = 0; m < MT; ++m) {
+        const v4d ev = xe[m][0] + xe[m][1], od = xo[m][0] + xo[m][1];
+        sse[m] += ev * ev;
+        sso[m] += od * od;
+      }
+    } else {
+      __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+      double* const op = g.out + (p / g.ppr) * g.out_row + (p % g.ppr) * g.out_plane + 2 * (16 * jt + lr) + par;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int j = 16 * m + q + 4 * r;                     // output rows 2j (even) and 2j+1 (odd)
-        op[(int64_t)(2 * j) * N] = ev[r];
-        op[(int64_t)(2 * j + 1) * N] = od[r];
+      for (int m = 0; m < MT; ++m) {
+        const v4d ev = xe[m][0] + xe[m][1], od = xo[m][0] + xo[m][1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = 16 * m + q + 4 * r;                   // output rows 2j (even) and 2j+1 (odd)
+          op[(int64_t)(2 * j) * N] = ev[r];
+          op[(int64_t)(2 * j + 1) * N] = od[r];
+        }
       }
     }
-    warm = true;
-    slot0 = (slot0 + RT) % RING;
-    cur = nxt;
+  }
+  if constexpr (RED) {
+    // this workgroup's planes all have y = first % ppr (the grid is a multiple of ppr): add its sums to its own partial plane
+    __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+    double* const sp = g.ss + ((int64_t)(blockIdx.x / g.ppr) * g.ppr + (first % g.ppr)) * (N * N) + 2 * (16 * jt + lr) + par;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 16 * m + q + 4 * r;
+        sp[(int64_t)(2 * j) * N] += sse[m][r];
+        sp[(int64_t)(2 * j + 1) * N] += sso[m][r];
+      }
   }
 }
 
@@ -474,13 +516,15 @@ int launch_fwd(const FoldArgs& g, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
 }
 
-template <int N>
+template <int N, bool RED>
 int launch_inv(const FoldArgs& g, hipStream_t st) {
   using K = InvCfg<N, 3>;
-  auto kern = xz_fold_inv_kernel<N>;
+  auto kern = xz_fold_inv_kernel<N, RED>;
   static std::atomic<uint64_t> attr_done{0};
   if (int rc = ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), K::LDS)) return rc;
-  const int64_t nwg = g.nplanes < 2048 ? g.nplanes : 2048;
+  int64_t nwg = g.nplanes < 2048 ? g.nplanes : 2048;
+  if (RED) nwg = nwg / g.ppr * g.ppr;                          // every workgroup keeps one y: grid = whole rows of planes
+  if (nwg <= 0) return GEOBO_E_ARG;
   hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), K::LDS, st, g);
   return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
 }
@@ -520,7 +564,8 @@ extern "C" int geobo_xz2d_fold(int inverse, int n, int64_t rows, int planes_per_
   g.in = in; g.in_row = in_row; g.in_plane = in_plane; g.out = out; g.out_row = out_row; g.out_plane = out_plane;
   g.Fz = Fz; g.Fx = Fx; g.ppr = planes_per_row; g.nplanes = rows * planes_per_row;
   g.row_off = nullptr; g.edge = nullptr; g.edge_row = 0;
-  return inverse ? launch_inv<64>(g, (hipStream_t)stream) : launch_fwd<64>(g, (hipStream_t)stream);
+  g.in2 = nullptr; g.in2_row = 0; g.r2_first = 0; g.ss = nullptr;
+  return inverse ? launch_inv<64, false>(g, (hipStream_t)stream) : launch_fwd<64>(g, (hipStream_t)stream);
 }
 
 extern "C" int geobo_xz2d_fold_lattice(int n, int64_t rows, int planes_per_row, const double* Q, const int64_t* row_off,
@@ -537,5 +582,31 @@ extern "C" int geobo_xz2d_fold_lattice(int n, int64_t rows, int planes_per_row, 
   g.in = Q; g.in_row = 0; g.in_plane = q_plane; g.out = out; g.out_row = out_row; g.out_plane = out_plane;
   g.Fz = Fz; g.Fx = Fx; g.ppr = planes_per_row; g.nplanes = rows * planes_per_row;
   g.row_off = row_off; g.edge = edge; g.edge_row = edge_row;
+  g.in2 = nullptr; g.in2_row = 0; g.r2_first = 0; g.ss = nullptr;
   return launch_fwd<64>(g, (hipStream_t)stream);
+}
+
+extern "C" int geobo_xz2d_fold_inv_ss_slots(int n, int64_t rows, int planes_per_row) {
+  if (n != 64 || rows <= 0 || planes_per_row <= 0) return 0;
+  const int64_t np = rows * planes_per_row;
+  const int64_t nwg = (np < 2048 ? np : 2048) / planes_per_row * planes_per_row;
+  return (int)(nwg / planes_per_row);
+}
+
+extern "C" int geobo_xz2d_fold_inv_ss(int n, int64_t rows, int planes_per_row, const double* in, int64_t in_row, int64_t in_plane,
+                                      const double* in2, int64_t in2_row, int64_t r2_first, const double* Fx, const double* Fz,
+                                      double* ss, void* stream) {
+  if (!in || !Fx || !Fz || !ss) return GEOBO_E_ARG;
+  if (rows <= 0 || planes_per_row <= 0) return GEOBO_OK;
+  if (in2 && (r2_first < 0 || r2_first > rows)) return GEOBO_E_ARG;
+  if ((in_row & 1) || (in_plane & 1) || (in2_row & 1) || ((uintptr_t)in & 15) || ((uintptr_t)in2 & 15) || ((uintptr_t)Fx & 15) ||
+      ((uintptr_t)Fz & 15))
+    return GEOBO_E_ALIGN;
+  if (n != 64 || planes_per_row > 2048) return GEOBO_E_UNSUPPORTED;
+  FoldArgs g;
+  g.in = in; g.in_row = in_row; g.in_plane = in_plane; g.out = nullptr; g.out_row = 0; g.out_plane = 0;
+  g.Fz = Fz; g.Fx = Fx; g.ppr = planes_per_row; g.nplanes = rows * planes_per_row;
+  g.row_off = nullptr; g.edge = nullptr; g.edge_row = 0;
+  g.in2 = in2; g.in2_row = in2_row; g.r2_first = in2 ? r2_first : rows; g.ss = ss;
+  return launch_inv<64, true>(g, (hipStream_t)stream);
 }

@@ -101,6 +101,21 @@ def k_block_grid(table, nx, ny, nz, rows, col0, out, row0=0, nr=None):
     return out
 
 
+def colgemv(X, v, out=None, ws=None):
+    """out[c] = sum_r X[r, c] v[r]  (X: 2-D row-major CUDA float64, unit column stride, even width)."""
+    lib = require_gpu()
+    ld = _rowmajor(X, "X")
+    m, n = X.shape
+    assert _chk(v, "v").numel() >= m
+    if out is None:
+        out = torch.empty(n, dtype=F64, device=X.device)
+    nbytes = lib.geobo_colgemv_ws_bytes(m, n)
+    if ws is None or ws.numel() * 8 < nbytes:
+        ws = torch.empty(max(nbytes // 8, 1), dtype=F64, device=X.device)
+    _lib.check(lib.geobo_colgemv(m, n, _p(X), ld, _p(v), _p(_chk(out, "out")), _p(ws), ws.numel() * 8, _stream()), "geobo_colgemv")
+    return out
+
+
 def convert(src, dst):
     """dst[r, c] = src[r, c] across fp64 <-> fp32 (2-D views, unit column stride, even widths and leading dimensions)."""
     lib = require_gpu()
@@ -327,6 +342,20 @@ def xz2d_fold(inverse, n, rows, ppr, src, in_row, in_plane, Fx, Fz, out, out_row
     _lib.check(lib.geobo_xz2d_fold(1 if inverse else 0, int(n), int(rows), int(ppr), _p(_chk(src, "src")), int(in_row), int(in_plane),
                                    _p(_chk(Fx, "Fx")), _p(_chk(Fz, "Fz")), _p(_chk(out, "out")), int(out_row), int(out_plane), _stream()),
                "geobo_xz2d_fold")
+
+
+def xz2d_fold_inv_ss_slots(n, rows, ppr):
+    return _lib.load().geobo_xz2d_fold_inv_ss_slots(int(n), int(rows), int(ppr))
+
+
+def xz2d_fold_inv_ss(n, rows, ppr, src, in_row, in_plane, Fx, Fz, ss, src2=None, in2_row=0, r2_first=0):
+    """Inverse radix-2 transform fused with the sum of squares over the rows (geobo_xz2d_fold_inv_ss): ss[slot][y][n*n] +=
+    sum_r (inverse(src[r][y] (+ src2[r - r2_first][y] for r >= r2_first)))^2."""
+    lib = require_gpu()
+    assert _chk(ss, "ss").numel() >= xz2d_fold_inv_ss_slots(n, rows, ppr) * ppr * n * n
+    _lib.check(lib.geobo_xz2d_fold_inv_ss(int(n), int(rows), int(ppr), _p(_chk(src, "src")), int(in_row), int(in_plane),
+                                          _p(_chk(src2, "src2")) if src2 is not None else None, int(in2_row), int(r2_first),
+                                          _p(_chk(Fx, "Fx")), _p(_chk(Fz, "Fz")), _p(ss), _stream()), "geobo_xz2d_fold_inv_ss")
 
 
 def tile_rows(m, m_valid, tile=256, group=64):

@@ -82,6 +82,14 @@ int geobo_k_block_f32(int kernel_id, const double* rx, const double* ry, const d
 int geobo_k_block_grid(int nx, int ny, int nz, const double* table, const int64_t* rows, int64_t row0, int64_t nr, int64_t col0,
                        int64_t ncols, int out_f32, void* out, int64_t ld, void* stream);
 
+/* Weighted column sums  out[c] = sum_(r < m) X[r, c] * v[r]  of a row-major matrix (n even, ld even, X 16-byte aligned): the two
+ * streams of the posterior MEAN in its transposed form (inversion.py:114-116, mu = V^T u with V = L^-1 (A K)):
+ *     w = Linv^T u  (m = n = M),   mu = (A K)^T w  (m = M, n = the voxel-property columns)  --  V is not needed for the mean.
+ * ws: geobo_colgemv_ws_bytes(m, n) (row-slice partials, summed in a fixed order: deterministic). */
+size_t geobo_colgemv_ws_bytes(int64_t m, int64_t n);
+int geobo_colgemv(int64_t m, int64_t n, const double* X, int64_t ld, const double* v, double* out, void* ws, size_t ws_bytes,
+                  void* stream);
+
 /* fp32-assembly mode (config 5): A K lives in HBM as fp32 and the fp64 MFMA kernels are handed fp64 panels.
  *   geobo_convert: 2-D strided precision conversion, to_f32 = 1: dst(float)[r*ld_dst + c] = (float)src(double)[r*ld_src + c],
  *                  to_f32 = 0: float -> double; cols and both leading dimensions even, 8-byte aligned bases;
@@ -239,6 +247,18 @@ int geobo_xcorr_reduce(int nx, int nz, int64_t rows, int planes, const double* i
 int geobo_xz2d_fold_lattice(int n, int64_t rows, int planes_per_row, const double* Q, const int64_t* row_off, int64_t q_plane,
                             const double* edge, int64_t edge_row, const double* Fx, const double* Fz, double* out,
                             int64_t out_row, int64_t out_plane, void* stream);
+
+/* Inverse radix-2 transform FUSED WITH THE SUM OF SQUARES over the rows (the posterior variance, inversion.py:117 / :238:
+ * diag(K - V^T V) needs sum_m V[m, q]^2 only): for every plane (r, y), r < rows, y < planes_per_row, the n x n result
+ * X_r[y] = Fx^T-step(Fz^T-step(S_r[y])) is squared and accumulated, never stored.  Rows r >= r2_first are the SUM of two
+ * spectra (in and in2: V rows that receive contributions of two operators) -- both contractions are linear, the first step
+ * accumulates over the terms.  ss: geobo_xz2d_fold_inv_ss_slots(n, rows, planes_per_row) partial cubes [slot][y][n*n] that the call
+ * ADDS to (zero them once per reduction; a slot / y pair is owned by one workgroup per launch: no atomics, deterministic);
+ * sum over the slots afterwards.  n = 64; in2 may be NULL. */
+int geobo_xz2d_fold_inv_ss_slots(int n, int64_t rows, int planes_per_row);
+int geobo_xz2d_fold_inv_ss(int n, int64_t rows, int planes_per_row, const double* in, int64_t in_row, int64_t in_plane,
+                           const double* in2, int64_t in2_row, int64_t r2_first, const double* Fx, const double* Fz, double* ss,
+                           void* stream);
 
 /* y step of the lattice Gram: the same (m x k) matrix G from the left of every row,  out[r][i][c] = sum_j G[i][j] in[r][j][c]
  * for r < rows, c < C (in: rows of k x C at in + r*in_row, out: rows of m x C at out + r*out_row; strides in doubles).

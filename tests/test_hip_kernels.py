@@ -564,6 +564,49 @@ def test_lattice_gram_boundary_slab_correlation(hip, ny, nrows):
         assert (out - ref).abs().max().item() <= 1e-12 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("rows,ppr,r2", [(5, 7, None), (70, 64, None), (70, 64, 33), (40, 16, 0), (300, 64, 140)])
+def test_inverse_transform_with_sum_of_squares(hip, rows, ppr, r2):
+    """geobo_xz2d_fold_inv_ss: sum over the rows of the squared inverse transforms, with a second spectrum added for rows >= r2,
+    against the storing inverse kernel + torch; several launches accumulate into the same partial cubes."""
+    from geobo_amd.spectral import folded_matrices
+    n, P = 64, 128
+    F = hip.to_dev(np.stack(folded_matrices(n), axis=2))
+    src = _rand((rows, ppr * P * P + 8), 51)
+    src2 = _rand((rows, ppr * P * P + 8), 52) if r2 is not None else None
+    out = torch.empty((rows, ppr * n * n), dtype=torch.float64, device="cuda")
+    tot = src.clone()
+    if r2 is not None:
+        tot[r2:] += src2[:rows - r2]
+    hip.xz2d_fold(True, n, rows, ppr, tot, tot.stride(0), P * P, F, F, out, out.stride(0), n * n)
+    ref = (out.view(rows, ppr, n * n) ** 2).sum(0)
+    slots = hip.xz2d_fold_inv_ss_slots(n, rows, ppr)
+    assert slots >= 1
+    ss = torch.zeros((slots, ppr, n * n), dtype=torch.float64, device="cuda")
+    # two launches over disjoint row ranges accumulate into the same partial cubes
+    cut = rows // 2 if r2 is None else r2
+    if cut > 0:
+        hip.xz2d_fold_inv_ss(n, cut, ppr, src, src.stride(0), P * P, F, F, ss)
+    if r2 is None:
+        hip.xz2d_fold_inv_ss(n, rows - cut, ppr, src[cut:], src.stride(0), P * P, F, F, ss)
+    else:
+        hip.xz2d_fold_inv_ss(n, rows - cut, ppr, src[cut:], src.stride(0), P * P, F, F, ss, src2=src2, in2_row=src2.stride(0), r2_first=0)
+    got = ss.sum(0)
+    assert (got - ref).abs().max().item() <= 1e-12 * ref.abs().max().item()
+    if r2 is not None and 0 < r2 < rows:    # one launch with the two-term rows starting in the middle
+        ss2 = torch.zeros_like(ss)
+        hip.xz2d_fold_inv_ss(n, rows, ppr, src, src.stride(0), P * P, F, F, ss2, src2=src2, in2_row=src2.stride(0), r2_first=r2)
+        assert (ss2.sum(0) - ref).abs().max().item() <= 1e-12 * ref.abs().max().item()
+
+
+def test_colgemv_matches_torch(hip):
+    for m, n in ((8448, 8448), (300, 4096), (1000, 70000)):
+        X = _rand((m, n + 6), 61)[:, :n]
+        v = _rand((m,), 62)
+        got = hip.colgemv(X, v)
+        ref = X.t() @ v
+        assert (got - ref).abs().max().item() <= 1e-12 * ref.abs().max().item()
+
+
 def test_a_sens_slab_origin_is_validated_by_the_library(hip):
     """col_origin travels through the C ABI: a compact slab buffer equals the same columns of the full-width operator, and a request
     whose columns do not fit one buffer row (full-width call with a short leading dimension, slab in front of the buffer's origin) is
