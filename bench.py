@@ -366,10 +366,11 @@ def main():
         d["flop"] += fl
         d["alg"] += alg
         d["valu"] += valu
-    single = [k for k in stages if k in ("ak_fused_grid", "ak_fused", "posterior_reduce", "aka_gemm_nt")]
+    single = [k for k in stages if k in ("ak_fused_grid", "ak_fused", "posterior_reduce", "posterior_zgemm", "aka_gemm_nt")]
     dom = max(single, key=lambda k: stages[k]["seconds"]) if single else None
     kernel_names = {"ak_fused_grid": "geobo_ak_fused_grid (gemm_f64_kernel<4,2,TAB>)", "ak_fused": "geobo_ak_fused (gemm_f64_kernel<4,2,GEN>)",
                     "posterior_reduce": "geobo_posterior_reduce (gemm_f64_kernel<4,2,NN,REDUCE>)",
+                    "posterior_zgemm": "geobo_gemm_nn, triangular X: Z = L^-1[:, operator columns] A (gemm_f64_kernel<4,2,NN>; two launches per step)",
                     "aka_gemm_nt": "geobo_gemm_nt (gemm_f64_kernel<4,2,NT>)"}
 
     if rank == 0:

@@ -212,6 +212,7 @@ class PosteriorEngine:
         self._spectral = None
         self._lattice_plan = None
         self._gram, self._lam, self._edgeV = None, {}, {}
+        self._gens = {}             # Toeplitz generators of the covariance blocks (s, j) of the last A K assembly
         # row-sharded spectral product (N > 1): every rank transforms Ms/world sensor rows of each operator for ALL voxels
         # and one all-to-all hands each peer the block-columns it owns; needs equal shards
         ncs = {shard_columns(self.N_pad, world, r)[1] - shard_columns(self.N_pad, world, r)[0] for r in range(world)}
@@ -548,6 +549,7 @@ class PosteriorEngine:
             for jj, j in enumerate(props):
                 tab = self._cov_table(hip.kernel_id(name, s_ != j), lengths[j], lengths[s_], W[s_][j], amp)
                 lams.append(sp.eigenvalues(tab))
+                self._gens[(s_, j)] = lams[-1]          # (the transposed posterior path applies the same blocks to L^-1 A_s)
                 outs.append(AK[s_ * self.Ms_pad:s_ * self.Ms_pad + self.Ms, jj * nc:(jj + 1) * nc])
             fl, fv = sp.flops(self.Ms, len(props), y1 - y0), sp.flops_valu(self.Ms, len(props), y1 - y0)
             if not self.f32 and not isinstance(A, StreamedOperator):
@@ -890,6 +892,83 @@ class PosteriorEngine:
             y[2 * self.Ms_pad:2 * self.Ms_pad + len(y_d)] = y_d
         return hip.to_dev(y, self.device)
 
+    def _zpath_ok(self, AK, props, A_g, A_m):
+        """The transposed posterior path needs: one rank, fp64 A K, the radix-2 transform kernels and the Toeplitz y stage of this grid,
+        unpadded sensor rows and voxel columns, the covariance generators of the last A K assembly."""
+        if (self.world != 1 or AK.dtype != F64 or not self.use_spectral or self.exchange or self.Ms != self.Ms_pad or self.N != self.N_pad
+                or os.environ.get("GEOBO_POSTERIOR", "zpath") != "zpath"):
+            return False
+        sp = self._spectral
+        if sp is None or not (sp.fused_xz and sp.fold and sp.dense_y and self.nx == self.nz and "x" in sp.F and sp.ny <= 64):
+            return False
+        return self.Ms_pad % sp.R == 0 and all((s_, j) in self._gens for s_ in (0, 1) for j in props)
+
+    def _resident_operator(self, A, func):
+        """A materialised copy of a forward operator that the route so far only kept implicitly (stencil table + boundary slabs)."""
+        if not isinstance(A, StreamedOperator):
+            return A
+        R = self._workspace2d("A_" + func, self.Ms_pad, self.N_pad)
+        xed, yed, zed = A.axes_dev
+        hip.a_sens(A.func, A.Bv, A.locd, self.nx, self.ny, self.nz, xed, yed, zed, A.mul, A.div, R, plan=A.plan, ws=A.lws)
+        return R
+
+    def _posterior_zpath(self, Linv, AK, u, A_g, A_m, sel_t, lengths, W, name, amp, props, M_pad):
+        """Posterior mean and variance in the TRANSPOSED order (round 3).  V = L^-1 (A3 K) is (L^-1 A3) K as well, and A3 is block
+        diagonal: applying L^-1 to the forward operators costs M x Ms x N per operator -- independent of the number of property blocks
+        and only over the operator's own columns of L^-1 -- where applying it to A K costs M^2 / 2 x N per property block:
+            Z_g = Linv[:, grav columns] A_g,   Z_m = Linv[:, magn columns] A_m                (fp64 MFMA GEMMs, triangular X: 1.8e13 flop
+                                                                                               at 64^3 instead of 3.6e13)
+            V_j = Z_g K_0j + Z_m K_1j  (+ the drill term in the last rows only: L^-1 is lower triangular)
+        and the covariance products run through the same spectral kernels as A K, with the inverse transform squaring and summing
+        its output planes over the rows instead of storing them (geobo_xz2d_fold_inv_ss): V is never written.  The mean needs no V
+        at all: mu = (A K)^T (L^-T u), two weighted column sums.  Same arithmetic up to summation order (inversion.py:114-117)."""
+        sp, N, Msp, P_c, Md = self._spectral, self.N, self.Ms_pad, len(props), 0 if sel_t is None else sel_t.numel()
+        nx, ny, nz = self.nx, self.ny, self.nz
+        cws = self._workspace("colgemv_ws", (max(hip.colgemv_ws_doubles(M_pad, M_pad), hip.colgemv_ws_doubles(M_pad, AK.shape[1])),))
+        w = self._timed("posterior_mean", 0.0, lambda: hip.colgemv(Linv, u, ws=cws))
+        mu_l = self._timed("posterior_mean", 0.0, lambda: hip.colgemv(AK, w, ws=cws))
+        Ag = self._timed("a_sens_grav", 0.0, lambda: self._resident_operator(A_g, "grav"))
+        Am = self._timed("a_sens_magn", 0.0, lambda: self._resident_operator(A_m, "magn"))
+        Zg, Zm = self._workspace2d("Zg", 2 * Msp, N), self._workspace2d("Zm", Msp, N)
+        tri = sum(min(256 * (bi + 1), Msp) for bi in range(Msp // 256)) * 256.0          # executed k-extent x rows of a triangular block
+        fl = 2.0 * N * (2 * tri + 1.0 * Msp * Msp)
+        alg = 2.0 * N * (2 * (Msp * (Msp + 1) / 2.0) + 1.0 * Msp * Msp)
+
+        def zgemm():
+            hip.gemm_nn(Linv[:2 * Msp, :Msp], Ag[:Msp, :N], Zg, x_lower=True)
+            hip.gemm_nn(Linv[Msp:2 * Msp, Msp:2 * Msp], Am[:Msp, :N], Zm, x_lower=True)
+        self._timed("posterior_zgemm", fl, zgemm, alg=alg)
+        slots = hip.xz2d_fold_inv_ss_slots(nx, sp.R, ny)
+        ss = [self._workspace("post_ss_%d" % jj, (slots, ny, nx * nz)) for jj in range(P_c)]
+        for t in ss:
+            t.zero_()
+        gens_g, gens_m = [self._gens[(0, j)] for j in props], [self._gens[(1, j)] for j in props]
+        self._timed("posterior_spectral", sp.flops_ss(Msp, Msp, P_c), lambda: sp.reduce_ss(Zg, 2 * Msp, gens_g, Zm, Msp, gens_m, ss),
+                    valu=3.0 * Msp * P_c * 2.0 * ny * ny * sp.Px * sp.Pz)
+        ssum = torch.stack([t.sum(0).reshape(-1) for t in ss])                            # (P_c, N), voxel order (iy, ix, iz)
+        if Md:
+            # rows behind the sensor rows: L^-1 is lower triangular, so only THEY see the drill columns.  One 128-row tile through the
+            # storing product, three terms (gravity, magnetic, drill block rows of K), squared and summed here.
+            T = 128
+
+            def drill_rows():
+                Zgd, Zmd, Zdd = (self._workspace2d(nm, T, N) for nm in ("Zg_d", "Zm_d", "Zd_d"))
+                hip.gemm_nn(Linv[2 * Msp:2 * Msp + T, :Msp], Ag[:Msp, :N], Zgd)
+                hip.gemm_nn(Linv[2 * Msp:2 * Msp + T, Msp:2 * Msp], Am[:Msp, :N], Zmd)
+                Zdd.zero_()
+                Zdd[:, sel_t] = Linv[2 * Msp:2 * Msp + T, 2 * Msp:2 * Msp + Md]
+                gens_d = [sp.eigenvalues(self._cov_table(hip.kernel_id(name, 2 != j), lengths[j], lengths[2], W[2][j], amp)) for j in props]
+                Vd = [self._workspace2d("Vd_%d" % jj, T, N) for jj in range(P_c)]
+                tmp = [self._workspace2d("Vt_%d" % jj, T, N) for jj in range(P_c)]
+                sp.product(Zgd, T, gens_g, Vd)
+                for Zx, gx in ((Zmd, gens_m), (Zdd, gens_d)):
+                    sp.product(Zx, T, gx, tmp)
+                    for jj in range(P_c):
+                        Vd[jj].add_(tmp[jj])
+                return torch.stack([(Vd[jj][:Md] ** 2).sum(0) for jj in range(P_c)])
+            ssum = ssum + self._timed("posterior_drill_rows", 0.0, drill_rows)
+        return mu_l, (amp * 1.0 - ssum).reshape(-1)
+
     @_on_device
     def posterior(self, A_g, A_m, sel, y_g, y_m, y_d, lengths, crossweights, kernelfunc, gp_sigma, gp_amp=1.0,
                   props=(0, 1, 2), calclogl=True, want_mean_var=True):
@@ -944,7 +1023,9 @@ class PosteriorEngine:
             fl = 2.0 * AK.shape[1] * sum(64.0 * 64 * g + 2560.0 for g in range((Mv + 63) // 64))
             Mu = 2 * self.Ms + len(sel)                                  # unpadded observation rows
             nv = len(props) * min(self.nc, max(self.N - self.c0, 0))     # this rank's voxel-property columns
-            if AK.dtype == F64:
+            if self._zpath_ok(AK, props, A_g, A_m):
+                mu_l, var_l = self._posterior_zpath(Linv, AK, u, A_g, A_m, sel_t, lengths, W, kernelfunc, gp_amp, props, M_pad)
+            elif AK.dtype == F64:
                 mu_l, var_l = self._timed("posterior_reduce", fl, lambda: hip.posterior_reduce(
                     Linv, AK, u, gp_amp * 1.0, self._workspace("post_ws", (hip.posterior_ws_doubles(M_pad, AK.shape[1]),)), m_valid=Mv),
                     alg=(1.0 * Mu * Mu + 4.0 * Mu) * nv)

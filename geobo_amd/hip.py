@@ -488,6 +488,10 @@ def potrf_ws_doubles(m):
     return max(_lib.load().geobo_potrf_ws_bytes(int(m)) // 8, 1)
 
 
+def colgemv_ws_doubles(m, n):
+    return max(_lib.load().geobo_colgemv_ws_bytes(int(m), int(n)) // 8, 1)
+
+
 def posterior_ws_doubles(m, ncols):
     return max(_lib.load().geobo_posterior_ws_bytes(int(m), int(ncols)) // 8, 1)
 

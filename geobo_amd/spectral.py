@@ -347,3 +347,41 @@ class SpectralProduct:
                 hip.toeplitz_y(ny, C, R, t2, [gens[jj] for jj in js], u2, ylo, yhi, plane=Cp)
                 for i, jj in enumerate(js):
                     self.backward_xz(u2[i], R, ylo, yhi, [(ya, yb, o[jj][r0:], o[jj].stride(0)) for ya, yb, o in slabs])
+
+    # ---- posterior variance in the transposed order (engine._posterior_zpath) ------------------------------------------------------
+    def reduce_ss(self, Zg, Mg, gens_g, Zm, m_first, gens_m, ss):
+        """ss[j][slot][y][x*z] += sum_m V_j[m]^2  with  V_j[m] = Zg[m] * K_0j  (+ Zm[m - m_first] * K_1j for m >= m_first),  m < Mg:
+        rows of L^-1 A_s carried through the covariance product and squared on the way out of the inverse transform -- V is never
+        written.  Zg: (>= Mg x N) rows, Zm: (>= Mg - m_first x N) rows or None; gens_g[j] / gens_m[j]: Toeplitz generators of the
+        blocks (0, j) / (1, j) (eigenvalues()); ss[j]: zeroed partial cubes (hip.xz2d_fold_inv_ss_slots(nx, R, ny) slots each).
+        m_first must be a multiple of the batch size R (a batch is entirely one-term or entirely two-term)."""
+        nx, ny, nz, C, Cp, R = self.nx, self.ny, self.nz, self.Px * self.Pz, self.Cp, self.R
+        assert self.fused_xz and self.fold and nx == nz and "x" in self.F and self.dense_y
+        assert Zm is None or m_first % R == 0
+        P_c = len(gens_g)
+        for r0 in range(0, Mg, R):
+            Rb = min(R, Mg - r0)
+            two = Zm is not None and r0 >= m_first
+            t2g = self.forward_zx(Zg[r0:], Rb, self.G, src_row_stride=Zg.stride(0), out_name="T2")
+            t2m = self.forward_zx(Zm[r0 - m_first:], Rb, self.G, src_row_stride=Zm.stride(0), out_name="T2b") if two else None
+            for j in range(0, P_c, 2):
+                js = list(range(j, min(j + 2, P_c)))
+                sg = [self.buf(("S", "S1")[i], Rb * ny * Cp) for i in range(len(js))]
+                hip.toeplitz_y(ny, C, Rb, t2g, [gens_g[jj] for jj in js], sg, 0, ny, plane=Cp)
+                sm = None
+                if two:
+                    sm = [self.buf(("Sb", "S1b")[i], Rb * ny * Cp) for i in range(len(js))]
+                    hip.toeplitz_y(ny, C, Rb, t2m, [gens_m[jj] for jj in js], sm, 0, ny, plane=Cp)
+                for i, jj in enumerate(js):
+                    hip.xz2d_fold_inv_ss(nx, Rb, ny, sg[i], ny * Cp, Cp, self.F["x"], self.F["z"], ss[jj],
+                                         src2=sm[i] if two else None, in2_row=ny * Cp, r2_first=0)
+
+    def flops_ss(self, rows_one, rows_two, nblocks):
+        """Executed flop of reduce_ss: rows_one one-term rows, rows_two two-term rows (forward + y stage per term, one second
+        inverse step per row; the first inverse step per term)."""
+        nx, ny, nz, Px, Pz = self.nx, self.ny, self.nz, self.Px, self.Pz
+        fwd = 1.0 * ny * (nx * nz * Pz + Px * nx * Pz)                 # folded: half the plain products
+        toe = 2.0 * ny * ny * Px * Pz
+        inv1, inv2 = 1.0 * ny * Px * Pz * nz, 1.0 * ny * nx * Px * nz
+        terms = rows_one + 2 * rows_two
+        return terms * (fwd + nblocks * (toe + inv1)) + (rows_one + rows_two) * nblocks * inv2

