@@ -85,7 +85,7 @@ def synthetic_inputs(inv, md):
 
 
 PMC_FILES = {"ak_fused_grid": "r01_pmc_ak_fused_grid_v2.json", "posterior_reduce": "r03_pmc_posterior_reduce.json",
-             "k_block_grid": "r03_pmc_k_block_grid_f64.json"}
+             "k_block_grid": "r03_pmc_k_block_grid_f64.json", "toeplitz_y": "r02_pmc_toeplitz_y.json"}
 GPU_DENSE_ROUTE = "profiles/r01_bench64_dense.json"   # builder-run bench line of `--method dense` (same algorithm as the CPU sample)
 
 
@@ -366,11 +366,12 @@ def main():
         d["flop"] += fl
         d["alg"] += alg
         d["valu"] += valu
-    single = [k for k in stages if k in ("ak_fused_grid", "ak_fused", "posterior_reduce", "posterior_zgemm", "aka_gemm_nt")]
+    single = [k for k in stages if k in ("ak_fused_grid", "ak_fused", "posterior_reduce", "posterior_zgemm", "aka_gemm_nt", "kernel:toeplitz_y")]
     dom = max(single, key=lambda k: stages[k]["seconds"]) if single else None
     kernel_names = {"ak_fused_grid": "geobo_ak_fused_grid (gemm_f64_kernel<4,2,TAB>)", "ak_fused": "geobo_ak_fused (gemm_f64_kernel<4,2,GEN>)",
                     "posterior_reduce": "geobo_posterior_reduce (gemm_f64_kernel<4,2,NN,REDUCE>)",
                     "posterior_zgemm": "geobo_gemm_nn, triangular X: Z = L^-1[:, operator columns] A (gemm_f64_kernel<4,2,NN>; two launches per step)",
+                    "kernel:toeplitz_y": "geobo_toeplitz_y (toeplitz_y_kernel<64>): y stage of the covariance products (A K and V = (L^-1 A) K)",
                     "aka_gemm_nt": "geobo_gemm_nt (gemm_f64_kernel<4,2,NT>)"}
 
     if rank == 0:
@@ -386,7 +387,31 @@ def main():
         F_valu = sum(d["valu"] for d in mfma.values()) / a.steps
         step_ms = sorted(1e3 * (b - a_) for a_, b in zip(marks[:-1], marks[1:]))
         roof = None
-        if dom:
+        if dom == "kernel:toeplitz_y":
+            # HBM / fp64-VALU co-limited stream kernel: algorithmic bytes (spectrum read once + one output slab per property block)
+            d = stages[dom]
+            calls = d["calls"]
+            mean_s = d["seconds"] / calls
+            by = d["alg"] / calls
+            vflop = 2.0 * 2 * eng.ny * eng.ny * 4 * eng.nx * eng.nz * 256        # FMA flop of a 256-row, two-block launch
+            traffic, tsrc = None, None
+            try:
+                p = json.load(open(os.path.join(ROOT, "profiles", PMC_FILES["toeplitz_y"])))
+                traffic = p["derived"]["hbm_bytes_per_launch_corrected"] * by / p["derived"]["algorithmic_bytes"]
+                tsrc = "profiles/" + PMC_FILES["toeplitz_y"]
+            except Exception:
+                pass
+            roof = {"bound": "hbm", "kernel": kernel_names[dom], "achieved": by / mean_s / 1e9, "peak": 8000.0, "unit": "GB/s",
+                    "frac": by / mean_s / 8e12, "traffic": traffic,
+                    "traffic_source": None if tsrc is None else tsrc + " (committed rocprofv3 --pmc passes of the same kernel: FETCH_SIZE x2 + "
+                    "WRITE_SIZE, scaled by the algorithmic bytes; not collected in this run)",
+                    "launches_timed": calls, "bytes_per_launch": by, "bytes_per_launch_is": "algorithmic: the batch's (x, z)-spectrum read once "
+                    "(8 B x rows x ny x 4 nx nz) + one output slab per property block",
+                    "mean_launch_s": mean_s, "median_launch_s": sorted(d["durs"])[calls // 2],
+                    "co_limit": {"what": "fp64 VALU: one mode per lane, ny^2 FMA per mode and block (no matrix operand is shared between modes)",
+                                 "achieved_TFLOPs_fp64_valu_full_launch": vflop / mean_s / 1e12, "peak_TFLOPs": FP64_MATRIX_PEAK_TFLOPS},
+                    "share_of_step": d["seconds"] / dt}
+        elif dom:
             d = stages[dom]
             calls = d["calls"]
             mean_s = d["seconds"] / calls

@@ -162,6 +162,22 @@ int colgemv_splits(int64_t m, int64_t n) {
   return (int)(rs < 1 ? 1 : rs);
 }
 
+// ---- transposed lattice application, step 2a: W[r][kx][iz][ky] = lamW[kx][iz][ky] * lhat[r][ky][kx] ---------------------------
+// (lattice_gram.LatticeGram.apply_transpose: rows of L^-1 restricted to an operator's columns, convolved with the operator's stencil
+//  table through its (y, x) eigen-decomposition.)  One workgroup per (row, kx): each thread fetches its lhat[r][ky][kx] once (a
+// strided 8-byte read out of a 128 KB tile that stays in cache) and streams nz products, coalesced over ky.  HBM-write bound.
+__global__ void __launch_bounds__(256) lattice_wbuild_kernel(const double* __restrict__ lamW, const double* __restrict__ lhat, int Py, int Px,
+                                                             int nz, double* __restrict__ W) {
+  const int kx = blockIdx.x, r = blockIdx.y;
+  const double* lh = lhat + (int64_t)r * Py * Px + kx;
+  const double* lw = lamW + (int64_t)kx * nz * Py;
+  double* w = W + ((int64_t)r * Px + kx) * nz * Py;
+  const int ky = threadIdx.x % Py, ph = threadIdx.x / Py, nph = 256 / Py;     // 256 threads = (256 / Py) iz phases x Py ky lanes
+  if (ph >= nph) return;
+  const double l = lh[(int64_t)ky * Px];
+  for (int iz = ph; iz < nz; iz += nph) w[iz * Py + ky] = lw[iz * Py + ky] * l;
+}
+
 // 2-D strided precision conversion (rows x cols, cols even): the fp32-assembly mode keeps A K in fp32 in HBM and hands the fp64
 // MFMA kernels fp64 panels.  Pure streaming: 12 B per element.
 template <typename SRC, typename DST>
@@ -473,6 +489,15 @@ extern "C" int geobo_colgemv(int64_t m, int64_t n, const double* X, int64_t ld, 
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(colgemv_kernel, dim3((unsigned)((n + 511) / 512), (unsigned)rs), dim3(256), 0, st, X, ld, m, n, v, rows_per, (double*)ws);
   hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const double*)ws, rs, n, out);
+  return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
+}
+
+extern "C" int geobo_lattice_wbuild(int64_t rows, int Py, int Px, int nz, const double* lamW, const double* lhat, double* W,
+                                    void* stream) {
+  if (!lamW || !lhat || !W) return GEOBO_E_ARG;
+  if (rows <= 0) return GEOBO_OK;
+  if (Py <= 0 || Px <= 0 || nz <= 0 || Py > 256 || rows > 65535) return GEOBO_E_UNSUPPORTED;
+  hipLaunchKernelGGL(lattice_wbuild_kernel, dim3((unsigned)Px, (unsigned)rows), dim3(256), 0, (hipStream_t)stream, lamW, lhat, Py, Px, nz, W);
   return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
 }
 

@@ -212,6 +212,7 @@ class PosteriorEngine:
         self._spectral = None
         self._lattice_plan = None
         self._gram, self._lam, self._edgeV = None, {}, {}
+        self._lamW, self._edgeVt = {}, {}     # transposed lattice application: permuted eigen-data, boundary-slab spectra
         self._gens = {}             # Toeplitz generators of the covariance blocks (s, j) of the last A K assembly
         # row-sharded spectral product (N > 1): every rank transforms Ms/world sensor rows of each operator for ALL voxels
         # and one all-to-all hands each peer the block-columns it owns; needs equal shards
@@ -364,6 +365,8 @@ class PosteriorEngine:
             self._lam[func] = None if lam is None else (A, lam)      # valid for exactly this operator tensor
         self._A = {k: v for k, v in self._A.items() if k[0] != func}  # one operator per type stays resident
         self._edgeV = {k: v for k, v in self._edgeV.items() if k[0] != func}   # (spectra of the previous operator's boundary slabs)
+        self._edgeVt = {k: v for k, v in self._edgeVt.items() if k[0] != func}
+        self._lamW.pop(func, None)
         self._A[key] = A
         return A
 
@@ -380,6 +383,14 @@ class PosteriorEngine:
         if self._spectral is None:
             self._spectral = SpectralProduct(self.nx, self.ny, self.nz, self.device)
         return self._spectral.lattice_feed
+
+    def _spectral_product(self):
+        """The grid's SpectralProduct, its per-kernel timer following the engine's kernel_events switch."""
+        from .spectral import SpectralProduct
+        if self._spectral is None:
+            self._spectral = SpectralProduct(self.nx, self.ny, self.nz, self.device)
+        self._spectral.kernel_timer = None if self.kernel_events is None else (lambda name, by, fn: self._timed(name, 0.0, fn, alg=by))
+        return self._spectral
 
     def _timed(self, name, flops, fn, alg=0.0, valu=0.0):
         """Run fn(); when kernel_events is a list, bracket it with HIP events on the launch stream (torch's current one).
@@ -462,7 +473,7 @@ class PosteriorEngine:
         """Drop the resident forward operators (the benchmark rebuilds them inside every timed step)."""
         self._A = {}
         self._lam = {}
-        self._edgeV = {}
+        self._edgeV, self._edgeVt, self._lamW = {}, {}, {}
         self._lattice_plan = None      # host analysis of the survey geometry + its device copies: part of the operator build
 
     # ---- stages ------------------------------------------------------------------------------------------------
@@ -536,10 +547,7 @@ class PosteriorEngine:
 
     def _assemble_AK_spectral(self, AK, A_g, A_m, lengths, W, name, amp, props):
         """Sensor rows of AK through the real-DFT route (geobo_amd/spectral.py): same product, ~200x fewer flops."""
-        from .spectral import SpectralProduct
-        if self._spectral is None:
-            self._spectral = SpectralProduct(self.nx, self.ny, self.nz, self.device)
-        sp, sset, nc = self._spectral, self.s, self.nc
+        sp, sset, nc = self._spectral_product(), self.s, self.nc
         plane = self.nx * self.nz
         y0, y1 = self.c0 // plane, self.c1 // plane
         if self.exchange:
@@ -912,6 +920,28 @@ class PosteriorEngine:
         hip.a_sens(A.func, A.Bv, A.locd, self.nx, self.ny, self.nz, xed, yed, zed, A.mul, A.div, R, plan=A.plan, ws=A.lws)
         return R
 
+    def _lattice_Z(self, Lview, nrows, func, A, out):
+        """out[r, :N] = sum_c Lview[r, c] A[c, :]  for a lattice-survey operator, without touching A: interior slabs through the stencil
+        table's eigen-data, the two boundary slabs through their x-DFT spectra (lattice_gram.apply_transpose / edge_apply_transpose)."""
+        gram, pl, ny = self._gram, self.nx * self.nz, self.ny
+        lam = self._lam[func][1]
+        hit = self._lamW.get(func)
+        if hit is None or hit[0] is not lam:
+            hit = self._lamW[func] = (lam, gram.transpose_tables(lam))
+        gram.apply_transpose(Lview, nrows, hit[1], out)
+        for k, iy in enumerate((0, ny - 1)):
+            if isinstance(A, StreamedOperator) and A.lattice is not None:
+                ycols = A.edge[:, k * pl:(k + 1) * pl]
+            elif isinstance(A, StreamedOperator):
+                ycols = A.slab_into(self._workspace2d("op_slab", self.Ms_pad, pl), iy, iy + 1)
+            else:
+                ycols = A[:, iy * pl:(iy + 1) * pl]
+            key = (func, k)
+            vt = self._edgeVt.get(key)
+            if vt is None or vt[0] != ycols.data_ptr():
+                vt = self._edgeVt[key] = (ycols.data_ptr(), gram.edge_eigen_t(ycols))
+            gram.edge_apply_transpose(Lview, nrows, vt[1], out[:, iy * pl:(iy + 1) * pl])
+
     def _posterior_zpath(self, Linv, AK, u, A_g, A_m, sel_t, lengths, W, name, amp, props, M_pad):
         """Posterior mean and variance in the TRANSPOSED order (round 3).  V = L^-1 (A3 K) is (L^-1 A3) K as well, and A3 is block
         diagonal: applying L^-1 to the forward operators costs M x Ms x N per operator -- independent of the number of property blocks
@@ -927,17 +957,31 @@ class PosteriorEngine:
         cws = self._workspace("colgemv_ws", (max(hip.colgemv_ws_doubles(M_pad, M_pad), hip.colgemv_ws_doubles(M_pad, AK.shape[1])),))
         w = self._timed("posterior_mean", 0.0, lambda: hip.colgemv(Linv, u, ws=cws))
         mu_l = self._timed("posterior_mean", 0.0, lambda: hip.colgemv(AK, w, ws=cws))
-        Ag = self._timed("a_sens_grav", 0.0, lambda: self._resident_operator(A_g, "grav"))
-        Am = self._timed("a_sens_magn", 0.0, lambda: self._resident_operator(A_m, "magn"))
         Zg, Zm = self._workspace2d("Zg", 2 * Msp, N), self._workspace2d("Zm", Msp, N)
-        tri = sum(min(256 * (bi + 1), Msp) for bi in range(Msp // 256)) * 256.0          # executed k-extent x rows of a triangular block
-        fl = 2.0 * N * (2 * tri + 1.0 * Msp * Msp)
-        alg = 2.0 * N * (2 * (Msp * (Msp + 1) / 2.0) + 1.0 * Msp * Msp)
+        # Z = L^-1[:, operator columns] A: on a lattice survey a (y, x) convolution of every row's sensor image with the operator's
+        # stencil table (lattice_gram.apply_transpose: 2e8 flop per row), otherwise two triangular MFMA GEMMs (2.1e9 flop per row)
+        lat = (self._gram is not None and self._gram.edge_supported() and Msp == nx * ny and os.environ.get("GEOBO_Z_LATTICE", "1") != "0"
+               and all(self._lam.get(f) is not None and self._lam[f][0] is A for f, A in (("grav", A_g), ("magn", A_m))))
+        if lat:
+            gram = self._gram
+            fl = 3 * Msp * (gram.flops(1, ny) + 2 * 3 * 2.0 * 128 * 128 * 64)
 
-        def zgemm():
-            hip.gemm_nn(Linv[:2 * Msp, :Msp], Ag[:Msp, :N], Zg, x_lower=True)
-            hip.gemm_nn(Linv[Msp:2 * Msp, Msp:2 * Msp], Am[:Msp, :N], Zm, x_lower=True)
-        self._timed("posterior_zgemm", fl, zgemm, alg=alg)
+            def zlattice():
+                self._lattice_Z(Linv[:2 * Msp, :Msp], 2 * Msp, "grav", A_g, Zg)
+                self._lattice_Z(Linv[Msp:2 * Msp, Msp:2 * Msp], Msp, "magn", A_m, Zm)
+            self._timed("posterior_zlattice", fl, zlattice)
+            Ag = Am = None
+        else:
+            Ag = self._timed("a_sens_grav", 0.0, lambda: self._resident_operator(A_g, "grav"))
+            Am = self._timed("a_sens_magn", 0.0, lambda: self._resident_operator(A_m, "magn"))
+            tri = sum(min(256 * (bi + 1), Msp) for bi in range(Msp // 256)) * 256.0      # executed k-extent x rows of a triangular block
+            fl = 2.0 * N * (2 * tri + 1.0 * Msp * Msp)
+            alg = 2.0 * N * (2 * (Msp * (Msp + 1) / 2.0) + 1.0 * Msp * Msp)
+
+            def zgemm():
+                hip.gemm_nn(Linv[:2 * Msp, :Msp], Ag[:Msp, :N], Zg, x_lower=True)
+                hip.gemm_nn(Linv[Msp:2 * Msp, Msp:2 * Msp], Am[:Msp, :N], Zm, x_lower=True)
+            self._timed("posterior_zgemm", fl, zgemm, alg=alg)
         slots = hip.xz2d_fold_inv_ss_slots(nx, sp.R, ny)
         ss = [self._workspace("post_ss_%d" % jj, (slots, ny, nx * nz)) for jj in range(P_c)]
         for t in ss:
@@ -953,8 +997,12 @@ class PosteriorEngine:
 
             def drill_rows():
                 Zgd, Zmd, Zdd = (self._workspace2d(nm, T, N) for nm in ("Zg_d", "Zm_d", "Zd_d"))
-                hip.gemm_nn(Linv[2 * Msp:2 * Msp + T, :Msp], Ag[:Msp, :N], Zgd)
-                hip.gemm_nn(Linv[2 * Msp:2 * Msp + T, Msp:2 * Msp], Am[:Msp, :N], Zmd)
+                if lat:
+                    self._lattice_Z(Linv[2 * Msp:2 * Msp + T, :Msp], T, "grav", A_g, Zgd)
+                    self._lattice_Z(Linv[2 * Msp:2 * Msp + T, Msp:2 * Msp], T, "magn", A_m, Zmd)
+                else:
+                    hip.gemm_nn(Linv[2 * Msp:2 * Msp + T, :Msp], Ag[:Msp, :N], Zgd)
+                    hip.gemm_nn(Linv[2 * Msp:2 * Msp + T, Msp:2 * Msp], Am[:Msp, :N], Zmd)
                 Zdd.zero_()
                 Zdd[:, sel_t] = Linv[2 * Msp:2 * Msp + T, 2 * Msp:2 * Msp + Md]
                 gens_d = [sp.eigenvalues(self._cov_table(hip.kernel_id(name, 2 != j), lengths[j], lengths[2], W[2][j], amp)) for j in props]

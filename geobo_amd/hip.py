@@ -101,6 +101,18 @@ def k_block_grid(table, nx, ny, nz, rows, col0, out, row0=0, nr=None):
     return out
 
 
+def lattice_wbuild(rows, Py, Px, nz, lamW, lhat, W):
+    """W[r][kx][iz][ky] = lamW[kx][iz][ky] * lhat[r][ky][kx]  (geobo_lattice_wbuild)."""
+    lib = require_gpu()
+    done = 0
+    while done < rows:
+        nb = min(rows - done, 65535)
+        _lib.check(lib.geobo_lattice_wbuild(nb, int(Py), int(Px), int(nz), _p(_chk(lamW, "lamW")),
+                                            C.c_void_p(_chk(lhat, "lhat").data_ptr() + done * Py * Px * 8),
+                                            C.c_void_p(_chk(W, "W").data_ptr() + done * Px * nz * Py * 8), _stream()), "geobo_lattice_wbuild")
+        done += nb
+
+
 def colgemv(X, v, out=None, ws=None):
     """out[c] = sum_r X[r, c] v[r]  (X: 2-D row-major CUDA float64, unit column stride, even width)."""
     lib = require_gpu()

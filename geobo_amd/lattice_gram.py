@@ -78,6 +78,17 @@ class LatticeGram:
         column (ix, iz), with E[(jy, jx), (ix, iz)] = kappa_jy(ix - jx, iz) exactly (lattice survey: the node offsets are bit-identical
         for equal index differences, hip.lattice_plan).  Returns V [nx slots][2 x 64 (C / S, jy)][2 x nz (cos / sin, iz)]."""
         nx, ny, nz = self.nx, self.ny, self.nz
+        Kc_s, Ks_s, K64 = self._edge_spectra(E)
+        V = torch.zeros((nx, 2, 64, 2, nz), dtype=F64, device=self.device)          # [slot][C | S][jy (64 slots)][cos | sin][iz]
+        V[1:, 0, :ny, 0], V[1:, 0, :ny, 1] = Kc_s[1:], Ks_s[1:]
+        V[1:, 1, :ny, 0], V[1:, 1, :ny, 1] = -Ks_s[1:], Kc_s[1:]
+        V[0, 0, :ny, 0] = Kc_s[0]                                                   # frequency 0
+        V[0, 1, :ny, 1] = K64                                                       # frequency nx (a cosine, stored in the slot's second place)
+        return V.view(nx, 128, 2 * nz)
+
+    def _edge_spectra(self, E):
+        """x-DFT of the slab's stencil kappa_jy(d, iz): (Kc [slot][jy][iz], Ks [slot][jy][iz], K_nx [jy][iz]); slot 0 carries frequency 0."""
+        nx, ny, nz = self.nx, self.ny, self.nz
         F2, _ = self._edge_consts()
         Ev = E[:ny * nx]
         kap = torch.zeros((2, ny, nx, 2 * nz), dtype=F64, device=self.device)      # [+ / -][jy][d][iz | compute-extent padding]
@@ -89,13 +100,7 @@ class LatticeGram:
         even = T[0] + T[1]                                                          # cosine parts: kappa(d) and kappa(-d) add
         Ks = (T[0] - T[1])[:, :, 1]                                                 # sine parts: they subtract
         Kc = even[:, :, 0]
-        V = torch.zeros((nx, 2, 64, 2, nz), dtype=F64, device=self.device)          # [slot][C | S][jy (64 slots)][cos | sin][iz]
-        Kc_s, Ks_s = Kc.permute(1, 0, 2), Ks.permute(1, 0, 2)                       # [slot][jy][iz]
-        V[1:, 0, :ny, 0], V[1:, 0, :ny, 1] = Kc_s[1:], Ks_s[1:]
-        V[1:, 1, :ny, 0], V[1:, 1, :ny, 1] = -Ks_s[1:], Kc_s[1:]
-        V[0, 0, :ny, 0] = Kc_s[0]                                                   # frequency 0
-        V[0, 1, :ny, 1] = even[:, 0, 1]                                             # frequency nx (a cosine, stored in the slot's second place)
-        return V.view(nx, 128, 2 * nz)
+        return Kc.permute(1, 0, 2).contiguous(), Ks.permute(1, 0, 2).contiguous(), even[:, 0, 1].contiguous()
 
     def edge_rows(self, X, nrows, V, out):
         """out[r, :ny*nx] += X[r, :nx*nz] . E^T for r < nrows, E given by its spectrum V (edge_eigen).  X: view starting at the slab's
@@ -120,6 +125,82 @@ class LatticeGram:
             oT = sp.buf("LG_EOT", 64 * nx * RB)                                      # [jy][jx][row]
             hip.gemm_batched(True, 128, Rp, 2 * nx, FiT, 2 * nx, 0, o2, 64 * Rp, Rp, oT, Rp, nx * Rp, nx, R, ny)
             out[r0:r0 + R, :ny * nx] += oT[:ny * nx * Rp].view(ny * nx, Rp)[:, :R].t()
+
+    # ---- the TRANSPOSED application: rows of L^-1 (one operator's columns) -> rows of L^-1 A  ---------------------------------------
+    # Z[r][iy, ix, iz] = sum_(jy, jx) l_r[jy, jx] A[(jy, jx), (iy, ix, iz)]:  on the interior slabs a (y, x) convolution of the row's
+    # sensor image with the stencil table Q (z as a channel, Q even: the same eigen-data Lambda as the Gram),
+    #     Z_r[:, :, iz] = crop (Gy x Gx)^T [ Lambda[:, :, iz] * ((Gy x Gx) l_r) ],
+    # on the two boundary slabs an x-convolution per sensor row jy through the full real DFT.  2e8 flop per row instead of the
+    # 2 Ms N = 2.1e9 of the GEMM  L^-1[:, operator columns] A  that the transposed posterior path would otherwise spend.
+    #   1. lhat = Gy l Gx^T                                   geobo_xz2d(_fold), one 64 x 64 plane per row
+    #   2. W[kx][iz][ky] = LambdaW[kx][iz][ky] * lhat[ky][kx]    geobo_lattice_wbuild (8.4 MB per row, write bound)
+    #   3. U[ix][(iz, ky)] = Gx^T[ix][kx] W[kx][(iz, ky)]        geobo_gemm_batched (NN, one 128 x 8192 x 128 product per row)
+    #   4. Z[iy][(ix, iz)] = Gy0^T[iy][ky] U[(ix, iz)][ky]       geobo_gemm_batched (NT; rows iy = 0, ny-1 of Gy^T zeroed)
+    #   5. boundary slabs: edge_apply_transpose (three batched GEMMs per 1024 rows)
+    def transpose_tables(self, lam):
+        """LambdaW[kx][iz][ky] from the Gram's eigen-data lam = Lambda^T[ky][z][kx] / (Py Px)."""
+        return lam.view(self.Py, self.nz, self.Px).permute(2, 1, 0).contiguous().view(-1)
+
+    def apply_transpose(self, Lrows, nrows, lamW, out):
+        """out[r, :ny*nx*nz] = interior-slab part of  sum_c Lrows[r, c] A[c, :]  (boundary slabs zero), r < nrows.
+        Lrows: (>= nrows x ny*nx) view of L^-1's columns of this operator (16-byte aligned, even row stride)."""
+        nx, ny, nz, Px, Py, sp = self.nx, self.ny, self.nz, self.Px, self.Py, self.sp
+        assert Lrows.stride(1) == 1 and Lrows.stride(0) % 2 == 0 and out.stride(1) == 1
+        if getattr(self, "_GyT0", None) is None:
+            g = sp.GT["y"].clone()                     # (ny x Py, padded rows): output rows of the two boundary slabs do not come from Q
+            g[0] = 0.0
+            g[ny - 1] = 0.0
+            self._GyT0 = g
+        R = self.R
+        for r0 in range(0, nrows, R):
+            Rb = min(R, nrows - r0)
+            lh = sp.buf("LG_Lh", R * Py * Px)
+            if sp.fold and ny == nx and "y" in sp.F:
+                hip.xz2d_fold(False, ny, Rb, 1, Lrows[r0:], Lrows.stride(0), ny * nx, sp.F["y"], sp.F["x"], lh, Py * Px, Py * Px)
+            else:
+                hip.xz2d(False, ny, nx, Rb, 1, Lrows[r0:], Lrows.stride(0), ny * nx, sp.G["y"], sp.G["x"], lh, Py * Px, Py * Px)
+            W = sp.buf("LG_W", R * Px * nz * Py)
+            hip.lattice_wbuild(Rb, Py, Px, nz, lamW, lh, W)
+            U = sp.buf("LG_U", R * nx * nz * Py)
+            hip.gemm_batched(True, 128, nz * Py, Px, sp.GT["x"], Px, 0, W, nz * Py, Px * nz * Py, U, nz * Py, nx * nz * Py, nx, nz * Py, Rb)
+            hip.gemm_batched(False, 128, nx * nz, Py, self._GyT0, Py, 0, U, Py, nx * nz * Py, out[r0:], nx * nz, out.stride(0), ny, nx * nz, Rb)
+
+    def edge_eigen_t(self, E):
+        """Spectrum of one boundary slab for the transposed application: Vt [nx slots][2 x nz (C / S, iz)][2 x 64 (cos / sin, jy)]
+        (same transforms Kc, Ks of the slab's x-Toeplitz stencil as edge_eigen; the convolution theorem instead of the correlation's)."""
+        nx, ny, nz = self.nx, self.ny, self.nz
+        Kc_s, Ks_s, K64 = self._edge_spectra(E)                                      # [slot][jy][iz], [slot][jy][iz], [jy][iz]
+        Vt = torch.zeros((nx, 2, nz, 2, 64), dtype=F64, device=self.device)          # [slot][C | S][iz][cos | sin][jy (64 slots)]
+        Kc_t, Ks_t = Kc_s.transpose(1, 2), Ks_s.transpose(1, 2)                      # [slot][iz][jy]
+        Vt[1:, 0, :, 0, :ny], Vt[1:, 0, :, 1, :ny] = Kc_t[1:], -Ks_t[1:]             # Outc = Lc Kc - Ls Ks
+        Vt[1:, 1, :, 0, :ny], Vt[1:, 1, :, 1, :ny] = Ks_t[1:], Kc_t[1:]              # Outs = Lc Ks + Ls Kc
+        Vt[0, 0, :, 0, :ny] = Kc_t[0]                                                # frequency 0
+        Vt[0, 1, :, 1, :ny] = K64.t()                                                # frequency nx
+        return Vt.view(nx, 2 * nz, 128)
+
+    def edge_apply_transpose(self, Lrows, nrows, Vt, out):
+        """out[r, (ix, iz)] = sum_(jy, jx) Lrows[r, jy*nx+jx] kappa_jy(ix - jx, iz)  for r < nrows: one boundary slab of L^-1 A.
+        out: (>= nrows x nx*nz) view of the slab's columns."""
+        nx, ny, nz, sp = self.nx, self.ny, self.nz, self.sp
+        RB = self.EDGE_ROWS
+        F2, FiT = self._edge_consts()
+        end = Lrows.storage_offset() + (nrows - 1) * Lrows.stride(0) + 128 * nx
+        if end > Lrows.untyped_storage().nbytes() // 8:                               # compute extents of the first GEMM overhang the row
+            Lc = sp.buf("LG_EX", nrows * ny * nx + 128 * nx)[:nrows * ny * nx].view(nrows, ny * nx)
+            Lc.copy_(Lrows[:nrows, :ny * nx])
+            Lrows = Lc
+        for r0 in range(0, nrows, RB):
+            R = min(RB, nrows - r0)
+            Rp = (R + 127) // 128 * 128
+            Lh = sp.buf("LG_EXh", RB * 2 * nx * 64)                                   # [row][(slot, cs)][jy]
+            if ny < 64:
+                Lh.zero_()                                                            # (jy slots >= ny meet zero columns of Vt: keep them finite)
+            hip.gemm_batched(False, 2 * nx, 128, nx, F2, nx, 0, Lrows[r0:], nx, Lrows.stride(0), Lh, 64, 2 * nx * 64, 2 * nx, ny, R)
+            o2 = sp.buf("LG_EO2", nx * 128 * RB)                                      # [slot][(C | S, iz)][row]
+            hip.gemm_batched(False, 128, Rp, 128, Vt, 128, 128 * 128, Lh, 2 * nx * 64, 128, o2, Rp, 128 * Rp, 2 * nz, R, nx)
+            oT = sp.buf("LG_EOT", 64 * nx * RB)                                       # [iz][ix][row]
+            hip.gemm_batched(True, 128, Rp, 2 * nx, FiT, 2 * nx, 0, o2, 64 * Rp, Rp, oT, Rp, nx * Rp, nx, R, nz)
+            out[r0:r0 + R, :nx * nz].view(R, nx, nz).copy_(oT[:nz * nx * Rp].view(nz, nx, Rp)[:, :, :R].permute(2, 1, 0))
 
     @staticmethod
     def supported(nx, ny, nz):

@@ -159,6 +159,15 @@ class SpectralProduct:
         g = 128 // math.gcd(nx * ny, 128)
         self.R = max(g, rows_per_batch // g * g)
         self._bufs = {}
+        self.kernel_timer = None     # callable(name, algorithmic_bytes, fn) -> fn(): the engine's HIP-event bracket for single kernels
+
+    def _ystage(self, ny, C, R, src, tabs, outs, y0, y1, plane):
+        """geobo_toeplitz_y launch, bracketed for the bench's per-kernel roofline when a timer is set: algorithmic bytes = the rows'
+        (x, z)-spectrum read once + one output slab per property block."""
+        fn = lambda: hip.toeplitz_y(ny, C, R, src, tabs, outs, y0, y1, plane=plane)
+        if self.kernel_timer is None:
+            return fn()
+        return self.kernel_timer("kernel:toeplitz_y", 8.0 * R * C * (ny + len(tabs) * (y1 - y0)), fn)
 
     def buf(self, name, n):
         b = self._bufs.get(name)
@@ -344,7 +353,7 @@ class SpectralProduct:
             for j in range(0, len(gens), 3):              # up to three property blocks per read of the (x, z)-spectrum
                 js = list(range(j, min(j + 3, len(gens))))
                 u2 = [self.buf(("S", "S1", "S2")[i], R * n_out) for i in range(len(js))]
-                hip.toeplitz_y(ny, C, R, t2, [gens[jj] for jj in js], u2, ylo, yhi, plane=Cp)
+                self._ystage(ny, C, R, t2, [gens[jj] for jj in js], u2, ylo, yhi, Cp)
                 for i, jj in enumerate(js):
                     self.backward_xz(u2[i], R, ylo, yhi, [(ya, yb, o[jj][r0:], o[jj].stride(0)) for ya, yb, o in slabs])
 
@@ -367,11 +376,11 @@ class SpectralProduct:
             for j in range(0, P_c, 2):
                 js = list(range(j, min(j + 2, P_c)))
                 sg = [self.buf(("S", "S1")[i], Rb * ny * Cp) for i in range(len(js))]
-                hip.toeplitz_y(ny, C, Rb, t2g, [gens_g[jj] for jj in js], sg, 0, ny, plane=Cp)
+                self._ystage(ny, C, Rb, t2g, [gens_g[jj] for jj in js], sg, 0, ny, Cp)
                 sm = None
                 if two:
                     sm = [self.buf(("Sb", "S1b")[i], Rb * ny * Cp) for i in range(len(js))]
-                    hip.toeplitz_y(ny, C, Rb, t2m, [gens_m[jj] for jj in js], sm, 0, ny, plane=Cp)
+                    self._ystage(ny, C, Rb, t2m, [gens_m[jj] for jj in js], sm, 0, ny, Cp)
                 for i, jj in enumerate(js):
                     hip.xz2d_fold_inv_ss(nx, Rb, ny, sg[i], ny * Cp, Cp, self.F["x"], self.F["z"], ss[jj],
                                          src2=sm[i] if two else None, in2_row=ny * Cp, r2_first=0)

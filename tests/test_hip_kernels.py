@@ -607,6 +607,39 @@ def test_colgemv_matches_torch(hip):
         assert (got - ref).abs().max().item() <= 1e-12 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("ny,nrows", [(64, 300), (48, 130)])
+def test_lattice_transposed_application_matches_the_gemm(hip, ny, nrows):
+    """Rows of L^-1 A on a lattice survey without A: LatticeGram.apply_transpose (interior slabs through the stencil table's eigen-data)
+    + edge_apply_transpose (the two padded slabs through their x-DFT spectra) against the plain product with the materialised
+    operator (gravity and magnetic, random row vectors with a triangular cut)."""
+    from geobo_amd.engine import PosteriorEngine
+    from geobo_amd.lattice_gram import LatticeGram
+    nx = nz = 64
+    s = settings_for(nx, ny, nz)
+    eng = PosteriorEngine(s, operators="resident")
+    xe, ye, ze = eng.node_axes()
+    X, Y = np.meshgrid(0.5 * (xe[:-1] + xe[1:]), 0.5 * (ye[:-1] + ye[1:]))
+    loc = np.c_[X.ravel(), Y.ravel(), np.full(nx * ny, s.zmax + s.zoff)]
+    pl, N, Ms = nx * nz, nx * ny * nz, nx * ny
+    for func, B in (("grav", s.magneticField * 0.0), ("magn", s.magneticField)):
+        A = eng.operator(func, loc, B=B)
+        lam = eng._lam[func][1]
+        gram = eng._gram
+        assert lam is not None and gram.edge_supported()
+        L = _rand((nrows + 1, Ms + 8448), 81 + len(func))[:nrows + 1, :]
+        L[:40, 40:] = 0.0                                                      # (a triangular corner like L^-1's)
+        Lv = L[:nrows, :Ms]
+        ref = Lv @ A[:Ms, :N]
+        out = torch.full((nrows, N + 16), float("nan"), dtype=torch.float64, device="cuda")[:, :N]
+        gram.apply_transpose(Lv, nrows, gram.transpose_tables(lam), out)
+        assert bool((out[:, :pl] == 0).all()) and bool((out[:, (ny - 1) * pl:] == 0).all())
+        for k, iy in enumerate((0, ny - 1)):
+            gram.edge_apply_transpose(Lv, nrows, gram.edge_eigen_t(A[:, iy * pl:(iy + 1) * pl]), out[:, iy * pl:(iy + 1) * pl])
+        err = (out - ref).abs().max().item() / ref.abs().max().item()
+        print("transposed lattice application, %s, ny = %d: %.2e" % (func, ny, err))
+        assert err <= 1e-12
+
+
 def test_a_sens_slab_origin_is_validated_by_the_library(hip):
     """col_origin travels through the C ABI: a compact slab buffer equals the same columns of the full-width operator, and a request
     whose columns do not fit one buffer row (full-width call with a short leading dimension, slab in front of the buffer's origin) is

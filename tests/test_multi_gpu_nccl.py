@@ -111,6 +111,7 @@ def test_emulated_rank_runs_the_sharded_path_alone():
     four = out["ranks"]["4"]
     assert four["row_exchange"] and four["row_gram"]
     assert 0.0 < four["compute_ms_per_step_measured"] < 0.5 * out["one_rank"]["ms_per_step"]
-    assert four["stage_ms_measured"]["posterior_reduce"] < 0.3 * out["one_rank"]["stage_ms"]["posterior_reduce"]
+    post1 = sum(v for k, v in out["one_rank"]["stage_ms"].items() if k.startswith("posterior"))   # (one rank: the transposed path)
+    assert four["stage_ms_measured"]["posterior_reduce"] < 0.5 * post1
     for v in four["predicted"].values():
         assert v["step_ms_no_overlap"] >= v["step_ms_all_to_all_under_compute"] >= four["compute_ms_per_step_measured"]
