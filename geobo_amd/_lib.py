@@ -23,6 +23,8 @@ SIGNATURES = {
     "geobo_k_block_f32": (_int, [_int, _dp, _dp, _dp, _i64, _dp, _dp, _dp, _i64, _f64, _f64, _f64, _f64, _dp, _i64, _dp]),
     "geobo_k_block_grid": (_int, [_int, _int, _int, _dp, _dp, _i64, _i64, _i64, _i64, _int, _dp, _i64, _dp]),
     "geobo_lattice_wbuild": (_int, [_i64, _int, _int, _int, _dp, _dp, _dp, _dp]),
+    "geobo_lattice_wplanes": (_int, [_i64, _int, _int, _int, _dp, _dp, _dp, _dp]),
+    "geobo_xz2d_fold_inv_strided": (_int, [_int, _i64, _int, _dp, _i64, _i64, _dp, _dp, _dp, _i64, _i64, _i64, _dp]),
     "geobo_colgemv_ws_bytes": (_sz, [_i64, _i64]),
     "geobo_colgemv": (_int, [_i64, _i64, _dp, _i64, _dp, _dp, _dp, _sz, _dp]),
     "geobo_convert": (_int, [_int, _dp, _i64, _dp, _i64, _i64, _i64, _dp]),

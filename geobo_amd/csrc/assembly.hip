@@ -162,10 +162,21 @@ int colgemv_splits(int64_t m, int64_t n) {
   return (int)(rs < 1 ? 1 : rs);
 }
 
-// ---- transposed lattice application, step 2a: W[r][kx][iz][ky] = lamW[kx][iz][ky] * lhat[r][ky][kx] ---------------------------
-// (lattice_gram.LatticeGram.apply_transpose: rows of L^-1 restricted to an operator's columns, convolved with the operator's stencil
-//  table through its (y, x) eigen-decomposition.)  One workgroup per (row, kx): each thread fetches its lhat[r][ky][kx] once (a
-// strided 8-byte read out of a 128 KB tile that stays in cache) and streams nz products, coalesced over ky.  HBM-write bound.
+// ---- transposed lattice application: spectral planes  W[r][iz][ky][kx] = Lambda3[iz][ky][kx] * lhat[r][ky][kx] --------------------
+// (lattice_gram.LatticeGram: rows of L^-1 restricted to an operator's columns, convolved with the operator's stencil table through
+//  its (y, x) eigen-decomposition.)  One workgroup per (row, iz) plane of Py x Px doubles; lhat[r] (128 KB) and Lambda3 (8 MB) stay in
+//  cache, the launch is bound by its HBM writes.  mode 1: the older layout W[r][kx][iz][ky] = lamW[kx][iz][ky] * lhat[r][ky][kx] that feeds
+//  the two batched-GEMM inverse steps (grids the fused inverse transform has no instance for).
+__global__ void __launch_bounds__(256) lattice_wplanes_kernel(const double* __restrict__ lam3, const double* __restrict__ lhat, int64_t plane,
+                                                              int nz, double* __restrict__ W) {
+  const int iz = blockIdx.x;
+  const int64_t r = blockIdx.y;
+  const v2d* l3 = reinterpret_cast<const v2d*>(lam3 + (int64_t)iz * plane);
+  const v2d* lh = reinterpret_cast<const v2d*>(lhat + r * plane);
+  v2d* w = reinterpret_cast<v2d*>(W + (r * nz + iz) * plane);
+  for (int64_t e = threadIdx.x; e < plane / 2; e += 256) w[e] = l3[e] * lh[e];
+}
+
 __global__ void __launch_bounds__(256) lattice_wbuild_kernel(const double* __restrict__ lamW, const double* __restrict__ lhat, int Py, int Px,
                                                              int nz, double* __restrict__ W) {
   const int kx = blockIdx.x, r = blockIdx.y;
@@ -498,6 +509,18 @@ extern "C" int geobo_lattice_wbuild(int64_t rows, int Py, int Px, int nz, const 
   if (rows <= 0) return GEOBO_OK;
   if (Py <= 0 || Px <= 0 || nz <= 0 || Py > 256 || rows > 65535) return GEOBO_E_UNSUPPORTED;
   hipLaunchKernelGGL(lattice_wbuild_kernel, dim3((unsigned)Px, (unsigned)rows), dim3(256), 0, (hipStream_t)stream, lamW, lhat, Py, Px, nz, W);
+  return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
+}
+
+extern "C" int geobo_lattice_wplanes(int64_t rows, int Py, int Px, int nz, const double* lam3, const double* lhat, double* W,
+                                     void* stream) {
+  if (!lam3 || !lhat || !W) return GEOBO_E_ARG;
+  if (rows <= 0) return GEOBO_OK;
+  if (Py <= 0 || Px <= 0 || nz <= 0 || ((Py * Px) & 1) || rows > 65535 || ((uintptr_t)lam3 & 15) || ((uintptr_t)lhat & 15) ||
+      ((uintptr_t)W & 15))
+    return GEOBO_E_ALIGN;
+  hipLaunchKernelGGL(lattice_wplanes_kernel, dim3((unsigned)nz, (unsigned)rows), dim3(256), 0, (hipStream_t)stream, lam3, lhat,
+                     (int64_t)Py * Px, nz, W);
   return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
 }
 

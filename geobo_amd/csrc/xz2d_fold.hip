@@ -38,6 +38,7 @@ typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 struct FoldArgs {
   const double* in; int64_t in_row, in_plane;    // plane (r, p) at in + r*in_row + p*in_plane (row-major, dense)
   double* out; int64_t out_row, out_plane;
+  int64_t out_rs;                                // inverse: doubles between consecutive rows of an output plane (n: dense planes)
   const double* Fz;                              // [n][n/2][2]: (Fe, Fo) of the contiguous axis ("z")
   const double* Fx;                              // the same for the row axis ("x")
   int ppr; int64_t nplanes;
@@ -358,8 +359,8 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int j = 16 * m + q + 4 * r;                   // output rows 2j (even) and 2j+1 (odd)
-          op[(int64_t)(2 * j) * N] = ev[r];
-          op[(int64_t)(2 * j + 1) * N] = od[r];
+          op[(int64_t)(2 * j) * g.out_rs] = ev[r];
+          op[(int64_t)(2 * j + 1) * g.out_rs] = od[r];
         }
       }
     }
@@ -562,7 +563,7 @@ extern "C" int geobo_xz2d_fold(int inverse, int n, int64_t rows, int planes_per_
   if (n != 64) return GEOBO_E_UNSUPPORTED;
   FoldArgs g;
   g.in = in; g.in_row = in_row; g.in_plane = in_plane; g.out = out; g.out_row = out_row; g.out_plane = out_plane;
-  g.Fz = Fz; g.Fx = Fx; g.ppr = planes_per_row; g.nplanes = rows * planes_per_row;
+  g.Fz = Fz; g.Fx = Fx; g.ppr = planes_per_row; g.nplanes = rows * planes_per_row; g.out_rs = n;
   g.row_off = nullptr; g.edge = nullptr; g.edge_row = 0;
   g.in2 = nullptr; g.in2_row = 0; g.r2_first = 0; g.ss = nullptr;
   return inverse ? launch_inv<64, false>(g, (hipStream_t)stream) : launch_fwd<64>(g, (hipStream_t)stream);
@@ -580,7 +581,7 @@ extern "C" int geobo_xz2d_fold_lattice(int n, int64_t rows, int planes_per_row, 
   if (n != 64) return GEOBO_E_UNSUPPORTED;
   FoldArgs g;
   g.in = Q; g.in_row = 0; g.in_plane = q_plane; g.out = out; g.out_row = out_row; g.out_plane = out_plane;
-  g.Fz = Fz; g.Fx = Fx; g.ppr = planes_per_row; g.nplanes = rows * planes_per_row;
+  g.Fz = Fz; g.Fx = Fx; g.ppr = planes_per_row; g.nplanes = rows * planes_per_row; g.out_rs = n;
   g.row_off = row_off; g.edge = edge; g.edge_row = edge_row;
   g.in2 = nullptr; g.in2_row = 0; g.r2_first = 0; g.ss = nullptr;
   return launch_fwd<64>(g, (hipStream_t)stream);
@@ -604,9 +605,25 @@ extern "C" int geobo_xz2d_fold_inv_ss(int n, int64_t rows, int planes_per_row, c
     return GEOBO_E_ALIGN;
   if (n != 64 || planes_per_row > 2048) return GEOBO_E_UNSUPPORTED;
   FoldArgs g;
-  g.in = in; g.in_row = in_row; g.in_plane = in_plane; g.out = nullptr; g.out_row = 0; g.out_plane = 0;
+  g.in = in; g.in_row = in_row; g.in_plane = in_plane; g.out = nullptr; g.out_row = 0; g.out_plane = 0; g.out_rs = n;
   g.Fz = Fz; g.Fx = Fx; g.ppr = planes_per_row; g.nplanes = rows * planes_per_row;
   g.row_off = nullptr; g.edge = nullptr; g.edge_row = 0;
   g.in2 = in2; g.in2_row = in2_row; g.r2_first = in2 ? r2_first : rows; g.ss = ss;
   return launch_inv<64, true>(g, (hipStream_t)stream);
+}
+
+extern "C" int geobo_xz2d_fold_inv_strided(int n, int64_t rows, int planes_per_row, const double* in, int64_t in_row, int64_t in_plane,
+                                           const double* Fx, const double* Fz, double* out, int64_t out_row, int64_t out_plane,
+                                           int64_t out_rowstride, void* stream) {
+  if (!in || !out || !Fx || !Fz) return GEOBO_E_ARG;
+  if (rows <= 0 || planes_per_row <= 0) return GEOBO_OK;
+  if (out_rowstride < n) return GEOBO_E_ARG;
+  if ((in_row & 1) || (in_plane & 1) || ((uintptr_t)in & 15) || ((uintptr_t)Fx & 15) || ((uintptr_t)Fz & 15)) return GEOBO_E_ALIGN;
+  if (n != 64) return GEOBO_E_UNSUPPORTED;
+  FoldArgs g;
+  g.in = in; g.in_row = in_row; g.in_plane = in_plane; g.out = out; g.out_row = out_row; g.out_plane = out_plane; g.out_rs = out_rowstride;
+  g.Fz = Fz; g.Fx = Fx; g.ppr = planes_per_row; g.nplanes = rows * planes_per_row;
+  g.row_off = nullptr; g.edge = nullptr; g.edge_row = 0;
+  g.in2 = nullptr; g.in2_row = 0; g.r2_first = 0; g.ss = nullptr;
+  return launch_inv<64, false>(g, (hipStream_t)stream);
 }

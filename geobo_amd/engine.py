@@ -366,7 +366,7 @@ class PosteriorEngine:
         self._A = {k: v for k, v in self._A.items() if k[0] != func}  # one operator per type stays resident
         self._edgeV = {k: v for k, v in self._edgeV.items() if k[0] != func}   # (spectra of the previous operator's boundary slabs)
         self._edgeVt = {k: v for k, v in self._edgeVt.items() if k[0] != func}
-        self._lamW.pop(func, None)
+        self._lamW = {k: v for k, v in self._lamW.items() if k[0] != func}
         self._A[key] = A
         return A
 
@@ -920,15 +920,18 @@ class PosteriorEngine:
         hip.a_sens(A.func, A.Bv, A.locd, self.nx, self.ny, self.nz, xed, yed, zed, A.mul, A.div, R, plan=A.plan, ws=A.lws)
         return R
 
-    def _lattice_Z(self, Lview, nrows, func, A, out):
+    def _lattice_Z(self, Lview, nrows, func, A, out, zx=False):
         """out[r, :N] = sum_c Lview[r, c] A[c, :]  for a lattice-survey operator, without touching A: interior slabs through the stencil
         table's eigen-data, the two boundary slabs through their x-DFT spectra (lattice_gram.apply_transpose / edge_apply_transpose)."""
         gram, pl, ny = self._gram, self.nx * self.nz, self.ny
         lam = self._lam[func][1]
-        hit = self._lamW.get(func)
+        hit = self._lamW.get((func, zx))
         if hit is None or hit[0] is not lam:
-            hit = self._lamW[func] = (lam, gram.transpose_tables(lam))
-        gram.apply_transpose(Lview, nrows, hit[1], out)
+            hit = self._lamW[(func, zx)] = (lam, gram.transpose_tables3(lam) if zx else gram.transpose_tables(lam))
+        if zx:
+            gram.apply_transpose_zx(Lview, nrows, hit[1], out)      # rows as [iy][iz][ix]
+        else:
+            gram.apply_transpose(Lview, nrows, hit[1], out)
         for k, iy in enumerate((0, ny - 1)):
             if isinstance(A, StreamedOperator) and A.lattice is not None:
                 ycols = A.edge[:, k * pl:(k + 1) * pl]
@@ -940,7 +943,7 @@ class PosteriorEngine:
             vt = self._edgeVt.get(key)
             if vt is None or vt[0] != ycols.data_ptr():
                 vt = self._edgeVt[key] = (ycols.data_ptr(), gram.edge_eigen_t(ycols))
-            gram.edge_apply_transpose(Lview, nrows, vt[1], out[:, iy * pl:(iy + 1) * pl])
+            gram.edge_apply_transpose(Lview, nrows, vt[1], out[:, iy * pl:(iy + 1) * pl], zx=zx)
 
     def _posterior_zpath(self, Linv, AK, u, A_g, A_m, sel_t, lengths, W, name, amp, props, M_pad):
         """Posterior mean and variance in the TRANSPOSED order (round 3).  V = L^-1 (A3 K) is (L^-1 A3) K as well, and A3 is block
@@ -966,9 +969,11 @@ class PosteriorEngine:
             gram = self._gram
             fl = 3 * Msp * (gram.flops(1, ny) + 2 * 3 * 2.0 * 128 * 128 * 64)
 
+            zx = gram.zx_supported()          # rows of Z as [iy][iz][ix]: the fused inverse transform writes them, the products below follow
+
             def zlattice():
-                self._lattice_Z(Linv[:2 * Msp, :Msp], 2 * Msp, "grav", A_g, Zg)
-                self._lattice_Z(Linv[Msp:2 * Msp, Msp:2 * Msp], Msp, "magn", A_m, Zm)
+                self._lattice_Z(Linv[:2 * Msp, :Msp], 2 * Msp, "grav", A_g, Zg, zx=zx)
+                self._lattice_Z(Linv[Msp:2 * Msp, Msp:2 * Msp], Msp, "magn", A_m, Zm, zx=zx)
             self._timed("posterior_zlattice", fl, zlattice)
             Ag = Am = None
         else:
@@ -987,9 +992,15 @@ class PosteriorEngine:
         for t in ss:
             t.zero_()
         gens_g, gens_m = [self._gens[(0, j)] for j in props], [self._gens[(1, j)] for j in props]
-        self._timed("posterior_spectral", sp.flops_ss(Msp, Msp, P_c), lambda: sp.reduce_ss(Zg, 2 * Msp, gens_g, Zm, Msp, gens_m, ss),
+        zx = lat and zx
+        swap = (lambda g: g.view(ny, sp.Px, sp.Pz).transpose(1, 2).contiguous().view(-1)) if zx else (lambda g: g)   # tables of transposed planes
+        tg, tm = [swap(g) for g in gens_g], [swap(g) for g in gens_m]
+        self._timed("posterior_spectral", sp.flops_ss(Msp, Msp, P_c), lambda: sp.reduce_ss(Zg, 2 * Msp, tg, Zm, Msp, tm, ss),
                     valu=3.0 * Msp * P_c * 2.0 * ny * ny * sp.Px * sp.Pz)
-        ssum = torch.stack([t.sum(0).reshape(-1) for t in ss])                            # (P_c, N), voxel order (iy, ix, iz)
+        if zx:
+            ssum = torch.stack([t.sum(0).view(ny, nz, nx).transpose(1, 2).reshape(-1) for t in ss])   # planes came out as [iz][ix]
+        else:
+            ssum = torch.stack([t.sum(0).reshape(-1) for t in ss])                        # (P_c, N), voxel order (iy, ix, iz)
         if Md:
             # rows behind the sensor rows: L^-1 is lower triangular, so only THEY see the drill columns.  One 128-row tile through the
             # storing product, three terms (gravity, magnetic, drill block rows of K), squared and summed here.

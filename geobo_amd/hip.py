@@ -113,6 +113,26 @@ def lattice_wbuild(rows, Py, Px, nz, lamW, lhat, W):
         done += nb
 
 
+def lattice_wplanes(rows, Py, Px, nz, lam3, lhat, W):
+    """W[r][iz][ky][kx] = lam3[iz][ky][kx] * lhat[r][ky][kx]  (geobo_lattice_wplanes)."""
+    lib = require_gpu()
+    done = 0
+    while done < rows:
+        nb = min(rows - done, 65535)
+        _lib.check(lib.geobo_lattice_wplanes(nb, int(Py), int(Px), int(nz), _p(_chk(lam3, "lam3")),
+                                             C.c_void_p(_chk(lhat, "lhat").data_ptr() + done * Py * Px * 8),
+                                             C.c_void_p(_chk(W, "W").data_ptr() + done * nz * Py * Px * 8), _stream()), "geobo_lattice_wplanes")
+        done += nb
+
+
+def xz2d_fold_inv_strided(n, rows, ppr, src, in_row, in_plane, Fx, Fz, out, out_row, out_plane, out_rowstride):
+    """Inverse radix-2 transform with strided output rows (geobo_xz2d_fold_inv_strided)."""
+    lib = require_gpu()
+    _lib.check(lib.geobo_xz2d_fold_inv_strided(int(n), int(rows), int(ppr), _p(_chk(src, "src")), int(in_row), int(in_plane), _p(_chk(Fx, "Fx")),
+                                               _p(_chk(Fz, "Fz")), _p(_chk(out, "out")), int(out_row), int(out_plane), int(out_rowstride),
+                                               _stream()), "geobo_xz2d_fold_inv_strided")
+
+
 def colgemv(X, v, out=None, ws=None):
     """out[c] = sum_r X[r, c] v[r]  (X: 2-D row-major CUDA float64, unit column stride, even width)."""
     lib = require_gpu()

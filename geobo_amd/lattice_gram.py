@@ -165,6 +165,31 @@ class LatticeGram:
             hip.gemm_batched(True, 128, nz * Py, Px, sp.GT["x"], Px, 0, W, nz * Py, Px * nz * Py, U, nz * Py, nx * nz * Py, nx, nz * Py, Rb)
             hip.gemm_batched(False, 128, nx * nz, Py, self._GyT0, Py, 0, U, Py, nx * nz * Py, out[r0:], nx * nz, out.stride(0), ny, nx * nz, Rb)
 
+    def transpose_tables3(self, lam):
+        """Lambda3[iz][ky][kx] (spectral planes per z channel) from the Gram's eigen-data lam = Lambda^T[ky][z][kx] / (Py Px)."""
+        return lam.view(self.Py, self.nz, self.Px).permute(1, 0, 2).contiguous().view(-1)
+
+    def zx_supported(self):
+        return self.nx == self.ny == self.nz == 64 and self.sp.fold and "y" in self.sp.F and os.environ.get("GEOBO_Z_FUSED", "1") != "0"
+
+    def apply_transpose_zx(self, Lrows, nrows, lam3, out):
+        """The same product as apply_transpose with steps 2-4 as ONE fused inverse two-axis transform per (row, z channel) plane
+        (geobo_xz2d_fold_inv_strided: the radix-2 kernel of the covariance product, 17 ms for the 786 432 planes of a 64^3 step where the
+        two batched-GEMM inverse steps -- half of whose 128-row tiles is padding -- took 85 ms), writing rows in the layout
+        out[r][iy][iz][ix]: x and z trade places in every plane, which the covariance product that follows does not mind (square planes,
+        identical transform matrices; its Toeplitz tables and the final sums are transposed accordingly).  Boundary slabs: as computed
+        from the stencil table (wrong) -- edge_apply_transpose(..., zx=True) overwrites them.  nx = ny = nz = 64."""
+        nx, ny, nz, Px, Py, sp = self.nx, self.ny, self.nz, self.Px, self.Py, self.sp
+        assert self.zx_supported() and Lrows.stride(1) == 1 and Lrows.stride(0) % 2 == 0 and out.stride(1) == 1
+        R = self.R
+        for r0 in range(0, nrows, R):
+            Rb = min(R, nrows - r0)
+            lh = sp.buf("LG_Lh", R * Py * Px)
+            hip.xz2d_fold(False, ny, Rb, 1, Lrows[r0:], Lrows.stride(0), ny * nx, sp.F["y"], sp.F["x"], lh, Py * Px, Py * Px)
+            W = sp.buf("LG_W", R * nz * Py * Px)
+            hip.lattice_wplanes(Rb, Py, Px, nz, lam3, lh, W)
+            hip.xz2d_fold_inv_strided(ny, Rb, nz, W, nz * Py * Px, Py * Px, sp.F["y"], sp.F["x"], out[r0:], out.stride(0), nx, nz * nx)
+
     def edge_eigen_t(self, E):
         """Spectrum of one boundary slab for the transposed application: Vt [nx slots][2 x nz (C / S, iz)][2 x 64 (cos / sin, jy)]
         (same transforms Kc, Ks of the slab's x-Toeplitz stencil as edge_eigen; the convolution theorem instead of the correlation's)."""
@@ -178,9 +203,9 @@ class LatticeGram:
         Vt[0, 1, :, 1, :ny] = K64.t()                                                # frequency nx
         return Vt.view(nx, 2 * nz, 128)
 
-    def edge_apply_transpose(self, Lrows, nrows, Vt, out):
+    def edge_apply_transpose(self, Lrows, nrows, Vt, out, zx=False):
         """out[r, (ix, iz)] = sum_(jy, jx) Lrows[r, jy*nx+jx] kappa_jy(ix - jx, iz)  for r < nrows: one boundary slab of L^-1 A.
-        out: (>= nrows x nx*nz) view of the slab's columns."""
+        out: (>= nrows x nx*nz) view of the slab's columns; zx: the slab is stored as [iz][ix] (apply_transpose_zx's row layout)."""
         nx, ny, nz, sp = self.nx, self.ny, self.nz, self.sp
         RB = self.EDGE_ROWS
         F2, FiT = self._edge_consts()
@@ -200,7 +225,11 @@ class LatticeGram:
             hip.gemm_batched(False, 128, Rp, 128, Vt, 128, 128 * 128, Lh, 2 * nx * 64, 128, o2, Rp, 128 * Rp, 2 * nz, R, nx)
             oT = sp.buf("LG_EOT", 64 * nx * RB)                                       # [iz][ix][row]
             hip.gemm_batched(True, 128, Rp, 2 * nx, FiT, 2 * nx, 0, o2, 64 * Rp, Rp, oT, Rp, nx * Rp, nx, R, nz)
-            out[r0:r0 + R, :nx * nz].view(R, nx, nz).copy_(oT[:nz * nx * Rp].view(nz, nx, Rp)[:, :, :R].permute(2, 1, 0))
+            res = oT[:nz * nx * Rp].view(nz, nx, Rp)[:, :, :R]
+            if zx:
+                out[r0:r0 + R, :nx * nz].view(R, nz, nx).copy_(res.permute(2, 0, 1))
+            else:
+                out[r0:r0 + R, :nx * nz].view(R, nx, nz).copy_(res.permute(2, 1, 0))
 
     @staticmethod
     def supported(nx, ny, nz):

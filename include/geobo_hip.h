@@ -91,6 +91,9 @@ int geobo_k_block_grid(int nx, int ny, int nz, const double* table, const int64_
  * lhat the (y, x) real-DFT of the row's sensor image (Py x Px) and lamW the eigen-data of the operator's stencil table; the two
  * inverse transforms that follow are geobo_gemm_batched launches.  Py <= 256, rows <= 65535. */
 int geobo_lattice_wbuild(int64_t rows, int Py, int Px, int nz, const double* lamW, const double* lhat, double* W, void* stream);
+/* The same products laid out as spectral PLANES, W[r][iz][ky][kx] = lam3[iz][ky][kx] * lhat[r][ky][kx]: every (r, iz) plane then
+ * goes through the fused inverse two-axis transform (geobo_xz2d_fold_inv_strided) straight into the row of L^-1 A. */
+int geobo_lattice_wplanes(int64_t rows, int Py, int Px, int nz, const double* lam3, const double* lhat, double* W, void* stream);
 
 size_t geobo_colgemv_ws_bytes(int64_t m, int64_t n);
 int geobo_colgemv(int64_t m, int64_t n, const double* X, int64_t ld, const double* v, double* out, void* ws, size_t ws_bytes,
@@ -261,6 +264,14 @@ int geobo_xz2d_fold_lattice(int n, int64_t rows, int planes_per_row, const doubl
  * accumulates over the terms.  ss: geobo_xz2d_fold_inv_ss_slots(n, rows, planes_per_row) partial cubes [slot][y][n*n] that the call
  * ADDS to (zero them once per reduction; a slot / y pair is owned by one workgroup per launch: no atomics, deterministic);
  * sum over the slots afterwards.  n = 64; in2 may be NULL. */
+/* Inverse radix-2 transform whose output planes need not be dense: row i of plane (r, p) goes to
+ * out + r*out_row + p*out_plane + i*out_rowstride (n contiguous doubles).  With out_plane = n and out_rowstride = planes*n the planes
+ * of a row interleave: the transposed lattice application writes L^-1 A rows as [iy][iz][ix] this way (one inverse (y, x) transform
+ * per z channel).  n = 64. */
+int geobo_xz2d_fold_inv_strided(int n, int64_t rows, int planes_per_row, const double* in, int64_t in_row, int64_t in_plane,
+                                const double* Fx, const double* Fz, double* out, int64_t out_row, int64_t out_plane,
+                                int64_t out_rowstride, void* stream);
+
 int geobo_xz2d_fold_inv_ss_slots(int n, int64_t rows, int planes_per_row);
 int geobo_xz2d_fold_inv_ss(int n, int64_t rows, int planes_per_row, const double* in, int64_t in_row, int64_t in_plane,
                            const double* in2, int64_t in2_row, int64_t r2_first, const double* Fx, const double* Fz, double* ss,

@@ -638,6 +638,15 @@ def test_lattice_transposed_application_matches_the_gemm(hip, ny, nrows):
         err = (out - ref).abs().max().item() / ref.abs().max().item()
         print("transposed lattice application, %s, ny = %d: %.2e" % (func, ny, err))
         assert err <= 1e-12
+        if gram.zx_supported():        # the fused form: one inverse two-axis transform per (row, z) plane, rows written as [iy][iz][ix]
+            out2 = torch.full((nrows, N + 16), float("nan"), dtype=torch.float64, device="cuda")[:, :N]
+            gram.apply_transpose_zx(Lv, nrows, gram.transpose_tables3(lam), out2)
+            for k, iy in enumerate((0, ny - 1)):
+                gram.edge_apply_transpose(Lv, nrows, gram.edge_eigen_t(A[:, iy * pl:(iy + 1) * pl]), out2[:, iy * pl:(iy + 1) * pl], zx=True)
+            got = out2.view(nrows, ny, nz, nx).transpose(2, 3).reshape(nrows, N)
+            err2 = (got - ref).abs().max().item() / ref.abs().max().item()
+            print("  fused (zx layout): %.2e" % err2)
+            assert err2 <= 1e-12
 
 
 def test_a_sens_slab_origin_is_validated_by_the_library(hip):
