@@ -220,8 +220,17 @@ class PosteriorEngine:
         # Worth it from 4 ranks: with 2 the exchange moves a quarter of A K (8.8 GB at 64^3) over ONE xGMI link (~0.1 s),
         # more than the forward passes it saves; replicated forward passes + slab-cropped backward passes win there.
         xmode = os.environ.get("GEOBO_SPECTRAL_EXCHANGE", "auto")
+        # Row-sharded posterior (round 3, _posterior_rows): on a lattice survey nothing downstream of A K needs voxel-column shards --
+        # AkA comes from this rank's own sensor rows, the posterior from this rank's rows of L^-1 -- so the all-to-all disappears
+        # altogether and the row form pays from 2 ranks.  Decided per step (_rows_posterior_ok: survey, stencil, kernels); the
+        # static part of the conditions switches the row form on for 2 and 3 ranks as well.
+        from .lattice_gram import LatticeGram
+        self.rows_static = (self.use_spectral and world > 1 and self.Ms % world == 0 and LatticeGram.supported(self.nx, self.ny, self.nz)
+                            and not self.f32 and not self.streamed and self.Ms == self.Ms_pad
+                            and os.environ.get("GEOBO_POSTERIOR", "zpath") == "zpath" and os.environ.get("GEOBO_Z_LATTICE", "1") != "0")
         self.exchange = (self.use_spectral and world > 1 and self.Ms % world == 0 and len(ncs) == 1
-                         and xmode != "0" and (world >= 4 or xmode == "1"))
+                         and xmode != "0" and (world >= 4 or xmode == "1" or self.rows_static))
+        self._rowpath = False           # this step runs the row-sharded posterior (set by the A K assembly)
         if self.streamed and not self.use_spectral:
             raise ValueError("streamed operators feed the spectral product: needs the spectral method's grid conditions")
         # Communicator of the row exchange.  Default: the caller's own group -- collectives of one communicator run in issue order on
@@ -492,6 +501,15 @@ class PosteriorEngine:
         off_d = 2 * self.Ms_pad
         M_pad = hip.pad_m(off_d + Md)
         nc = self.nc
+        self._rowpath = False
+        if self.exchange and self.rows_static:
+            self._spectral_product()
+            if self._rows_posterior_ok():
+                # row-sharded step: no column shard of A K exists (and none is allocated) -- row blocks over all voxels instead
+                self._finish_exchange()  # (an exchange left over by a call that failed between its start and its factorisation)
+                self._rowpath = True
+                self._assemble_rows(lengths, W, name, amp, props)
+                return None, M_pad
         AK = self._workspace2d("AK", M_pad, len(props) * nc, dtype=hip.F32 if self.f32 else F64)
         # every sensor/drill row is overwritten below; only the padding must be defined: rows behind each row block
         # (zero, so that AkA / V get zero rows) and voxel columns >= N of the last shard (finite: they meet zero A columns)
@@ -605,6 +623,32 @@ class PosteriorEngine:
         self._pending_exchange = (AK, pending, props)
         if not self._row_gram():
             self._finish_exchange()      # AkA by the GEMM reads the received columns of A K
+
+    def _rows_posterior_ok(self):
+        """True when this step can run without any voxel-column shard of A K: row Gram for AkA (lattice survey, even stencils, both
+        operators), and the transposed posterior's kernels for this grid (see _zpath_ok) with whole transform batches per rank."""
+        sp = self._spectral
+        if not (self.rows_static and self._row_gram() and sp is not None and self._gram is not None and self._gram.edge_supported()):
+            return False
+        if not (sp.fused_xz and sp.fold and sp.dense_y and "x" in sp.F and self.N == self.N_pad):
+            return False
+        return (self.Ms // self.world) % sp.R == 0 and all(f in self._Aedge and f in self._Arows for f in ("grav", "magn"))
+
+    def _assemble_rows(self, lengths, W, name, amp, props):
+        """Row-sharded A K without an exchange: this rank's sensor rows of both operators through the covariance product for ALL
+        voxels and every property block, kept as (rows_r x N) row blocks -- the input of the row Gram (blocks 0, 1) and of the mean."""
+        sp, rows_r = self._spectral, self.Ms // self.world
+        self._fullrows = {}
+        for s_, func in ((0, "grav"), (1, "magn")):
+            lams, outs = [], []
+            for j in props:
+                lams.append(sp.eigenvalues(self._cov_table(hip.kernel_id(name, s_ != j), lengths[j], lengths[s_], W[s_][j], amp)))
+                self._gens[(s_, j)] = lams[-1]
+                outs.append(self._workspace2d("fullrows_%d%d" % (s_, j), rows_r, self.N_pad))
+                self._fullrows[(s_, j)] = outs[-1]
+            Ar = self._Arows[func]
+            self._timed("spectral_product", sp.flops(rows_r, len(props), self.ny), lambda: sp.product(Ar, rows_r, lams, outs),
+                        valu=sp.flops_valu(rows_r, len(props)))
 
     def _finish_exchange(self):
         """Wait for the row exchange and put the received blocks into A K.  With the row-sharded lattice Gram nothing reads those
@@ -920,7 +964,7 @@ class PosteriorEngine:
         hip.a_sens(A.func, A.Bv, A.locd, self.nx, self.ny, self.nz, xed, yed, zed, A.mul, A.div, R, plan=A.plan, ws=A.lws)
         return R
 
-    def _lattice_Z(self, Lview, nrows, func, A, out, zx=False):
+    def _lattice_Z(self, Lview, nrows, func, A, out, zx=False, edge=None):
         """out[r, :N] = sum_c Lview[r, c] A[c, :]  for a lattice-survey operator, without touching A: interior slabs through the stencil
         table's eigen-data, the two boundary slabs through their x-DFT spectra (lattice_gram.apply_transpose / edge_apply_transpose)."""
         gram, pl, ny = self._gram, self.nx * self.nz, self.ny
@@ -933,7 +977,9 @@ class PosteriorEngine:
         else:
             gram.apply_transpose(Lview, nrows, hit[1], out)
         for k, iy in enumerate((0, ny - 1)):
-            if isinstance(A, StreamedOperator) and A.lattice is not None:
+            if edge is not None:                      # (row-sharded form: the two boundary slabs of every sensor are kept apart)
+                ycols = edge[:, k * pl:(k + 1) * pl]
+            elif isinstance(A, StreamedOperator) and A.lattice is not None:
                 ycols = A.edge[:, k * pl:(k + 1) * pl]
             elif isinstance(A, StreamedOperator):
                 ycols = A.slab_into(self._workspace2d("op_slab", self.Ms_pad, pl), iy, iy + 1)
@@ -1028,6 +1074,95 @@ class PosteriorEngine:
             ssum = ssum + self._timed("posterior_drill_rows", 0.0, drill_rows)
         return mu_l, (amp * 1.0 - ssum).reshape(-1)
 
+    def _posterior_rows(self, Linv, u, sel_t, lengths, W, name, amp, props, M_pad):
+        """The transposed posterior (see _posterior_zpath) sharded by ROWS of L^-1 over the ranks: rank r carries the rows of its own
+        Ms / G gravity and Ms / G magnetic sensors (2 + 1 row blocks of Z = L^-1 A) and a 1/G share of the 128-row drill tile through
+        the covariance product; the partial sums of squares and the partial means (this rank's rows of A K, weighted) meet in ONE
+        all-reduce of 2 P_c N doubles (8 MB at 64^3).  No voxel-column shard of anything exists.  Returns (mu, var), (P_c, N) each,
+        complete on every rank."""
+        sp, N, Msp, P_c, Md = self._spectral, self.N, self.Ms_pad, len(props), 0 if sel_t is None else sel_t.numel()
+        nx, ny, nz, G, r = self.nx, self.ny, self.nz, self.world, self.rank
+        rows_r = self.Ms // G
+        a0, a1 = r * rows_r, Msp + r * rows_r
+        red = self._workspace("rows_reduce", (2, P_c, N))
+        mu, ssq = red[0], red[1]
+        cws = self._workspace("colgemv_ws", (max(hip.colgemv_ws_doubles(M_pad, M_pad), hip.colgemv_ws_doubles(rows_r, self.N_pad)),))
+
+        def mean():
+            w = hip.colgemv(Linv, u, ws=cws)                                   # L^-T u
+            tmp = self._workspace("rows_mu_tmp", (self.N_pad,))
+            for jj, j in enumerate(props):
+                hip.colgemv(self._fullrows[(0, j)], w[a0:a0 + rows_r], out=tmp, ws=cws)
+                mu[jj].copy_(tmp[:N])
+                hip.colgemv(self._fullrows[(1, j)], w[a1:a1 + rows_r], out=tmp, ws=cws)
+                mu[jj].add_(tmp[:N])
+            if Md and r == 0:                                                  # the drill rows of A K are rows of K itself
+                Xd = self._workspace2d("fullrows_drill", (Md + 127) // 128 * 128, self.N_pad)
+                for jj, j in enumerate(props):
+                    self._cov_rows(name, 2, j, lengths, W, amp, sel_t, 0, Xd[:Md, :N])
+                    hip.colgemv(Xd[:Md], w[2 * Msp:2 * Msp + Md], out=tmp, ws=cws)
+                    mu[jj].add_(tmp[:N])
+        self._timed("posterior_mean", 0.0, mean)
+        gram = self._gram
+        zx = gram.zx_supported()
+        Zg, Zm = self._workspace2d("Zg", 2 * rows_r, N), self._workspace2d("Zm", rows_r, N)
+        Eg, Em = self._Aedge["grav"], self._Aedge["magn"]
+        fl = 3 * rows_r * (gram.flops(1, ny) + 2 * 3 * 2.0 * 128 * 128 * 64)
+
+        def zlattice():
+            self._lattice_Z(Linv[a0:a0 + rows_r, :Msp], rows_r, "grav", None, Zg, zx=zx, edge=Eg)
+            self._lattice_Z(Linv[a1:a1 + rows_r, :Msp], rows_r, "grav", None, Zg[rows_r:], zx=zx, edge=Eg)
+            self._lattice_Z(Linv[a1:a1 + rows_r, Msp:2 * Msp], rows_r, "magn", None, Zm, zx=zx, edge=Em)
+        self._timed("posterior_zlattice", fl, zlattice)
+        slots = hip.xz2d_fold_inv_ss_slots(nx, sp.R, ny)
+        ss = [self._workspace("post_ss_%d" % jj, (slots, ny, nx * nz)) for jj in range(P_c)]
+        for t in ss:
+            t.zero_()
+        gens_g, gens_m = [self._gens[(0, j)] for j in props], [self._gens[(1, j)] for j in props]
+        swap = (lambda g: g.view(ny, sp.Px, sp.Pz).transpose(1, 2).contiguous().view(-1)) if zx else (lambda g: g)
+        tg, tm = [swap(g) for g in gens_g], [swap(g) for g in gens_m]
+        self._timed("posterior_spectral", sp.flops_ss(rows_r, rows_r, P_c), lambda: sp.reduce_ss(Zg, 2 * rows_r, tg, Zm, rows_r, tm, ss),
+                    valu=3.0 * rows_r * P_c * 2.0 * ny * ny * sp.Px * sp.Pz)
+        for jj, t in enumerate(ss):
+            if zx:
+                ssq[jj].copy_(t.sum(0).view(ny, nz, nx).transpose(1, 2).reshape(-1))
+            else:
+                ssq[jj].copy_(t.sum(0).reshape(-1))
+        # the 128-row tile behind the sensor rows (only it sees the drill columns of L^-1): Tr rows per rank
+        T = 128
+        Tr = T // G if T % G == 0 else T
+        d0 = r * Tr if T % G == 0 else 0
+        nd = max(0, min(Md - d0, Tr)) if (T % G == 0 or r == 0) else 0
+        if nd:
+            def drill_rows():
+                Zgd, Zmd, Zdd = (self._workspace2d(nm, T, N) for nm in ("Zg_d", "Zm_d", "Zd_d"))
+                b0 = 2 * Msp + d0
+                self._lattice_Z(Linv[b0:b0 + nd, :Msp], nd, "grav", None, Zgd, edge=Eg)
+                self._lattice_Z(Linv[b0:b0 + nd, Msp:2 * Msp], nd, "magn", None, Zmd, edge=Em)
+                Zdd[:nd].zero_()
+                Zdd[:nd, sel_t] = Linv[b0:b0 + nd, 2 * Msp:2 * Msp + Md]
+                gens_d = [sp.eigenvalues(self._cov_table(hip.kernel_id(name, 2 != j), lengths[j], lengths[2], W[2][j], amp)) for j in props]
+                Vd = [self._workspace2d("Vd_%d" % jj, T, N) for jj in range(P_c)]
+                tmp = [self._workspace2d("Vt_%d" % jj, T, N) for jj in range(P_c)]
+                sp.product(Zgd, nd, gens_g, Vd)
+                for Zx, gx in ((Zmd, gens_m), (Zdd, gens_d)):
+                    sp.product(Zx, nd, gx, tmp)
+                    for jj in range(P_c):
+                        Vd[jj][:nd].add_(tmp[jj][:nd])
+                for jj in range(P_c):
+                    ssq[jj].add_((Vd[jj][:nd] ** 2).sum(0))
+            self._timed("posterior_drill_rows", 0.0, drill_rows)
+        self._timed("xgmi_all_reduce", 0.0, lambda: allreduce_sum_(red, G, self.group))
+        return mu, amp * 1.0 - ssq
+
+    def _full_to_host(self, t, props, slot):
+        """(P_c, N) device result, complete on this rank -> the reference's (3N,) property-major host vector (NaN: blocks not computed)."""
+        h = self._to_host(t.reshape(-1), slot)
+        out = np.full(3 * self.N, np.nan)
+        for jj, j in enumerate(props):
+            out[j * self.N:(j + 1) * self.N] = h[jj * self.N:(jj + 1) * self.N]
+        return out
+
     @_on_device
     def posterior(self, A_g, A_m, sel, y_g, y_m, y_d, lengths, crossweights, kernelfunc, gp_sigma, gp_amp=1.0,
                   props=(0, 1, 2), calclogl=True, want_mean_var=True):
@@ -1075,7 +1210,13 @@ class PosteriorEngine:
                 out["logl"] = 0.0
         if not want_mean_var:
             check_factor()
-        if want_mean_var:
+        if want_mean_var and self._rowpath:
+            mu_f, var_f = self._posterior_rows(Linv, u, sel_t, lengths, W, kernelfunc, gp_amp, props, M_pad)
+            check_factor()
+            t = self._tick("posterior", t)
+            out["mu"], out["var"] = self._full_to_host(mu_f, props, 0), self._full_to_host(var_f, props, 1)
+            self._tick("d2h", t)
+        elif want_mean_var:
             # executed flop: every 64-row wavefront group g of the valid rows contracts the 64 g columns in front of its diagonal
             # block in full, and of the block itself the 16-row sub-groups' chunks at or below the diagonal (40 of 64 MFMA steps)
             Mv = 2 * self.Ms_pad + len(sel)

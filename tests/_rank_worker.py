@@ -36,7 +36,7 @@ def main():
     dist.all_reduce(ones)
     if rank == 0:
         np.savez(out, cubes=np.asarray(cubes), logl=inv.logl, world=int(ones.item()), exchange=bool(inv.engine.exchange),
-                 row_gram=bool(inv.engine._row_gram()))
+                 row_gram=bool(inv.engine._row_gram()), rowpath=bool(inv.engine._rowpath))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -15,12 +15,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run_ranks(n, backend, out, size="32", extra=()):
+def _run_ranks(n, backend, out, size="32", extra=(), env_extra=None):
+    _release_device_memory()
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update(env_extra or {})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "_rank_worker.py"), backend, out, str(size), *extra]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
@@ -64,19 +66,41 @@ def test_single_device_gloo_ranks_match_single_rank(tmp_path):
         assert normwise(a, b) <= 1e-10
 
 
-def test_four_gloo_ranks_row_exchange_and_row_gram(tmp_path):
-    """The >= 4-rank form end to end on the one device of this box (gloo transport): row-sharded spectral product + all-to-all of
-    A K block-columns + row-sharded lattice Gram (AkA by all-gather of row blocks) + sharded posterior, against the 1-rank run.
-    64 x 48 x 64 is the smallest grid the lattice Gram is instantiated for."""
-    one = _run_ranks(1, "gloo", str(tmp_path / "h1.npz"), "64x48x64")
-    four = _run_ranks(4, "gloo", str(tmp_path / "h4.npz"), "64x48x64")
+@pytest.mark.parametrize("posterior", ["rows", "columns"])
+def test_four_gloo_ranks_row_exchange_and_row_gram(posterior, tmp_path):
+    """The multi-rank forms of a lattice survey end to end on the one device of this box (gloo transport), against the 1-rank run.
+    rows (default, round 3): row-sharded spectral product, row-sharded lattice Gram (AkA by all-gather of row blocks), row-sharded
+    transposed posterior (one all-reduce of partial means and sums of squares) -- no all-to-all, no column shard of A K;
+    columns (GEOBO_POSTERIOR=dense: the round-2 form, still what fp32 / streamed modes and non-lattice surveys run): the same with
+    the all-to-all of A K block-columns and the column-sharded fused reduction.  64 x 48 x 64 is the smallest grid the lattice Gram is
+    instantiated for (the fused (row, z)-plane transform of the rows form needs 64^3: the next test)."""
+    env = {} if posterior == "rows" else {"GEOBO_POSTERIOR": "dense"}
+    one = _run_ranks(1, "gloo", str(tmp_path / "h1.npz"), "64x48x64", env_extra=env)
+    four = _run_ranks(4, "gloo", str(tmp_path / "h4.npz"), "64x48x64", env_extra=env)
     assert int(four["world"]) == 4 and bool(four["exchange"]) and bool(four["row_gram"])
+    assert bool(four["rowpath"]) == (posterior == "rows")
     for a, b in zip(four["cubes"], one["cubes"]):
         if np.isnan(b).all():
             assert np.isnan(a).all()
         else:
             assert normwise(a, b) <= 1e-10
     assert abs(float(four["logl"]) - float(one["logl"])) <= 1e-10 * abs(float(one["logl"]))
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_gloo_ranks_row_sharded_posterior_at_64(world, tmp_path):
+    """64^3 (the bench workload) on 2 and 8 ranks sharing this box's device: the row-sharded posterior with the fused (row, z)-plane
+    inverse transform (rows of L^-1 A in the [iy][iz][ix] layout), the drill tile split over the ranks, one all-reduce -- against
+    the 1-rank transposed posterior."""
+    one = _run_ranks(1, "gloo", str(tmp_path / "s1.npz"), "64")
+    many = _run_ranks(world, "gloo", str(tmp_path / "sN.npz"), "64")
+    assert int(many["world"]) == world and bool(many["rowpath"]) and bool(many["row_gram"])
+    for a, b in zip(many["cubes"], one["cubes"]):
+        if np.isnan(b).all():
+            assert np.isnan(a).all()
+        else:
+            assert normwise(a, b) <= 1e-10
+    assert abs(float(many["logl"]) - float(one["logl"])) <= 1e-10 * abs(float(one["logl"]))
 
 
 @pytest.mark.parametrize("assembly,operators,size", [("f32", "streamed", "32"), ("f64", "streamed", "32"), ("f32", "resident", "32"),
@@ -98,20 +122,85 @@ def test_large_cube_modes_on_the_row_exchange_path(assembly, operators, size, tm
             assert normwise(a, b) <= tol
 
 
+def test_emulated_ranks_partial_posteriors_add_up():
+    """The row-sharded posterior at the bench's own shape, 64^3 on 8 ranks (512 sensor rows and 16 drill-tile rows per rank), one
+    emulated rank after the other on this device: the partial means and partial sums of squares of the 8 ranks -- what the
+    all-reduce would add -- must add up to the 1-rank posterior.  (A K, the row Gram and the transposed posterior of every rank run
+    for real; only AkA, which a lone rank cannot assemble, is the 1-rank step's.)"""
+    import bench
+    from conftest import settings_for
+    from geobo_amd.inversion import Inversion
+    from geobo_amd.sharding import EmulatedGroup
+    G, n = 8, 64
+    s = settings_for(n, n, n, kernelfunc="matern32")
+    gp_length = np.array([200.0, 202.0, 204.0])
+
+    def run(inv, data, keep=None):
+        cap = {}
+        orig = inv.engine.posterior
+
+        def wrapped(*a, **k):
+            r = orig(*a, **k)
+            cap["mu"], cap["var"] = np.array(r["mu"]), np.array(r["var"])
+            return r
+        inv.engine.posterior = wrapped
+        inv.engine.aka_hook = keep
+        grav, mag, loc, drill0 = data
+        inv.engine.clear_operators()
+        inv.gp_length = gp_length.copy()
+        inv.cubing(grav, mag, drill0[drill0 != 0], loc, drill0)
+        return cap
+    inv1 = Inversion(settings=s, props=(0, 1))
+    data = bench.synthetic_inputs(inv1, 50)
+    kept = {}
+    one = run(inv1, data, keep=lambda AkA: kept.__setitem__("AkA", AkA.clone()))
+    true_AkA = kept["AkA"]
+    del inv1
+    torch.cuda.empty_cache()
+    mu, var = None, None
+    for r in range(G):
+        inv = Inversion(settings=s, props=(0, 1), rank=r, world=G, group=EmulatedGroup(r, G))
+        inv.sensor_locations = data[2]
+        part = run(inv, data, keep=lambda AkA: AkA.copy_(true_AkA))
+        assert inv.engine._rowpath and inv.engine._row_gram()
+        mu = part["mu"] if mu is None else mu + part["mu"]
+        var = part["var"] if var is None else var + part["var"]
+        del inv
+        torch.cuda.empty_cache()
+    ok = ~np.isnan(one["mu"])
+    assert ok.sum() == 2 * n ** 3 and np.isnan(mu[~ok]).all()
+    assert normwise(mu[ok], one["mu"][ok]) <= 1e-11
+    # var_r = amp - ss_r: the sum over ranks is (G - 1) amp + the 1-rank variance
+    amp = np.median((var[ok] - one["var"][ok]) / (G - 1))
+    assert abs(amp - 1.0) <= 1e-9
+    assert np.abs(var[ok] - (G - 1) * amp - one["var"][ok]).max() <= 1e-11
+    _release_device_memory()
+
+
+def _release_device_memory():
+    """Engines built inside the pytest process leave their workspaces in torch's caching allocator; the tests below start other
+    processes on the same device."""
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
 def test_emulated_rank_runs_the_sharded_path_alone():
     """tools/emulate_rank.py (per-rank compute measured on one device, step times predicted): rank 0 of 4 of the
     64^3 step through the real engine path with an EmulatedGroup -- row exchange, row-sharded lattice Gram, the true AkA put in
     place for the replicated factorisation -- must run, report the forms it used, and cost less than the 1-rank step."""
     import json
+    _release_device_memory()
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "emulate_rank.py"), "--of", "4", "--steps", "1", "--warmup", "1"],
                        cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert "PREDICTED, NOT MEASURED" in out["what"]
     four = out["ranks"]["4"]
-    assert four["row_exchange"] and four["row_gram"]
+    assert four["row_posterior"] and four["row_gram"]
     assert 0.0 < four["compute_ms_per_step_measured"] < 0.5 * out["one_rank"]["ms_per_step"]
-    post1 = sum(v for k, v in out["one_rank"]["stage_ms"].items() if k.startswith("posterior"))   # (one rank: the transposed path)
-    assert four["stage_ms_measured"]["posterior_reduce"] < 0.5 * post1
+    post1 = sum(v for k, v in out["one_rank"]["stage_ms"].items() if k.startswith("posterior"))
+    post4 = sum(v for k, v in four["stage_ms_measured"].items() if k.startswith("posterior"))
+    assert post4 < 0.5 * post1
     for v in four["predicted"].values():
-        assert v["step_ms_no_overlap"] >= v["step_ms_all_to_all_under_compute"] >= four["compute_ms_per_step_measured"]
+        assert v["step_ms"] >= four["compute_ms_per_step_measured"]

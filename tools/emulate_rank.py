@@ -4,7 +4,8 @@
 
 No multi-GPU node has been available to the builder (SCALE_r01 / r02 are `skipped` records), so DESIGN.md section 7's scaling table
 rests on what one device can measure: for every G the engine is built as rank r of G with a `sharding.EmulatedGroup` -- the SAME
-code path a real rank runs (row-sharded transforms, crop per destination, row-sharded lattice Gram, column-sharded posterior), with
+code path a real rank runs (row-sharded transforms, row-sharded lattice Gram, row-sharded transposed posterior; with
+GEOBO_POSTERIOR=dense the round-2 form: crop per destination, all-to-all, column-sharded posterior), with
   all-to-all of A K block-columns   -> this rank's own send buffer stands in for what the peers would send (right size, finite)
   all-gather of AkA row blocks      -> own block in every slot, then the TRUE AkA (kept from a 1-rank step) is put in its place
                                        so that the replicated factorisation is the real one
@@ -91,8 +92,9 @@ def main():
         ms, st = run(inv, grav, mag, loc, drill0, a.steps, a.warmup)
         P_c, nc = 2, eng.nc
         rows_r = Ms // G
+        rowp = bool(eng._rowpath)              # row-sharded posterior: no all-to-all, no slices; one all-reduce of 2 P_c N doubles
         # bytes this rank SENDS per collective (fp64)
-        a2a_per_peer = rows_r * P_c * nc * 8.0 if eng.exchange else 0.0            # one operator, one destination
+        a2a_per_peer = rows_r * P_c * nc * 8.0 if (eng.exchange and not rowp) else 0.0   # one operator, one destination
         a2a_total = 2 * (G - 1) * a2a_per_peer                                       # both operators, all peers
         if eng.exchange and eng._row_gram():
             aka_bytes_in = (G - 1) * 2.0 * rows_r * 2 * Ms_pad * 8.0                 # all-gather of row blocks: what a rank receives
@@ -100,21 +102,22 @@ def main():
         else:
             aka_bytes_in = 2.0 * (G - 1) / G * true_AkA.numel() * 8.0                # ring all-reduce: 2 (G-1)/G S per rank
             aka_kind = "all_reduce of the partial AkA"
-        slices = (G - 1) * P_c * nc * 8.0 * 2                                         # mu and var slices received
+        slices = 0.0 if rowp else (G - 1) * P_c * nc * 8.0 * 2                        # mu and var slices received
+        allred = 2.0 * P_c * N * 8.0 if rowp else 0.0                                 # partial means and sums of squares
         pred = {}
         for label, link in (("153 GB/s per link (task statement)", 153e9), ("64 GB/s per link and direction (conservative)", 64e9)):
             links = min(G - 1, 7)
-            t_a2a = 2 * a2a_per_peer / link * 1e3 if eng.exchange else 0.0           # every peer over its own link, both operators in sequence
+            t_a2a = 2 * a2a_per_peer / link * 1e3                                    # every peer over its own link, both operators in sequence
             t_aka = aka_bytes_in / (links * link) * 1e3
-            t_sl = slices / (links * link) * 1e3 + 0.05
+            t_sl = (slices + 2.0 * (G - 1) / G * allred) / (links * link) * 1e3 + 0.05
             # shared communicator (the default): the all-to-all runs under the second operator's transforms and the row Gram; what does
             # not fit there is exposed in front of the all-gather
-            hide = st.get("spectral_product", 0.0) / 2 + st.get("aka_lattice", 0.0) if eng.exchange else 0.0
+            hide = st.get("spectral_product", 0.0) / 2 + st.get("aka_lattice", 0.0) if (eng.exchange and not rowp) else 0.0
             exposed = max(0.0, t_a2a - hide) + t_aka + t_sl
-            pred[label] = dict(all_to_all_ms=round(t_a2a, 2), aka_collective_ms=round(t_aka, 2), slices_ms=round(t_sl, 2),
-                               step_ms_no_overlap=round(ms + t_a2a + t_aka + t_sl, 1), step_ms_all_to_all_under_compute=round(ms + exposed, 1),
+            pred[label] = dict(all_to_all_ms=round(t_a2a, 2), aka_collective_ms=round(t_aka, 2), slices_or_all_reduce_ms=round(t_sl, 2),
+                               step_ms_no_overlap=round(ms + t_a2a + t_aka + t_sl, 1), step_ms=round(ms + exposed, 1),
                                speedup_vs_one_rank=round(ms1 / (ms + exposed), 2))
-        out["ranks"][str(G)] = dict(rank=r, row_exchange=bool(eng.exchange), row_gram=bool(eng._row_gram()),
+        out["ranks"][str(G)] = dict(rank=r, row_exchange=bool(eng.exchange and not rowp), row_posterior=rowp, row_gram=bool(eng._row_gram()),
                                     compute_ms_per_step_measured=round(ms, 2), stage_ms_measured=st,
                                     replicated_ms=round(st.get("potrf_inv", 0.0), 2),
                                     bytes_sent_all_to_all=a2a_total, aka_collective=aka_kind, bytes_received_aka=aka_bytes_in,
