@@ -1,6 +1,7 @@
 """N > 1 host path on CPU: two gloo ranks shard the voxel columns exactly as the GPU engine does
 (geobo_amd/sharding.py), exchange the partial AkA with the product's all-reduce and the mu/var slices with its
-all-gather, and must reproduce the unsharded oracle posterior."""
+all-gather, and must reproduce the unsharded oracle posterior.  The row-sharded form of round 3 (gather_rows of AkA row blocks, one
+all-reduce of partial means and sums of squares of the transposed posterior) is covered the same way."""
 import os
 import socket
 
@@ -83,6 +84,86 @@ def test_two_rank_sharded_posterior_matches_reference(world):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    mu, var, AkA = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    f = load_golden("tiny_matern32.npz")
+    assert np.abs(AkA - f["AkA"]).max() / np.abs(f["AkA"]).max() < 1e-13
+    assert np.abs(mu - f["mu"]).max() / np.abs(f["mu"]).max() < 1e-10
+    assert np.abs(var - f["var"]).max() / np.abs(f["var"]).max() < 1e-10
+
+
+def _rows_worker(rank, world, port, q):
+    """The ROW-sharded form (round 3; engine._assemble_rows / _aka_local_rows / _posterior_rows): a rank owns mg / world sensor rows
+    of each operator and a share of the drill rows; AkA arrives by gather_rows, the partial means and sums of squares of the
+    transposed posterior V = (L^-1 A3) K meet in ONE allreduce_sum_."""
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from scipy.linalg import cholesky, solve_triangular
+    from geobo_amd.sharding import allreduce_sum_, gather_rows
+    from oracle import geobo_oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    f = load_golden("tiny_matern32.npz")
+    N, props = 480, (0, 1, 2)
+    P3 = O.grid_points((10, 8, 6), (100., 100., 100.))
+    lengths = O.mutate_lengths(f["gp_length_in"].copy())
+    W = O.weight_matrix((1.0, 0.2, 0.2))
+    A = {0: f["A_g"], 1: f["A_m"]}
+    sel, y = f["sel"], f["Fs3"]
+    mg, md = 80, sel.size
+    M = 2 * mg + md
+    rows_r = mg // world
+    a0 = rank * rows_r
+    D2 = O.sqdist(P3, P3)
+    K = {(i, j): O.k_block("matern32", D2, lengths, W, i, j) for i in (0, 1, 2) for j in props}
+    # this rank's sensor rows of A K over ALL voxels, every property block
+    AKr = {(s_, j): A[s_][a0:a0 + rows_r] @ K[(s_, j)] for s_ in (0, 1) for j in props}
+    loc = np.stack([np.concatenate([AKr[(s_, 0)] @ A[0].T, AKr[(s_, 1)] @ A[1].T], axis=1) for s_ in (0, 1)])   # (2, rows_r, 2 mg)
+    allrows = gather_rows(torch.from_numpy(loc), world).numpy()                       # <- product collective #1
+    AkA = np.zeros((M, M))
+    for src in range(world):
+        for s_ in (0, 1):
+            AkA[s_ * mg + src * rows_r:s_ * mg + (src + 1) * rows_r, :2 * mg] = allrows[src, s_]
+    AkA[2 * mg:, :2 * mg] = np.concatenate([K[(2, 0)][sel] @ A[0].T, K[(2, 1)][sel] @ A[1].T], axis=1)   # drill rows: every rank
+    AkA[:2 * mg, 2 * mg:] = AkA[2 * mg:, :2 * mg].T
+    AkA[2 * mg:, 2 * mg:] = O.k_block("matern32", O.sqdist(P3[sel]), lengths, W, 2, 2)
+    AkA += np.diag(np.r_[np.full(2 * mg, 0.01), np.full(md, 0.01)])
+    L = cholesky(AkA, lower=True)
+    Linv = solve_triangular(L, np.eye(M), lower=True)
+    u = Linv @ y
+    w = Linv.T @ u
+    dper = -(-md // world)
+    drows = np.arange(rank * dper, min(md, (rank + 1) * dper))                        # this rank's share of the drill rows
+    mine = np.r_[a0:a0 + rows_r, mg + a0:mg + a0 + rows_r, 2 * mg + drows].astype(int)
+    red = np.zeros((2, len(props), N))
+    for jj, j in enumerate(props):
+        red[0, jj] = AKr[(0, j)].T @ w[a0:a0 + rows_r] + AKr[(1, j)].T @ w[mg + a0:mg + a0 + rows_r]
+        if rank == 0:
+            red[0, jj] += K[(2, j)][sel].T @ w[2 * mg:]
+        Z_g, Z_m, Z_d = Linv[mine, :mg] @ A[0], Linv[mine, mg:2 * mg] @ A[1], Linv[mine, 2 * mg:]
+        V = Z_g @ K[(0, j)] + Z_m @ K[(1, j)] + Z_d @ K[(2, j)][sel]
+        red[1, jj] = np.einsum("mq,mq->q", V, V)
+    t = torch.from_numpy(red)
+    allreduce_sum_(t, world)                                                           # <- product collective #2
+    if rank == 0:
+        q.put((t[0].reshape(-1).numpy().copy(), (1.0 - t[1]).reshape(-1).numpy().copy(), AkA))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_row_sharded_transposed_posterior_matches_reference(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rows_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     mu, var, AkA = q.get(timeout=180)
