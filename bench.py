@@ -7,17 +7,21 @@
 A "step" is one full pass of the hot path over one synthetic survey: everything about the forward operators A_g/A_m that the
 route needs built on the device (stencil tables + boundary slabs on a lattice survey -- no operator is materialised there --, incl.
 the host analysis of the survey geometry and its uploads), A K by the spectral route (radix-2 real-DFT transforms over x and z,
-Toeplitz blocks over y), AkA (lattice Gram), Cholesky + L^-1, posterior mean + variance, D2H of the cubes.  Workload = BASELINE
+Toeplitz blocks over y), AkA (lattice Gram), Cholesky + L^-1, posterior mean + variance in the transposed order (round 3:
+V = (L^-1 A3) K -- rows of L^-1 A through the same covariance kernels, squared and summed on the way out of the inverse transform;
+the mean as two weighted column sums of A K), D2H of the cubes.  Workload = BASELINE
 config 3/4: 64^3 voxels of 100 m, gravity + magnetics joint inversion (density and magnetic-susceptibility cubes, P_out = 2),
 Matern-3/2 kernel with lengths (2.00, 2.02, 2.04) x 100 m, 50 drill-core constraints, M = 4096 + 4096 + 50 observation rows.
-With N > 1 the SAME problem is sharded over the ranks (strong scaling): 1-2 ranks one all-reduce of the
-partial AkA, from 4 ranks one all-to-all of A K block-columns per operator + one all-gather of AkA row blocks; always one all-gather
-of the mu/var slices.
+With N > 1 the SAME problem is sharded over the ranks (strong scaling) by ROWS: a rank owns Ms / N sensor rows
+of each operator (its rows of A K over all voxels, its row blocks of AkA, its rows of L^-1 A); collectives: one all-gather of the AkA
+row blocks and one all-reduce of the partial means and sums of squares (2 P N doubles).  (Surveys off the lattice, fp32 assembly and
+streamed operators keep the round-2 forms: voxel-column shards, all-reduce of the partial AkA or all-to-all of A K block-columns.)
 
 Prints ONE JSON line on rank 0 (see the driver contract); extra objects:
-  roofline      dominant kernel = geobo_posterior_reduce on the default route (fp64 MFMA; geobo_ak_fused_grid with --method dense):
-                ALGORITHMIC flops per launch / mean launch duration measured with HIP events on the launch stream,
-                against the 78.6 TFLOP/s fp64 matrix peak
+  roofline      dominant kernel = geobo_toeplitz_y on the default route (the y stage of every covariance product, 30 % of the step;
+                HBM / fp64-VALU co-limited): ALGORITHMIC bytes per launch (spectrum read once + one output slab per property block)
+                / mean launch duration measured with HIP events on the launch stream, against 8 TB/s.  (GEOBO_POSTERIOR=dense:
+                geobo_posterior_reduce, --method dense: geobo_ak_fused_grid -- fp64 MFMA, algorithmic flop against 78.6 TFLOP/s.)
   roofline_assembly  the HBM-bound regime of SURVEY 8(d): one materialised covariance block (geobo_k_block), bytes written per
                 launch / HIP-event duration against 8 TB/s (outside the timed steps)
   cpu_baseline  the NumPy/OpenBLAS oracle (kind "port") timed on this box's host cores on a bounded column sample of
@@ -433,11 +437,11 @@ def main():
             "dtype": "f64" if a.assembly == "f64" else "f32 assembly / f64 accumulate+factorise", "data": "synthetic",
             "config": {"workload": "%d^3 voxel cube (100 m), gravity+magnetics joint inversion, %s kernel lengths (2.00,2.02,2.04)x100 m, "
                                    "%d drill constraints, M=%d rows, %s cubes (P_out=%d)" % (n, a.kernel, a.drill, M, "density+magsus" + ("+drill" if p_out == 3 else ""), p_out),
-                       "N_voxels": N, "M_rows": M, "props_out": p_out, "parallelism": "voxel-column shards x%d" % world,
+                       "N_voxels": N, "M_rows": M, "props_out": p_out, "parallelism": ("sensor-row shards x%d" if eng._rowpath else "voxel-column shards x%d") % world,
                        "backend": a.backend if world > 1 else None, "ranks_reported_by_backend": ranks_reported,
                        "method": "spectral" if inv.engine.use_spectral else "dense", "assembly": a.assembly, "operators": a.operators,
                        "operators_in_use": sorted({"streamed" if type(v).__name__ == "StreamedOperator" else "resident" for v in inv.engine._A.values()}),
-                       "row_exchange": bool(inv.engine.exchange),
+                       "row_exchange": bool(inv.engine.exchange and not inv.engine._rowpath), "row_posterior": bool(inv.engine._rowpath),
                        "ms_per_step_median": step_ms[len(step_ms) // 2], "ms_per_step_all_rank0": [round(v, 2) for v in step_ms],
                        "ms_per_step_in_order_rank0": [round(1e3 * (b - a_), 2) for a_, b in zip(marks[:-1], marks[1:])],
                        "cube_checksums": [float(np.abs(cubes[i]).sum()) for i in ((0, 1, 3, 4) if p_out == 2 else range(6))],

@@ -4,12 +4,17 @@ Reference path replaced (file:line in the reference checkout):
     kernels.py:158-195 create_cov  +  inversion.py:92-117 predict3  (K, A K A^T + S, Cholesky, V, mu, diag cov)
     sensormodel.py:29-93 A_sens    (forward operators, built on the device)
 
-Algorithm (same results as the reference, never holding an N x N object; SURVEY.md section 8(a)):
-    1. AK[s-rows, j-cols] = A_s K_sj             fused fp64-MFMA kernel, K tile generated from coordinates
-       AK[d-rows, j-cols] = K_2j[sel, :]         k_block with gathered drill rows
-    2. AkA = AK A3^T + diag(sigma^2)             MFMA GEMM-NT; drill columns by symmetry
+Algorithm (same results as the reference, never holding an N x N object; SURVEY.md section 8(a); DESIGN.md section 2):
+    1. AK[s-rows, j-cols] = A_s K_sj             spectral route on the regular grid (spectral.py: radix-2 real transforms over x, z,
+                                                 Toeplitz blocks over y); fused fp64-MFMA contraction with the K tile generated in the
+                                                 kernel for everything else
+       AK[d-rows, j-cols] = K_2j[sel, :]         gather from the block's lattice table (k_block_grid) / k_block from coordinates
+    2. AkA = AK A3^T + diag(sigma^2)             lattice Gram on a lattice survey (lattice_gram.py), else MFMA GEMM-NT
     3. L = chol(AkA), Linv = L^-1, u = Linv y    blocked Cholesky on MFMA tiles, wavefront-shuffle TRMV
-    4. mu = (Linv AK)^T u, var = amp - colsum((Linv AK)^2)   MFMA GEMM fused with the column reductions
+    4. mu = AK^T (Linv^T u),  var = amp - colsum(V^2),  V = (Linv A3) K      transposed posterior (_posterior_zpath; round 3): rows of
+                                                 Linv A3 through the kernels of step 1, squared and summed on the way out; V never stored
+       or, where that path does not apply (grids without the radix-2 / Toeplitz-y kernels, padded sensor rows, fp32 assembly, dense method):
+       mu = (Linv AK)^T u, var = amp - colsum((Linv AK)^2)                    MFMA GEMM fused with the column reductions
 
 HBM layout (all fp64, row-major, zero padded -- include/geobo_hip.h "PADDING CONTRACT"):
     x,y,z      3 x N_pad                 voxel coordinates (SoA), N_pad = pad128(N)
@@ -18,10 +23,12 @@ HBM layout (all fp64, row-major, zero padded -- include/geobo_hip.h "PADDING CON
     AkA/L      M_pad x M_pad             M_pad = pad256(2*Ms_pad + M_d); padding rows carry identity
     Linv       M_pad x M_pad
 
-Multi-GPU (one process per GPU, torch.distributed/RCCL): voxel COLUMNS of A K / V are sharded across ranks in units of 128
-(= y-slabs of the cube).  1-2 ranks: forward transforms replicated, AkA partial sums by one all-reduce, mu/var slices by one
-all-gather.  From 4 ranks: sensor ROWS are sharded through the transforms, one all-to-all per operator hands every peer the
-block-columns it owns, AkA arrives as row blocks (row-sharded lattice Gram + all-gather), mu/var slices by one all-gather.
+Multi-GPU (one process per GPU, torch.distributed/RCCL).  Lattice survey, fp64, resident operators (round 3): sharded by ROWS -- a
+rank owns Ms / G sensor rows of each operator: its rows of A K over all voxels, its row blocks of AkA (all-gather), its rows of
+Linv A3 (one all-reduce of the partial means and sums of squares); no column shard of anything (_assemble_rows, _posterior_rows).
+Otherwise voxel COLUMNS of A K / V are sharded in units of 128 (= y-slabs of the cube): 1-2 ranks with replicated forward transforms
+and one all-reduce of the partial AkA, from 4 ranks with row-sharded transforms and one all-to-all of A K block-columns per
+operator; mu / var slices by one all-gather.
 DESIGN.md section 7.
 """
 import math

@@ -262,7 +262,8 @@ class LatticeGram:
     def flops(self, rows, Ly=None):
         nx, ny, nz, Px, Py = self.nx, self.ny, self.nz, self.Px, self.Py
         Ly = ny if Ly is None else Ly
-        return rows * 2.0 * (hip.pad_n(Py) * nx * nz * Ly + Py * Px * nx * nz + ny * Py * Px + ny * nx * Px)
+        h = 0.5 if (self.sp.fold and nx == nz == 64) else 1.0     # radix-2 x step and back-transform: half the MFMAs of the plain products
+        return rows * 2.0 * (hip.pad_n(Py) * nx * nz * Ly + h * Py * Px * nx * nz + h * (ny * Py * Px + ny * nx * Px))
 
     def gram_rows(self, X, nrows, lam, out, y0=0, y1=None):
         """out[r, :ny*nx] = interior-slab part of (A K)[r] . A^T for r < nrows.  X: (>= nrows x >= (y1-y0)*nx*nz) rows of A K for

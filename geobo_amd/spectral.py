@@ -271,6 +271,8 @@ class SpectralProduct:
         if self.pair_xz:                            # diag(Mx, Mx) on stacked plane pairs: the x steps run over the zero blocks too
             fwd += 2.0 * ny * Px * Pz * nx
             bwd += 2.0 * slab * nx * Pz * Px
+        if self.fused_xz and self.fold and "x" in self.F and nx == nz:
+            fwd, bwd = 0.5 * fwd, 0.5 * bwd         # radix-2 kernels: one even-input and one odd-input sum per spectral pair
         if self.dense_y:
             # ny <= 64: the kernel computes every output y and stores the slab; ny = 128: chunks of 16 outputs covering the slab
             bwd += 2.0 * ny * (ny if ny <= 64 else (slab + 15) // 16 * 16) * Px * Pz
