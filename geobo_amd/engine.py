@@ -1055,30 +1055,9 @@ class PosteriorEngine:
         else:
             ssum = torch.stack([t.sum(0).reshape(-1) for t in ss])                        # (P_c, N), voxel order (iy, ix, iz)
         if Md:
-            # rows behind the sensor rows: L^-1 is lower triangular, so only THEY see the drill columns.  One 128-row tile through the
-            # storing product, three terms (gravity, magnetic, drill block rows of K), squared and summed here.
-            T = 128
-
-            def drill_rows():
-                Zgd, Zmd, Zdd = (self._workspace2d(nm, T, N) for nm in ("Zg_d", "Zm_d", "Zd_d"))
-                if lat:
-                    self._lattice_Z(Linv[2 * Msp:2 * Msp + T, :Msp], T, "grav", A_g, Zgd)
-                    self._lattice_Z(Linv[2 * Msp:2 * Msp + T, Msp:2 * Msp], T, "magn", A_m, Zmd)
-                else:
-                    hip.gemm_nn(Linv[2 * Msp:2 * Msp + T, :Msp], Ag[:Msp, :N], Zgd)
-                    hip.gemm_nn(Linv[2 * Msp:2 * Msp + T, Msp:2 * Msp], Am[:Msp, :N], Zmd)
-                Zdd.zero_()
-                Zdd[:, sel_t] = Linv[2 * Msp:2 * Msp + T, 2 * Msp:2 * Msp + Md]
-                gens_d = [sp.eigenvalues(self._cov_table(hip.kernel_id(name, 2 != j), lengths[j], lengths[2], W[2][j], amp)) for j in props]
-                Vd = [self._workspace2d("Vd_%d" % jj, T, N) for jj in range(P_c)]
-                tmp = [self._workspace2d("Vt_%d" % jj, T, N) for jj in range(P_c)]
-                sp.product(Zgd, T, gens_g, Vd)
-                for Zx, gx in ((Zmd, gens_m), (Zdd, gens_d)):
-                    sp.product(Zx, T, gx, tmp)
-                    for jj in range(P_c):
-                        Vd[jj].add_(tmp[jj])
-                return torch.stack([(Vd[jj][:Md] ** 2).sum(0) for jj in range(P_c)])
-            ssum = ssum + self._timed("posterior_drill_rows", 0.0, drill_rows)
+            ssum = ssum + self._timed("posterior_drill_rows", 0.0, lambda: self._drill_rows_ss(
+                Linv, 0, Md, sel_t, lengths, W, name, amp, props, gens_g, gens_m,
+                (lambda Lv, n, func, out: self._lattice_Z(Lv, n, func, A_g if func == "grav" else A_m, out)) if lat else None, Ag, Am))
         return mu_l, (amp * 1.0 - ssum).reshape(-1)
 
     def _posterior_rows(self, Linv, u, sel_t, lengths, W, name, amp, props, M_pad):
@@ -1135,32 +1114,52 @@ class PosteriorEngine:
                 ssq[jj].copy_(t.sum(0).view(ny, nz, nx).transpose(1, 2).reshape(-1))
             else:
                 ssq[jj].copy_(t.sum(0).reshape(-1))
-        # the 128-row tile behind the sensor rows (only it sees the drill columns of L^-1): Tr rows per rank
-        T = 128
-        Tr = T // G if T % G == 0 else T
-        d0 = r * Tr if T % G == 0 else 0
-        nd = max(0, min(Md - d0, Tr)) if (T % G == 0 or r == 0) else 0
+        # the rows behind the sensor rows (only they see the drill columns of L^-1): an equal share per rank
+        dper = -(-Md // G)
+        d0 = min(Md, r * dper)
+        nd = min(Md, d0 + dper) - d0
         if nd:
             def drill_rows():
-                Zgd, Zmd, Zdd = (self._workspace2d(nm, T, N) for nm in ("Zg_d", "Zm_d", "Zd_d"))
-                b0 = 2 * Msp + d0
-                self._lattice_Z(Linv[b0:b0 + nd, :Msp], nd, "grav", None, Zgd, edge=Eg)
-                self._lattice_Z(Linv[b0:b0 + nd, Msp:2 * Msp], nd, "magn", None, Zmd, edge=Em)
-                Zdd[:nd].zero_()
-                Zdd[:nd, sel_t] = Linv[b0:b0 + nd, 2 * Msp:2 * Msp + Md]
-                gens_d = [sp.eigenvalues(self._cov_table(hip.kernel_id(name, 2 != j), lengths[j], lengths[2], W[2][j], amp)) for j in props]
-                Vd = [self._workspace2d("Vd_%d" % jj, T, N) for jj in range(P_c)]
-                tmp = [self._workspace2d("Vt_%d" % jj, T, N) for jj in range(P_c)]
-                sp.product(Zgd, nd, gens_g, Vd)
-                for Zx, gx in ((Zmd, gens_m), (Zdd, gens_d)):
-                    sp.product(Zx, nd, gx, tmp)
-                    for jj in range(P_c):
-                        Vd[jj][:nd].add_(tmp[jj][:nd])
+                part = self._drill_rows_ss(Linv, d0, nd, sel_t, lengths, W, name, amp, props, gens_g, gens_m,
+                                           lambda Lv, n, func, out: self._lattice_Z(Lv, n, func, None, out, edge=Eg if func == "grav" else Em),
+                                           None, None)
                 for jj in range(P_c):
-                    ssq[jj].add_((Vd[jj][:nd] ** 2).sum(0))
+                    ssq[jj].add_(part[jj])
             self._timed("posterior_drill_rows", 0.0, drill_rows)
         self._timed("xgmi_all_reduce", 0.0, lambda: allreduce_sum_(red, G, self.group))
         return mu, amp * 1.0 - ssq
+
+    def _drill_rows_ss(self, Linv, d0, nd, sel_t, lengths, W, name, amp, props, gens_g, gens_m, lattice_Z, Ag, Am):
+        """(P_c, N) sums of squares of V = L^-1 (A3 K) over the drill rows d0 .. d0 + nd of the row block behind the sensor rows:
+        L^-1 is lower triangular, so only THESE rows see the drill columns.  Tiles of up to 128 rows through the storing covariance
+        product, three terms (gravity, magnetic, drill block rows of K), squared and summed here.  lattice_Z(Lview, n, func, out):
+        rows of L^-1 A on a lattice survey; None: MFMA GEMMs against the resident operators Ag / Am (whole 128-row tiles)."""
+        sp, N, Msp, P_c, Md, T = self._spectral, self.N, self.Ms_pad, len(props), sel_t.numel(), 128
+        Zgd, Zmd, Zdd = (self._workspace2d(nm, T, N) for nm in ("Zg_d", "Zm_d", "Zd_d"))
+        Vd = [self._workspace2d("Vd_%d" % jj, T, N) for jj in range(P_c)]
+        tmp = [self._workspace2d("Vt_%d" % jj, T, N) for jj in range(P_c)]
+        gens_d = [sp.eigenvalues(self._cov_table(hip.kernel_id(name, 2 != j), lengths[j], lengths[2], W[2][j], amp)) for j in props]
+        acc = torch.zeros((P_c, N), dtype=F64, device=self.device)
+        for c0 in range(d0, d0 + nd, T):
+            n = min(T, d0 + nd - c0)
+            b0 = 2 * Msp + c0
+            if lattice_Z is not None:
+                lattice_Z(Linv[b0:b0 + n, :Msp], n, "grav", Zgd)
+                lattice_Z(Linv[b0:b0 + n, Msp:2 * Msp], n, "magn", Zmd)
+            else:
+                nt = min(T, Linv.shape[0] - b0)          # (M_pad is a multiple of 256: whole tiles unless the caller's share starts mid-tile)
+                hip.gemm_nn(Linv[b0:b0 + nt, :Msp], Ag[:Msp, :N], Zgd)
+                hip.gemm_nn(Linv[b0:b0 + nt, Msp:2 * Msp], Am[:Msp, :N], Zmd)
+            Zdd[:n].zero_()
+            Zdd[:n, sel_t] = Linv[b0:b0 + n, 2 * Msp:2 * Msp + Md]
+            sp.product(Zgd, n, gens_g, Vd)
+            for Zx, gx in ((Zmd, gens_m), (Zdd, gens_d)):
+                sp.product(Zx, n, gx, tmp)
+                for jj in range(P_c):
+                    Vd[jj][:n].add_(tmp[jj][:n])
+            for jj in range(P_c):
+                acc[jj].add_((Vd[jj][:n] ** 2).sum(0))
+        return acc
 
     def _full_to_host(self, t, props, slot):
         """(P_c, N) device result, complete on this rank -> the reference's (3N,) property-major host vector (NaN: blocks not computed)."""

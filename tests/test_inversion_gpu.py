@@ -5,6 +5,7 @@ Tiers (hard part 1):
   T3 end to end      -- operators built on the device too: <= 1e-8 normwise per cube (north-star tolerance)
 """
 import json
+import gc
 import os
 
 import numpy as np
@@ -331,6 +332,57 @@ def test_streamed_operators_give_the_same_cubes(assembly):
                 assert np.array_equal(a, b, equal_nan=True)
             else:    # AkA panels accumulate in a different order than the split-K slices / one sweep
                 assert np.isnan(b).all() if np.isnan(a).all() else normwise(b, a) <= 1e-11
+
+
+@pytest.mark.parametrize("dims,kernel,props,md,jitter", [((64, 48, 64), "matern32", (0, 1, 2), 20, False),
+                                                         ((64, 64, 64), "exp", (0, 1), 0, False),
+                                                         ((64, 64, 64), "matern32", (0, 1, 2), 50, False),
+                                                         ((64, 16, 64), "sparse", (0, 1, 2), 7, False),
+                                                         ((64, 48, 64), "exp", (0, 1), 150, False),      # two drill-row tiles
+                                                         ((64, 48, 64), "matern32", (0, 1), 20, True)])
+def test_transposed_posterior_matches_the_fused_reduction(dims, kernel, props, md, jitter, monkeypatch):
+    """The transposed posterior (round 3: V = (L^-1 A3) K through the covariance kernels, mean as weighted column sums of A K) against
+    the fused MFMA reduction over L^-1 (A K) (round 1-2; inversion.py:114-117 literally) on the same step: every form of
+    Z = L^-1 A -- fused (row, z)-plane inverse transform (64^3), the two-GEMM inverse (ny = 48), triangular MFMA GEMMs against the
+    materialised operator (GEOBO_Z_LATTICE=0; ny = 16; a survey OFF the lattice: sensor heights jittered) -- with and without drill
+    rows, two and three property blocks, all three covariance functions."""
+    import bench
+    s = settings_for(*dims, kernelfunc=kernel)
+    forms = [("dense", {"GEOBO_POSTERIOR": "dense"}), ("default", {}), ("two-GEMM inverse", {"GEOBO_Z_FUSED": "0"}), ("GEMM Z", {"GEOBO_Z_LATTICE": "0"})]
+    out, seen, inputs = {}, {}, None
+    for name, env in forms:
+        for k in ("GEOBO_POSTERIOR", "GEOBO_Z_FUSED", "GEOBO_Z_LATTICE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        inv = _inv(s, props=props)
+        if inputs is None:
+            inputs = bench.synthetic_inputs(inv, md)
+            if jitter:
+                loc = inputs[2].copy()
+                loc[:, 2] += np.random.default_rng(5).uniform(0.0, 3.0, loc.shape[0])      # no two sensors at one height: no lattice plan
+                inputs = (inputs[0], inputs[1], loc, inputs[3])
+        grav, mag, loc, drill0 = inputs
+        inv.engine.clear_operators()
+        inv.gp_length = np.array([200.0, 202.0, 204.0])
+        inv.engine.kernel_events = []
+        out[name] = inv.cubing(grav, mag, drill0[drill0 != 0], loc, drill0)
+        seen[name] = {e[0] for e in inv.engine.kernel_events if e[0].startswith("posterior")}
+        inv.engine.kernel_events = None
+        del inv
+        gc.collect()                     # (engine <-> closure cycles: the workspaces of a 64^3 engine are ~100 GB)
+        torch.cuda.empty_cache()
+    lattice = dims[1] in (48, 64) and not jitter
+    assert seen["dense"] == {"posterior_reduce"}
+    assert ("posterior_zlattice" if lattice else "posterior_zgemm") in seen["default"] and "posterior_reduce" not in seen["default"]
+    assert "posterior_zgemm" in seen["GEMM Z"] and "posterior_zlattice" not in seen["GEMM Z"]
+    ref = out["dense"]
+    for name, _ in forms[1:]:
+        errs = [normwise(a, b) for a, b in zip(out[name], ref) if not np.isnan(b).all()]
+        print(dims, kernel, name, " ".join("%.1e" % e for e in errs))
+        assert len(errs) == 2 * len(props) and max(errs) <= 1e-11
+        for a, b in zip(out[name], ref):
+            assert np.isnan(a).all() == np.isnan(b).all()
 
 
 def test_fp32_assembly_tracks_fp64_at_32_and_the_headline_shape():
