@@ -167,14 +167,36 @@ int colgemv_splits(int64_t m, int64_t n) {
 //  its (y, x) eigen-decomposition.)  One workgroup per (row, iz) plane of Py x Px doubles; lhat[r] (128 KB) and Lambda3 (8 MB) stay in
 //  cache, the launch is bound by its HBM writes.  mode 1: the older layout W[r][kx][iz][ky] = lamW[kx][iz][ky] * lhat[r][ky][kx] that feeds
 //  the two batched-GEMM inverse steps (grids the fused inverse transform has no instance for).
+// Blocking: a workgroup keeps ZG z-planes of a 2048-double chunk of Lambda3 in registers and sweeps its share of the rows, so that
+// the table is read 8 times per launch and lhat once per ZG planes (one workgroup per (row, iz) plane re-read the 8 MB table for
+// every row out of L2 / MALL -- as many bytes as the launch writes: 3.5 TB/s; this form: the write-only ceiling).
+constexpr int WP_ZG = 8, WP_CH = 1024;      // z-planes per workgroup; v2d elements per chunk (4 per thread)
 __global__ void __launch_bounds__(256) lattice_wplanes_kernel(const double* __restrict__ lam3, const double* __restrict__ lhat, int64_t plane,
-                                                              int nz, double* __restrict__ W) {
-  const int iz = blockIdx.x;
-  const int64_t r = blockIdx.y;
-  const v2d* l3 = reinterpret_cast<const v2d*>(lam3 + (int64_t)iz * plane);
-  const v2d* lh = reinterpret_cast<const v2d*>(lhat + r * plane);
-  v2d* w = reinterpret_cast<v2d*>(W + (r * nz + iz) * plane);
-  for (int64_t e = threadIdx.x; e < plane / 2; e += 256) w[e] = l3[e] * lh[e];
+                                                              int nz, int64_t rows, double* __restrict__ W) {
+  const int64_t nch = plane / 2 / WP_CH;
+  const int64_t ch = blockIdx.x % nch;
+  const int z0 = (int)(blockIdx.x / nch) * WP_ZG;
+  const int nzg = nz - z0 < WP_ZG ? nz - z0 : WP_ZG;
+  v2d lam[WP_ZG][4];
+#pragma unroll
+  for (int g = 0; g < WP_ZG; ++g)
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      lam[g][k] = g < nzg ? reinterpret_cast<const v2d*>(lam3 + (int64_t)(z0 + g) * plane)[ch * WP_CH + k * 256 + threadIdx.x] : (v2d){0.0, 0.0};
+  for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+    const v2d* lh = reinterpret_cast<const v2d*>(lhat + r * plane) + ch * WP_CH + threadIdx.x;
+    v2d l[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) l[k] = lh[k * 256];
+    v2d* w = reinterpret_cast<v2d*>(W + (r * nz + z0) * plane) + ch * WP_CH + threadIdx.x;
+#pragma unroll
+    for (int g = 0; g < WP_ZG; ++g) {
+      if (g < nzg) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w[(int64_t)g * (plane / 2) + k * 256] = lam[g][k] * l[k];
+      }
+    }
+  }
 }
 
 __global__ void __launch_bounds__(256) lattice_wbuild_kernel(const double* __restrict__ lamW, const double* __restrict__ lhat, int Py, int Px,
@@ -519,8 +541,11 @@ extern "C" int geobo_lattice_wplanes(int64_t rows, int Py, int Px, int nz, const
   if (Py <= 0 || Px <= 0 || nz <= 0 || ((Py * Px) & 1) || rows > 65535 || ((uintptr_t)lam3 & 15) || ((uintptr_t)lhat & 15) ||
       ((uintptr_t)W & 15))
     return GEOBO_E_ALIGN;
-  hipLaunchKernelGGL(lattice_wplanes_kernel, dim3((unsigned)nz, (unsigned)rows), dim3(256), 0, (hipStream_t)stream, lam3, lhat,
-                     (int64_t)Py * Px, nz, W);
+  const int64_t plane = (int64_t)Py * Px;
+  if (plane % (2 * WP_CH)) return GEOBO_E_UNSUPPORTED;
+  const unsigned gx = (unsigned)(plane / 2 / WP_CH * ((nz + WP_ZG - 1) / WP_ZG));
+  const unsigned gy = (unsigned)(rows < 32 ? rows : 32);                     // 64 x 32 workgroups at 64^3: 8 rows each for a 256-row batch
+  hipLaunchKernelGGL(lattice_wplanes_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, lam3, lhat, plane, nz, rows, W);
   return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
 }
 

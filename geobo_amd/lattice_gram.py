@@ -47,7 +47,7 @@ class LatticeGram:
         gy0[:, 0] = 0.0
         gy0[:, self.ny - 1] = 0.0
         self.Gy0 = gy0
-        self.R = 256
+        self.R = int(os.environ.get("GEOBO_GRAM_ROWS", "256"))       # rows per batch
 
     # ---- boundary slabs: x-correlation through the full real DFT (module docstring, item 4) -----------------------------------
     EDGE_ROWS = 1024     # rows per batch: 64 frequency slots x 8 column tiles = 512 tiles per batched GEMM (two per CU)

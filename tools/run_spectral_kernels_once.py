@@ -40,7 +40,7 @@ if which in ("all", "xcorr"):
     timed("xcorr", R * P * 2.0 * P * n * n, R * P * (n * n + P) * 8.0,
           lambda: hip.xcorr_reduce(n, n, R, P, src, src.stride(0), n * n, Gx, lam, out, out.stride(0), P))
 # ---- radix-2 kernels (round 2): flop = what the folded kernels execute on the matrix pipe (half of the plain products) -------
-if which in ("all", "fold_fwd", "fold_bwd", "xcorr_fold"):
+if which in ("all", "fold_fwd", "fold_bwd", "xcorr_fold", "fold_inv_ss", "fold_inv_strided"):
     import numpy as np
     from geobo_amd.spectral import folded_matrices
     F = hip.to_dev(np.stack(folded_matrices(n), axis=2))
@@ -102,3 +102,29 @@ if which in ("all", "edge_rows"):
     V = gram.edge_eigen(E)
     X, out = rnd(1025, 2 * n * n), torch.zeros((1024, n * n), dtype=torch.float64, device=dev)
     timed("edge_rows", 1024 * 3 * 2.0 * 128 * 128 * 64, 1024 * (n * n + n * n) * 8.0, lambda: gram.edge_rows(X[:, :n * n + 64], 1024, V, out))
+# ---- transposed posterior (round 3) ---------------------------------------------------------------------------------------------
+if which in ("all", "fold_inv_ss"):
+    # inverse transform fused with the sum of squares over rows, two-term input (V = Zg K0j + Zm K1j): reads both y-stage outputs of a
+    # 256-row batch, writes nothing but the 32 partial cubes it adds into
+    s1, s2 = rnd(R, n * P * P), rnd(R, n * P * P)
+    slots = hip.xz2d_fold_inv_ss_slots(n, R, n)
+    ss = torch.zeros((slots, n, n * n), dtype=torch.float64, device=dev)
+    timed("xz2d_fold_inv_ss", R * n * 1.0 * (2 * P * P * n + n * P * n), 2.0 * R * n * P * P * 8.0,
+          lambda: hip.xz2d_fold_inv_ss(n, R, n, s1, n * P * P, P * P, F, F, ss, src2=s2, in2_row=n * P * P, r2_first=0))
+    del s1, s2, ss
+if which in ("all", "fold_inv_strided"):
+    # rows of L^-1 A on a lattice survey: one inverse two-axis transform per (row, z) plane of W = Lambda[iz] * lhat_r, written as [iy][iz][ix]
+    W, out = rnd(R, n * P * P), torch.empty((R, n * n * n), dtype=torch.float64, device=dev)
+    timed("xz2d_fold_inv_strided", R * n * 1.0 * (P * P * n + n * P * n), R * n * (n * n + P * P) * 8.0,
+          lambda: hip.xz2d_fold_inv_strided(n, R, n, W, n * P * P, P * P, F, F, out, out.stride(0), n, n * n))
+    del W, out
+if which in ("all", "wplanes"):
+    lam3, lh = rnd(n * P * P), rnd(R * P * P)
+    W = torch.empty(R * n * P * P, dtype=torch.float64, device=dev)
+    timed("lattice_wplanes", R * n * P * P * 1.0, (R * n * P * P + R * P * P + n * P * P) * 8.0, lambda: hip.lattice_wplanes(R, P, P, n, lam3, lh, W))
+    del lam3, lh, W
+if which in ("all", "colgemv"):
+    # posterior mean: weighted column sums of A K (8448 x 2 N)
+    m_, n_ = 8448, 2 * n * n * n
+    X, v = rnd(m_, n_), rnd(m_)
+    timed("colgemv", 2.0 * m_ * n_, m_ * n_ * 8.0, lambda: hip.colgemv(X, v))
