@@ -16,6 +16,7 @@ and HIP-event stage times are recorded.  The step time of a real run is then PRE
 The JSON says so in every table it prints.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -81,8 +82,11 @@ def main():
                     "replaced by their local part (tools/emulate_rank.py), plus a link-rate model for the bytes the collectives move",
                workload="%d^3, Matern-3/2 (2.00,2.02,2.04)x100 m, %d drill rows, P_out = 2" % (n, a.drill),
                one_rank=dict(ms_per_step=round(ms1, 2), stage_ms=st1), ranks={})
+    inv1.engine.kernel_events = None
     del inv1
+    gc.collect()                     # (engine <-> closure cycles keep the ~100 GB of workspaces alive otherwise)
     torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
     for G in [int(v) for v in a.of.split(",") if v]:
         r = min(a.rank, G - 1)
         inv = Inversion(settings=s, props=(0, 1), rank=r, world=G, group=EmulatedGroup(r, G), operators="resident")
@@ -123,7 +127,9 @@ def main():
                                     bytes_sent_all_to_all=a2a_total, aka_collective=aka_kind, bytes_received_aka=aka_bytes_in,
                                     predicted=pred, memory_GB=round(torch.cuda.max_memory_allocated() / 1e9, 1))
         print("G = %d: compute %.1f ms (1 rank: %.1f ms); stages %s" % (G, ms, ms1, st), file=sys.stderr, flush=True)
+        eng.aka_hook = None
         del inv, eng
+        gc.collect()
         torch.cuda.empty_cache()
         torch.cuda.reset_peak_memory_stats()
     print(json.dumps(out))
