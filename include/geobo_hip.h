@@ -86,18 +86,19 @@ int geobo_k_block_grid(int nx, int ny, int nz, const double* table, const int64_
  * streams of the posterior MEAN in its transposed form (inversion.py:114-116, mu = V^T u with V = L^-1 (A K)):
  *     w = Linv^T u  (m = n = M),   mu = (A K)^T w  (m = M, n = the voxel-property columns)  --  V is not needed for the mean.
  * ws: geobo_colgemv_ws_bytes(m, n) (row-slice partials, summed in a fixed order: deterministic). */
+size_t geobo_colgemv_ws_bytes(int64_t m, int64_t n);
+int geobo_colgemv(int64_t m, int64_t n, const double* X, int64_t ld, const double* v, double* out, void* ws, size_t ws_bytes,
+                  void* stream);
+
 /* Step of the TRANSPOSED lattice application (rows of L^-1 restricted to one operator's columns -> rows of L^-1 A on a lattice
  * survey, geobo_amd/lattice_gram.py::apply_transpose):  W[r][kx][iz][ky] = lamW[kx][iz][ky] * lhat[r][ky][kx]  for r < rows, with
  * lhat the (y, x) real-DFT of the row's sensor image (Py x Px) and lamW the eigen-data of the operator's stencil table; the two
  * inverse transforms that follow are geobo_gemm_batched launches.  Py <= 256, rows <= 65535. */
 int geobo_lattice_wbuild(int64_t rows, int Py, int Px, int nz, const double* lamW, const double* lhat, double* W, void* stream);
 /* The same products laid out as spectral PLANES, W[r][iz][ky][kx] = lam3[iz][ky][kx] * lhat[r][ky][kx]: every (r, iz) plane then
- * goes through the fused inverse two-axis transform (geobo_xz2d_fold_inv_strided) straight into the row of L^-1 A. */
+ * goes through the fused inverse two-axis transform (geobo_xz2d_fold_inv_strided) straight into the row of L^-1 A.
+ * Py * Px a multiple of 2048 (GEOBO_E_UNSUPPORTED otherwise), rows <= 65535; bound by its HBM writes. */
 int geobo_lattice_wplanes(int64_t rows, int Py, int Px, int nz, const double* lam3, const double* lhat, double* W, void* stream);
-
-size_t geobo_colgemv_ws_bytes(int64_t m, int64_t n);
-int geobo_colgemv(int64_t m, int64_t n, const double* X, int64_t ld, const double* v, double* out, void* ws, size_t ws_bytes,
-                  void* stream);
 
 /* fp32-assembly mode (config 5): A K lives in HBM as fp32 and the fp64 MFMA kernels are handed fp64 panels.
  *   geobo_convert: 2-D strided precision conversion, to_f32 = 1: dst(float)[r*ld_dst + c] = (float)src(double)[r*ld_src + c],
