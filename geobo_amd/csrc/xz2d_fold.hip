@@ -235,6 +235,15 @@ __device__ __forceinline__ void inv_step1(v2d (&a)[KP], const double (&gz)[KP], 
   if constexpr (T + 1 < KP) inv_step1<KP, T + 1>(a, gz, sgn, d);
 }
 
+// the same over one half of the k-steps (MUL mode: 8 fragment reads in flight instead of 16 -- the registers the staged loads need)
+template <int KH, int T, int G0, int KP>
+__device__ __forceinline__ void inv_step1h(v2d (&a)[KH], const double (&gz)[KP], double sgn, v4d (&d)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a[T]) : "n"(KH - 1 - T));
+  const double uv = __builtin_fma(sgn, a[T].y, a[T].x);
+  d[T & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(uv, gz[G0 + T], d[T & 3], 0, 0, 0);
+  if constexpr (T + 1 < KH) inv_step1h<KH, T + 1, G0, KP>(a, gz, sgn, d);
+}
+
 template <int N, int RING>
 struct InvCfg {
   static constexpr int NW = 4, P = 2 * N, RT = P / 16, KP = N / 4, ROWB = P * 8, CHB = 16 * ROWB, ND = CHB / 1024 / NW;
@@ -243,8 +252,14 @@ struct InvCfg {
   static_assert(N == 64 && ND >= 1 && RT >= RING - 1 && N / 16 == NW && LPR == 64, "shape");
 };
 
-template <int N, bool RED>
+// MODE 0: planes stored; 1 (RED): squared and summed over the rows (geobo_xz2d_fold_inv_ss); 2 (MUL): stored, and the input plane
+// (r, iz) is the PRODUCT of two cache-resident planes, in[iz] * in2[r] (geobo_xz2d_fold_inv_mul: rows of L^-1 A on a lattice survey,
+// W = Lambda[iz] * lhat_r never exists in memory).  MUL stages its chunks through registers instead of LDS-DMA: every thread loads
+// its 4 x 16 bytes of both factors one chunk ahead, multiplies and writes the ring slot itself; no load is in flight across the
+// chunk barrier, so that barrier may be a plain __syncthreads().
+template <int N, int MODE>
 __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
+  constexpr bool RED = MODE == 1, MUL = MODE == 2;
   constexpr int RING = 3;
   using K = InvCfg<N, RING>;
   constexpr int RT = K::RT, KP = K::KP, MT = K::MT, H = N / 2;
@@ -283,10 +298,44 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
       __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(ring + slot * K::CHB + row * 1024), 16, 0, 0);
     }
   };
-  const double* cur = plane_ptr(first, 0);
-  __syncthreads();
+  // MUL: the two factors of plane p; fetch = this thread's 16-byte pieces of chunk c of both (row w + 4 j of the chunk, slot lane),
+  // commit = their products into the ring slot, where the DMA of the other modes would have put the chunk
+  auto planeA = [&](int64_t p) { return g.in + (p % g.ppr) * g.in_plane; };
+  auto planeB = [&](int64_t p) { return g.in2 + (p / g.ppr) * g.in2_row; };
+  v2d fa[K::ND], fb[K::ND];
+  unsigned fo[K::ND];                                         // byte offset of this thread's piece j inside a chunk (32-bit, per lane)
 #pragma unroll
-  for (int c = 0; c < RING - 1; ++c) stage(cur, c, c);
+  for (int j = 0; j < K::ND; ++j) {
+    const int row = w + K::NW * j;
+    fo[j] = (unsigned)(rowperm(row) * K::ROWB + ((lane ^ (row & 15)) << 4));
+  }
+  auto fetch = [&](const double* pa, const double* pb, int c) {
+    const char* ca = reinterpret_cast<const char*>(pa) + (size_t)c * K::CHB;       // uniform: scalar base + 32-bit lane offset
+    const char* cb = reinterpret_cast<const char*>(pb) + (size_t)c * K::CHB;
+#pragma unroll
+    for (int j = 0; j < K::ND; ++j) {
+      fa[j] = *reinterpret_cast<const v2d*>(ca + fo[j]);
+      fb[j] = *reinterpret_cast<const v2d*>(cb + fo[j]);
+    }
+  };
+  auto commit = [&](int slot) {
+#pragma unroll
+    for (int j = 0; j < K::ND; ++j) {
+      const int row = w + K::NW * j;
+      *reinterpret_cast<v2d*>(ring + slot * K::CHB + row * 1024 + (lane << 4)) = fa[j] * fb[j];
+    }
+  };
+  const double* cur = MUL ? planeA(first) : plane_ptr(first, 0);
+  const double* curB = MUL ? planeB(first) : nullptr;
+  __syncthreads();
+  if constexpr (MUL) {
+    fetch(cur, curB, 0);
+    commit(0);
+    fetch(cur, curB, 1);
+  } else {
+#pragma unroll
+    for (int c = 0; c < RING - 1; ++c) stage(cur, c, c);
+  }
   int slot0 = 0;
   bool warm = false;
   v4d sse[MT], sso[MT];                                       // RED: sum over this workgroup's planes of the squared outputs
@@ -298,9 +347,17 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
     for (int term = 0; term < nt; ++term) {
     const bool last_term = term + 1 == nt;
     const int64_t pn = last_term ? (p + pstep < g.nplanes ? p + pstep : p) : p;
-    const double* nxt = plane_ptr(pn, last_term ? 0 : term + 1);
+    const double* nxt = MUL ? planeA(pn) : plane_ptr(pn, last_term ? 0 : term + 1);
+    const double* nxtB = MUL ? planeB(pn) : nullptr;
 #pragma unroll
     for (int c = 0; c < RT; ++c) {
+      if constexpr (MUL) {
+        commit((slot0 + c + 1) % RING);                       // chunk c + 1 (fetched during chunk c - 1): its slot was last read at c - 2
+        __syncthreads();
+        if (c + 2 < RT) fetch(cur, curB, c + 2);
+        else if (c + 2 == RT) fetch(nxt, nxtB, 0);
+        // (chunk 1 of the next plane is fetched behind step 2: its 16 registers do not fit beside T and the output tiles)
+      } else {
       // (reduction form: no stores inside the loop, hence no drain before them -- every chunk takes the counted wait)
       if (RED || !(c <= RING - 2 && warm)) __builtin_amdgcn_s_waitcnt(vmcnt_imm((RING - 2) * K::ND));
       __builtin_amdgcn_s_barrier();
@@ -309,22 +366,35 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
         if (cn < RT) stage(cur, cn, (slot0 + cn) % RING);
         else stage(nxt, cn - RT, (slot0 + cn) % RING);
       }
+      }
       const unsigned xs = ring_lds + ((slot0 + c) % RING) * K::CHB + lr * K::ROWB;
+      v4d d[4];
+      d[0] = d[1] = d[2] = d[3] = (v4d){0., 0., 0., 0.};
+      if constexpr (MUL) {
+        constexpr int KH = KP / 2;
+        v2d ah[KH];
+#pragma unroll
+        for (int t = 0; t < KH; ++t) asm volatile("ds_read_b128 %0, %1" : "=v"(ah[t]) : "v"(xs + (((4 * t + q) ^ lr) << 4)));
+        inv_step1h<KH, 0, 0, KP>(ah, gz, sgn, d);
+#pragma unroll
+        for (int t = 0; t < KH; ++t) asm volatile("ds_read_b128 %0, %1" : "=v"(ah[t]) : "v"(xs + (((4 * (t + KH) + q) ^ lr) << 4)));
+        inv_step1h<KH, 0, KH, KP>(ah, gz, sgn, d);
+      } else {
       v2d a[KP];
 #pragma unroll
       for (int t = 0; t < KP; ++t) {
         const unsigned addr = xs + (((4 * t + q) ^ lr) << 4);    // slot b = 4 t + q: the pair (s[2b], s[2b+1]) of row lr
         asm volatile("ds_read_b128 %0, %1" : "=v"(a[t]) : "v"(addr));
       }
-      v4d d[4];
-      d[0] = d[1] = d[2] = d[3] = (v4d){0., 0., 0., 0.};
       inv_step1<KP, 0>(a, gz, sgn, d);
+      }
       const v4d tc = (d[0] + d[1]) + (d[2] + d[3]);
       t1[c] = (RED && term > 0) ? t1[c] + tc : tc;
     }
     warm = true;
     slot0 = (slot0 + RT) % RING;
     cur = nxt;
+    curB = nxtB;
     }   // terms
     // ---- step 2: row pairs (2 bx, 2 bx+1) sit in registers (2h, 2h+1): U = sum, V = difference; even output rows from U with
     //      Fe_x, odd output rows from V with Fo_x; A = (Fe_x, Fo_x)[bx = 8 rt + 4 h + q][j = 16 m + lr] from one b128 read ------
@@ -351,7 +421,8 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
         sso[m] += od * od;
       }
     } else {
-      __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+      if constexpr (MUL) fetch(cur, curB, 1);                 // (cur / curB already name the next plane)
+      else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
       double* const op = g.out + (p / g.ppr) * g.out_row + (p % g.ppr) * g.out_plane + 2 * (16 * jt + lr) + par;
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
@@ -517,10 +588,11 @@ int launch_fwd(const FoldArgs& g, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
 }
 
-template <int N, bool RED>
+template <int N, int MODE>
 int launch_inv(const FoldArgs& g, hipStream_t st) {
   using K = InvCfg<N, 3>;
-  auto kern = xz_fold_inv_kernel<N, RED>;
+  constexpr bool RED = MODE == 1;
+  auto kern = xz_fold_inv_kernel<N, MODE>;
   static std::atomic<uint64_t> attr_done{0};
   if (int rc = ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), K::LDS)) return rc;
   int64_t nwg = g.nplanes < 2048 ? g.nplanes : 2048;
@@ -566,7 +638,7 @@ extern "C" int geobo_xz2d_fold(int inverse, int n, int64_t rows, int planes_per_
   g.Fz = Fz; g.Fx = Fx; g.ppr = planes_per_row; g.nplanes = rows * planes_per_row; g.out_rs = n;
   g.row_off = nullptr; g.edge = nullptr; g.edge_row = 0;
   g.in2 = nullptr; g.in2_row = 0; g.r2_first = 0; g.ss = nullptr;
-  return inverse ? launch_inv<64, false>(g, (hipStream_t)stream) : launch_fwd<64>(g, (hipStream_t)stream);
+  return inverse ? launch_inv<64, 0>(g, (hipStream_t)stream) : launch_fwd<64>(g, (hipStream_t)stream);
 }
 
 extern "C" int geobo_xz2d_fold_lattice(int n, int64_t rows, int planes_per_row, const double* Q, const int64_t* row_off,
@@ -609,7 +681,7 @@ extern "C" int geobo_xz2d_fold_inv_ss(int n, int64_t rows, int planes_per_row, c
   g.Fz = Fz; g.Fx = Fx; g.ppr = planes_per_row; g.nplanes = rows * planes_per_row;
   g.row_off = nullptr; g.edge = nullptr; g.edge_row = 0;
   g.in2 = in2; g.in2_row = in2_row; g.r2_first = in2 ? r2_first : rows; g.ss = ss;
-  return launch_inv<64, true>(g, (hipStream_t)stream);
+  return launch_inv<64, 1>(g, (hipStream_t)stream);
 }
 
 extern "C" int geobo_xz2d_fold_inv_strided(int n, int64_t rows, int planes_per_row, const double* in, int64_t in_row, int64_t in_plane,
@@ -625,5 +697,22 @@ extern "C" int geobo_xz2d_fold_inv_strided(int n, int64_t rows, int planes_per_r
   g.Fz = Fz; g.Fx = Fx; g.ppr = planes_per_row; g.nplanes = rows * planes_per_row;
   g.row_off = nullptr; g.edge = nullptr; g.edge_row = 0;
   g.in2 = nullptr; g.in2_row = 0; g.r2_first = 0; g.ss = nullptr;
-  return launch_inv<64, false>(g, (hipStream_t)stream);
+  return launch_inv<64, 0>(g, (hipStream_t)stream);
+}
+
+extern "C" int geobo_xz2d_fold_inv_mul(int n, int64_t rows, int planes_per_row, const double* a, int64_t a_plane, const double* b,
+                                       int64_t b_row, const double* Fx, const double* Fz, double* out, int64_t out_row,
+                                       int64_t out_plane, int64_t out_rowstride, void* stream) {
+  if (!a || !b || !out || !Fx || !Fz) return GEOBO_E_ARG;
+  if (rows <= 0 || planes_per_row <= 0) return GEOBO_OK;
+  if (out_rowstride < n) return GEOBO_E_ARG;
+  if ((a_plane & 1) || (b_row & 1) || ((uintptr_t)a & 15) || ((uintptr_t)b & 15) || ((uintptr_t)Fx & 15) || ((uintptr_t)Fz & 15))
+    return GEOBO_E_ALIGN;
+  if (n != 64) return GEOBO_E_UNSUPPORTED;
+  FoldArgs g;
+  g.in = a; g.in_row = 0; g.in_plane = a_plane; g.out = out; g.out_row = out_row; g.out_plane = out_plane; g.out_rs = out_rowstride;
+  g.Fz = Fz; g.Fx = Fx; g.ppr = planes_per_row; g.nplanes = rows * planes_per_row;
+  g.row_off = nullptr; g.edge = nullptr; g.edge_row = 0;
+  g.in2 = b; g.in2_row = b_row; g.r2_first = 0; g.ss = nullptr;
+  return launch_inv<64, 2>(g, (hipStream_t)stream);
 }

@@ -133,6 +133,14 @@ def xz2d_fold_inv_strided(n, rows, ppr, src, in_row, in_plane, Fx, Fz, out, out_
                                                _stream()), "geobo_xz2d_fold_inv_strided")
 
 
+def xz2d_fold_inv_mul(n, rows, ppr, a, a_plane, b, b_row, Fx, Fz, out, out_row, out_plane, out_rowstride):
+    """Inverse radix-2 transform of the planes a[p] * b[r] (elementwise), strided output rows (geobo_xz2d_fold_inv_mul)."""
+    lib = require_gpu()
+    _lib.check(lib.geobo_xz2d_fold_inv_mul(int(n), int(rows), int(ppr), _p(_chk(a, "a")), int(a_plane), _p(_chk(b, "b")), int(b_row),
+                                           _p(_chk(Fx, "Fx")), _p(_chk(Fz, "Fz")), _p(_chk(out, "out")), int(out_row), int(out_plane),
+                                           int(out_rowstride), _stream()), "geobo_xz2d_fold_inv_mul")
+
+
 def colgemv(X, v, out=None, ws=None):
     """out[c] = sum_r X[r, c] v[r]  (X: 2-D row-major CUDA float64, unit column stride, even width)."""
     lib = require_gpu()

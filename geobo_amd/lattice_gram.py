@@ -186,6 +186,10 @@ class LatticeGram:
             Rb = min(R, nrows - r0)
             lh = sp.buf("LG_Lh", R * Py * Px)
             hip.xz2d_fold(False, ny, Rb, 1, Lrows[r0:], Lrows.stride(0), ny * nx, sp.F["y"], sp.F["x"], lh, Py * Px, Py * Px)
+            if os.environ.get("GEOBO_Z_MUL", "1") != "0":
+                # W[r][iz] = Lambda3[iz] * lhat_r is formed inside the inverse kernel, chunk by chunk, from the two cache-resident factors
+                hip.xz2d_fold_inv_mul(ny, Rb, nz, lam3, Py * Px, lh, Py * Px, sp.F["y"], sp.F["x"], out[r0:], out.stride(0), nx, nz * nx)
+                continue
             W = sp.buf("LG_W", R * nz * Py * Px)
             hip.lattice_wplanes(Rb, Py, Px, nz, lam3, lh, W)
             hip.xz2d_fold_inv_strided(ny, Rb, nz, W, nz * Py * Px, Py * Px, sp.F["y"], sp.F["x"], out[r0:], out.stride(0), nx, nz * nx)

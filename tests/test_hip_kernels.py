@@ -608,7 +608,7 @@ def test_colgemv_matches_torch(hip):
 
 
 @pytest.mark.parametrize("ny,nrows", [(64, 300), (48, 130)])
-def test_lattice_transposed_application_matches_the_gemm(hip, ny, nrows):
+def test_lattice_transposed_application_matches_the_gemm(hip, ny, nrows, monkeypatch):
     """Rows of L^-1 A on a lattice survey without A: LatticeGram.apply_transpose (interior slabs through the stencil table's eigen-data)
     + edge_apply_transpose (the two padded slabs through their x-DFT spectra) against the plain product with the materialised
     operator (gravity and magnetic, random row vectors with a triangular cut)."""
@@ -647,6 +647,13 @@ def test_lattice_transposed_application_matches_the_gemm(hip, ny, nrows):
             err2 = (got - ref).abs().max().item() / ref.abs().max().item()
             print("  fused (zx layout): %.2e" % err2)
             assert err2 <= 1e-12
+            # the product W = Lambda * lhat formed inside the inverse kernel (default) against W written and read back: same arithmetic
+            monkeypatch.setenv("GEOBO_Z_MUL", "0")
+            out3 = torch.full((nrows, N + 16), float("nan"), dtype=torch.float64, device="cuda")[:, :N]
+            gram.apply_transpose_zx(Lv, nrows, gram.transpose_tables3(lam), out3)
+            monkeypatch.delenv("GEOBO_Z_MUL")
+            pl2 = slice(pl, N - pl)                     # (the boundary slabs of out2 were overwritten above)
+            assert torch.equal(out3[:, pl2], out2[:, pl2])
 
 
 def test_a_sens_slab_origin_is_validated_by_the_library(hip):
