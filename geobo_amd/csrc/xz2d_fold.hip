@@ -237,11 +237,23 @@ __device__ __forceinline__ void inv_step1(v2d (&a)[KP], const double (&gz)[KP], 
 
 // the same over one half of the k-steps (MUL mode: 8 fragment reads in flight instead of 16 -- the registers the staged loads need)
 template <int KH, int T, int G0, int KP>
-__device__ __forceinline__ void inv_step1h(v2d (&a)[KH], const double (&gz)[KP], double sgn, v4d (&d)[4]) {
+__device__ __forceinline__ void inv_step1h(v2d (&a)[KH], const double (&gz)[KP], double sgn, v4d (&d)[2]) {
   asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a[T]) : "n"(KH - 1 - T));
   const double uv = __builtin_fma(sgn, a[T].y, a[T].x);
-  d[T & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(uv, gz[G0 + T], d[T & 3], 0, 0, 0);
+  d[T & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(uv, gz[G0 + T], d[T & 1], 0, 0, 0);   // two chains: a dependent fp64 MFMA issues back to back
   if constexpr (T + 1 < KH) inv_step1h<KH, T + 1, G0, KP>(a, gz, sgn, d);
+}
+
+// rolling window (MUL mode): KW fragment reads in flight at all times -- element T + KW is requested into the register pair element T
+// has just been taken out of, so only the first KW reads of a chunk are exposed
+template <int KW, int T, int KP>
+__device__ __forceinline__ void inv_step1r(v2d (&a)[KW], const double (&gz)[KP], double sgn, v4d (&d)[2], unsigned xs, int q, int lr) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a[T % KW]) : "n"(T + KW < KP ? KW - 1 : KP - 1 - T));
+  const double uv = __builtin_fma(sgn, a[T % KW].y, a[T % KW].x);
+  if constexpr (T + KW < KP)
+    asm volatile("ds_read_b128 %0, %1" : "=v"(a[T % KW]) : "v"(xs + (((4 * (T + KW) + q) ^ lr) << 4)), "v"(uv));   // (after uv was formed)
+  d[T & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(uv, gz[T], d[T & 1], 0, 0, 0);
+  if constexpr (T + 1 < KP) inv_step1r<KW, T + 1, KP>(a, gz, sgn, d, xs, q, lr);
 }
 
 template <int N, int RING>
@@ -255,8 +267,8 @@ struct InvCfg {
 // MODE 0: planes stored; 1 (RED): squared and summed over the rows (geobo_xz2d_fold_inv_ss); 2 (MUL): stored, and the input plane
 // (r, iz) is the PRODUCT of two cache-resident planes, in[iz] * in2[r] (geobo_xz2d_fold_inv_mul: rows of L^-1 A on a lattice survey,
 // W = Lambda[iz] * lhat_r never exists in memory).  MUL stages its chunks through registers instead of LDS-DMA: every thread loads
-// its 4 x 16 bytes of both factors one chunk ahead, multiplies and writes the ring slot itself; no load is in flight across the
-// chunk barrier, so that barrier may be a plain __syncthreads().
+// its 4 x 16 bytes of both factors two chunks ahead (two register sets), multiplies and writes the ring slot itself; the chunk
+// barrier waits for those LDS writes only.
 template <int N, int MODE>
 __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
   constexpr bool RED = MODE == 1, MUL = MODE == 2;
@@ -300,38 +312,51 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
   };
   // MUL: the two factors of plane p; fetch = this thread's 16-byte pieces of chunk c of both (row w + 4 j of the chunk, slot lane),
   // commit = their products into the ring slot, where the DMA of the other modes would have put the chunk
-  auto planeA = [&](int64_t p) { return g.in + (p % g.ppr) * g.in_plane; };
-  auto planeB = [&](int64_t p) { return g.in2 + (p / g.ppr) * g.in2_row; };
-  v2d fa[K::ND], fb[K::ND];
+  // MUL: the two factors of plane p through buffer descriptors (uniform base in SGPRs + one 32-bit lane offset per piece + the
+  // chunk's scalar offset: no 64-bit address arithmetic per load); fetch = this thread's 16-byte pieces of chunk c of both factors
+  // (row w + 4 j of the chunk, slot lane), commit = their products into the ring slot, where the DMA of the other modes would have
+  // put the chunk
+  using rsrc_t = __amdgpu_buffer_rsrc_t;
+  using u32x4 = decltype(__builtin_amdgcn_raw_buffer_load_b128(*static_cast<rsrc_t*>(nullptr), 0, 0, 0));
+  auto planeA = [&](int64_t p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(g.in + (p % g.ppr) * g.in_plane), 0, RT * K::CHB, 0x00020000);
+  };
+  auto planeB = [&](int64_t p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(g.in2 + (p / g.ppr) * g.in2_row), 0, RT * K::CHB, 0x00020000);
+  };
+  v2d fa[2][K::ND], fb[2][K::ND];                             // two sets: chunk k lives in set k % 2 from its fetch (chunk k - 3) to its commit
   unsigned fo[K::ND];                                         // byte offset of this thread's piece j inside a chunk (32-bit, per lane)
 #pragma unroll
   for (int j = 0; j < K::ND; ++j) {
     const int row = w + K::NW * j;
     fo[j] = (unsigned)(rowperm(row) * K::ROWB + ((lane ^ (row & 15)) << 4));
   }
-  auto fetch = [&](const double* pa, const double* pb, int c) {
-    const char* ca = reinterpret_cast<const char*>(pa) + (size_t)c * K::CHB;       // uniform: scalar base + 32-bit lane offset
-    const char* cb = reinterpret_cast<const char*>(pb) + (size_t)c * K::CHB;
+  auto fetch = [&](rsrc_t ra, rsrc_t rb, int c) {
 #pragma unroll
     for (int j = 0; j < K::ND; ++j) {
-      fa[j] = *reinterpret_cast<const v2d*>(ca + fo[j]);
-      fb[j] = *reinterpret_cast<const v2d*>(cb + fo[j]);
+      fa[c & 1][j] = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(ra, fo[j], c * K::CHB, 0));
+      fb[c & 1][j] = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(rb, fo[j], c * K::CHB, 0));
     }
   };
-  auto commit = [&](int slot) {
+  auto commit = [&](int c, int slot) {
+    // pin the staged registers HERE: left alone, the scheduler forms the products right behind the loads (fewer live registers) and
+    // waits for loads it has just issued in the middle of the previous chunk
+#pragma unroll
+    for (int j = 0; j < K::ND; ++j) asm volatile("" : "+v"(fa[c & 1][j]), "+v"(fb[c & 1][j]));
 #pragma unroll
     for (int j = 0; j < K::ND; ++j) {
       const int row = w + K::NW * j;
-      *reinterpret_cast<v2d*>(ring + slot * K::CHB + row * 1024 + (lane << 4)) = fa[j] * fb[j];
+      *reinterpret_cast<v2d*>(ring + slot * K::CHB + row * 1024 + (lane << 4)) = fa[c & 1][j] * fb[c & 1][j];
     }
   };
-  const double* cur = MUL ? planeA(first) : plane_ptr(first, 0);
-  const double* curB = MUL ? planeB(first) : nullptr;
+  const double* cur = MUL ? nullptr : plane_ptr(first, 0);
+  rsrc_t curA = planeA(MUL ? first : 0), curB = planeB(MUL ? first : 0);
   __syncthreads();
   if constexpr (MUL) {
-    fetch(cur, curB, 0);
-    commit(0);
-    fetch(cur, curB, 1);
+    fetch(curA, curB, 0);
+    fetch(curA, curB, 1);
+    commit(0, 0);
+    fetch(curA, curB, 2);
   } else {
 #pragma unroll
     for (int c = 0; c < RING - 1; ++c) stage(cur, c, c);
@@ -347,16 +372,17 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
     for (int term = 0; term < nt; ++term) {
     const bool last_term = term + 1 == nt;
     const int64_t pn = last_term ? (p + pstep < g.nplanes ? p + pstep : p) : p;
-    const double* nxt = MUL ? planeA(pn) : plane_ptr(pn, last_term ? 0 : term + 1);
-    const double* nxtB = MUL ? planeB(pn) : nullptr;
+    const double* nxt = MUL ? nullptr : plane_ptr(pn, last_term ? 0 : term + 1);
+    const rsrc_t nxtA = planeA(MUL ? pn : 0), nxtB = planeB(MUL ? pn : 0);
 #pragma unroll
     for (int c = 0; c < RT; ++c) {
       if constexpr (MUL) {
-        commit((slot0 + c + 1) % RING);                       // chunk c + 1 (fetched during chunk c - 1): its slot was last read at c - 2
-        __syncthreads();
-        if (c + 2 < RT) fetch(cur, curB, c + 2);
-        else if (c + 2 == RT) fetch(nxt, nxtB, 0);
-        // (chunk 1 of the next plane is fetched behind step 2: its 16 registers do not fit beside T and the output tiles)
+        commit(c + 1, (slot0 + c + 1) % RING);                // chunk c + 1 (fetched during chunk c - 2): its slot was last read at c - 2
+        // the ring writes must have landed, the staged loads of chunk c + 2 must NOT be waited for (__syncthreads drains vmcnt too)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (c + 3 < RT) fetch(curA, curB, c + 3);             // into the set the commit has just freed
+        else if (c + 3 < RT + 2) fetch(nxtA, nxtB, c + 3 - RT);
+        // (chunk 2 of the next plane is fetched behind step 2: a second set of 16 registers does not fit beside T and the output tiles)
       } else {
       // (reduction form: no stores inside the loop, hence no drain before them -- every chunk takes the counted wait)
       if (RED || !(c <= RING - 2 && warm)) __builtin_amdgcn_s_waitcnt(vmcnt_imm((RING - 2) * K::ND));
@@ -368,18 +394,19 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
       }
       }
       const unsigned xs = ring_lds + ((slot0 + c) % RING) * K::CHB + lr * K::ROWB;
-      v4d d[4];
-      d[0] = d[1] = d[2] = d[3] = (v4d){0., 0., 0., 0.};
+      v4d tc;
       if constexpr (MUL) {
         constexpr int KH = KP / 2;
         v2d ah[KH];
+        v4d d2[2];
+        d2[0] = d2[1] = (v4d){0., 0., 0., 0.};
 #pragma unroll
         for (int t = 0; t < KH; ++t) asm volatile("ds_read_b128 %0, %1" : "=v"(ah[t]) : "v"(xs + (((4 * t + q) ^ lr) << 4)));
-        inv_step1h<KH, 0, 0, KP>(ah, gz, sgn, d);
-#pragma unroll
-        for (int t = 0; t < KH; ++t) asm volatile("ds_read_b128 %0, %1" : "=v"(ah[t]) : "v"(xs + (((4 * (t + KH) + q) ^ lr) << 4)));
-        inv_step1h<KH, 0, KH, KP>(ah, gz, sgn, d);
+        inv_step1r<KH, 0, KP>(ah, gz, sgn, d2, xs, q, lr);
+        tc = d2[0] + d2[1];
       } else {
+      v4d d[4];
+      d[0] = d[1] = d[2] = d[3] = (v4d){0., 0., 0., 0.};
       v2d a[KP];
 #pragma unroll
       for (int t = 0; t < KP; ++t) {
@@ -387,13 +414,14 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
         asm volatile("ds_read_b128 %0, %1" : "=v"(a[t]) : "v"(addr));
       }
       inv_step1<KP, 0>(a, gz, sgn, d);
+      tc = (d[0] + d[1]) + (d[2] + d[3]);
       }
-      const v4d tc = (d[0] + d[1]) + (d[2] + d[3]);
       t1[c] = (RED && term > 0) ? t1[c] + tc : tc;
     }
     warm = true;
     slot0 = (slot0 + RT) % RING;
     cur = nxt;
+    curA = nxtA;
     curB = nxtB;
     }   // terms
     // ---- step 2: row pairs (2 bx, 2 bx+1) sit in registers (2h, 2h+1): U = sum, V = difference; even output rows from U with
@@ -421,7 +449,7 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
         sso[m] += od * od;
       }
     } else {
-      if constexpr (MUL) fetch(cur, curB, 1);                 // (cur / curB already name the next plane)
+      if constexpr (MUL) fetch(curA, curB, 2);                // (curA / curB already name the next plane)
       else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
       double* const op = g.out + (p / g.ppr) * g.out_row + (p % g.ppr) * g.out_plane + 2 * (16 * jt + lr) + par;
 #pragma unroll

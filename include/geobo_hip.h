@@ -277,7 +277,8 @@ int geobo_xz2d_fold_inv_strided(int n, int64_t rows, int planes_per_row, const d
  * one per plane index, b + r*b_row: one per row): the transposed lattice application has W[r][iz] = Lambda[iz] * lhat_r as its
  * input, and both factors stay in cache where W (8.4 MB per row at 64^3) would be written to HBM and read back.  The kernel stages
  * its chunks through registers (two loads, one multiply, one LDS store per 16 bytes) instead of LDS-DMA and is bound by the matrix
- * pipe.  Same arithmetic as geobo_lattice_wplanes + geobo_xz2d_fold_inv_strided (bit-identical output).  n = 64. */
+ * pipe.  Same arithmetic as geobo_lattice_wplanes + geobo_xz2d_fold_inv_strided up to the summation order of the first contraction
+ * (1e-15).  n = 64. */
 int geobo_xz2d_fold_inv_mul(int n, int64_t rows, int planes_per_row, const double* a, int64_t a_plane, const double* b, int64_t b_row,
                             const double* Fx, const double* Fz, double* out, int64_t out_row, int64_t out_plane,
                             int64_t out_rowstride, void* stream);

@@ -653,7 +653,8 @@ def test_lattice_transposed_application_matches_the_gemm(hip, ny, nrows, monkeyp
             gram.apply_transpose_zx(Lv, nrows, gram.transpose_tables3(lam), out3)
             monkeypatch.delenv("GEOBO_Z_MUL")
             pl2 = slice(pl, N - pl)                     # (the boundary slabs of out2 were overwritten above)
-            assert torch.equal(out3[:, pl2], out2[:, pl2])
+            dev = (out3[:, pl2] - out2[:, pl2]).abs().max().item() / out2[:, pl2].abs().max().item()
+            assert dev <= 1e-14                        # (the k-steps of the first contraction are summed in two chains there, four here)
 
 
 def test_a_sens_slab_origin_is_validated_by_the_library(hip):

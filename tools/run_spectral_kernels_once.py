@@ -40,7 +40,7 @@ if which in ("all", "xcorr"):
     timed("xcorr", R * P * 2.0 * P * n * n, R * P * (n * n + P) * 8.0,
           lambda: hip.xcorr_reduce(n, n, R, P, src, src.stride(0), n * n, Gx, lam, out, out.stride(0), P))
 # ---- radix-2 kernels (round 2): flop = what the folded kernels execute on the matrix pipe (half of the plain products) -------
-if which in ("all", "fold_fwd", "fold_bwd", "xcorr_fold", "fold_inv_ss", "fold_inv_strided"):
+if which in ("all", "fold_fwd", "fold_bwd", "xcorr_fold", "fold_inv_ss", "fold_inv_strided", "fold_inv_mul"):
     import numpy as np
     from geobo_amd.spectral import folded_matrices
     F = hip.to_dev(np.stack(folded_matrices(n), axis=2))
@@ -128,3 +128,11 @@ if which in ("all", "colgemv"):
     m_, n_ = 8448, 2 * n * n * n
     X, v = rnd(m_, n_), rnd(m_)
     timed("colgemv", 2.0 * m_ * n_, m_ * n_ * 8.0, lambda: hip.colgemv(X, v))
+if which in ("all", "fold_inv_mul"):
+    # the same rows of L^-1 A with W = Lambda[iz] * lhat_r formed inside the kernel from the two cache-resident factors: reads 8 MB + 33 MB
+    # (once each, algorithmically), writes the rows
+    lam3, lh = rnd(n * P * P), rnd(R * P * P)
+    out = torch.empty((R, n * n * n), dtype=torch.float64, device=dev)
+    timed("xz2d_fold_inv_mul", R * n * 1.0 * (P * P * n + n * P * n), (n * P * P + R * P * P + R * n * n * n) * 8.0,
+          lambda: hip.xz2d_fold_inv_mul(n, R, n, lam3, P * P, lh, P * P, F, F, out, out.stride(0), n, n * n))
+    del lam3, lh, out
