@@ -644,19 +644,22 @@ class PosteriorEngine:
 
     def _assemble_rows(self, lengths, W, name, amp, props):
         """Row-sharded A K without an exchange: this rank's sensor rows of both operators through the covariance product for ALL
-        voxels and every property block, kept as (rows_r x N) row blocks -- the input of the row Gram (blocks 0, 1) and of the mean."""
+        voxels, property blocks 0 and 1 (what AkA = A K A3^T contracts: the input of the row Gram), kept as (rows_r x N) row blocks.
+        No other block of A K is needed anywhere: the posterior runs in the transposed order, the mean through _mean_rows."""
         sp, rows_r = self._spectral, self.Ms // self.world
         self._fullrows = {}
         for s_, func in ((0, "grav"), (1, "magn")):
             lams, outs = [], []
             for j in props:
-                lams.append(sp.eigenvalues(self._cov_table(hip.kernel_id(name, s_ != j), lengths[j], lengths[s_], W[s_][j], amp)))
-                self._gens[(s_, j)] = lams[-1]
-                outs.append(self._workspace2d("fullrows_%d%d" % (s_, j), rows_r, self.N_pad))
-                self._fullrows[(s_, j)] = outs[-1]
+                gen = sp.eigenvalues(self._cov_table(hip.kernel_id(name, s_ != j), lengths[j], lengths[s_], W[s_][j], amp))
+                self._gens[(s_, j)] = gen
+                if j in (0, 1):
+                    lams.append(gen)
+                    outs.append(self._workspace2d("fullrows_%d%d" % (s_, j), rows_r, self.N_pad))
+                    self._fullrows[(s_, j)] = outs[-1]
             Ar = self._Arows[func]
-            self._timed("spectral_product", sp.flops(rows_r, len(props), self.ny), lambda: sp.product(Ar, rows_r, lams, outs),
-                        valu=sp.flops_valu(rows_r, len(props)))
+            self._timed("spectral_product", sp.flops(rows_r, 2, self.ny), lambda: sp.product(Ar, rows_r, lams, outs),
+                        valu=sp.flops_valu(rows_r, 2))
 
     def _finish_exchange(self):
         """Wait for the row exchange and put the received blocks into A K.  With the row-sharded lattice Gram nothing reads those
@@ -1011,9 +1014,8 @@ class PosteriorEngine:
         at all: mu = (A K)^T (L^-T u), two weighted column sums.  Same arithmetic up to summation order (inversion.py:114-117)."""
         sp, N, Msp, P_c, Md = self._spectral, self.N, self.Ms_pad, len(props), 0 if sel_t is None else sel_t.numel()
         nx, ny, nz = self.nx, self.ny, self.nz
-        cws = self._workspace("colgemv_ws", (max(hip.colgemv_ws_doubles(M_pad, M_pad), hip.colgemv_ws_doubles(M_pad, AK.shape[1])),))
+        cws = self._workspace("colgemv_ws", (max(hip.colgemv_ws_doubles(M_pad, M_pad), hip.colgemv_ws_doubles(Msp, self.N_pad)),))
         w = self._timed("posterior_mean", 0.0, lambda: hip.colgemv(Linv, u, ws=cws))
-        mu_l = self._timed("posterior_mean", 0.0, lambda: hip.colgemv(AK, w, ws=cws))
         Zg, Zm = self._workspace2d("Zg", 2 * Msp, N), self._workspace2d("Zm", Msp, N)
         # Z = L^-1[:, operator columns] A: on a lattice survey a (y, x) convolution of every row's sensor image with the operator's
         # stencil table (lattice_gram.apply_transpose: 2e8 flop per row), otherwise two triangular MFMA GEMMs (2.1e9 flop per row)
@@ -1030,6 +1032,7 @@ class PosteriorEngine:
                 self._lattice_Z(Linv[Msp:2 * Msp, Msp:2 * Msp], Msp, "magn", A_m, Zm, zx=zx)
             self._timed("posterior_zlattice", fl, zlattice)
             Ag = Am = None
+            vec_of = lambda func, wv, out: self._lattice_Z(wv.view(1, -1), 1, func, A_g if func == "grav" else A_m, out)
         else:
             Ag = self._timed("a_sens_grav", 0.0, lambda: self._resident_operator(A_g, "grav"))
             Am = self._timed("a_sens_magn", 0.0, lambda: self._resident_operator(A_m, "magn"))
@@ -1041,6 +1044,8 @@ class PosteriorEngine:
                 hip.gemm_nn(Linv[:2 * Msp, :Msp], Ag[:Msp, :N], Zg, x_lower=True)
                 hip.gemm_nn(Linv[Msp:2 * Msp, Msp:2 * Msp], Am[:Msp, :N], Zm, x_lower=True)
             self._timed("posterior_zgemm", fl, zgemm, alg=alg)
+            vec_of = lambda func, wv, out: hip.colgemv((Ag if func == "grav" else Am)[:Msp, :N], wv, out=out[0], ws=cws)
+        mu_l = self._timed("posterior_mean", 0.0, lambda: self._mean_rows(w, sel_t, lengths, W, name, amp, props, vec_of)).reshape(-1)
         slots = hip.xz2d_fold_inv_ss_slots(nx, sp.R, ny)
         ss = [self._workspace("post_ss_%d" % jj, (slots, ny, nx * nz)) for jj in range(P_c)]
         for t in ss:
@@ -1063,37 +1068,27 @@ class PosteriorEngine:
 
     def _posterior_rows(self, Linv, u, sel_t, lengths, W, name, amp, props, M_pad):
         """The transposed posterior (see _posterior_zpath) sharded by ROWS of L^-1 over the ranks: rank r carries the rows of its own
-        Ms / G gravity and Ms / G magnetic sensors (2 + 1 row blocks of Z = L^-1 A) and a 1/G share of the 128-row drill tile through
-        the covariance product; the partial sums of squares and the partial means (this rank's rows of A K, weighted) meet in ONE
-        all-reduce of 2 P_c N doubles (8 MB at 64^3).  No voxel-column shard of anything exists.  Returns (mu, var), (P_c, N) each,
-        complete on every rank."""
+        Ms / G gravity and Ms / G magnetic sensors (2 + 1 row blocks of Z = L^-1 A) and a 1/G share of the drill rows through the
+        covariance product; the partial sums of squares meet in ONE all-reduce of P_c N doubles (4 MB at 64^3); the mean is three rows
+        through the covariance product and every rank forms it whole (_mean_rows).  No voxel-column shard of anything exists.
+        Returns (mu, var), (P_c, N) each, complete on every rank."""
         sp, N, Msp, P_c, Md = self._spectral, self.N, self.Ms_pad, len(props), 0 if sel_t is None else sel_t.numel()
         nx, ny, nz, G, r = self.nx, self.ny, self.nz, self.world, self.rank
         rows_r = self.Ms // G
         a0, a1 = r * rows_r, Msp + r * rows_r
-        red = self._workspace("rows_reduce", (2, P_c, N))
-        mu, ssq = red[0], red[1]
-        cws = self._workspace("colgemv_ws", (max(hip.colgemv_ws_doubles(M_pad, M_pad), hip.colgemv_ws_doubles(rows_r, self.N_pad)),))
+        ssq = self._workspace("rows_reduce", (P_c, N))
+        cws = self._workspace("colgemv_ws", (hip.colgemv_ws_doubles(M_pad, M_pad),))
+        Eg, Em = self._Aedge["grav"], self._Aedge["magn"]
 
         def mean():
+            # every rank forms the whole mean itself (three rows through the covariance product: cheaper than an all-reduce of it)
             w = hip.colgemv(Linv, u, ws=cws)                                   # L^-T u
-            tmp = self._workspace("rows_mu_tmp", (self.N_pad,))
-            for jj, j in enumerate(props):
-                hip.colgemv(self._fullrows[(0, j)], w[a0:a0 + rows_r], out=tmp, ws=cws)
-                mu[jj].copy_(tmp[:N])
-                hip.colgemv(self._fullrows[(1, j)], w[a1:a1 + rows_r], out=tmp, ws=cws)
-                mu[jj].add_(tmp[:N])
-            if Md and r == 0:                                                  # the drill rows of A K are rows of K itself
-                Xd = self._workspace2d("fullrows_drill", (Md + 127) // 128 * 128, self.N_pad)
-                for jj, j in enumerate(props):
-                    self._cov_rows(name, 2, j, lengths, W, amp, sel_t, 0, Xd[:Md, :N])
-                    hip.colgemv(Xd[:Md], w[2 * Msp:2 * Msp + Md], out=tmp, ws=cws)
-                    mu[jj].add_(tmp[:N])
-        self._timed("posterior_mean", 0.0, mean)
+            return self._mean_rows(w, sel_t, lengths, W, name, amp, props,
+                                   lambda func, wv, out: self._lattice_Z(wv.view(1, -1), 1, func, None, out, edge=Eg if func == "grav" else Em))
+        mu = self._timed("posterior_mean", 0.0, mean)
         gram = self._gram
         zx = gram.zx_supported()
         Zg, Zm = self._workspace2d("Zg", 2 * rows_r, N), self._workspace2d("Zm", rows_r, N)
-        Eg, Em = self._Aedge["grav"], self._Aedge["magn"]
         fl = 3 * rows_r * (gram.flops(1, ny) + 2 * 3 * 2.0 * 128 * 128 * 64)
 
         def zlattice():
@@ -1127,8 +1122,33 @@ class PosteriorEngine:
                 for jj in range(P_c):
                     ssq[jj].add_(part[jj])
             self._timed("posterior_drill_rows", 0.0, drill_rows)
-        self._timed("xgmi_all_reduce", 0.0, lambda: allreduce_sum_(red, G, self.group))
+        self._timed("xgmi_all_reduce", 0.0, lambda: allreduce_sum_(ssq, G, self.group))
         return mu, amp * 1.0 - ssq
+
+    def _mean_rows(self, w, sel_t, lengths, W, name, amp, props, vec_of):
+        """Posterior mean (P_c, N):  mu_j = (A3 K)[:, block j]^T w  re-associated as  K_.j (A3^T w)  -- the covariance blocks are
+        symmetric, so three N-vectors (A_g^T w_g, A_m^T w_m, the drill weights scattered to their voxels) go through the covariance
+        product as ONE row each (0.3 ms) where the weighted column sums of A K read all of it (35 GB at 64^3: 6 ms).
+        vec_of(func, weights, out (1 x N)): out = A_func^T weights.  w = L^-T u (inversion.py:105,115)."""
+        sp, N, Msp, P_c = self._spectral, self.N, self.Ms_pad, len(props)
+        Md = 0 if sel_t is None else sel_t.numel()
+        V = self._workspace2d("mean_rows", 4, N)
+        vec_of("grav", w[:Msp], V[0:1])
+        vec_of("magn", w[Msp:2 * Msp], V[1:2])
+        terms = [(V[0:1], 0), (V[1:2], 1)]
+        if Md:
+            V[2].zero_()
+            V[2][sel_t] = w[2 * Msp:2 * Msp + Md]
+            terms.append((V[2:3], 2))
+        mu = torch.zeros((P_c, N), dtype=F64, device=self.device)
+        tmp = [self._workspace2d("mean_tmp_%d" % jj, 2, N) for jj in range(P_c)]
+        for rows, s_ in terms:
+            gens = [self._gens[(s_, j)] if s_ < 2 else
+                    sp.eigenvalues(self._cov_table(hip.kernel_id(name, s_ != j), lengths[j], lengths[s_], W[s_][j], amp)) for j in props]
+            sp.product(rows, 1, gens, tmp)
+            for jj in range(P_c):
+                mu[jj].add_(tmp[jj][0])
+        return mu
 
     def _drill_rows_ss(self, Linv, d0, nd, sel_t, lengths, W, name, amp, props, gens_g, gens_m, lattice_Z, Ag, Am):
         """(P_c, N) sums of squares of V = L^-1 (A3 K) over the drill rows d0 .. d0 + nd of the row block behind the sensor rows:

@@ -124,8 +124,8 @@ def test_large_cube_modes_on_the_row_exchange_path(assembly, operators, size, tm
 
 def test_emulated_ranks_partial_posteriors_add_up():
     """The row-sharded posterior at the bench's own shape, 64^3 on 8 ranks (512 sensor rows and 16 drill-tile rows per rank), one
-    emulated rank after the other on this device: the partial means and partial sums of squares of the 8 ranks -- what the
-    all-reduce would add -- must add up to the 1-rank posterior.  (A K, the row Gram and the transposed posterior of every rank run
+    emulated rank after the other on this device: the partial sums of squares of the 8 ranks -- what the all-reduce would
+    add -- must add up to the 1-rank posterior variance, and every rank's mean (formed whole on each rank) must be the 1-rank mean.  (A K, the row Gram and the transposed posterior of every rank run
     for real; only AkA, which a lone rank cannot assemble, is the 1-rank step's.)"""
     import bench
     from conftest import settings_for
@@ -163,7 +163,9 @@ def test_emulated_ranks_partial_posteriors_add_up():
         inv.sensor_locations = data[2]
         part = run(inv, data, keep=lambda AkA: AkA.copy_(true_AkA))
         assert inv.engine._rowpath and inv.engine._row_gram()
-        mu = part["mu"] if mu is None else mu + part["mu"]
+        ok1 = ~np.isnan(one["mu"])
+        assert normwise(part["mu"][ok1], one["mu"][ok1]) <= 1e-11       # the mean is formed whole on every rank
+        mu = part["mu"]
         var = part["var"] if var is None else var + part["var"]
         del inv
         torch.cuda.empty_cache()

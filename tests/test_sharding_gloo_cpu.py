@@ -98,8 +98,8 @@ def test_two_rank_sharded_posterior_matches_reference(world):
 
 def _rows_worker(rank, world, port, q):
     """The ROW-sharded form (round 3; engine._assemble_rows / _aka_local_rows / _posterior_rows): a rank owns mg / world sensor rows
-    of each operator and a share of the drill rows; AkA arrives by gather_rows, the partial means and sums of squares of the
-    transposed posterior V = (L^-1 A3) K meet in ONE allreduce_sum_."""
+    of each operator and a share of the drill rows; AkA arrives by gather_rows, the partial sums of squares of the transposed
+    posterior V = (L^-1 A3) K meet in ONE allreduce_sum_; the mean K (A3^T L^-T u) is formed whole on every rank."""
     import sys
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -142,18 +142,20 @@ def _rows_worker(rank, world, port, q):
     dper = -(-md // world)
     drows = np.arange(rank * dper, min(md, (rank + 1) * dper))                        # this rank's share of the drill rows
     mine = np.r_[a0:a0 + rows_r, mg + a0:mg + a0 + rows_r, 2 * mg + drows].astype(int)
-    red = np.zeros((2, len(props), N))
+    red = np.zeros((len(props), N))
+    mu = np.zeros((len(props), N))
+    e_d = np.zeros(N)
+    e_d[sel] = w[2 * mg:]
     for jj, j in enumerate(props):
-        red[0, jj] = AKr[(0, j)].T @ w[a0:a0 + rows_r] + AKr[(1, j)].T @ w[mg + a0:mg + a0 + rows_r]
-        if rank == 0:
-            red[0, jj] += K[(2, j)][sel].T @ w[2 * mg:]
+        # the mean whole on every rank: mu_j = K_0j (A_g^T w_g) + K_1j (A_m^T w_m) + K_2j (drill weights at their voxels)
+        mu[jj] = K[(0, j)].T @ (A[0].T @ w[:mg]) + K[(1, j)].T @ (A[1].T @ w[mg:2 * mg]) + K[(2, j)].T @ e_d
         Z_g, Z_m, Z_d = Linv[mine, :mg] @ A[0], Linv[mine, mg:2 * mg] @ A[1], Linv[mine, 2 * mg:]
         V = Z_g @ K[(0, j)] + Z_m @ K[(1, j)] + Z_d @ K[(2, j)][sel]
-        red[1, jj] = np.einsum("mq,mq->q", V, V)
+        red[jj] = np.einsum("mq,mq->q", V, V)
     t = torch.from_numpy(red)
     allreduce_sum_(t, world)                                                           # <- product collective #2
     if rank == 0:
-        q.put((t[0].reshape(-1).numpy().copy(), (1.0 - t[1]).reshape(-1).numpy().copy(), AkA))
+        q.put((mu.reshape(-1).copy(), (1.0 - t).reshape(-1).numpy().copy(), AkA))
     dist.barrier()
     dist.destroy_process_group()
 
