@@ -503,7 +503,11 @@ class PosteriorEngine:
             self.timings[name] = self.timings.get(name, 0.0) + (now - t0)
         return now
 
-    def _assemble_AK(self, A_g, A_m, sel_t, lengths, W, name, amp, props):
+    def _assemble_AK(self, A_g, A_m, sel_t, lengths, W, name, amp, props, sym=False):
+        """A K.  sym (posterior() sets it when the step will run in the transposed order on a lattice survey): only the blocks AkA's
+        LOWER triangle needs -- (grav rows, blocks 0 and 1), (magn rows, block 1), the drill rows; AkA[magn rows, grav columns] is the
+        transpose of AkA[grav rows, magn columns], and nothing but AkA reads A K in that order (_mean_rows, _posterior_zpath)."""
+        self._ak_sym = bool(sym)
         xyz = self.grid_points()
         Md = 0 if sel_t is None else sel_t.numel()
         off_d = 2 * self.Ms_pad
@@ -528,7 +532,7 @@ class PosteriorEngine:
             for jj in range(len(props)):
                 AK[:, jj * nc + max(self.N - self.c0, 0):(jj + 1) * nc].zero_()
         if self.use_spectral:
-            self._assemble_AK_spectral(AK, A_g, A_m, lengths, W, name, amp, props)
+            self._assemble_AK_spectral(AK, A_g, A_m, lengths, W, name, amp, props, sym)
         for jj, j in enumerate(props):
             cols = slice(jj * nc, (jj + 1) * nc)
             for s_, A in ((0, A_g), (1, A_m)):
@@ -571,7 +575,7 @@ class PosteriorEngine:
         colc = tuple(c[col0:col0 + out.shape[1]] for c in xyz)
         return hip.k_block(kid, rows, colc, lengths[j], lengths[i], W[i][j], amp, out)
 
-    def _assemble_AK_spectral(self, AK, A_g, A_m, lengths, W, name, amp, props):
+    def _assemble_AK_spectral(self, AK, A_g, A_m, lengths, W, name, amp, props, sym=False):
         """Sensor rows of AK through the real-DFT route (geobo_amd/spectral.py): same product, ~200x fewer flops."""
         sp, sset, nc = self._spectral_product(), self.s, self.nc
         plane = self.nx * self.nz
@@ -582,10 +586,13 @@ class PosteriorEngine:
             lams, outs = [], []
             for jj, j in enumerate(props):
                 tab = self._cov_table(hip.kernel_id(name, s_ != j), lengths[j], lengths[s_], W[s_][j], amp)
-                lams.append(sp.eigenvalues(tab))
-                self._gens[(s_, j)] = lams[-1]          # (the transposed posterior path applies the same blocks to L^-1 A_s)
+                gen = sp.eigenvalues(tab)
+                self._gens[(s_, j)] = gen               # (the transposed posterior path applies the same blocks to L^-1 A_s)
+                if sym and (s_, j) not in ((0, 0), (0, 1), (1, 1)):
+                    continue
+                lams.append(gen)
                 outs.append(AK[s_ * self.Ms_pad:s_ * self.Ms_pad + self.Ms, jj * nc:(jj + 1) * nc])
-            fl, fv = sp.flops(self.Ms, len(props), y1 - y0), sp.flops_valu(self.Ms, len(props), y1 - y0)
+            fl, fv = sp.flops(self.Ms, len(lams), y1 - y0), sp.flops_valu(self.Ms, len(lams), y1 - y0)
             if not self.f32 and not isinstance(A, StreamedOperator):
                 self._timed("spectral_product", fl, lambda: sp.product(A, self.Ms, lams, outs, y0, y1), valu=fv)
                 continue
@@ -595,7 +602,7 @@ class PosteriorEngine:
                 # stored as fp32 (fp32 assembly); one batch = the spectral product's own batch size
                 Rb = sp.R
                 abuf = self._op_rows_buffer() if isinstance(A, StreamedOperator) else None
-                scr = [self._workspace2d("ak_rows64_%d" % jj, Rb, nc) for jj in range(len(props))] if self.f32 else None
+                scr = [self._workspace2d("ak_rows64_%d" % jj, Rb, nc) for jj in range(len(lams))] if self.f32 else None
                 for r0 in range(0, self.Ms, Rb):
                     R = min(Rb, self.Ms - r0)
                     if abuf is not None and A.lattice is not None:
@@ -605,7 +612,7 @@ class PosteriorEngine:
                     dst = [b[:R] for b in scr] if scr is not None else [o[r0:r0 + R] for o in outs]
                     sp.product(src, R, lams, dst, y0, y1)
                     if scr is not None:
-                        for jj in range(len(props)):
+                        for jj in range(len(lams)):
                             hip.convert(dst[jj], outs[jj][r0:r0 + R])
             self._timed("spectral_product", fl, batches, valu=fv)
 
@@ -653,13 +660,13 @@ class PosteriorEngine:
             for j in props:
                 gen = sp.eigenvalues(self._cov_table(hip.kernel_id(name, s_ != j), lengths[j], lengths[s_], W[s_][j], amp))
                 self._gens[(s_, j)] = gen
-                if j in (0, 1):
+                if (s_, j) in ((0, 0), (0, 1), (1, 1)):
                     lams.append(gen)
                     outs.append(self._workspace2d("fullrows_%d%d" % (s_, j), rows_r, self.N_pad))
                     self._fullrows[(s_, j)] = outs[-1]
             Ar = self._Arows[func]
-            self._timed("spectral_product", sp.flops(rows_r, 2, self.ny), lambda: sp.product(Ar, rows_r, lams, outs),
-                        valu=sp.flops_valu(rows_r, 2))
+            self._timed("spectral_product", sp.flops(rows_r, len(lams), self.ny), lambda: sp.product(Ar, rows_r, lams, outs),
+                        valu=sp.flops_valu(rows_r, len(lams)))
 
     def _finish_exchange(self):
         """Wait for the row exchange and put the received blocks into A K.  With the row-sharded lattice Gram nothing reads those
@@ -801,6 +808,8 @@ class PosteriorEngine:
         AkA.zero_()
         if self._row_gram() and self._fullrows:
             return self._assemble_AkA_rows(AkA, M_pad, A_g, A_m, sel_t, lengths, name, amp, gp_sigma, props)
+        if getattr(self, "_ak_sym", False):
+            return self._assemble_AkA_sym(AkA, AK, M_pad, A_g, A_m, sel_t, lengths, name, amp, gp_sigma, props)
         # only the LOWER triangle of AkA is consumed (Cholesky, lower=True): block column s needs rows >= s*Ms_pad, and
         # tiles strictly above the diagonal are skipped inside the GEMM (47 % fewer tiles at 64^3)
         for s_, A in ((0, A_g), (1, A_m)):
@@ -881,12 +890,55 @@ class PosteriorEngine:
         allreduce_sum_(AkA, self.world, self.group)
         return self._finish_AkA(AkA, M_pad, sel_t, lengths, name, amp, gp_sigma)
 
+    def _sym_ok(self, A_g, A_m):
+        """The symmetric plan of A K / AkA (see _assemble_AK): the step will run in the transposed order (_zpath_static_ok) and AkA is
+        the lattice Gram for both operators, boundary slabs through their spectra."""
+        if not self._zpath_static_ok():
+            return False
+        return (self._gram is not None and self._gram.edge_supported() and self.Ms_pad == self.nx * self.ny
+                and all(self._lam.get(f) is not None and self._lam[f][0] is A for f, A in (("grav", A_g), ("magn", A_m))))
+
+    def _assemble_AkA_sym(self, AkA, AK, M_pad, A_g, A_m, sel_t, lengths, name, amp, gp_sigma, props):
+        """AkA on one device from the blocks of A K the symmetric plan keeps, row block by row block through the lattice Gram:
+        [grav rows -> grav columns], [grav rows -> magn columns] (transposed into the lower-left block, which is what the
+        factorisation reads), [magn rows -> magn columns], drill rows -> both.  A quarter of the Gram's and of A K's work less than the
+        block-column form, which computes the lower-left block from A_m K_10 as well."""
+        gram, pl, ny, Msp, nc = self._gram, self.nx * self.nz, self.ny, self.Ms_pad, self.nc
+        Md, off_d = 0 if sel_t is None else sel_t.numel(), 2 * self.Ms_pad
+        lam = {0: self._lam["grav"][1], 1: self._lam["magn"][1]}
+        ops = {0: A_g, 1: A_m}
+
+        def edge_cols(sp_, k, iy):
+            A = ops[sp_]
+            if isinstance(A, StreamedOperator):
+                return A.edge[:, k * pl:(k + 1) * pl] if A.lattice is not None else A.slab_into(self._workspace2d("op_slab", Msp, pl), iy, iy + 1)
+            return A[:, iy * pl:(iy + 1) * pl]
+
+        def rows_times_AT(X, nrows, sp_, out):
+            gram.gram_rows(X, nrows, lam[sp_], out, 0, ny)
+            for k, iy in enumerate((0, ny - 1)):
+                gram.edge_rows(X[:, iy * pl:], nrows, self._edge_spectrum(("grav", "magn")[sp_], k, edge_cols(sp_, k, iy)), out)
+        blk = lambda r0, j: AK[r0:, props.index(j) * nc:(props.index(j) + 1) * nc]
+
+        def run():
+            rows_times_AT(blk(0, 0), self.Ms, 0, AkA[0:, 0:Msp])
+            rows_times_AT(blk(0, 1), self.Ms, 1, AkA[0:, Msp:2 * Msp])
+            rows_times_AT(blk(Msp, 1), self.Ms, 1, AkA[Msp:, Msp:2 * Msp])
+            AkA[Msp:2 * Msp, :Msp] = AkA[:Msp, Msp:2 * Msp].t()
+            if Md:
+                rows_times_AT(blk(off_d, 0), Md, 0, AkA[off_d:, 0:Msp])
+                rows_times_AT(blk(off_d, 1), Md, 1, AkA[off_d:, Msp:2 * Msp])
+        self._timed("aka_lattice", gram.flops(3 * self.Ms + 2 * Md, ny), run)
+        return self._finish_AkA(AkA, M_pad, sel_t, lengths, name, amp, gp_sigma)
+
     def _aka_local_rows(self, props, sel_t, lengths, W, name, amp):
         """Row blocks of AkA this rank owns in the row-sharded form: (2, rows_r, 2 Ms_pad) for its gravity / magnetic sensor rows,
         and the drill rows (every rank computes those 50 rows itself: cheaper than shipping them)."""
         gram, pl, G = self._gram, self.nx * self.nz, self.world
         rows_r, Md = self.Ms // G, 0 if sel_t is None else sel_t.numel()
-        loc = self._workspace("aka_rows_local", (2, rows_r, 2 * self.Ms_pad))
+        # [grav rows -> grav | magn columns] and [magn rows -> magn columns]: the block (magn rows, grav columns) is the transpose of
+        # (grav rows, magn columns) and is filled in after the all-gather
+        loc = self._workspace("aka_rows_local", (rows_r, 3 * self.Ms_pad))
         loc.zero_()
         lam = {0: self._lam["grav"][1], 1: self._lam["magn"][1]}
         edge = {0: self._Aedge["grav"], 1: self._Aedge["magn"]}
@@ -900,9 +952,8 @@ class PosteriorEngine:
                     gram.edge_rows(X[:, iy * pl:], nrows, self._edge_spectrum(("grav", "magn")[sp_], k, ycols), out)
                 else:
                     hip.gemm_nt(X[:, iy * pl:(iy + 1) * pl], ycols, out, alpha=1.0, beta=1.0, m_valid=nrows)
-        for s_ in (0, 1):
-            for sp_ in (0, 1):
-                rows_times_AT(self._fullrows[(s_, sp_)], rows_r, sp_, loc[s_][:, sp_ * self.Ms_pad:(sp_ + 1) * self.Ms_pad])
+        for k, (s_, sp_) in enumerate(((0, 0), (0, 1), (1, 1))):
+            rows_times_AT(self._fullrows[(s_, sp_)], rows_r, sp_, loc[:, k * self.Ms_pad:(k + 1) * self.Ms_pad])
         drill = None
         if Md:
             Mdp = (Md + 127) // 128 * 128
@@ -919,13 +970,15 @@ class PosteriorEngine:
         """AkA from row blocks (row exchange + lattice Gram): local correlation of this rank's sensor rows, one all-gather."""
         W = self._W
         rows_r, Md, off_d = self.Ms // self.world, 0 if sel_t is None else sel_t.numel(), 2 * self.Ms_pad
-        fl = self._gram.flops(2 * rows_r + Md, self.ny) * 2
+        fl = self._gram.flops(3 * rows_r + 2 * Md, self.ny)
         loc, drill = self._timed("aka_lattice", fl, lambda: self._aka_local_rows(props, sel_t, lengths, W, name, amp))
         allrows = self._timed("xgmi_all_gather", 0.0, lambda: gather_rows(loc, self.world, self.group))
+        Msp = self.Ms_pad
         for src in range(self.world):
-            for s_ in (0, 1):
-                r0 = s_ * self.Ms_pad + src * rows_r
-                AkA[r0:r0 + rows_r, :off_d].copy_(allrows[src, s_])
+            r0 = src * rows_r
+            AkA[r0:r0 + rows_r, :off_d].copy_(allrows[src][:, :off_d])
+            AkA[Msp + r0:Msp + r0 + rows_r, Msp:off_d].copy_(allrows[src][:, off_d:])
+        AkA[Msp:off_d, :Msp] = AkA[:Msp, Msp:off_d].t()
         if Md:
             AkA[off_d:off_d + Md, :off_d].copy_(drill[:Md])
         return self._finish_AkA(AkA, M_pad, sel_t, lengths, name, amp, gp_sigma)
@@ -955,16 +1008,21 @@ class PosteriorEngine:
             y[2 * self.Ms_pad:2 * self.Ms_pad + len(y_d)] = y_d
         return hip.to_dev(y, self.device)
 
-    def _zpath_ok(self, AK, props, A_g, A_m):
+    def _zpath_static_ok(self):
         """The transposed posterior path needs: one rank, fp64 A K, the radix-2 transform kernels and the Toeplitz y stage of this grid,
-        unpadded sensor rows and voxel columns, the covariance generators of the last A K assembly."""
-        if (self.world != 1 or AK.dtype != F64 or not self.use_spectral or self.exchange or self.Ms != self.Ms_pad or self.N != self.N_pad
+        unpadded sensor rows and voxel columns."""
+        if (self.world != 1 or self.f32 or not self.use_spectral or self.exchange or self.Ms != self.Ms_pad or self.N != self.N_pad
                 or os.environ.get("GEOBO_POSTERIOR", "zpath") != "zpath"):
             return False
-        sp = self._spectral
-        if sp is None or not (sp.fused_xz and sp.fold and sp.dense_y and self.nx == self.nz and "x" in sp.F and sp.ny <= 64):
+        sp = self._spectral_product()
+        if not (sp.fused_xz and sp.fold and sp.dense_y and self.nx == self.nz and "x" in sp.F and sp.ny <= 64):
             return False
-        return self.Ms_pad % sp.R == 0 and all((s_, j) in self._gens for s_ in (0, 1) for j in props)
+        return self.Ms_pad % sp.R == 0
+
+    def _zpath_ok(self, AK, props, A_g, A_m):
+        """... and the covariance generators of the last A K assembly."""
+        return (self._zpath_static_ok() and AK is not None and AK.dtype == F64
+                and all((s_, j) in self._gens for s_ in (0, 1) for j in props))
 
     def _resident_operator(self, A, func):
         """A materialised copy of a forward operator that the route so far only kept implicitly (stencil table + boundary slabs)."""
@@ -1203,7 +1261,8 @@ class PosteriorEngine:
         t = self._tick("start")
         # the data vector goes up first: a pageable host-to-device copy blocks the host until the stream reaches it
         y = self._pad_y(y_g, y_m, y_d, hip.pad_m(2 * self.Ms_pad + len(sel)))
-        AK, M_pad = self._assemble_AK(A_g, A_m, sel_t, lengths, W, kernelfunc, gp_amp, props)
+        AK, M_pad = self._assemble_AK(A_g, A_m, sel_t, lengths, W, kernelfunc, gp_amp, props,
+                                      sym=self._sym_ok(A_g, A_m))
         t = self._tick("ak_fused", t)
         AkA = self._assemble_AkA(AK, M_pad, A_g, A_m, sel_t, lengths, kernelfunc, gp_amp, gp_sigma, props)
         if self.aka_hook is not None:          # tools/emulate_rank.py: keep the assembled matrix (1 rank) / put the true one in place
@@ -1250,7 +1309,10 @@ class PosteriorEngine:
             fl = 2.0 * AK.shape[1] * sum(64.0 * 64 * g + 2560.0 for g in range((Mv + 63) // 64))
             Mu = 2 * self.Ms + len(sel)                                  # unpadded observation rows
             nv = len(props) * min(self.nc, max(self.N - self.c0, 0))     # this rank's voxel-property columns
-            if self._zpath_ok(AK, props, A_g, A_m):
+            zp = self._zpath_ok(AK, props, A_g, A_m)
+            if self._ak_sym and not zp:
+                raise RuntimeError("internal: A K was assembled for the transposed posterior, which is not available")
+            if zp:
                 mu_l, var_l = self._posterior_zpath(Linv, AK, u, A_g, A_m, sel_t, lengths, W, kernelfunc, gp_amp, props, M_pad)
             elif AK.dtype == F64:
                 mu_l, var_l = self._timed("posterior_reduce", fl, lambda: hip.posterior_reduce(
@@ -1274,7 +1336,7 @@ class PosteriorEngine:
                                    self.N_pad, self.world, to_host=self._to_host)
             out["mu"], out["var"] = mu, var
             self._tick("d2h", t)
-        self.last = dict(L=L, Linv=Linv, u=u, AK=AK, props=props, sel=sel)
+        self.last = dict(L=L, Linv=Linv, u=u, AK=AK, AK_complete=AK is not None and not self._ak_sym, props=props, sel=sel)
         return out
 
     @_on_device
@@ -1283,7 +1345,8 @@ class PosteriorEngine:
         the device (A K, L^-1) -- what `predict3(full_cov=True)` returns.  Small cubes only: 9 N^2 doubles are built on the
         device and copied to the host, exactly the object the matrix-free path exists to avoid."""
         last = getattr(self, "last", None)
-        if last is None or tuple(last["props"]) != (0, 1, 2) or self.world != 1 or last["AK"].dtype != F64:
+        if (last is None or tuple(last["props"]) != (0, 1, 2) or self.world != 1 or not last.get("AK_complete", True)
+                or last["AK"].dtype != F64):
             raise RuntimeError("full covariance needs a single-rank fp64 posterior() with all three property blocks")
         n3 = 3 * self.N_pad
         if n3 * n3 * 8 * 2 > limit_bytes:

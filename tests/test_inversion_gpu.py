@@ -385,6 +385,34 @@ def test_transposed_posterior_matches_the_fused_reduction(dims, kernel, props, m
             assert np.isnan(a).all() == np.isnan(b).all()
 
 
+@pytest.mark.parametrize("dims,md", [((64, 48, 64), 20), ((64, 64, 64), 0)])
+def test_symmetric_gram_plan_matches_the_block_column_form(dims, md):
+    """A K / AkA as posterior() assembles them for the transposed order (sym: (grav rows, blocks 0 and 1), (magn rows, block 1); AkA's
+    lower-left block transposed from the upper-right one) against the block-column form that computes A_m K_10 and correlates it as
+    well: the lower triangle the factorisation reads must agree."""
+    import bench
+    import geobo_amd.engine as E
+    s = settings_for(*dims, kernelfunc="matern32")
+    inv = _inv(s, props=(0, 1))
+    grav, mag, loc, drill0 = bench.synthetic_inputs(inv, md)
+    eng = inv.engine
+    eng.clear_operators()
+    A_g, A_m = eng.operator("grav", loc, B=s.magneticField * 0.), eng.operator("magn", loc, B=s.magneticField)
+    sel = np.nonzero(drill0.reshape(-1) != 0)[0] if md else np.zeros(0, dtype=np.int64)
+    sel_t = torch.as_tensor(sel, device="cuda") if md else None
+    lengths = [float(v) for v in E.create_cov_lengths(np.array([200.0, 202.0, 204.0]))]
+    W = E.weight_matrix(s.gp_coeff)
+    eng._W = W
+    out = {}
+    for sym in (False, True):
+        assert (not sym) or eng._sym_ok(A_g, A_m)
+        AK, M_pad = eng._assemble_AK(A_g, A_m, sel_t, lengths, W, "matern32", 1.0, (0, 1), sym=sym)
+        out[sym] = torch.tril(eng._assemble_AkA(AK, M_pad, A_g, A_m, sel_t, lengths, "matern32", 1.0, s.gp_err, (0, 1))).clone()
+    d = (out[True] - out[False]).abs().max().item() / out[False].abs().max().item()
+    print(dims, "symmetric plan vs block columns: %.2e" % d)
+    assert d <= 1e-13
+
+
 def test_fp32_assembly_tracks_fp64_at_32_and_the_headline_shape():
     """fp32 assembly vs the fp64 route on the same inputs: 32^3 (config 2's size) and 64^3 x 2 properties (headline shape)."""
     import bench
@@ -710,6 +738,8 @@ def _independent_checks_64(inv, s, G, Ag_o, Am_o, sens, lengths, W, what):
             r = sens[k]
             w = {j: O.ak_row_fft(G, A_o[k], "matern32", lengths, W, s_, j) for j in (0, 1, 2)}
             for jj, j in enumerate((0, 1)):                                  # rows of A K (the spectral product, P_c = 2)
+                if eng._ak_sym and (s_, j) == (1, 0):
+                    continue     # not assembled: AkA's lower-left block is the transpose of (grav rows, magn columns) -- checked below
                 got = AK[off[s_] + r, jj * N:(jj + 1) * N].cpu().numpy()
                 e = np.abs(got - w[j]).max() / np.abs(w[j]).max()
                 print("64^3 [%s] A K row %d block (%d,%d) vs oracle: %.2e" % (what, r, s_, j, e))

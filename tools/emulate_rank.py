@@ -101,7 +101,7 @@ def main():
         a2a_per_peer = rows_r * P_c * nc * 8.0 if (eng.exchange and not rowp) else 0.0   # one operator, one destination
         a2a_total = 2 * (G - 1) * a2a_per_peer                                       # both operators, all peers
         if eng.exchange and eng._row_gram():
-            aka_bytes_in = (G - 1) * 2.0 * rows_r * 2 * Ms_pad * 8.0                 # all-gather of row blocks: what a rank receives
+            aka_bytes_in = (G - 1) * rows_r * (3.0 if rowp else 4.0) * Ms_pad * 8.0   # all-gather of row blocks: what a rank receives
             aka_kind = "all_gather of AkA row blocks"
         else:
             aka_bytes_in = 2.0 * (G - 1) / G * true_AkA.numel() * 8.0                # ring all-reduce: 2 (G-1)/G S per rank
