@@ -860,9 +860,10 @@ def test_row_sharded_exchange_matches_dense_columns():
 
 
 def test_row_sharded_lattice_gram_matches_the_single_rank_AkA():
-    """Row exchange + lattice Gram (>= 4 ranks): every rank correlates its OWN sensor rows of A K (all voxels, taken from its send
-    buffer before the all-to-all) with the stencil table and AkA arrives as row blocks by an all-gather.  Four ranks simulated on
-    one device; the assembled matrix against the single-rank AkA (lower triangle incl. drill rows)."""
+    """Row-sharded lattice Gram: every rank correlates its OWN sensor rows of A K (all voxels; the three blocks AkA's lower triangle
+    needs) with the stencil tables and AkA arrives as row blocks by an all-gather, the (magn, grav) block transposed from
+    (grav, magn).  Four ranks simulated on one device; the assembled matrix against the single-rank block-column AkA (lower triangle
+    incl. drill rows)."""
     import geobo_amd.engine as E
     from geobo_amd.spectral import SpectralProduct
     nx, ny, nz = 64, 48, 64
@@ -891,21 +892,23 @@ def test_row_sharded_lattice_gram_matches_the_single_rank_AkA():
         assert e.exchange
         e.operator("grav", loc), e.operator("magn", loc)
         assert e._row_gram()
-        e._spectral = e._spectral or SpectralProduct(nx, ny, nz, e.device)
-        send = [e._exchange_send(s_, func, lengths, W, "matern32", 1.0, props) for s_, func in ((0, "grav"), (1, "magn"))]
-        e._keep_full_rows(send, props)
+        e._spectral_product()
+        assert e._rows_posterior_ok()
+        e._assemble_rows(lengths, W, "matern32", 1.0, props)       # this rank's rows of A K: (grav, 0), (grav, 1), (magn, 1)
         lo, dr = e._aka_local_rows(props, sel_t, lengths, W, "matern32", 1.0)
         blocks.append(lo.clone())
         drill = dr.clone()
-        del e, send, lo, dr
+        del e, lo, dr
+        gc.collect()
         torch.cuda.empty_cache()
     eng = E.PosteriorEngine(s, rank=0, world=world)
-    rows_r, off_d, Md = eng.Ms // world, 2 * eng.Ms_pad, sel_t.numel()
+    rows_r, Msp, off_d, Md = eng.Ms // world, eng.Ms_pad, 2 * eng.Ms_pad, sel_t.numel()
     AkA = torch.zeros((M_pad, M_pad), dtype=torch.float64, device="cuda")
-    for src in range(world):
-        for s_ in (0, 1):
-            r0 = s_ * eng.Ms_pad + src * rows_r
-            AkA[r0:r0 + rows_r, :off_d] = blocks[src][s_]
+    for src in range(world):                                       # what _assemble_AkA_rows does with the gathered blocks
+        r0 = src * rows_r
+        AkA[r0:r0 + rows_r, :off_d] = blocks[src][:, :off_d]
+        AkA[Msp + r0:Msp + r0 + rows_r, Msp:off_d] = blocks[src][:, off_d:]
+    AkA[Msp:off_d, :Msp] = AkA[:Msp, Msp:off_d].t()
     AkA[off_d:off_d + Md, :off_d] = drill[:Md]
     got = torch.tril(eng._finish_AkA(AkA, M_pad, sel_t, lengths, "matern32", 1.0, s.gp_err))
     d = (got - ref).abs().max().item()
