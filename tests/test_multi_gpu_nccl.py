@@ -87,6 +87,19 @@ def test_four_gloo_ranks_row_exchange_and_row_gram(posterior, tmp_path):
     assert abs(float(four["logl"]) - float(one["logl"])) <= 1e-10 * abs(float(one["logl"]))
 
 
+def test_two_gloo_ranks_row_sharded_posterior_three_property_blocks(tmp_path):
+    """The row-sharded form with all three property blocks (the drill-core property has no sensor rows of its own: its cubes come from
+    the cross blocks K_02, K_12, K_22 alone) on 2 ranks against the 1-rank run, 64 x 48 x 64."""
+    env = {"GEOBO_TEST_PROPS": "3"}
+    one = _run_ranks(1, "gloo", str(tmp_path / "p1.npz"), "64x48x64", env_extra=env)
+    two = _run_ranks(2, "gloo", str(tmp_path / "p2.npz"), "64x48x64", env_extra=env)
+    assert int(two["world"]) == 2 and bool(two["rowpath"])
+    assert not any(np.isnan(c).all() for c in one["cubes"])
+    for a, b in zip(two["cubes"], one["cubes"]):
+        assert normwise(a, b) <= 1e-10
+    assert abs(float(two["logl"]) - float(one["logl"])) <= 1e-10 * abs(float(one["logl"]))
+
+
 @pytest.mark.parametrize("world", [2, 8])
 def test_gloo_ranks_row_sharded_posterior_at_64(world, tmp_path):
     """64^3 (the bench workload) on 2 and 8 ranks sharing this box's device: the row-sharded posterior with the fused (row, z)-plane
