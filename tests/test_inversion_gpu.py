@@ -349,7 +349,7 @@ def test_transposed_posterior_matches_the_fused_reduction(dims, kernel, props, m
     import bench
     s = settings_for(*dims, kernelfunc=kernel)
     forms = [("dense", {"GEOBO_POSTERIOR": "dense"}), ("default", {}), ("two-GEMM inverse", {"GEOBO_Z_FUSED": "0"}), ("GEMM Z", {"GEOBO_Z_LATTICE": "0"})]
-    out, seen, inputs = {}, {}, None
+    out, seen, nll, inputs = {}, {}, {}, None
     for name, env in forms:
         for k in ("GEOBO_POSTERIOR", "GEOBO_Z_FUSED", "GEOBO_Z_LATTICE"):
             monkeypatch.delenv(k, raising=False)
@@ -369,6 +369,9 @@ def test_transposed_posterior_matches_the_fused_reduction(dims, kernel, props, m
         out[name] = inv.cubing(grav, mag, drill0[drill0 != 0], loc, drill0)
         seen[name] = {e[0] for e in inv.engine.kernel_events if e[0].startswith("posterior")}
         inv.engine.kernel_events = None
+        if kernel != "matern32":          # (equal lengths: the Matern cross term is NaN there, as in the reference)
+            # likelihood-only evaluation (optimize_gp's objective): A K / AkA in whatever plan the form uses, no posterior
+            nll[name] = inv.calc_logl(np.array([1.0, 2.0, 1.0, 0.2, 0.2]))
         del inv
         gc.collect()                     # (engine <-> closure cycles: the workspaces of a 64^3 engine are ~100 GB)
         torch.cuda.empty_cache()
@@ -376,6 +379,8 @@ def test_transposed_posterior_matches_the_fused_reduction(dims, kernel, props, m
     assert seen["dense"] == {"posterior_reduce"}
     assert ("posterior_zlattice" if lattice else "posterior_zgemm") in seen["default"] and "posterior_reduce" not in seen["default"]
     assert "posterior_zgemm" in seen["GEMM Z"] and "posterior_zlattice" not in seen["GEMM Z"]
+    for name, v in nll.items():
+        assert np.isfinite(v) and abs(v - nll["dense"]) <= 1e-10 * abs(nll["dense"]), (name, v, nll["dense"])
     ref = out["dense"]
     for name, _ in forms[1:]:
         errs = [normwise(a, b) for a, b in zip(out[name], ref) if not np.isnan(b).all()]
