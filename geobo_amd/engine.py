@@ -1240,13 +1240,22 @@ class PosteriorEngine:
                 acc[jj].add_((Vd[jj][:n] ** 2).sum(0))
         return acc
 
-    def _full_to_host(self, t, props, slot):
-        """(P_c, N) device result, complete on this rank -> the reference's (3N,) property-major host vector (NaN: blocks not computed)."""
-        h = self._to_host(t.reshape(-1), slot)
-        out = np.full(3 * self.N, np.nan)
-        for jj, j in enumerate(props):
-            out[j * self.N:(j + 1) * self.N] = h[jj * self.N:(jj + 1) * self.N]
-        return out
+    def _results_to_host(self, mu, var, props):
+        """(P_c N) device mean and variance, complete on this rank -> the reference's two (3N,) property-major host vectors (NaN: blocks
+        not computed).  One device-to-host copy and one synchronisation for both; only the missing blocks are filled."""
+        N, P_c = self.N, len(props)
+        h = self._to_host(torch.cat([mu.reshape(-1)[:P_c * N], var.reshape(-1)[:P_c * N]]), 0)
+        outs = []
+        for k in range(2):
+            out = np.empty(3 * N)
+            for j in range(3):
+                if j in props:
+                    jj = props.index(j)
+                    out[j * N:(j + 1) * N] = h[(k * P_c + jj) * N:(k * P_c + jj + 1) * N]
+                else:
+                    out[j * N:(j + 1) * N] = np.nan
+            outs.append(out)
+        return outs
 
     @_on_device
     def posterior(self, A_g, A_m, sel, y_g, y_m, y_d, lengths, crossweights, kernelfunc, gp_sigma, gp_amp=1.0,
@@ -1300,7 +1309,7 @@ class PosteriorEngine:
             mu_f, var_f = self._posterior_rows(Linv, u, sel_t, lengths, W, kernelfunc, gp_amp, props, M_pad)
             check_factor()
             t = self._tick("posterior", t)
-            out["mu"], out["var"] = self._full_to_host(mu_f, props, 0), self._full_to_host(var_f, props, 1)
+            out["mu"], out["var"] = self._results_to_host(mu_f, var_f, props)
             self._tick("d2h", t)
         elif want_mean_var:
             # executed flop: every 64-row wavefront group g of the valid rows contracts the 64 g columns in front of its diagonal
@@ -1330,11 +1339,14 @@ class PosteriorEngine:
                 mu_l, var_l = self._timed("posterior_reduce", fl, panels, alg=(1.0 * Mu * Mu + 4.0 * Mu) * nv)
             check_factor()
             t = self._tick("posterior", t)
-            mu = assemble_columns(gather_slices(mu_l, len(props), self.N_pad, self.world, self.group), props, self.N,
-                                  self.N_pad, self.world, to_host=self._to_host)
-            var = assemble_columns(gather_slices(var_l, len(props), self.N_pad, self.world, self.group), props, self.N,
-                                   self.N_pad, self.world, to_host=self._to_host)
-            out["mu"], out["var"] = mu, var
+            if self.world == 1 and self.N == self.N_pad:
+                out["mu"], out["var"] = self._results_to_host(mu_l, var_l, props)
+            else:
+                mu = assemble_columns(gather_slices(mu_l, len(props), self.N_pad, self.world, self.group), props, self.N,
+                                      self.N_pad, self.world, to_host=self._to_host)
+                var = assemble_columns(gather_slices(var_l, len(props), self.N_pad, self.world, self.group), props, self.N,
+                                       self.N_pad, self.world, to_host=self._to_host)
+                out["mu"], out["var"] = mu, var
             self._tick("d2h", t)
         self.last = dict(L=L, Linv=Linv, u=u, AK=AK, AK_complete=AK is not None and not self._ak_sym, props=props, sel=sel)
         return out
