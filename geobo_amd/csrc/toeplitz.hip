@@ -58,9 +58,15 @@ typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 // at all.  Groups of GX inputs, double buffered: group g+1 is requested before the FMAs of group g.
 constexpr int GX = 4;
 
-template <int NY, int OC, int G>
+template <int NY, int OC, int G, int O0 = 0>
 __device__ __forceinline__ void toeplitz_group(const double (&t)[NY], double (&acc)[OC], double (&xb)[2][GX], unsigned xaddr, int xstep) {
   constexpr int NGX = NY / GX;
+  if constexpr (G == 0) {
+    // the first group is requested HERE, inside the (possibly branched-to) body that consumes it: registers an inline-asm read is
+    // still filling must not cross a branch -- the compiler may copy them at the join before the data has landed
+#pragma unroll
+    for (int i = 0; i < GX; ++i) asm volatile("ds_read_b64 %0, %1" : "=v"(xb[0][i]) : "v"(xaddr + (unsigned)(i * xstep)));
+  }
   __builtin_amdgcn_sched_barrier(0);   // keep the groups apart: interleaving them costs registers the table needs
   if constexpr (G + 1 < NGX) {
 #pragma unroll
@@ -77,24 +83,26 @@ __device__ __forceinline__ void toeplitz_group(const double (&t)[NY], double (&a
     const double x = xb[G & 1][i];
 #pragma unroll
     for (int o = 0; o < OC; ++o) {
-      const int d = o - yp;
+      const int d = O0 + o - yp;
       acc[o] = (yp == 0) ? t[d < 0 ? -d : d] * x : __builtin_fma(t[d < 0 ? -d : d], x, acc[o]);
     }
   }
-  if constexpr (G + 1 < NGX) toeplitz_group<NY, OC, G + 1>(t, acc, xb, xaddr, xstep);
+  if constexpr (G + 1 < NGX) toeplitz_group<NY, OC, G + 1, O0>(t, acc, xb, xaddr, xstep);
 }
 
-// Workgroup = 2 * nprop waves sharing ONE row at a time: wave (prop, half).  The next row streams into the other half
-// of a 2 x NY x 512 B LDS ring by LDS-DMA (no registers, issued a whole row -- ~7 us of arithmetic -- ahead), so the
-// VALU never waits on HBM and each input is fetched once per workgroup for both property blocks.
-template <int NY>
+// Workgroup = 2 * nprop * Q waves sharing ONE row at a time: wave (prop, part q of a half, half).  The next row streams into the
+// other half of a 2 x NY x 512 B LDS ring by LDS-DMA (no registers, issued a whole row -- ~7 us of arithmetic -- ahead), so the
+// VALU never waits on HBM and each input is fetched once per workgroup for both property blocks.  Q = 2 (a single property block:
+// every half of the outputs split between two waves) keeps four waves per workgroup -- the LDS ring allows two workgroups per CU,
+// and with two waves each the one-block launches of the symmetric A K plan ran at 3.5 TB/s against 4.4 for the two-block ones.
+template <int NY, int Q>
 __global__ void __launch_bounds__(256, 2) toeplitz_y_kernel(ToeplitzArgs g) {
-  constexpr int OC = NY / 2;
+  constexpr int OC = NY / 2 / Q;
   __shared__ __attribute__((aligned(16))) double xs[2][NY][64];
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nw = 2 * g.nprop;
+  const int nw = 2 * g.nprop * Q;
   const unsigned lane8 = (unsigned)lane * 8u;
-  const int prop = w >> 1, half = w & 1;
+  const int prop = w / (2 * Q), half = w & 1, qq = (w >> 1) % Q;
   const int64_t C = g.S, c0 = (int64_t)blockIdx.x * 64;     // C: plane stride of the data from here on (the table's is g.C)
   const int C8 = (int)(C * 8), out_bytes = (g.y1 - g.y0) * C8;
   double t[NY];
@@ -130,9 +138,12 @@ __global__ void __launch_bounds__(256, 2) toeplitz_y_kernel(ToeplitzArgs g) {
     }
     double acc[OC], xb[2][GX];
     const unsigned xaddr = (unsigned)(uintptr_t)(lds_ptr_t)&xs[b][half ? NY - 1 : 0][0] + lane8;
-#pragma unroll
-    for (int i = 0; i < GX; ++i) asm volatile("ds_read_b64 %0, %1" : "=v"(xb[0][i]) : "v"(xaddr + (unsigned)(i * xstep)));
-    toeplitz_group<NY, OC, 0>(t, acc, xb, xaddr, xstep);
+    if constexpr (Q == 1) {
+      toeplitz_group<NY, OC, 0>(t, acc, xb, xaddr, xstep);
+    } else {
+      if (qq == 0) toeplitz_group<NY, OC, 0, 0>(t, acc, xb, xaddr, xstep);      // (the distances o - y' index the register table: static)
+      else toeplitz_group<NY, OC, 0, OC>(t, acc, xb, xaddr, xstep);
+    }
     // pin the sums here: otherwise the tail of every sum is sunk into its (predicated) store block, which keeps the last
     // inputs and half the table live across all of them (spills; scratch reloads are VMEM and drain the prefetch)
 #pragma unroll
@@ -146,7 +157,7 @@ __global__ void __launch_bounds__(256, 2) toeplitz_y_kernel(ToeplitzArgs g) {
     asm volatile("" : "+s"(y0), "+s"(y1), "+s"(pitch));
 #pragma unroll
     for (int o = 0; o < OC; ++o) {
-      const int y = ybase + ysgn * o;
+      const int y = ybase + ysgn * (qq * OC + o);
       if (y >= y0 && y < y1) st_lane(dst, lane8, (y - y0) * pitch, acc[o]);
     }
     po += rstep * ostep;
@@ -290,7 +301,10 @@ template <int NY>
 int launch(const ToeplitzArgs& g, hipStream_t st) {
   int64_t gy = g.R < 4 ? g.R : 4;  // 256 column blocks x 4 at 64^3: every workgroup sweeps R/4 rows with one table load
   while ((g.C / 64) * gy < 1024 && gy < g.R) ++gy;
-  hipLaunchKernelGGL((toeplitz_y_kernel<NY>), dim3((unsigned)(g.C / 64), (unsigned)gy), dim3(128 * g.nprop), 0, st, g);
+  if (g.nprop == 1 && NY % 4 == 0 && NY >= 32)
+    hipLaunchKernelGGL((toeplitz_y_kernel<NY, 2>), dim3((unsigned)(g.C / 64), (unsigned)gy), dim3(256), 0, st, g);
+  else
+    hipLaunchKernelGGL((toeplitz_y_kernel<NY, 1>), dim3((unsigned)(g.C / 64), (unsigned)gy), dim3(128 * g.nprop), 0, st, g);
   return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
 }
 
