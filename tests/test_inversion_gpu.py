@@ -390,6 +390,39 @@ def test_transposed_posterior_matches_the_fused_reduction(dims, kernel, props, m
             assert np.isnan(a).all() == np.isnan(b).all()
 
 
+def test_transposed_posterior_in_an_ill_conditioned_regime():
+    """Length scales of 8 voxels, noise 0.01, amplitude 2 (the corner optimize_gp explores; cond(AkA) ~ 1e7 where the other cases have
+    ~1e5): the transposed order against the fused reduction on 64 x 48 x 64.  Both are the reference's arithmetic re-associated, so
+    they may differ by cond x eps -- the bound is the north-star tolerance of the cubes."""
+    import bench
+    s = settings_for(64, 48, 64, kernelfunc="exp", gp_err=[0.01, 0.01, 0.01])
+    out, inputs = {}, None
+    for name in ("dense", "zpath"):
+        os.environ.pop("GEOBO_POSTERIOR", None)
+        if name == "dense":
+            os.environ["GEOBO_POSTERIOR"] = "dense"
+        try:
+            inv = _inv(s, props=(0, 1))
+            if inputs is None:
+                inputs = bench.synthetic_inputs(inv, 20)
+            grav, mag, loc, drill0 = inputs
+            inv.engine.clear_operators()
+            inv.gp_amp = 2.0
+            inv.gp_length = np.array([800.0, 800.0, 800.0])
+            out[name] = inv.cubing(grav, mag, drill0[drill0 != 0], loc, drill0)
+            if name == "zpath":
+                Ld = torch.diagonal(inv.engine.last["L"])[:2 * inv.engine.Ms]
+                print("diag(L) range %.2e .. %.2e" % (Ld.min().item(), Ld.max().item()))
+        finally:
+            os.environ.pop("GEOBO_POSTERIOR", None)
+        del inv
+        gc.collect()
+        torch.cuda.empty_cache()
+    errs = [normwise(a, b) for a, b in zip(out["zpath"], out["dense"]) if not np.isnan(b).all()]
+    print("ill-conditioned, transposed vs fused:", " ".join("%.1e" % e for e in errs))
+    assert len(errs) == 4 and max(errs) <= 1e-8
+
+
 @pytest.mark.parametrize("dims,md", [((64, 48, 64), 20), ((64, 64, 64), 0)])
 def test_symmetric_gram_plan_matches_the_block_column_form(dims, md):
     """A K / AkA as posterior() assembles them for the transposed order (sym: (grav rows, blocks 0 and 1), (magn rows, block 1); AkA's
