@@ -77,6 +77,46 @@ def soak(seed=0, seconds=None, iters=60, verbose=True):
             e = (outs[j] - ref).abs().max().item() / ref.abs().max().item()
             if not e < 1e-13:
                 bad += 1; print("toeplitz R=%d C=%d err %.3e" % (R, C, e), flush=True)
+        # single-block launch (every half of the outputs split between two waves), random output slab
+        ya = int(rng.integers(0, n - 1)); yb = int(rng.integers(ya + 1, n + 1))
+        out1 = torch.empty((R, yb - ya, C), dtype=torch.float64, device="cuda")
+        hip.toeplitz_y(n, C, R, srct.reshape(-1), [tabs[0].reshape(-1)], [out1.reshape(-1)], ya, yb)
+        ref = torch.einsum("ypc,rpc->ryc", tabs[0][idx], srct)[:, ya:yb]
+        e = (out1 - ref).abs().max().item() / ref.abs().max().item()
+        if not e < 1e-13:
+            bad += 1; print("toeplitz single block R=%d C=%d slab [%d, %d) err %.3e" % (R, C, ya, yb, e), flush=True)
+        # ---- round 3: the inverse transform's other modes on the same plane counts -------------------------------------------
+        rows2, ppr2 = int(rng.integers(1, 24)), int(rng.integers(1, 96))
+        s1 = rnd(rows2, ppr2 * P * P + 16)
+        ref1 = torch.einsum("ai,rpik,bk->rpab", GfT, s1[:, :ppr2 * P * P].reshape(rows2, ppr2, P, P), GfT)
+        # (a) strided rows: planes written as [y][p][x] instead of [p][y][x]
+        outs_ = torch.empty((rows2, n * ppr2 * n), dtype=torch.float64, device="cuda")
+        hip.xz2d_fold_inv_strided(n, rows2, ppr2, s1, s1.stride(0), P * P, Ff, Ff, outs_, outs_.stride(0), n, ppr2 * n)
+        e = (outs_.reshape(rows2, n, ppr2, n).permute(0, 2, 1, 3) - ref1).abs().max().item() / ref1.abs().max().item()
+        if not e < 1e-13:
+            bad += 1; print("fold_inv_strided rows=%d ppr=%d err %.3e" % (rows2, ppr2, e), flush=True)
+        # (b) product input: plane (r, p) = a[p] * b[r], formed in the kernel
+        fa_, fb_ = rnd(ppr2, P * P), rnd(rows2, P * P)
+        refm = torch.einsum("ai,rpik,bk->rpab", GfT, (fa_[None, :, :] * fb_[:, None, :]).reshape(rows2, ppr2, P, P), GfT)
+        outm = torch.empty((rows2, n * ppr2 * n), dtype=torch.float64, device="cuda")
+        hip.xz2d_fold_inv_mul(n, rows2, ppr2, fa_, P * P, fb_, P * P, Ff, Ff, outm, outm.stride(0), n, ppr2 * n)
+        e = (outm.reshape(rows2, n, ppr2, n).permute(0, 2, 1, 3) - refm).abs().max().item() / refm.abs().max().item()
+        if not e < 1e-13:
+            bad += 1; print("fold_inv_mul rows=%d ppr=%d err %.3e" % (rows2, ppr2, e), flush=True)
+        # (c) sum of squares over the rows, rows >= r2 with a second term
+        s2 = rnd(rows2, ppr2 * P * P + 16)
+        r2 = int(rng.integers(0, rows2 + 1))
+        slots = hip.xz2d_fold_inv_ss_slots(n, rows2, ppr2)
+        ss = torch.zeros((slots, ppr2, n * n), dtype=torch.float64, device="cuda")
+        hip.xz2d_fold_inv_ss(n, rows2, ppr2, s1, s1.stride(0), P * P, Ff, Ff, ss, src2=s2 if r2 < rows2 else None, in2_row=s2.stride(0),
+                             r2_first=r2)
+        tot = ref1.clone()
+        if r2 < rows2:
+            tot[r2:] += torch.einsum("ai,rpik,bk->rpab", GfT, s2[:rows2 - r2, :ppr2 * P * P].reshape(rows2 - r2, ppr2, P, P), GfT)
+        refs_ = (tot ** 2).sum(0).reshape(ppr2, n * n)
+        e = (ss.sum(0) - refs_).abs().max().item() / refs_.abs().max().item()
+        if not e < 1e-12:
+            bad += 1; print("fold_inv_ss rows=%d ppr=%d r2=%d err %.3e" % (rows2, ppr2, r2, e), flush=True)
     if verbose:
         print("soak: %d iterations, %d mismatches" % (it, bad))
     return it, bad
