@@ -167,7 +167,9 @@ class SpectralProduct:
         fn = lambda: hip.toeplitz_y(ny, C, R, src, tabs, outs, y0, y1, plane=plane)
         if self.kernel_timer is None:
             return fn()
-        return self.kernel_timer("kernel:toeplitz_y", 8.0 * R * C * (ny + len(tabs) * (y1 - y0)), fn)
+        # (one name per kernel symbol: single-block launches run toeplitz_y_kernel<ny, 2>, the others <ny, 1>)
+        name = "kernel:toeplitz_y" if len(tabs) >= 2 or ny == 128 else "kernel:toeplitz_y_single"
+        return self.kernel_timer(name, 8.0 * R * C * (ny + len(tabs) * (y1 - y0)), fn)
 
     def buf(self, name, n):
         b = self._bufs.get(name)
