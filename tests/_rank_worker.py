@@ -29,7 +29,7 @@ def main():
     props = (0, 1) if dims[0] >= 64 and os.environ.get("GEOBO_TEST_PROPS", "") != "3" else (0, 1, 2)
     inv = Inversion(settings=s, props=props, rank=rank, world=world, device="cuda:%d" % local,
                     assembly=assembly, operators=operators)
-    grav, mag, loc, drill0 = bench.synthetic_inputs(inv, 20)
+    grav, mag, loc, drill0 = bench.synthetic_inputs(inv, int(os.environ.get("GEOBO_TEST_DRILL", "20")))
     inv.engine.clear_operators()
     inv.gp_length = np.array([200.0, 202.0, 204.0])
     cubes = inv.cubing(grav, mag, drill0[drill0 != 0], loc, drill0)

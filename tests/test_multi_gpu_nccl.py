@@ -100,6 +100,19 @@ def test_two_gloo_ranks_row_sharded_posterior_three_property_blocks(tmp_path):
     assert abs(float(two["logl"]) - float(one["logl"])) <= 1e-10 * abs(float(one["logl"]))
 
 
+def test_two_gloo_ranks_row_sharded_posterior_without_drill_rows(tmp_path):
+    """No drill constraints (M = 2 Ms exactly: no rows behind the sensor rows, no drill share, no drill term in the mean)."""
+    env = {"GEOBO_TEST_DRILL": "0"}
+    one = _run_ranks(1, "gloo", str(tmp_path / "d1.npz"), "64x48x64", env_extra=env)
+    two = _run_ranks(2, "gloo", str(tmp_path / "d2.npz"), "64x48x64", env_extra=env)
+    assert int(two["world"]) == 2 and bool(two["rowpath"])
+    for a, b in zip(two["cubes"], one["cubes"]):
+        if np.isnan(b).all():
+            assert np.isnan(a).all()
+        else:
+            assert normwise(a, b) <= 1e-10
+
+
 @pytest.mark.parametrize("world", [2, 8])
 def test_gloo_ranks_row_sharded_posterior_at_64(world, tmp_path):
     """64^3 (the bench workload) on 2 and 8 ranks sharing this box's device: the row-sharded posterior with the fused (row, z)-plane
