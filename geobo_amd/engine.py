@@ -442,6 +442,16 @@ class PosteriorEngine:
         torch.cuda.current_stream(self.device).synchronize()
         return buf[:n].numpy()
 
+    def _to_host_async(self, t, slot=0):
+        """Queue the copy of _to_host without waiting for it: the returned array is valid after the caller's next synchronize of the
+        current stream (one wait for all the read-backs of a step: status word, likelihood statistics, mean and variance)."""
+        n = t.numel()
+        buf = self._host.get(slot)
+        if buf is None or buf.numel() < n or buf.dtype != t.dtype:
+            buf = self._host[slot] = torch.empty(max(n, 1), dtype=t.dtype, pin_memory=True)
+        buf[:n].copy_(t.detach().reshape(-1), non_blocking=True)
+        return buf[:n].numpy()
+
     def _workspace2d(self, name, rows, cols, pad=16, dtype=F64):
         """(rows x cols) view of a persistent buffer whose leading dimension is cols + pad.  Power-of-two row strides
         (4 MiB for AK at 64^3) alias rows onto the same cache sets / channels and cost the GEMMs ~12 %; 128 bytes of
@@ -1240,11 +1250,11 @@ class PosteriorEngine:
                 acc[jj].add_((Vd[jj][:n] ** 2).sum(0))
         return acc
 
-    def _results_to_host(self, mu, var, props):
+    def _results_to_host(self, mu, var, props, queued=None):
         """(P_c N) device mean and variance, complete on this rank -> the reference's two (3N,) property-major host vectors (NaN: blocks
-        not computed).  One device-to-host copy and one synchronisation for both; only the missing blocks are filled."""
+        not computed).  One device-to-host copy for both; queued: the staging array of a copy that was queued (and waited for) already."""
         N, P_c = self.N, len(props)
-        h = self._to_host(torch.cat([mu.reshape(-1)[:P_c * N], var.reshape(-1)[:P_c * N]]), 0)
+        h = queued if queued is not None else self._to_host(torch.cat([mu.reshape(-1)[:P_c * N], var.reshape(-1)[:P_c * N]]), 0)
         outs = []
         for k in range(2):
             out = np.empty(3 * N)
@@ -1293,12 +1303,14 @@ class PosteriorEngine:
             # a failed factorisation costs the wasted launch, a good one (every step of a survey) no idle gap in front of it
             # the long wait of a step is spent HERE, in the stream's own synchronize: a pageable device-to-host copy that has to wait
             # for a busy stream itself now and then returns 25-30 ms late (one step in five at 64^3)
+            # ... and every read-back of the step is queued in front of that one wait (each further wait is a host wake-up: ~1 ms)
+            h_info = self._to_host_async(info, "info")
+            st = self._to_host_async(stats, "stats") if calclogl else None
             torch.cuda.current_stream(self.device).synchronize()
-            info_h = int(info.item())
+            info_h = int(h_info[0])
             if info_h != 0:
                 raise CholeskyError(info_h)
             if calclogl:
-                st = self._to_host(stats, "stats")
                 out["uu"], out["logdet"] = float(st[0]), float(st[1])
                 out["logl"] = -0.5 * (st[0] + st[1] + self.N * math.log(2 * math.pi))  # inversion.py:107-110
             else:
@@ -1307,9 +1319,11 @@ class PosteriorEngine:
             check_factor()
         if want_mean_var and self._rowpath:
             mu_f, var_f = self._posterior_rows(Linv, u, sel_t, lengths, W, kernelfunc, gp_amp, props, M_pad)
+            N_ = len(props) * self.N
+            hq = self._to_host_async(torch.cat([mu_f.reshape(-1)[:N_], var_f.reshape(-1)[:N_]]), 0)
             check_factor()
             t = self._tick("posterior", t)
-            out["mu"], out["var"] = self._results_to_host(mu_f, var_f, props)
+            out["mu"], out["var"] = self._results_to_host(mu_f, var_f, props, queued=hq)
             self._tick("d2h", t)
         elif want_mean_var:
             # executed flop: every 64-row wavefront group g of the valid rows contracts the 64 g columns in front of its diagonal
@@ -1337,10 +1351,13 @@ class PosteriorEngine:
                                                   gp_amp * 1.0, ws, m_valid=Mv) for cs in range(0, ncols, pw)]
                     return torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
                 mu_l, var_l = self._timed("posterior_reduce", fl, panels, alg=(1.0 * Mu * Mu + 4.0 * Mu) * nv)
+            one = self.world == 1 and self.N == self.N_pad
+            N_ = len(props) * self.N
+            hq = self._to_host_async(torch.cat([mu_l.reshape(-1)[:N_], var_l.reshape(-1)[:N_]]), 0) if one else None
             check_factor()
             t = self._tick("posterior", t)
-            if self.world == 1 and self.N == self.N_pad:
-                out["mu"], out["var"] = self._results_to_host(mu_l, var_l, props)
+            if one:
+                out["mu"], out["var"] = self._results_to_host(mu_l, var_l, props, queued=hq)
             else:
                 mu = assemble_columns(gather_slices(mu_l, len(props), self.N_pad, self.world, self.group), props, self.N,
                                       self.N_pad, self.world, to_host=self._to_host)
