@@ -26,6 +26,8 @@ SIGNATURES = {
     "geobo_lattice_wplanes": (_int, [_i64, _int, _int, _int, _dp, _dp, _dp, _dp]),
     "geobo_xz2d_fold_inv_strided": (_int, [_int, _i64, _int, _dp, _i64, _i64, _dp, _dp, _dp, _i64, _i64, _i64, _dp]),
     "geobo_xz2d_fold_inv_mul": (_int, [_int, _i64, _int, _dp, _i64, _dp, _i64, _dp, _dp, _dp, _i64, _i64, _i64, _dp]),
+    "geobo_sumsq_accum": (_int, [_i64, _i64, _dp, _i64, _dp, _i64, _int, _dp, _i64, _dp]),
+    "geobo_lamdot_z": (_int, [_i64, _int, _int, _int, _dp, _dp, _dp, _dp]),
     "geobo_colgemv_ws_bytes": (_sz, [_i64, _i64]),
     "geobo_colgemv": (_int, [_i64, _i64, _dp, _i64, _dp, _dp, _dp, _sz, _dp]),
     "geobo_convert": (_int, [_int, _dp, _i64, _dp, _i64, _i64, _i64, _dp]),

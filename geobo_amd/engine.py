@@ -39,6 +39,8 @@ import numpy as np
 import torch
 
 from . import geometry, hip
+from .plan import plan_route
+from .rowform import RowFormMixin
 from .sharding import (EmulatedGroup, allreduce_sum_, assemble_columns, backend_of, exchange_blocks, exchange_blocks_finish,
                        exchange_blocks_start, gather_rows, gather_slices, shard_columns)
 
@@ -169,7 +171,7 @@ class StreamedOperator:
         return out
 
 
-class PosteriorEngine:
+class PosteriorEngine(RowFormMixin):
     def __init__(self, settings, device=None, rank=0, world=1, group=None, profile=False, method="auto", assembly="f64",
                  operators="resident"):
         """assembly "f32": covariance tables rounded through fp32 and A K kept in fp32 in HBM (BASELINE config 5, "fp32 kernel
@@ -208,35 +210,34 @@ class PosteriorEngine:
         self._pending_exchange = None   # (A K, [(recv, work)], props) of a row exchange that has been started but not placed yet
         self.use_grid = self.nz >= 16 and self.nz % 2 == 0  # lattice-table generator (geobo_ak_fused_grid); coordinates otherwise
         # spectral (real-DFT) product: regular grid with extents % 16 == 0, unpadded voxel columns, shards on y-slab boundaries
-        plane = self.nx * self.nz
         if method not in ("auto", "dense", "spectral"):
             raise ValueError("method must be 'auto', 'dense' or 'spectral'")
         self.method = method
-        self.use_spectral = (method in ("auto", "spectral") and self.nx % 16 == 0 and self.ny % 16 == 0 and self.nz % 16 == 0
-                             and self.N == self.N_pad and self.c0 % plane == 0 and self.c1 % plane == 0 and self.nc > 0)
+        # every shape / rank-count / precision decision of a step comes from ONE pure function (plan.py, CPU-tested table); the
+        # GEOBO_* switches are overrides into it.  What a step then actually ran is recorded in self.step_route.
+        self.route = plan_route(self.nx, self.ny, self.nz, world=world, rank=rank, assembly=assembly, operators=operators, method=method,
+                                env=os.environ)
+        self.use_spectral = self.route.spectral
         if method == "spectral" and not self.use_spectral:
             raise ValueError("spectral method needs grid extents % 16 == 0 and column shards on y-slab boundaries")
+        if self.route.operators == "streamed":
+            self.streamed = True            # (residency cannot fit: the planner's note says so)
+        if self.route.note and self.N >= 32768:
+            import warnings
+            warnings.warn("geobo_amd route %s: %s" % (self.route.describe(), self.route.note), RuntimeWarning, stacklevel=3)
         self._spectral = None
         self._lattice_plan = None
         self._gram, self._lam, self._edgeV = None, {}, {}
         self._lamW, self._edgeVt = {}, {}     # transposed lattice application: permuted eigen-data, boundary-slab spectra
         self._gens = {}             # Toeplitz generators of the covariance blocks (s, j) of the last A K assembly
-        # row-sharded spectral product (N > 1): every rank transforms Ms/world sensor rows of each operator for ALL voxels
-        # and one all-to-all hands each peer the block-columns it owns; needs equal shards
-        ncs = {shard_columns(self.N_pad, world, r)[1] - shard_columns(self.N_pad, world, r)[0] for r in range(world)}
-        # Worth it from 4 ranks: with 2 the exchange moves a quarter of A K (8.8 GB at 64^3) over ONE xGMI link (~0.1 s),
-        # more than the forward passes it saves; replicated forward passes + slab-cropped backward passes win there.
-        xmode = os.environ.get("GEOBO_SPECTRAL_EXCHANGE", "auto")
-        # Row-sharded posterior (round 3, _posterior_rows): on a lattice survey nothing downstream of A K needs voxel-column shards --
-        # AkA comes from this rank's own sensor rows, the posterior from this rank's rows of L^-1 -- so the all-to-all disappears
-        # altogether and the row form pays from 2 ranks.  Decided per step (_rows_posterior_ok: survey, stencil, kernels); the
-        # static part of the conditions switches the row form on for 2 and 3 ranks as well.
-        from .lattice_gram import LatticeGram
-        self.rows_static = (self.use_spectral and world > 1 and self.Ms % world == 0 and LatticeGram.supported(self.nx, self.ny, self.nz)
-                            and not self.f32 and not self.streamed and self.Ms == self.Ms_pad
-                            and os.environ.get("GEOBO_POSTERIOR", "zpath") == "zpath" and os.environ.get("GEOBO_Z_LATTICE", "1") != "0")
-        self.exchange = (self.use_spectral and world > 1 and self.Ms % world == 0 and len(ncs) == 1
-                         and xmode != "0" and (world >= 4 or xmode == "1" or self.rows_static))
+        # Row form (plan.Route.family "rows", rowform.py): statically possible; whether a step takes it is decided when the operators
+        # are built (lattice survey, even stencils).  Column form from 4 ranks: row-sharded transforms + one all-to-all of A K block
+        # columns per operator (with 2 ranks the exchange would move a quarter of A K over ONE xGMI link, more than the forward passes
+        # it saves: replicated forward passes + slab-cropped backward passes there).
+        self.rows_static = self.route.rows
+        self.exchange = self.route.exchange
+        self._deny = {}                 # row form denied: "survey" -> (survey key, why), func -> ((survey key, B), why)
+        self.step_route = None          # family the last step ran in: "rows" | "single" | "columns"
         self._rowpath = False           # this step runs the row-sharded posterior (set by the A K assembly)
         if self.streamed and not self.use_spectral:
             raise ValueError("streamed operators feed the spectral product: needs the spectral method's grid conditions")
@@ -256,7 +257,7 @@ class PosteriorEngine:
             ranks = torch.distributed.get_process_group_ranks(group) if group is not None else list(range(torch.distributed.get_world_size()))
             if len(ranks) == world:
                 self._xgroup = _exchange_group(tuple(ranks), torch.distributed.get_backend(group))
-        self._Arows, self._Aedge, self._fullrows = {}, {}, {}
+        self._Arows, self._Aedge, self._fullrows, self._rowsrc, self._op_args = {}, {}, {}, {}, {}
         self._slab_ops = set()      # data pointers of operators that hold only this rank's column slab
         self._potrf_ctx = None
         self.kernel_events = None  # set to [] to record (name, flops, start, stop) HIP events per fused launch
@@ -293,7 +294,6 @@ class PosteriorEngine:
         s = self.s
         loc = np.ascontiguousarray(sensor_locations, dtype=np.float64)
         assert loc.shape == (self.Ms, 3), "A_sens handles exactly xNcube*yNcube sensors (sensormodel.py:54,58)"
-        partial = self.exchange and not full
         xe, ye, ze = self.node_axes() if axes is None else axes
         # survey on the cube's own x-y lattice (the reference's workflow): translation-invariant stencil, ~2000x fewer potentials
         plan = None
@@ -302,13 +302,30 @@ class PosteriorEngine:
             if self._lattice_plan is None or self._lattice_plan[0] != pkey:
                 self._lattice_plan = (pkey, hip.lattice_plan(loc, xe, ye, ze, self.nx, self.ny, self.nz, self.device))
             plan = self._lattice_plan[1]
+        # row form (rowform.py): this rank's sensor rows + the two boundary slabs of every sensor, nothing sharded by voxel columns.
+        # Needs a row-major lattice survey and even stencils; a denial holds for exactly the survey / field it was found for.
         Bkey = None if B is None else tuple(np.asarray(B, dtype=float))
+        skey = (loc.tobytes(), xe.tobytes(), ye.tobytes(), ze.tobytes())
+        if self._deny.get("survey", (skey,))[0] != skey:
+            self._allow_rows("survey")
+        if self._deny.get(func, ((skey, Bkey),))[0] != (skey, Bkey):
+            self._allow_rows(func)
+        if self.rows_static and not self._rows_denied and not full and (plan is None or not plan["rowmajor"]):
+            self._deny_rows("survey", skey, "the survey is not a row-major x-y lattice of the cube")
+        rows_mode = self.rows_static and not self._rows_denied and not full
+        self._op_args[func] = (sensor_locations, B, axes)
+        partial = self.exchange and not full and not rows_mode
         dkey = (func, Bkey, None if plan is None else self._lattice_plan[0])      # a stencil's evenness belongs to (field, survey geometry)
         stream_it = (self.streamed or (self.auto_ops and dkey not in self._auto_denied and self._implicit_operators_pay(plan))) and not full
-        key = (func, loc.tobytes(), Bkey, partial, stream_it)
+        if rows_mode and self.auto_ops and not stream_it and self.world == 1 and not self.route.single:
+            stream_it = True      # "auto" in the row form on one rank: rows are generated a transform batch at a time (a_sens on the lattice is a copy)
+        key = (func, loc.tobytes(), Bkey, partial, stream_it, rows_mode)
         if key in self._A:
             return self._A[key]
-        if partial and not stream_it:
+        rows_r = self.Ms // self.world if rows_mode else 0
+        if rows_mode and not stream_it and self.world > 1:
+            A = self._workspace2d("Arows_" + func, rows_r, self.N_pad)        # the handle of a row-form operator IS its row shard
+        elif partial and not stream_it:
             # row-exchange form: only this rank's y-slab of every sensor row is ever read (AkA operand of the N/G-deep GEMM):
             # a compact (Ms_pad x nc) buffer, columns c0 .. c1 (the kernels address columns absolutely: col_origin)
             A = self._workspace2d("Aslab_" + func, self.Ms_pad, self.nc)
@@ -331,6 +348,18 @@ class PosteriorEngine:
         lws = None
         if plan is not None:
             lws = self._workspace("a_sens_lattice_ws", (hip.a_sens_lattice_ws_doubles(self.nx, self.ny, self.nz),))
+        plane = self.nx * self.nz
+
+        def boundary_slabs():
+            """(Ms_pad x 2 nx nz): the two 1e6-padded boundary slabs of the operator for every sensor (their part of the Gram and of
+            L^-1 A goes through the slabs' x-DFT spectra)."""
+            E2 = self._workspace2d("Aedge_" + func, self.Ms_pad, 2 * plane)
+            if self.Ms_pad > self.Ms:
+                E2[self.Ms:].zero_()
+            for k, iy in enumerate((0, self.ny - 1)):
+                hip.a_sens(func, Bv, locd, self.nx, self.ny, self.nz, xed, yed, zed, mul, div, E2[:, k * plane:(k + 1) * plane], iy, iy + 1,
+                           plan=plan, ws=lws, col_origin=iy * plane)
+            return E2[:, :plane], E2[:, plane:2 * plane]
         if stream_it:
             A = StreamedOperator(self, func, Bv, mul, div, locd, (xed, yed, zed), plan, lws)
             lam = None
@@ -338,7 +367,10 @@ class PosteriorEngine:
                 # one two-sensor call leaves the stencil table Q in the lattice workspace (the Gram's eigen-data come from it)
                 tmp = self._workspace2d("op_rows2", 2, self.N_pad)
                 self._timed("a_sens_" + func, 0.0, lambda: A.rows_into(tmp, 0, 2))
-                lam = self._gram_eigen(plan, lws)
+                lam = self._gram_eigen(plan, lws, rows=rows_mode)
+                if lam is None and rows_mode:
+                    self._deny_rows(func, (skey, Bkey), "the %s stencil is not even in both lattice offsets" % func)
+                    return self.operator(func, sensor_locations, B=B, axes=axes, full=full)
                 if lam is None and not self.streamed:
                     # "auto" and the stencil is not even (no lattice Gram): AkA is an N-deep GEMM against the operator -- resident
                     self._auto_denied.add(dkey)
@@ -350,8 +382,36 @@ class PosteriorEngine:
                         and os.environ.get("GEOBO_LATTICE_FEED", "1") != "0"):
                     self._timed("a_sens_" + func, 0.0, lambda: A.keep_stencil(func))
             self._lam[func] = None if lam is None else (A, lam)
+            if rows_mode:
+                if A.lattice is not None:
+                    self._rowsrc[func] = ("lattice", A.lattice, 0)
+                    self._Aedge[func] = (A.edge[:, :plane], A.edge[:, plane:2 * plane])
+                else:
+                    self._rowsrc[func] = ("streamed", A, 0)
+                    self._Aedge[func] = self._timed("a_sens_" + func, 0.0, boundary_slabs)
+        elif rows_mode:
+            g0 = self.rank * rows_r
+
+            def build():
+                if self.N_pad > self.N:
+                    A[:, self.N:].zero_()
+                if self.world > 1:
+                    hip.a_sens(func, Bv, locd[g0:g0 + rows_r].contiguous(), self.nx, self.ny, self.nz, xed, yed, zed, mul, div, A, plan=plan,
+                               rows=slice(g0, g0 + rows_r), ws=lws)
+                    return boundary_slabs()
+                hip.a_sens(func, Bv, locd, self.nx, self.ny, self.nz, xed, yed, zed, mul, div, A, plan=plan, ws=lws)
+                return A[:, :plane], A[:, (self.ny - 1) * plane:self.ny * plane]     # (one rank: the slabs are columns of the operator itself)
+            edges = self._timed("a_sens_" + func, 0.0, build)
+            lam = self._gram_eigen(plan, lws, rows=True)
+            if lam is None:
+                self._deny_rows(func, (skey, Bkey), "the %s stencil is not even in both lattice offsets" % func)
+                return self.operator(func, sensor_locations, B=B, axes=axes, full=full)
+            self._lam[func] = (A, lam)
+            self._rowsrc[func] = ("tensor", A, g0)
+            self._Aedge[func] = edges
+            if self.world > 1:
+                self._Arows[func] = A
         elif partial:
-            plane = self.nx * self.nz
             rows_r = self.Ms // self.world
             Ar = self._workspace2d("Arows_" + func, rows_r, self.N_pad)
             loc_r = locd[self.rank * rows_r:(self.rank + 1) * rows_r].contiguous()
@@ -367,13 +427,7 @@ class PosteriorEngine:
             self._lam[func] = None if lam is None else (A, lam)
             if lam is not None:
                 # row-sharded lattice Gram: the two 1e6-padded boundary slabs of the operator, every sensor (their part of AkA is a GEMM)
-                E2 = self._workspace2d("Aedge_" + func, self.Ms_pad, 2 * plane)
-                if self.Ms_pad > self.Ms:
-                    E2[self.Ms:].zero_()
-                for k, iy in enumerate((0, self.ny - 1)):
-                    hip.a_sens(func, Bv, locd, self.nx, self.ny, self.nz, xed, yed, zed, mul, div, E2[:, k * plane:(k + 1) * plane], iy, iy + 1,
-                               plan=plan, ws=lws, col_origin=iy * plane)
-                self._Aedge[func] = E2
+                self._Aedge[func] = boundary_slabs()
         else:
             self._timed("a_sens_" + func, 0.0, lambda: hip.a_sens(func, Bv, locd, self.nx, self.ny, self.nz, xed, yed, zed, mul, div, A,
                                                                  plan=plan, ws=lws))
@@ -385,6 +439,23 @@ class PosteriorEngine:
         self._lamW = {k: v for k, v in self._lamW.items() if k[0] != func}
         self._A[key] = A
         return A
+
+    @property
+    def _rows_denied(self):
+        return bool(self._deny)
+
+    def _deny_rows(self, what, key, why):
+        """The row form is impossible for this survey / field: operator builds and steps take the column form (with the all-to-all only
+        where it pays without the row posterior: from 4 ranks) until an operator build with another survey / field lifts the denial.
+        Operators already built for the row form are dropped (posterior() rebuilds them from the recorded arguments)."""
+        self._deny[what] = (key, why)
+        self.exchange = self.route.exchange_without_rows
+        self._A = {k: v for k, v in self._A.items() if not k[5]}
+        self._rowsrc, self._Aedge = {}, {}
+
+    def _allow_rows(self, what):
+        if self._deny.pop(what, None) is not None and not self._deny:
+            self.exchange = self.route.exchange
 
     def _implicit_operators_pay(self, plan):
         """operators="auto": True when neither the transforms nor AkA need a materialised operator."""
@@ -501,6 +572,7 @@ class PosteriorEngine:
         self._A = {}
         self._lam = {}
         self._edgeV, self._edgeVt, self._lamW = {}, {}, {}
+        self._rowsrc, self._Aedge, self._Arows = {}, {}, {}
         self._lattice_plan = None      # host analysis of the survey geometry + its device copies: part of the operator build
 
     # ---- stages ------------------------------------------------------------------------------------------------
@@ -518,19 +590,20 @@ class PosteriorEngine:
         LOWER triangle needs -- (grav rows, blocks 0 and 1), (magn rows, block 1), the drill rows; AkA[magn rows, grav columns] is the
         transpose of AkA[grav rows, magn columns], and nothing but AkA reads A K in that order (_mean_rows, _posterior_zpath)."""
         self._ak_sym = bool(sym)
+        self._W = W
         xyz = self.grid_points()
         Md = 0 if sel_t is None else sel_t.numel()
         off_d = 2 * self.Ms_pad
         M_pad = hip.pad_m(off_d + Md)
         nc = self.nc
         self._rowpath = False
-        if self.exchange and self.rows_static:
+        if self.rows_static:
             self._spectral_product()
-            if self._rows_posterior_ok():
-                # row-sharded step: no column shard of A K exists (and none is allocated) -- row blocks over all voxels instead
+            if self._rows_agree(self._rows_ok(A_g, A_m)):
+                # row form: no column shard of A K exists (and none is allocated) -- AkA comes straight from chunks of the rank's rows
                 self._finish_exchange()  # (an exchange left over by a call that failed between its start and its factorisation)
                 self._rowpath = True
-                self._assemble_rows(lengths, W, name, amp, props)
+                self._fullrows = {}
                 return None, M_pad
         AK = self._workspace2d("AK", M_pad, len(props) * nc, dtype=hip.F32 if self.f32 else F64)
         # every sensor/drill row is overwritten below; only the padding must be defined: rows behind each row block
@@ -649,35 +722,6 @@ class PosteriorEngine:
         if not self._row_gram():
             self._finish_exchange()      # AkA by the GEMM reads the received columns of A K
 
-    def _rows_posterior_ok(self):
-        """True when this step can run without any voxel-column shard of A K: row Gram for AkA (lattice survey, even stencils, both
-        operators), and the transposed posterior's kernels for this grid (see _zpath_ok) with whole transform batches per rank."""
-        sp = self._spectral
-        if not (self.rows_static and self._row_gram() and sp is not None and self._gram is not None and self._gram.edge_supported()):
-            return False
-        if not (sp.fused_xz and sp.fold and sp.dense_y and "x" in sp.F and self.N == self.N_pad):
-            return False
-        return (self.Ms // self.world) % sp.R == 0 and all(f in self._Aedge and f in self._Arows for f in ("grav", "magn"))
-
-    def _assemble_rows(self, lengths, W, name, amp, props):
-        """Row-sharded A K without an exchange: this rank's sensor rows of both operators through the covariance product for ALL
-        voxels, property blocks 0 and 1 (what AkA = A K A3^T contracts: the input of the row Gram), kept as (rows_r x N) row blocks.
-        No other block of A K is needed anywhere: the posterior runs in the transposed order, the mean through _mean_rows."""
-        sp, rows_r = self._spectral, self.Ms // self.world
-        self._fullrows = {}
-        for s_, func in ((0, "grav"), (1, "magn")):
-            lams, outs = [], []
-            for j in props:
-                gen = sp.eigenvalues(self._cov_table(hip.kernel_id(name, s_ != j), lengths[j], lengths[s_], W[s_][j], amp))
-                self._gens[(s_, j)] = gen
-                if (s_, j) in ((0, 0), (0, 1), (1, 1)):
-                    lams.append(gen)
-                    outs.append(self._workspace2d("fullrows_%d%d" % (s_, j), rows_r, self.N_pad))
-                    self._fullrows[(s_, j)] = outs[-1]
-            Ar = self._Arows[func]
-            self._timed("spectral_product", sp.flops(rows_r, len(lams), self.ny), lambda: sp.product(Ar, rows_r, lams, outs),
-                        valu=sp.flops_valu(rows_r, len(lams)))
-
     def _finish_exchange(self):
         """Wait for the row exchange and put the received blocks into A K.  With the row-sharded lattice Gram nothing reads those
         columns before the posterior reduction (AkA comes from this rank's own rows, kept from the send buffers), so posterior()
@@ -788,8 +832,9 @@ class PosteriorEngine:
             hit = self._edgeV[key] = (ycols.data_ptr(), self._gram.edge_eigen(ycols))
         return hit[1]
 
-    def _gram_eigen(self, plan, lws):
-        """Eigen-data of the operator's stencil table for the lattice Gram (lattice_gram.py); None -> AkA by the N-deep GEMM."""
+    def _gram_eigen(self, plan, lws, rows=False):
+        """Eigen-data of the operator's stencil table for the lattice Gram (lattice_gram.py); None -> AkA by the N-deep GEMM.
+        rows: the row form asks (no column-shard arithmetic applies: every rank correlates whole rows)."""
         from .lattice_gram import LatticeGram
         plane = self.nx * self.nz
         Ly = (self.c1 - self.c0) // plane
@@ -799,9 +844,13 @@ class PosteriorEngine:
         if (not self.use_spectral or not plan["rowmajor"] or self.Ms_pad != self.Ms
                 or not LatticeGram.supported(self.nx, self.ny, self.nz) or os.environ.get("GEOBO_AKA_LATTICE", "1") == "0"):
             return None
-        form = lattice_gram_form(self.exchange, self.f32 or self.streamed, self.world, self.Ms, self.c0, self.c1, plane, self.N)
-        if form is None:
-            return None
+        if not rows:
+            # the column forms of the Gram run on the fused n = 64 kernels' grids only (their batched-GEMM stand-ins pay in the row form)
+            if not LatticeGram.fast(self.nx, self.ny, self.nz):
+                return None
+            form = lattice_gram_form(self.exchange, self.f32 or self.streamed, self.world, self.Ms, self.c0, self.c1, plane, self.N)
+            if form is None:
+                return None
         if self._spectral is None:
             from .spectral import SpectralProduct
             self._spectral = SpectralProduct(self.nx, self.ny, self.nz, self.device)
@@ -816,8 +865,8 @@ class PosteriorEngine:
         off_d = 2 * self.Ms_pad
         AkA = self._workspace("AkA", (M_pad, M_pad))
         AkA.zero_()
-        if self._row_gram() and self._fullrows:
-            return self._assemble_AkA_rows(AkA, M_pad, A_g, A_m, sel_t, lengths, name, amp, gp_sigma, props)
+        if self._rowpath or (self._row_gram() and self._fullrows):
+            return self._assemble_AkA_rows(AkA, M_pad, sel_t, lengths, name, amp, gp_sigma, props)
         if getattr(self, "_ak_sym", False):
             return self._assemble_AkA_sym(AkA, AK, M_pad, A_g, A_m, sel_t, lengths, name, amp, gp_sigma, props)
         # only the LOWER triangle of AkA is consumed (Cholesky, lower=True): block column s needs rows >= s*Ms_pad, and
@@ -941,58 +990,6 @@ class PosteriorEngine:
         self._timed("aka_lattice", gram.flops(3 * self.Ms + 2 * Md, ny), run)
         return self._finish_AkA(AkA, M_pad, sel_t, lengths, name, amp, gp_sigma)
 
-    def _aka_local_rows(self, props, sel_t, lengths, W, name, amp):
-        """Row blocks of AkA this rank owns in the row-sharded form: (2, rows_r, 2 Ms_pad) for its gravity / magnetic sensor rows,
-        and the drill rows (every rank computes those 50 rows itself: cheaper than shipping them)."""
-        gram, pl, G = self._gram, self.nx * self.nz, self.world
-        rows_r, Md = self.Ms // G, 0 if sel_t is None else sel_t.numel()
-        # [grav rows -> grav | magn columns] and [magn rows -> magn columns]: the block (magn rows, grav columns) is the transpose of
-        # (grav rows, magn columns) and is filled in after the all-gather
-        loc = self._workspace("aka_rows_local", (rows_r, 3 * self.Ms_pad))
-        loc.zero_()
-        lam = {0: self._lam["grav"][1], 1: self._lam["magn"][1]}
-        edge = {0: self._Aedge["grav"], 1: self._Aedge["magn"]}
-
-        def rows_times_AT(X, nrows, sp_, out):
-            # out[:nrows, :Ms] = X[:nrows] . A_sp^T : interior y-slabs by the (y, x) correlation, the two padded slabs by a GEMM
-            gram.gram_rows(X, nrows, lam[sp_], out, 0, self.ny)
-            for k, iy in enumerate((0, self.ny - 1)):
-                ycols = edge[sp_][:, k * pl:(k + 1) * pl]
-                if gram.edge_supported():
-                    gram.edge_rows(X[:, iy * pl:], nrows, self._edge_spectrum(("grav", "magn")[sp_], k, ycols), out)
-                else:
-                    hip.gemm_nt(X[:, iy * pl:(iy + 1) * pl], ycols, out, alpha=1.0, beta=1.0, m_valid=nrows)
-        for k, (s_, sp_) in enumerate(((0, 0), (0, 1), (1, 1))):
-            rows_times_AT(self._fullrows[(s_, sp_)], rows_r, sp_, loc[:, k * self.Ms_pad:(k + 1) * self.Ms_pad])
-        drill = None
-        if Md:
-            Mdp = (Md + 127) // 128 * 128
-            drill = self._workspace("aka_rows_drill", (Mdp, 2 * self.Ms_pad))
-            drill.zero_()
-            Xd = self._workspace2d("fullrows_drill", Mdp, self.N_pad)
-            for sp_ in (0, 1):
-                Xd.zero_()
-                self._cov_rows(name, 2, sp_, lengths, W, amp, sel_t, 0, Xd[:Md, :self.N])
-                rows_times_AT(Xd[:, :self.N], Md, sp_, drill[:, sp_ * self.Ms_pad:(sp_ + 1) * self.Ms_pad])
-        return loc, drill
-
-    def _assemble_AkA_rows(self, AkA, M_pad, A_g, A_m, sel_t, lengths, name, amp, gp_sigma, props):
-        """AkA from row blocks (row exchange + lattice Gram): local correlation of this rank's sensor rows, one all-gather."""
-        W = self._W
-        rows_r, Md, off_d = self.Ms // self.world, 0 if sel_t is None else sel_t.numel(), 2 * self.Ms_pad
-        fl = self._gram.flops(3 * rows_r + 2 * Md, self.ny)
-        loc, drill = self._timed("aka_lattice", fl, lambda: self._aka_local_rows(props, sel_t, lengths, W, name, amp))
-        allrows = self._timed("xgmi_all_gather", 0.0, lambda: gather_rows(loc, self.world, self.group))
-        Msp = self.Ms_pad
-        for src in range(self.world):
-            r0 = src * rows_r
-            AkA[r0:r0 + rows_r, :off_d].copy_(allrows[src][:, :off_d])
-            AkA[Msp + r0:Msp + r0 + rows_r, Msp:off_d].copy_(allrows[src][:, off_d:])
-        AkA[Msp:off_d, :Msp] = AkA[:Msp, Msp:off_d].t()
-        if Md:
-            AkA[off_d:off_d + Md, :off_d].copy_(drill[:Md])
-        return self._finish_AkA(AkA, M_pad, sel_t, lengths, name, amp, gp_sigma)
-
     def _finish_AkA(self, AkA, M_pad, sel_t, lengths, name, amp, gp_sigma):
         """Drill columns by symmetry, the drill-drill block, the noise variances on the diagonal (identity on the padding)."""
         xyz = self.grid_points()
@@ -1019,15 +1016,12 @@ class PosteriorEngine:
         return hip.to_dev(y, self.device)
 
     def _zpath_static_ok(self):
-        """The transposed posterior path needs: one rank, fp64 A K, the radix-2 transform kernels and the Toeplitz y stage of this grid,
-        unpadded sensor rows and voxel columns."""
-        if (self.world != 1 or self.f32 or not self.use_spectral or self.exchange or self.Ms != self.Ms_pad or self.N != self.N_pad
-                or os.environ.get("GEOBO_POSTERIOR", "zpath") != "zpath"):
+        """The one-rank transposed posterior on the fused kernels (plan.Route.single): one rank, fp64 A K, the radix-2 transform kernels
+        and the Toeplitz y stage of this grid, unpadded sensor rows and voxel columns."""
+        if not self.route.single or self.exchange:
             return False
-        sp = self._spectral_product()
-        if not (sp.fused_xz and sp.fold and sp.dense_y and self.nx == self.nz and "x" in sp.F and sp.ny <= 64):
-            return False
-        return self.Ms_pad % sp.R == 0
+        self._spectral_product()
+        return True
 
     def _zpath_ok(self, AK, props, A_g, A_m):
         """... and the covariance generators of the last A K assembly."""
@@ -1056,8 +1050,8 @@ class PosteriorEngine:
         else:
             gram.apply_transpose(Lview, nrows, hit[1], out)
         for k, iy in enumerate((0, ny - 1)):
-            if edge is not None:                      # (row-sharded form: the two boundary slabs of every sensor are kept apart)
-                ycols = edge[:, k * pl:(k + 1) * pl]
+            if edge is not None:                      # (row form: the two boundary slabs of every sensor, engine.operator)
+                ycols = edge[k]
             elif isinstance(A, StreamedOperator) and A.lattice is not None:
                 ycols = A.edge[:, k * pl:(k + 1) * pl]
             elif isinstance(A, StreamedOperator):
@@ -1133,65 +1127,6 @@ class PosteriorEngine:
                 Linv, 0, Md, sel_t, lengths, W, name, amp, props, gens_g, gens_m,
                 (lambda Lv, n, func, out: self._lattice_Z(Lv, n, func, A_g if func == "grav" else A_m, out)) if lat else None, Ag, Am))
         return mu_l, (amp * 1.0 - ssum).reshape(-1)
-
-    def _posterior_rows(self, Linv, u, sel_t, lengths, W, name, amp, props, M_pad):
-        """The transposed posterior (see _posterior_zpath) sharded by ROWS of L^-1 over the ranks: rank r carries the rows of its own
-        Ms / G gravity and Ms / G magnetic sensors (2 + 1 row blocks of Z = L^-1 A) and a 1/G share of the drill rows through the
-        covariance product; the partial sums of squares meet in ONE all-reduce of P_c N doubles (4 MB at 64^3); the mean is three rows
-        through the covariance product and every rank forms it whole (_mean_rows).  No voxel-column shard of anything exists.
-        Returns (mu, var), (P_c, N) each, complete on every rank."""
-        sp, N, Msp, P_c, Md = self._spectral, self.N, self.Ms_pad, len(props), 0 if sel_t is None else sel_t.numel()
-        nx, ny, nz, G, r = self.nx, self.ny, self.nz, self.world, self.rank
-        rows_r = self.Ms // G
-        a0, a1 = r * rows_r, Msp + r * rows_r
-        ssq = self._workspace("rows_reduce", (P_c, N))
-        cws = self._workspace("colgemv_ws", (hip.colgemv_ws_doubles(M_pad, M_pad),))
-        Eg, Em = self._Aedge["grav"], self._Aedge["magn"]
-
-        def mean():
-            # every rank forms the whole mean itself (three rows through the covariance product: cheaper than an all-reduce of it)
-            w = hip.colgemv(Linv, u, ws=cws)                                   # L^-T u
-            return self._mean_rows(w, sel_t, lengths, W, name, amp, props,
-                                   lambda func, wv, out: self._lattice_Z(wv.view(1, -1), 1, func, None, out, edge=Eg if func == "grav" else Em))
-        mu = self._timed("posterior_mean", 0.0, mean)
-        gram = self._gram
-        zx = gram.zx_supported()
-        Zg, Zm = self._workspace2d("Zg", 2 * rows_r, N), self._workspace2d("Zm", rows_r, N)
-        fl = 3 * rows_r * (gram.flops(1, ny) + 2 * 3 * 2.0 * 128 * 128 * 64)
-
-        def zlattice():
-            self._lattice_Z(Linv[a0:a0 + rows_r, :Msp], rows_r, "grav", None, Zg, zx=zx, edge=Eg)
-            self._lattice_Z(Linv[a1:a1 + rows_r, :Msp], rows_r, "grav", None, Zg[rows_r:], zx=zx, edge=Eg)
-            self._lattice_Z(Linv[a1:a1 + rows_r, Msp:2 * Msp], rows_r, "magn", None, Zm, zx=zx, edge=Em)
-        self._timed("posterior_zlattice", fl, zlattice)
-        slots = hip.xz2d_fold_inv_ss_slots(nx, sp.R, ny)
-        ss = [self._workspace("post_ss_%d" % jj, (slots, ny, nx * nz)) for jj in range(P_c)]
-        for t in ss:
-            t.zero_()
-        gens_g, gens_m = [self._gens[(0, j)] for j in props], [self._gens[(1, j)] for j in props]
-        swap = (lambda g: g.view(ny, sp.Px, sp.Pz).transpose(1, 2).contiguous().view(-1)) if zx else (lambda g: g)
-        tg, tm = [swap(g) for g in gens_g], [swap(g) for g in gens_m]
-        self._timed("posterior_spectral", sp.flops_ss(rows_r, rows_r, P_c), lambda: sp.reduce_ss(Zg, 2 * rows_r, tg, Zm, rows_r, tm, ss),
-                    valu=3.0 * rows_r * P_c * 2.0 * ny * ny * sp.Px * sp.Pz)
-        for jj, t in enumerate(ss):
-            if zx:
-                ssq[jj].copy_(t.sum(0).view(ny, nz, nx).transpose(1, 2).reshape(-1))
-            else:
-                ssq[jj].copy_(t.sum(0).reshape(-1))
-        # the rows behind the sensor rows (only they see the drill columns of L^-1): an equal share per rank
-        dper = -(-Md // G)
-        d0 = min(Md, r * dper)
-        nd = min(Md, d0 + dper) - d0
-        if nd:
-            def drill_rows():
-                part = self._drill_rows_ss(Linv, d0, nd, sel_t, lengths, W, name, amp, props, gens_g, gens_m,
-                                           lambda Lv, n, func, out: self._lattice_Z(Lv, n, func, None, out, edge=Eg if func == "grav" else Em),
-                                           None, None)
-                for jj in range(P_c):
-                    ssq[jj].add_(part[jj])
-            self._timed("posterior_drill_rows", 0.0, drill_rows)
-        self._timed("xgmi_all_reduce", 0.0, lambda: allreduce_sum_(ssq, G, self.group))
-        return mu, amp * 1.0 - ssq
 
     def _mean_rows(self, w, sel_t, lengths, W, name, amp, props, vec_of):
         """Posterior mean (P_c, N):  mu_j = (A3 K)[:, block j]^T w  re-associated as  K_.j (A3^T w)  -- the covariance blocks are
@@ -1280,8 +1215,12 @@ class PosteriorEngine:
         t = self._tick("start")
         # the data vector goes up first: a pageable host-to-device copy blocks the host until the stream reaches it
         y = self._pad_y(y_g, y_m, y_d, hip.pad_m(2 * self.Ms_pad + len(sel)))
+        if self.rows_static and not self._rows_denied and not self._rows_ok(A_g, A_m) and all(f in self._op_args for f in ("grav", "magn")):
+            # operators handed in from before a denial / a clear: rebuild them from the recorded arguments in the form this step takes
+            A_g, A_m = (self.operator(f, *self._op_args[f][:1], B=self._op_args[f][1], axes=self._op_args[f][2]) for f in ("grav", "magn"))
         AK, M_pad = self._assemble_AK(A_g, A_m, sel_t, lengths, W, kernelfunc, gp_amp, props,
-                                      sym=self._sym_ok(A_g, A_m))
+                                      sym=not self.rows_static and self._sym_ok(A_g, A_m))
+        self.step_route = "rows" if self._rowpath else ("single" if self._ak_sym else "columns")
         t = self._tick("ak_fused", t)
         AkA = self._assemble_AkA(AK, M_pad, A_g, A_m, sel_t, lengths, kernelfunc, gp_amp, gp_sigma, props)
         if self.aka_hook is not None:          # tools/emulate_rank.py: keep the assembled matrix (1 rank) / put the true one in place

@@ -156,6 +156,27 @@ def colgemv(X, v, out=None, ws=None):
     return out
 
 
+def sumsq_accum(a, b, rows, ss):
+    """ss[slot][c] += sum over the rows r = slot (mod slots) of (a[r, c] + b[r, c])^2  (geobo_sumsq_accum); b may be None.
+    a, b: 2-D row-major views (>= rows x n); ss: (slots, n) view with unit column stride."""
+    lib = require_gpu()
+    lda = _rowmajor(a, "a")
+    n = ss.shape[1]
+    assert a.shape[1] >= n and a.shape[0] >= rows and _rowmajor(ss, "ss") >= n
+    _lib.check(lib.geobo_sumsq_accum(int(rows), int(n), _p(a), lda, _p(b) if b is not None else None,
+                                     _rowmajor(b, "b") if b is not None else 0, ss.shape[0], _p(ss), ss.stride(0), _stream()),
+               "geobo_sumsq_accum")
+    return ss
+
+
+def lamdot_z(batch, planes, px, nz, D, lam, out):
+    """out[b][o] = sum_z D[b][o][z] * lam[b % planes][o][z]  (geobo_lamdot_z)."""
+    lib = require_gpu()
+    _lib.check(lib.geobo_lamdot_z(int(batch), int(planes), int(px), int(nz), _p(_chk(D, "D")), _p(_chk(lam, "lam")), _p(_chk(out, "out")),
+                                  _stream()), "geobo_lamdot_z")
+    return out
+
+
 def convert(src, dst):
     """dst[r, c] = src[r, c] across fp64 <-> fp32 (2-D views, unit column stride, even widths and leading dimensions)."""
     lib = require_gpu()

@@ -47,7 +47,15 @@ class LatticeGram:
         gy0[:, 0] = 0.0
         gy0[:, self.ny - 1] = 0.0
         self.Gy0 = gy0
-        self.R = int(os.environ.get("GEOBO_GRAM_ROWS", "256"))       # rows per batch
+        # rows per batch: 256 where the fused kernels run (1 GB of y-step output at 64^3); the shape-independent x step keeps
+        # D = Gx X for a whole batch (Py Px nz doubles per row: 67 MB at 128^3), ~2 GB per buffer
+        per_row = self.Py * self.Px * self.nz * 8
+        dflt = 256 if self.fast(self.nx, self.ny, self.nz) else max(8, min(256, (2 << 30) // per_row))
+        self.R = int(os.environ.get("GEOBO_GRAM_ROWS", str(dflt)))
+        # rows per batch of the transposed application (W = Lambda * lhat is Px nz Py doubles per row: 8.4 MB at 64^3, 67 MB at 128^3)
+        self.Rz = self.R if self.fast(self.nx, self.ny, self.nz) else max(8, min(256, (2 << 30) // per_row))
+        self.J = (self.ny + 63) // 64 * 64                          # jy slots of the boundary-slab spectra (whole 64-row halves of a GEMM tile)
+        self._lam_oz = {}
 
     # ---- boundary slabs: x-correlation through the full real DFT (module docstring, item 4) -----------------------------------
     EDGE_ROWS = 1024     # rows per batch: 64 frequency slots x 8 column tiles = 512 tiles per batched GEMM (two per CU)
@@ -59,43 +67,45 @@ class LatticeGram:
             nx = self.nx
             P = 2 * nx
             i = np.arange(nx)
-            F2 = np.zeros((nx, 2, nx))
+            F2 = np.zeros((hip.pad_n(2 * nx) // 2, 2, nx))           # (zero rows behind 2 nx: compute extents are multiples of 128)
             F2[0, 0], F2[0, 1] = 1.0, (-1.0) ** i
-            Fi = np.zeros((128, nx, 2))
+            Fi = np.zeros((hip.pad_n(nx), nx, 2))
             Fi[:nx, 0, 0], Fi[:nx, 0, 1] = 1.0 / P, ((-1.0) ** i) / P
             for w in range(1, nx):
                 ang = 2.0 * np.pi * ((w * i) % P) / P
                 F2[w, 0], F2[w, 1] = np.cos(ang), np.sin(ang)
                 Fi[:nx, w, 0], Fi[:nx, w, 1] = 2.0 / P * np.cos(ang), 2.0 / P * np.sin(ang)
-            self._edge_c = (hip.to_dev(F2.reshape(2 * nx, nx), self.device), hip.to_dev(Fi.reshape(128, 2 * nx), self.device))
+            self._edge_c = (hip.to_dev(F2.reshape(-1, nx), self.device), hip.to_dev(Fi.reshape(-1, 2 * nx), self.device))
         return self._edge_c
 
     def edge_supported(self):
-        return self.nx == 64 and self.nz == 64 and self.ny <= 64 and os.environ.get("GEOBO_GRAM_EDGE_SPECTRAL", "1") != "0"
+        return os.environ.get("GEOBO_GRAM_EDGE_SPECTRAL", "1") != "0"
 
     def edge_eigen(self, E):
         """Spectrum of one boundary slab of an operator.  E: (>= ny*nx rows) x (nx*nz) view of the slab's columns, row (jy, jx),
         column (ix, iz), with E[(jy, jx), (ix, iz)] = kappa_jy(ix - jx, iz) exactly (lattice survey: the node offsets are bit-identical
-        for equal index differences, hip.lattice_plan).  Returns V [nx slots][2 x 64 (C / S, jy)][2 x nz (cos / sin, iz)]."""
-        nx, ny, nz = self.nx, self.ny, self.nz
+        for equal index differences, hip.lattice_plan).  Returns V [nx slots][2 x J (C / S, jy)][2 x nz (cos / sin, iz)], J = ny rounded
+        up to 64."""
+        nx, ny, nz, J = self.nx, self.ny, self.nz, self.J
         Kc_s, Ks_s, K64 = self._edge_spectra(E)
-        V = torch.zeros((nx, 2, 64, 2, nz), dtype=F64, device=self.device)          # [slot][C | S][jy (64 slots)][cos | sin][iz]
+        V = torch.zeros((nx, 2, J, 2, nz), dtype=F64, device=self.device)           # [slot][C | S][jy (J slots)][cos | sin][iz]
         V[1:, 0, :ny, 0], V[1:, 0, :ny, 1] = Kc_s[1:], Ks_s[1:]
         V[1:, 1, :ny, 0], V[1:, 1, :ny, 1] = -Ks_s[1:], Kc_s[1:]
         V[0, 0, :ny, 0] = Kc_s[0]                                                   # frequency 0
         V[0, 1, :ny, 1] = K64                                                       # frequency nx (a cosine, stored in the slot's second place)
-        return V.view(nx, 128, 2 * nz)
+        return V.view(nx, 2 * J, 2 * nz)
 
     def _edge_spectra(self, E):
         """x-DFT of the slab's stencil kappa_jy(d, iz): (Kc [slot][jy][iz], Ks [slot][jy][iz], K_nx [jy][iz]); slot 0 carries frequency 0."""
         nx, ny, nz = self.nx, self.ny, self.nz
         F2, _ = self._edge_consts()
         Ev = E[:ny * nx]
-        kap = torch.zeros((2, ny, nx, 2 * nz), dtype=F64, device=self.device)      # [+ / -][jy][d][iz | compute-extent padding]
+        nzp = hip.pad_n(nz)
+        kap = torch.zeros((2, ny, nx, nzp), dtype=F64, device=self.device)         # [+ / -][jy][d][iz | compute-extent padding]
         kap[0, :, :, :nz] = Ev[0::nx].reshape(ny, nx, nz)                          # d = ix >= 0   (sensor column jx = 0)
         kap[1, :, 1:, :nz] = Ev[:, :nz].reshape(ny, nx, nz)[:, 1:]                 # d = -jx < 0   (voxel column ix = 0)
-        T = torch.empty((2, ny, 2 * nx, nz), dtype=F64, device=self.device)        # [+ / -][jy][(slot, cs)][iz]
-        hip.gemm_batched(True, 2 * nx, 2 * nz, nx, F2, nx, 0, kap, 2 * nz, nx * 2 * nz, T, nz, 2 * nx * nz, 2 * nx, nz, 2 * ny)
+        T = torch.empty((2 * ny * 2 * nx * nz + 4096,), dtype=F64, device=self.device)[:2 * ny * 2 * nx * nz].view(2, ny, 2 * nx, nz)   # [+ / -][jy][(slot, cs)][iz]
+        hip.gemm_batched(True, hip.pad_n(2 * nx), nzp, nx, F2, nx, 0, kap, nzp, nx * nzp, T, nz, 2 * nx * nz, 2 * nx, nz, 2 * ny)
         T = T.view(2, ny, nx, 2, nz)
         even = T[0] + T[1]                                                          # cosine parts: kappa(d) and kappa(-d) add
         Ks = (T[0] - T[1])[:, :, 1]                                                 # sine parts: they subtract
@@ -104,26 +114,27 @@ class LatticeGram:
 
     def edge_rows(self, X, nrows, V, out):
         """out[r, :ny*nx] += X[r, :nx*nz] . E^T for r < nrows, E given by its spectrum V (edge_eigen).  X: view starting at the slab's
-        first column (unit column stride, even row stride); 64 doubles behind the last row's slab must be readable (compute extents
-        of the first GEMM overhang the plane: inside the next slab / the next row everywhere but at the end of the buffer)."""
-        nx, ny, nz, sp = self.nx, self.ny, self.nz, self.sp
+        first column (unit column stride, even row stride); the compute extent of the first GEMM overhangs the plane by up to
+        pad128(nz) doubles (inside the next slab / the next row everywhere but at the end of the buffer: staged there)."""
+        nx, ny, nz, sp, J = self.nx, self.ny, self.nz, self.sp, self.J
         pl, RB = nx * nz, self.EDGE_ROWS
         F2, FiT = self._edge_consts()
         assert X.stride(1) == 1 and X.stride(0) % 2 == 0 and out.stride(1) == 1
-        end = X.storage_offset() + (nrows - 1) * X.stride(0) + pl + nz
+        nzp, nxp = hip.pad_n(nz), hip.pad_n(nx)
+        end = X.storage_offset() + (nrows - 1) * X.stride(0) + pl + nzp
         if end > X.untyped_storage().nbytes() // 8:                                 # no slack behind the last row: stage the rows
-            Xc = sp.buf("LG_EX", nrows * pl + 64)[:nrows * pl].view(nrows, pl)
+            Xc = sp.buf("LG_EX", nrows * pl + nzp)[:nrows * pl].view(nrows, pl)
             Xc.copy_(X[:nrows, :pl])
             X = Xc
         for r0 in range(0, nrows, RB):
             R = min(RB, nrows - r0)
             Rp = (R + 127) // 128 * 128
-            Xh = sp.buf("LG_EXh", RB * 2 * nx * nz)                                  # [row][(slot, cs)][iz]
-            hip.gemm_batched(True, 2 * nx, 2 * nz, nx, F2, nx, 0, X[r0:], nz, X.stride(0), Xh, nz, 2 * nx * nz, 2 * nx, nz, R)
-            o2 = sp.buf("LG_EO2", nx * 128 * RB)                                     # [slot][(C | S, jy)][row]
-            hip.gemm_batched(False, 128, Rp, 2 * nz, V, 2 * nz, 128 * 2 * nz, Xh, 2 * nx * nz, 2 * nz, o2, Rp, 128 * Rp, 128, R, nx)
-            oT = sp.buf("LG_EOT", 64 * nx * RB)                                      # [jy][jx][row]
-            hip.gemm_batched(True, 128, Rp, 2 * nx, FiT, 2 * nx, 0, o2, 64 * Rp, Rp, oT, Rp, nx * Rp, nx, R, ny)
+            Xh = sp.buf("LG_EXh", RB * 2 * nx * max(nz, J))                          # [row][(slot, cs)][iz]
+            hip.gemm_batched(True, hip.pad_n(2 * nx), nzp, nx, F2, nx, 0, X[r0:], nz, X.stride(0), Xh, nz, 2 * nx * nz, 2 * nx, nz, R)
+            o2 = sp.buf("LG_EO2", nx * 2 * max(J, nz) * RB)                          # [slot][(C | S, jy)][row]
+            hip.gemm_batched(False, 2 * J, Rp, 2 * nz, V, 2 * nz, 2 * J * 2 * nz, Xh, 2 * nx * nz, 2 * nz, o2, Rp, 2 * J * Rp, 2 * J, R, nx)
+            oT = sp.buf("LG_EOT", max(J, nz) * nx * RB)                              # [jy][jx][row]
+            hip.gemm_batched(True, nxp, Rp, 2 * nx, FiT, 2 * nx, 0, o2, J * Rp, Rp, oT, Rp, nx * Rp, nx, R, ny)
             out[r0:r0 + R, :ny * nx] += oT[:ny * nx * Rp].view(ny * nx, Rp)[:, :R].t()
 
     # ---- the TRANSPOSED application: rows of L^-1 (one operator's columns) -> rows of L^-1 A  ---------------------------------------
@@ -141,6 +152,26 @@ class LatticeGram:
         """LambdaW[kx][iz][ky] from the Gram's eigen-data lam = Lambda^T[ky][z][kx] / (Py Px)."""
         return lam.view(self.Py, self.nz, self.Px).permute(2, 1, 0).contiguous().view(-1)
 
+    def _lhat(self, Lrows, r0, Rb, lh):
+        """lh[r] (Py x Px) = Gy l_r Gx^T for the sensor images l_r = Lrows[r0 + r] (ny x nx): the radix-2 / fused two-axis kernels where
+        they are instantiated, two batched GEMM passes otherwise."""
+        nx, ny, Px, Py, sp = self.nx, self.ny, self.Px, self.Py, self.sp
+        if sp.fold and ny == nx and "y" in sp.F:
+            hip.xz2d_fold(False, ny, Rb, 1, Lrows[r0:], Lrows.stride(0), ny * nx, sp.F["y"], sp.F["x"], lh, Py * Px, Py * Px)
+        elif (ny, nx) in hip.XZ2D_SHAPES:
+            hip.xz2d(False, ny, nx, Rb, 1, Lrows[r0:], Lrows.stride(0), ny * nx, sp.G["y"], sp.G["x"], lh, Py * Px, Py * Px)
+        else:
+            src = Lrows[r0:]
+            nyp = hip.pad_n(ny)
+            end = src.storage_offset() + (Rb - 1) * src.stride(0) + nyp * nx
+            if end > src.untyped_storage().nbytes() // 8:                             # compute rows of the first pass overhang the image
+                Lc = sp.buf("LG_LX", Rb * ny * nx + nyp * nx)[:Rb * ny * nx].view(Rb, ny * nx)
+                Lc.copy_(src[:Rb, :ny * nx])
+                src = Lc
+            t1 = sp.buf("LG_Lt", Rb * ny * Px + nyp * Px)                             # [row][jy][kx]
+            hip.gemm_batched(False, nyp, hip.pad_n(Px), nx, src, nx, src.stride(0), sp.G["x"], nx, 0, t1, Px, ny * Px, ny, Px, Rb)
+            hip.gemm_batched(True, hip.pad_n(Py), hip.pad_n(Px), ny, sp.G["y"], ny, 0, t1, Px, ny * Px, lh, Px, Py * Px, Py, Px, Rb)
+
     def apply_transpose(self, Lrows, nrows, lamW, out):
         """out[r, :ny*nx*nz] = interior-slab part of  sum_c Lrows[r, c] A[c, :]  (boundary slabs zero), r < nrows.
         Lrows: (>= nrows x ny*nx) view of L^-1's columns of this operator (16-byte aligned, even row stride)."""
@@ -151,19 +182,16 @@ class LatticeGram:
             g[0] = 0.0
             g[ny - 1] = 0.0
             self._GyT0 = g
-        R = self.R
+        R = self.Rz
         for r0 in range(0, nrows, R):
             Rb = min(R, nrows - r0)
             lh = sp.buf("LG_Lh", R * Py * Px)
-            if sp.fold and ny == nx and "y" in sp.F:
-                hip.xz2d_fold(False, ny, Rb, 1, Lrows[r0:], Lrows.stride(0), ny * nx, sp.F["y"], sp.F["x"], lh, Py * Px, Py * Px)
-            else:
-                hip.xz2d(False, ny, nx, Rb, 1, Lrows[r0:], Lrows.stride(0), ny * nx, sp.G["y"], sp.G["x"], lh, Py * Px, Py * Px)
+            self._lhat(Lrows, r0, Rb, lh)
             W = sp.buf("LG_W", R * Px * nz * Py)
             hip.lattice_wbuild(Rb, Py, Px, nz, lamW, lh, W)
             U = sp.buf("LG_U", R * nx * nz * Py)
-            hip.gemm_batched(True, 128, nz * Py, Px, sp.GT["x"], Px, 0, W, nz * Py, Px * nz * Py, U, nz * Py, nx * nz * Py, nx, nz * Py, Rb)
-            hip.gemm_batched(False, 128, nx * nz, Py, self._GyT0, Py, 0, U, Py, nx * nz * Py, out[r0:], nx * nz, out.stride(0), ny, nx * nz, Rb)
+            hip.gemm_batched(True, hip.pad_n(nx), nz * Py, Px, sp.GT["x"], Px, 0, W, nz * Py, Px * nz * Py, U, nz * Py, nx * nz * Py, nx, nz * Py, Rb)
+            hip.gemm_batched(False, hip.pad_n(ny), nx * nz, Py, self._GyT0, Py, 0, U, Py, nx * nz * Py, out[r0:], nx * nz, out.stride(0), ny, nx * nz, Rb)
 
     def transpose_tables3(self, lam):
         """Lambda3[iz][ky][kx] (spectral planes per z channel) from the Gram's eigen-data lam = Lambda^T[ky][z][kx] / (Py Px)."""
@@ -195,40 +223,42 @@ class LatticeGram:
             hip.xz2d_fold_inv_strided(ny, Rb, nz, W, nz * Py * Px, Py * Px, sp.F["y"], sp.F["x"], out[r0:], out.stride(0), nx, nz * nx)
 
     def edge_eigen_t(self, E):
-        """Spectrum of one boundary slab for the transposed application: Vt [nx slots][2 x nz (C / S, iz)][2 x 64 (cos / sin, jy)]
+        """Spectrum of one boundary slab for the transposed application: Vt [nx slots][2 x nz (C / S, iz)][2 x J (cos / sin, jy)]
         (same transforms Kc, Ks of the slab's x-Toeplitz stencil as edge_eigen; the convolution theorem instead of the correlation's)."""
-        nx, ny, nz = self.nx, self.ny, self.nz
+        nx, ny, nz, J = self.nx, self.ny, self.nz, self.J
         Kc_s, Ks_s, K64 = self._edge_spectra(E)                                      # [slot][jy][iz], [slot][jy][iz], [jy][iz]
-        Vt = torch.zeros((nx, 2, nz, 2, 64), dtype=F64, device=self.device)          # [slot][C | S][iz][cos | sin][jy (64 slots)]
+        # (one spare slot of zeros: the compute rows of the per-slot GEMM, pad128(2 nz), may overhang the last slot)
+        Vt = torch.zeros((nx + 1, 2, nz, 2, J), dtype=F64, device=self.device)       # [slot][C | S][iz][cos | sin][jy (J slots)]
         Kc_t, Ks_t = Kc_s.transpose(1, 2), Ks_s.transpose(1, 2)                      # [slot][iz][jy]
-        Vt[1:, 0, :, 0, :ny], Vt[1:, 0, :, 1, :ny] = Kc_t[1:], -Ks_t[1:]             # Outc = Lc Kc - Ls Ks
-        Vt[1:, 1, :, 0, :ny], Vt[1:, 1, :, 1, :ny] = Ks_t[1:], Kc_t[1:]              # Outs = Lc Ks + Ls Kc
+        Vt[1:nx, 0, :, 0, :ny], Vt[1:nx, 0, :, 1, :ny] = Kc_t[1:], -Ks_t[1:]         # Outc = Lc Kc - Ls Ks
+        Vt[1:nx, 1, :, 0, :ny], Vt[1:nx, 1, :, 1, :ny] = Ks_t[1:], Kc_t[1:]          # Outs = Lc Ks + Ls Kc
         Vt[0, 0, :, 0, :ny] = Kc_t[0]                                                # frequency 0
         Vt[0, 1, :, 1, :ny] = K64.t()                                                # frequency nx
-        return Vt.view(nx, 2 * nz, 128)
+        return Vt.view(nx + 1, 2 * nz, 2 * J)
 
     def edge_apply_transpose(self, Lrows, nrows, Vt, out, zx=False):
         """out[r, (ix, iz)] = sum_(jy, jx) Lrows[r, jy*nx+jx] kappa_jy(ix - jx, iz)  for r < nrows: one boundary slab of L^-1 A.
         out: (>= nrows x nx*nz) view of the slab's columns; zx: the slab is stored as [iz][ix] (apply_transpose_zx's row layout)."""
-        nx, ny, nz, sp = self.nx, self.ny, self.nz, self.sp
+        nx, ny, nz, sp, J = self.nx, self.ny, self.nz, self.sp, self.J
         RB = self.EDGE_ROWS
         F2, FiT = self._edge_consts()
-        end = Lrows.storage_offset() + (nrows - 1) * Lrows.stride(0) + 128 * nx
+        nyp, nxp = hip.pad_n(ny), hip.pad_n(nx)
+        end = Lrows.storage_offset() + (nrows - 1) * Lrows.stride(0) + nyp * nx
         if end > Lrows.untyped_storage().nbytes() // 8:                               # compute extents of the first GEMM overhang the row
-            Lc = sp.buf("LG_EX", nrows * ny * nx + 128 * nx)[:nrows * ny * nx].view(nrows, ny * nx)
+            Lc = sp.buf("LG_EX", nrows * ny * nx + nyp * nx)[:nrows * ny * nx].view(nrows, ny * nx)
             Lc.copy_(Lrows[:nrows, :ny * nx])
             Lrows = Lc
         for r0 in range(0, nrows, RB):
             R = min(RB, nrows - r0)
             Rp = (R + 127) // 128 * 128
-            Lh = sp.buf("LG_EXh", RB * 2 * nx * 64)                                   # [row][(slot, cs)][jy]
-            if ny < 64:
+            Lh = sp.buf("LG_EXh", RB * 2 * nx * max(nz, J))                           # [row][(slot, cs)][jy]
+            if ny < J:
                 Lh.zero_()                                                            # (jy slots >= ny meet zero columns of Vt: keep them finite)
-            hip.gemm_batched(False, 2 * nx, 128, nx, F2, nx, 0, Lrows[r0:], nx, Lrows.stride(0), Lh, 64, 2 * nx * 64, 2 * nx, ny, R)
-            o2 = sp.buf("LG_EO2", nx * 128 * RB)                                      # [slot][(C | S, iz)][row]
-            hip.gemm_batched(False, 128, Rp, 128, Vt, 128, 128 * 128, Lh, 2 * nx * 64, 128, o2, Rp, 128 * Rp, 2 * nz, R, nx)
-            oT = sp.buf("LG_EOT", 64 * nx * RB)                                       # [iz][ix][row]
-            hip.gemm_batched(True, 128, Rp, 2 * nx, FiT, 2 * nx, 0, o2, 64 * Rp, Rp, oT, Rp, nx * Rp, nx, R, nz)
+            hip.gemm_batched(False, hip.pad_n(2 * nx), nyp, nx, F2, nx, 0, Lrows[r0:], nx, Lrows.stride(0), Lh, J, 2 * nx * J, 2 * nx, ny, R)
+            o2 = sp.buf("LG_EO2", nx * 2 * max(J, nz) * RB)                           # [slot][(C | S, iz)][row]
+            hip.gemm_batched(False, hip.pad_n(2 * nz), Rp, 2 * J, Vt, 2 * J, 2 * nz * 2 * J, Lh, 2 * nx * J, 2 * J, o2, Rp, 2 * nz * Rp, 2 * nz, R, nx)
+            oT = sp.buf("LG_EOT", max(J, nz) * nx * RB)                               # [iz][ix][row]
+            hip.gemm_batched(True, nxp, Rp, 2 * nx, FiT, 2 * nx, 0, o2, nz * Rp, Rp, oT, Rp, nx * Rp, nx, R, nz)
             res = oT[:nz * nx * Rp].view(nz, nx, Rp)[:, :, :R]
             if zx:
                 out[r0:r0 + R, :nx * nz].view(R, nz, nx).copy_(res.permute(2, 0, 1))
@@ -236,8 +266,15 @@ class LatticeGram:
                 out[r0:r0 + R, :nx * nz].view(R, nx, nz).copy_(res.permute(2, 1, 0))
 
     @staticmethod
-    def supported(nx, ny, nz):
+    def fast(nx, ny, nz):
+        """Grids whose x step and back-transform run on the fused kernels (geobo_xcorr_reduce(_fold), geobo_xz2d(_fold))."""
         return nx == 64 and nz == 64 and ny in (48, 64)
+
+    @staticmethod
+    def supported(nx, ny, nz):
+        """Any grid of the spectral route (extents in multiples of 16): the stages without a fused instance for the extent run as
+        batched MFMA GEMMs + geobo_lamdot_z."""
+        return nx % 16 == 0 and ny % 16 == 0 and nz % 16 == 0 and ny >= 16
 
     def eigen(self, Q, tol=1e-11):
         """Lambda^T[ky][z][kx] / (Py Px) from the stencil table Q[(2ny-3)][(2nx-1)][nz]; None if Q is not even in both offsets."""
@@ -267,7 +304,8 @@ class LatticeGram:
         nx, ny, nz, Px, Py = self.nx, self.ny, self.nz, self.Px, self.Py
         Ly = ny if Ly is None else Ly
         h = 0.5 if (self.sp.fold and nx == nz == 64) else 1.0     # radix-2 x step and back-transform: half the MFMAs of the plain products
-        return rows * 2.0 * (hip.pad_n(Py) * nx * nz * Ly + h * Py * Px * nx * nz + h * (ny * Py * Px + ny * nx * Px))
+        zsum = 0.0 if self.fast(nx, ny, nz) else 2.0 * Py * Px * nz  # (the stand-alone scaling + channel sum of the batched-GEMM form, fp64 VALU)
+        return rows * (2.0 * (hip.pad_n(Py) * nx * nz * Ly + h * Py * Px * nx * nz + h * (ny * Py * Px + ny * nx * Px)) + zsum)
 
     def gram_rows(self, X, nrows, lam, out, y0=0, y1=None):
         """out[r, :ny*nx] = interior-slab part of (A K)[r] . A^T for r < nrows.  X: (>= nrows x >= (y1-y0)*nx*nz) rows of A K for
@@ -292,10 +330,29 @@ class LatticeGram:
             s = sp.buf("LG_S", R * Py * Px)
             if sp.fold and nx == nz and "x" in sp.F:
                 hip.xcorr_reduce_fold(nx, R, Py, y1b, Py * plane, plane, sp.F["x"], lam, s, Py * Px, Px)
-            else:
+            elif (nx, nz) == (64, 64):
                 hip.xcorr_reduce(nx, nz, R, Py, y1b, Py * plane, plane, sp.G["x"], lam, s, Py * Px, Px)
+            else:
+                # any other extent: D[r, ky] = Gx X[r, ky] as a batch of small GEMMs, then the eigenvalue scaling and the channel sum
+                D = sp.buf("LG_D", R * Py * Px * nz)
+                hip.gemm_batched(True, hip.pad_n(Px), hip.pad_n(nz), nx, sp.G["x"], nx, 0, y1b, nz, plane, D, nz, Px * nz, Px, nz, R * Py)
+                hip.lamdot_z(R * Py, Py, Px, nz, D, self.lam_oz(lam), s)
             # "x" of geobo_xz2d is this grid's y axis, its "z" this grid's x axis: S_r (Py x Px) -> Gy^T S_r Gx (ny x nx)
             if sp.fold and ny == nx and "y" in sp.F:
                 hip.xz2d_fold(True, ny, R, 1, s, Py * Px, Py * Px, sp.F["y"], sp.F["x"], out[r0:], out.stride(0), ny * nx)
-            else:
+            elif (ny, nx) in hip.XZ2D_SHAPES:
                 hip.xz2d(True, ny, nx, R, 1, s, Py * Px, Py * Px, sp.GT["y"], sp.GT["x"], out[r0:], out.stride(0), ny * nx)
+            else:
+                t1 = sp.buf("LG_Bt", R * ny * Px + hip.pad_n(ny) * Px)             # [row][iy][kx]
+                hip.gemm_batched(True, hip.pad_n(ny), hip.pad_n(Px), Py, sp.GT["y"], Py, 0, s, Px, Py * Px, t1, Px, ny * Px, ny, Px, R)
+                hip.gemm_batched(True, hip.pad_n(ny), hip.pad_n(nx), Px, t1, Px, ny * Px, sp.G["x"], nx, 0, out[r0:], nx, out.stride(0), ny, nx, R)
+
+    def lam_oz(self, lam):
+        """The Gram's eigen-data as [ky][kx][z] (what geobo_lamdot_z reads) from eigen()'s [ky][z][kx]."""
+        hit = self._lam_oz.get(lam.data_ptr())
+        if hit is None or hit[0] is not lam:
+            self._lam_oz = {k: v for k, v in self._lam_oz.items() if v[0] is not lam}
+            if len(self._lam_oz) > 4:
+                self._lam_oz = {}
+            hit = self._lam_oz[lam.data_ptr()] = (lam, lam.view(self.Py, self.nz, self.Px).transpose(1, 2).contiguous().view(-1))
+        return hit[1]

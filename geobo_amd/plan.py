@@ -1,0 +1,124 @@
+"""Route planning: every shape / rank-count / precision decision of an inversion step as ONE pure function.
+
+`plan_route` maps (grid extents, world size, assembly precision, operator mode, method, environment overrides) to a `Route`: which
+algorithm family the engine runs (engine.py reads nothing else to decide) and which kernels carry each stage.  No device, no torch:
+the whole table is tested on the CPU for every BASELINE.json configuration x world in {1, 2, 4, 8}
+(tests/test_host_logic_cpu.py::test_route_table).  The behaviour-changing GEOBO_* environment switches are overrides INTO this
+function; what a step then does is recorded as `engine.route` / `engine.step_route` and in the bench line.
+
+Families (DESIGN.md sections 2 and 7):
+  "rows"     the structured algorithm sharded by SENSOR ROWS over world >= 1 ranks: the three blocks of A K that AkA's lower triangle
+             needs, row block by row block through the spectral product and straight on through the lattice Gram (A K is never held),
+             replicated Cholesky, transposed posterior V = (L^-1 A3) K on the rank's rows of L^-1, one all-gather + one all-reduce.
+             Needs a lattice survey with even stencils (decided per operator build: engine falls back to "columns").
+  "single"   one rank, fp64, the fused n = 64 kernels: the same algorithm with A K materialised once (engine._posterior_zpath,
+             _assemble_AkA_sym) and, with operators="auto", operator rows read as windows of the stencil table.
+  "columns"  voxel-column shards of A K / V (rounds 1-2): fused reduction L^-1 (A K), AkA by the N/G-deep GEMM or the column form of
+             the lattice Gram, row exchange (all-to-all) from 4 ranks.  What runs for surveys off the lattice, the dense method, padded
+             shapes and small grids without fused kernels.
+Reference call sites all of these replace: inversion.py:92-117 (predict3), kernels.py:158-195 (create_cov)."""
+from dataclasses import asdict, dataclass
+
+PAD_M, PAD_N = 256, 128
+XZ2D_SHAPES = ((48, 64), (64, 64), (64, 32))      # fused (x, z) transform instances (hip.XZ2D_SHAPES)
+XZ2D_FOLD_N = (64,)                               # radix-2 instances (hip.XZ2D_FOLD_N)
+TOEPLITZ_NY = (16, 32, 48, 64, 128)               # Toeplitz y-stage instances (hip.TOEPLITZ_NY)
+ROWS_MIN_VOXELS = 1 << 18                         # batched-GEMM forms of the row algorithm pay from 64^3 voxels ...
+ROWS_MIN_PLANE = 96 * 96                          # ... and (x, z) planes that fill the 128 x 128 GEMM tiles
+
+
+def _pad(v, m):
+    return (int(v) + m - 1) // m * m
+
+
+def shard_columns(n_pad, world, rank):
+    units = n_pad // PAD_N
+    return units * rank // world * PAD_N, units * (rank + 1) // world * PAD_N
+
+
+@dataclass(frozen=True)
+class Route:
+    spectral: bool          # A K through the real-DFT route (regular grid, extents % 16, unpadded voxels, slab-aligned shards)
+    family: str             # "rows" | "single" | "columns": what the engine attempts (a survey off the lattice demotes to "columns")
+    rows: bool              # the row form is statically possible
+    single: bool            # the one-rank fused-kernel form is statically possible
+    exchange: bool          # column form: row-sharded transforms + all-to-all of A K block columns
+    exchange_without_rows: bool   # ... when the row form is denied at operator-build time (off-lattice survey, uneven stencil)
+    operators: str          # "resident" | "streamed" | "auto" as requested, resolved to "streamed" where residency cannot fit
+    kernels: tuple          # (("xz", ...), ("y", ...), ("gram", ...), ("ss", ...)): which implementation carries each stage
+    note: str               # why a faster family stepped aside for this shape ("" when nothing did)
+
+    def describe(self):
+        k = dict(self.kernels)
+        return "%s/%s xz=%s y=%s gram=%s ss=%s%s" % ("spectral" if self.spectral else "dense", self.family, k["xz"], k["y"], k["gram"],
+                                                      k["ss"], " exchange" if self.exchange and self.family == "columns" else "")
+
+    def as_dict(self):
+        d = asdict(self)
+        d["kernels"] = dict(self.kernels)
+        return d
+
+
+def lattice_gram_fast(nx, ny, nz):
+    """Grids whose Gram x step / back-transform run on the fused kernels (lattice_gram.LatticeGram.fast)."""
+    return nx == 64 and nz == 64 and ny in (48, 64)
+
+
+def lattice_gram_supported(nx, ny, nz):
+    return nx % 16 == 0 and ny % 16 == 0 and nz % 16 == 0 and ny >= 16
+
+
+def plan_route(nx, ny, nz, world=1, rank=0, assembly="f64", operators="resident", method="auto", env=None):
+    env = {} if env is None else env
+    on = lambda key, default="1": env.get(key, default) != "0"
+    nx, ny, nz, world = int(nx), int(ny), int(nz), int(world)
+    N, Ms = nx * ny * nz, nx * ny
+    N_pad, Ms_pad = _pad(N, PAD_N), _pad(Ms, PAD_M)
+    plane = nx * nz
+    c0, c1 = shard_columns(N_pad, world, rank)
+    f32, streamed = assembly == "f32", operators == "streamed"
+    notes = []
+    spectral = (method in ("auto", "spectral") and nx % 16 == 0 and ny % 16 == 0 and nz % 16 == 0 and N == N_pad
+                and c0 % plane == 0 and c1 % plane == 0 and c1 > c0)
+    fused_xz = (nx, nz) in XZ2D_SHAPES and on("GEOBO_SPECTRAL_FUSED_XZ")
+    pair_xz = (nx, nz) == (32, 32) and (64, 32) in XZ2D_SHAPES and ny % 2 == 0 and on("GEOBO_SPECTRAL_FUSED_XZ")
+    fold = on("GEOBO_XZ_FOLD") and nx == nz and nx in XZ2D_FOLD_N
+    dense_y = ny in TOEPLITZ_NY and on("GEOBO_SPECTRAL_DENSE_Y")
+    fused_ss = fused_xz and fold and dense_y and ny <= 64
+    transposed = env.get("GEOBO_POSTERIOR", "zpath") == "zpath"
+    unpadded = Ms == Ms_pad and N == N_pad
+    single = world == 1 and not f32 and spectral and unpadded and transposed and fused_ss
+    gram_ok = lattice_gram_supported(nx, ny, nz) and on("GEOBO_AKA_LATTICE")
+    gram_fast = lattice_gram_fast(nx, ny, nz)
+    rows_mode = env.get("GEOBO_ROWS", "auto")           # "0": never; "1": wherever it is possible; "auto": where it pays
+    pays = (gram_fast and fused_ss) or (N >= ROWS_MIN_VOXELS and plane >= ROWS_MIN_PLANE)
+    xmode = env.get("GEOBO_SPECTRAL_EXCHANGE", "auto")    # "0": replicated forward transforms, column shards (also switches the row form off for N > 1)
+    rows = (spectral and unpadded and Ms % world == 0 and gram_ok and transposed and on("GEOBO_Z_LATTICE") and rows_mode != "0"
+            and (pays or rows_mode == "1") and not (single and rows_mode != "1") and (world == 1 or xmode != "0" or rows_mode == "1"))
+    ncs = {shard_columns(N_pad, world, r)[1] - shard_columns(N_pad, world, r)[0] for r in range(world)}
+    xbase = spectral and world > 1 and Ms % world == 0 and len(ncs) == 1 and xmode != "0"
+    exchange_without_rows = xbase and (world >= 4 or xmode == "1")
+    exchange = xbase and (world >= 4 or xmode == "1" or rows)
+    family = "rows" if rows else ("single" if single else "columns")
+    if spectral and family == "columns" and transposed:
+        if not unpadded:
+            notes.append("nx*ny = %d is not a multiple of %d (padded sensor rows): fused reduction L^-1 (A K) instead of the transposed order" % (Ms, PAD_M))
+        elif not pays:
+            notes.append("no fused kernels for %d x %d x %d and the grid is below %d voxels / %d-mode planes: N-deep Gram and fused reduction "
+                         "(2-6x the work of the structured forms)" % (nx, ny, nz, ROWS_MIN_VOXELS, ROWS_MIN_PLANE))
+        elif world > 1 and Ms % world:
+            notes.append("%d sensor rows do not divide over %d ranks: column shards" % (Ms, world))
+    if not spectral and method == "auto" and (nx % 16 or ny % 16 or nz % 16):
+        notes.append("grid extents %d x %d x %d are not multiples of 16: dense route (2 Ms N^2 flop per block pair)" % (nx, ny, nz))
+    # operator residency: one operator is Ms_pad x N_pad doubles; in the row form a rank only ever needs its rows + two boundary slabs
+    ops = operators
+    rows_r = Ms // world if Ms % world == 0 else Ms
+    if family == "rows" and not streamed and rows_r * N_pad * 8 > (40 << 30):
+        ops = "streamed"
+        notes.append("operator rows of a rank (%.0f GB) are generated per batch instead of being resident" % (rows_r * N_pad * 8 / 1e9))
+    kernels = (("xz", "fold" if (fused_xz and fold) else "fused" if fused_xz else "pair" if pair_xz else "gemm"),
+               ("y", "toeplitz" if dense_y else "spectrum"),
+               ("gram", ("fused" if gram_fast else "gemm") if (family in ("rows", "single") and gram_ok) else "per-step"),
+               ("ss", ("fused" if fused_ss else "stored") if family in ("rows", "single") else "reduction"))
+    return Route(spectral=spectral, family=family, rows=rows, single=single, exchange=exchange, exchange_without_rows=exchange_without_rows,
+                 operators=ops, kernels=kernels, note="; ".join(notes))

@@ -362,19 +362,46 @@ class SpectralProduct:
                     self.backward_xz(u2[i], R, ylo, yhi, [(ya, yb, o[jj][r0:], o[jj].stride(0)) for ya, yb, o in slabs])
 
     # ---- posterior variance in the transposed order (engine._posterior_zpath) ------------------------------------------------------
+    def fused_ss(self):
+        """True where the inverse transform itself squares and sums its output planes (geobo_xz2d_fold_inv_ss: the radix-2 kernels of
+        nx = nz = 64 with the Toeplitz y stage); elsewhere reduce_ss stores a batch of V rows and geobo_sumsq_accum reduces it."""
+        return self.fused_xz and self.fold and self.nx == self.nz and "x" in self.F and self.dense_y and self.ny <= 64
+
+    GENERIC_SS_SLOTS = 8
+
+    def ss_slots(self):
+        """Partial cubes per property block that reduce_ss adds to (sum over them afterwards)."""
+        return hip.xz2d_fold_inv_ss_slots(self.nx, self.R, self.ny) if self.fused_ss() else self.GENERIC_SS_SLOTS
+
     def reduce_ss(self, Zg, Mg, gens_g, Zm, m_first, gens_m, ss):
         """ss[j][slot][y][x*z] += sum_m V_j[m]^2  with  V_j[m] = Zg[m] * K_0j  (+ Zm[m - m_first] * K_1j for m >= m_first),  m < Mg:
         rows of L^-1 A_s carried through the covariance product and squared on the way out of the inverse transform -- V is never
         written.  Zg: (>= Mg x N) rows, Zm: (>= Mg - m_first x N) rows or None; gens_g[j] / gens_m[j]: Toeplitz generators of the
-        blocks (0, j) / (1, j) (eigenvalues()); ss[j]: zeroed partial cubes (hip.xz2d_fold_inv_ss_slots(nx, R, ny) slots each).
-        m_first must be a multiple of the batch size R (a batch is entirely one-term or entirely two-term)."""
+        blocks (0, j) / (1, j) (eigenvalues()); ss[j]: zeroed partial cubes (ss_slots() slots each).
+        Batches never straddle m_first (a batch is entirely one-term or entirely two-term).  Grids without the fused reduction
+        (fused_ss): the storing product of every batch into a scratch of R rows, then geobo_sumsq_accum."""
         nx, ny, nz, C, Cp, R = self.nx, self.ny, self.nz, self.Px * self.Pz, self.Cp, self.R
-        assert self.fused_xz and self.fold and nx == nz and "x" in self.F and self.dense_y
-        assert Zm is None or m_first % R == 0
         P_c = len(gens_g)
-        for r0 in range(0, Mg, R):
-            Rb = min(R, Mg - r0)
-            two = Zm is not None and r0 >= m_first
+        if Zm is None:
+            m_first = Mg
+        starts = list(range(0, min(m_first, Mg), R)) + list(range(m_first, Mg, R))
+        if not self.fused_ss():
+            N = self.N
+            for r0 in starts:
+                two = r0 >= m_first
+                Rb = min(R, (Mg if two else min(m_first, Mg)) - r0)
+                vg = [self.buf("SSV%d" % jj, R * N)[:R * N].view(R, N) for jj in range(P_c)]
+                self.product(Zg[r0:], Rb, gens_g, vg)
+                vm = None
+                if two:
+                    vm = [self.buf("SSW%d" % jj, R * N)[:R * N].view(R, N) for jj in range(P_c)]
+                    self.product(Zm[r0 - m_first:], Rb, gens_m, vm)
+                for jj in range(P_c):
+                    hip.sumsq_accum(vg[jj], vm[jj] if two else None, Rb, ss[jj].view(ss[jj].shape[0], -1))
+            return
+        for r0 in starts:
+            two = r0 >= m_first
+            Rb = min(R, (Mg if two else min(m_first, Mg)) - r0)
             t2g = self.forward_zx(Zg[r0:], Rb, self.G, src_row_stride=Zg.stride(0), out_name="T2")
             t2m = self.forward_zx(Zm[r0 - m_first:], Rb, self.G, src_row_stride=Zm.stride(0), out_name="T2b") if two else None
             for j in range(0, P_c, 2):

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GEOBO_VERSION 202 /* 201: flag word of geobo_gemm_nt, (64, 32) instance of geobo_xz2d, workspace layout of geobo_potrf_inv; 202: geobo_ymul, geobo_xz2d_fold_lattice */
+#define GEOBO_VERSION 203 /* 201: flag word of geobo_gemm_nt, (64, 32) instance of geobo_xz2d, workspace layout of geobo_potrf_inv; 202: geobo_ymul, geobo_xz2d_fold_lattice; 203: geobo_sumsq_accum, geobo_lamdot_z */
 
 #define GEOBO_PAD_M 256 /* row padding of M-like dimensions (observation rows)            */
 #define GEOBO_PAD_N 128 /* padding of voxel-like dimensions (columns / contraction index) */
@@ -335,6 +335,21 @@ int geobo_potrf_ctx_create(void** ctx);
 int geobo_potrf_ctx_destroy(void* ctx);
 int geobo_potrf_inv(int64_t m, double* A, int64_t ld, double* Linv, int64_t ldi, int* info, void* ws,
                     size_t ws_bytes, void* ctx, void* stream);
+
+/* Sum of squares over the rows of a batch of V = (L^-1 A3) K (the transposed order of inversion.py:114-117; diag of K - V^T V,
+ * inversion.py:238) for grids without the fused inverse-transform reduction (geobo_xz2d_fold_inv_ss, n = 64):
+ *     ss[slot][c] += sum_{r < rows, r % slots == slot} (a[r][c] + b[r][c])^2,   c < n      (b may be NULL: one-term rows)
+ * a, b: row-major (rows x n, lda / ldb), what the storing covariance product wrote; ss: `slots` partial vectors ld_ss apart that the
+ * call ADDS to (zero them once per reduction, sum over the slots afterwards).  A (slot, column) pair is owned by one thread and
+ * the rows are added in ascending order: deterministic.  n, lda, ldb, ld_ss even; pointers 16-byte aligned.  HBM bound. */
+int geobo_sumsq_accum(int64_t rows, int64_t n, const double* a, int64_t lda, const double* b, int64_t ldb, int slots, double* ss,
+                      int64_t ld_ss, void* stream);
+
+/* Eigenvalue scaling + channel sum of the lattice Gram's x step (AkA on a lattice survey, inversion.py:96) for grids without the
+ * fused kernel (geobo_xcorr_reduce(_fold), nx = nz = 64):  out[b][o] = sum_(z < nz) D[b][o][z] * lam[b % planes][o][z]
+ * for b < batch, o < px, with D = Gx X_b from a geobo_gemm_batched launch ([batch][px][nz], dense) and lam the stencil table's
+ * eigen-data as [planes][px][nz].  nz % 16 == 0; D, lam 16-byte aligned. */
+int geobo_lamdot_z(int64_t batch, int planes, int px, int nz, const double* D, const double* lam, double* out, void* stream);
 
 /* Posterior mean/variance without storing V = L^-1 (A K)   (inversion.py:114-117 + :238's np.diag):
  *     V = Linv * AK (tile by tile, MFMA),  mu[c] = sum_m V[m,c] u[m],  var[c] = prior_var - sum_m V[m,c]^2
