@@ -9,13 +9,17 @@ route needs built on the device (stencil tables + boundary slabs on a lattice su
 the host analysis of the survey geometry and its uploads), A K by the spectral route (radix-2 real-DFT transforms over x and z,
 Toeplitz blocks over y), AkA (lattice Gram), Cholesky + L^-1, posterior mean + variance in the transposed order (round 3:
 V = (L^-1 A3) K -- rows of L^-1 A through the same covariance kernels, squared and summed on the way out of the inverse transform;
-the mean as two weighted column sums of A K), D2H of the cubes.  Workload = BASELINE
+the mean as three rows -- A_g^T w_g, A_m^T w_m, the drill weights, w = L^-T u -- through the covariance product), D2H of the cubes.
+Which algorithm family a shape / rank count / precision runs in is decided by geobo_amd/plan.py and reported as `config.route`.
+Workload = BASELINE
 config 3/4: 64^3 voxels of 100 m, gravity + magnetics joint inversion (density and magnetic-susceptibility cubes, P_out = 2),
 Matern-3/2 kernel with lengths (2.00, 2.02, 2.04) x 100 m, 50 drill-core constraints, M = 4096 + 4096 + 50 observation rows.
 With N > 1 the SAME problem is sharded over the ranks (strong scaling) by ROWS: a rank owns Ms / N sensor rows
-of each operator (its rows of A K over all voxels, its row blocks of AkA, its rows of L^-1 A); collectives: one all-gather of the AkA
-row blocks and one all-reduce of the partial means and sums of squares (2 P N doubles).  (Surveys off the lattice, fp32 assembly and
-streamed operators keep the round-2 forms: voxel-column shards, all-reduce of the partial AkA or all-to-all of A K block-columns.)
+of each operator (its rows of A K over all voxels a chunk at a time, its row blocks of AkA, its rows of L^-1 A); collectives: one
+all-gather of the AkA row blocks and one all-reduce of the partial sums of squares (P N doubles; every rank forms the mean whole).
+HIP-event time of each collective per step is reported as `config.collective_ms_per_step` for every rank, next to every rank's stage
+table; `--check` re-runs the problem on rank 0 alone inside the same job and compares the cubes.  (Surveys off the lattice and the
+dense method keep the round-2 forms: voxel-column shards, all-reduce of the partial AkA or all-to-all of A K block-columns.)
 
 Prints ONE JSON line on rank 0 (see the driver contract); extra objects:
   roofline      dominant kernel = geobo_toeplitz_y on the default route (the y stage of every covariance product, 30 % of the step;
@@ -151,8 +155,8 @@ def assembly_roofline(inv, lengths, rows=8192, launches=5):
             "scaled by the algorithmic bytes; not collected in this run)",
             "launches_timed": launches, "bytes_per_launch": by, "bytes_per_launch_is": "algorithmic: 8 B per element of the %d x %d block written "
             "+ the 2N-entry lattice table and the row indices read once" % (rows, N), "mean_launch_s": mean_s, "median_launch_s": durs[len(durs) // 2],
-            "what": "materialised assembly of one covariance block (block (0,1) of create_cov, %s cross kernel) on the 64^3 grid: SURVEY 8(d) "
-                    "regime (i); not part of the timed step (the matrix-free path never materialises K)" % s.kernelfunc}
+            "what": "materialised assembly of one covariance block (block (0,1) of create_cov, %s cross kernel) on the %d x %d x %d grid: SURVEY 8(d) "
+                    "regime (i); not part of the timed step (the matrix-free path never materialises K)" % (s.kernelfunc, eng.nx, eng.ny, eng.nz)}
 
 
 def host_threads():
@@ -265,7 +269,9 @@ def relaunch_with_ranks(a):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % a.gpus, "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver (RCCL needs it)
+    # the task environment states that this image's driver supports dmabuf IPC only and exports HSA_ENABLE_IPC_MODE_LEGACY=0 for RCCL;
+    # kept for ranks started from a shell that lost it (no multi-GPU node was available to the builder to verify it is needed)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
@@ -291,6 +297,8 @@ def main():
     ap.add_argument("--cpu-dense-forms", default="", help="cube edges for the reference-shaped CPU form (a), e.g. '16' (~30 s) or '16,20'")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU dry runs)")
     ap.add_argument("--oversubscribe", action="store_true", help="dry runs: allow several ranks per device (gloo backend)")
+    ap.add_argument("--check", action="store_true", help="N > 1: after the timed steps rank 0 runs the same problem alone (a 1-rank engine on its "
+                    "own device, inside this job) and the line carries the largest normwise difference of the cubes and both checksum sets")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -379,6 +387,31 @@ def main():
                                          "spectrum): y stage of the covariance products (A K and V = (L^-1 A) K)",
                     "aka_gemm_nt": "geobo_gemm_nt (gemm_f64_kernel<4,2,NT>)"}
 
+    coll_names = {"xgmi_all_gather": "all_gather", "xgmi_all_reduce": "all_reduce", "xgmi_all_to_all": "all_to_all"}
+    my_table = {k: round(1e3 * v["seconds"] / a.steps, 3) for k, v in stages.items()}
+    my_coll = {coll_names[k]: round(1e3 * v["seconds"] / a.steps, 3) for k, v in stages.items() if k in coll_names}
+    tables, colls = [my_table], [my_coll]
+    if dist is not None:
+        tables, colls = [None] * world, [None] * world
+        dist.all_gather_object(tables, my_table)
+        dist.all_gather_object(colls, my_coll)
+    check = None
+    operators_in_use = sorted({"streamed" if type(v).__name__ == "StreamedOperator" else "resident" for v in inv.engine._A.values()})
+    if a.check and world > 1:
+        inv.engine.release()                   # (dry runs put all ranks on one device: make room for the 1-rank engine)
+        dist.barrier()
+        if rank == 0:
+            solo = Inversion(settings=s, props=(0, 1, 2)[:a.props], rank=0, world=1, device="cuda:%d" % local, method=a.method,
+                             assembly=a.assembly, operators=a.operators)
+            solo.gp_length = (gp_length.copy() if gp_length is not None else s.gp_lengthscale * np.asarray([s.xvoxsize] * 3))
+            ref = solo.cubing(grav, mag, drill0[drill0 != 0], loc, drill0)
+            idx = (0, 1, 3, 4) if a.props == 2 else range(6)
+            check = {"max_normwise_diff_vs_1_rank": max(float(np.abs(cubes[i] - ref[i]).max() / np.abs(ref[i]).max()) for i in idx),
+                     "cube_checksums_1_rank": [float(np.abs(ref[i]).sum()) for i in idx], "route_1_rank": solo.engine.route.describe(),
+                     "logl_diff": float(abs(inv.logl - solo.logl))}
+            del solo
+        dist.barrier()
+
     if rank == 0:
         eng = inv.engine
         N = eng.N
@@ -407,7 +440,11 @@ def main():
             except Exception:
                 pass
             roof = {"bound": "hbm", "kernel": kernel_names[dom], "achieved": by / mean_s / 1e9, "peak": 8000.0, "unit": "GB/s",
-                    "frac": by / mean_s / 8e12, "traffic": traffic,
+                    "frac": by / mean_s / 8e12, "frac_fp64_valu": vflop / mean_s / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
+                    "bound_note": "HBM and the fp64 VALU limit this kernel together (8 flop per byte): `frac` is the HBM side as the contract asks, "
+                                  "`frac_fp64_valu` the same launches against the 78.6 TFLOP/s vector peak at the nominal 2.4 GHz; a memory-bound "
+                                  "launch clocks at ~2.0 GHz inside the pipeline (GRBM_GUI_ACTIVE, DESIGN.md section 4), where the VALU side is ~1.2x that",
+                    "traffic": traffic,
                     "traffic_source": None if tsrc is None else tsrc + " (committed rocprofv3 --pmc passes of the same kernel: FETCH_SIZE x2 + "
                     "WRITE_SIZE, scaled by the algorithmic bytes; not collected in this run)",
                     "launches_timed": calls, "bytes_per_launch": by, "bytes_per_launch_is": "algorithmic: the batch's (x, z)-spectrum read once "
@@ -435,13 +472,19 @@ def main():
             "metric": "voxels/sec posterior (mean+var) for 64^3 x 2-prop joint inversion; fp64 roofline %",
             "value": value, "unit": "voxel-properties/s", "n_gpus": ranks_reported, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64" if a.assembly == "f64" else "f32 assembly / f64 accumulate+factorise", "data": "synthetic",
-            "config": {"workload": "%d^3 voxel cube (100 m), gravity+magnetics joint inversion, %s kernel lengths (2.00,2.02,2.04)x100 m, "
-                                   "%d drill constraints, M=%d rows, %s cubes (P_out=%d)" % (n, a.kernel, a.drill, M, "density+magsus" + ("+drill" if p_out == 3 else ""), p_out),
+            "dtype": "f64" if a.assembly == "f64" else "f32 assembly / f64 accumulate+factorise",
+            "data": "synthetic (the reference's cylinders model, simcube.py:83-92, plus a smooth trend 0.02 (x/X + 2 y/Y - z/Z) so that drill "
+                    "values are non-degenerate at every size; survey = A rho, A chi rounded through float32)",
+            "config": {"workload": "%d^3 voxel cube (100 m), gravity+magnetics joint inversion, %s kernel lengths %s, "
+                                   "%d drill constraints, M=%d rows, %s cubes (P_out=%d)" % (
+                                       n, a.kernel, "(2.00,2.02,2.04)x100 m" if gp_length is not None else "2 x 100 m (create_cov makes them (2.00,2.04,2.00))",
+                                       a.drill, M, "density+magsus" + ("+drill" if p_out == 3 else ""), p_out),
                        "N_voxels": N, "M_rows": M, "props_out": p_out, "parallelism": ("sensor-row shards x%d" if eng._rowpath else "voxel-column shards x%d") % world,
+                       "route": eng.route.describe(), "route_family_of_the_steps": eng.step_route, "route_note": eng.route.note or None,
+                       "collective_ms_per_step": colls, "stage_ms_per_step_by_rank": tables, "check_vs_1_rank": check,
                        "backend": a.backend if world > 1 else None, "ranks_reported_by_backend": ranks_reported,
                        "method": "spectral" if inv.engine.use_spectral else "dense", "assembly": a.assembly, "operators": a.operators,
-                       "operators_in_use": sorted({"streamed" if type(v).__name__ == "StreamedOperator" else "resident" for v in inv.engine._A.values()}),
+                       "operators_in_use": operators_in_use,
                        "row_exchange": bool(inv.engine.exchange and not inv.engine._rowpath), "row_posterior": bool(inv.engine._rowpath),
                        "ms_per_step_median": step_ms[len(step_ms) // 2], "ms_per_step_all_rank0": [round(v, 2) for v in step_ms],
                        "ms_per_step_in_order_rank0": [round(1e3 * (b - a_), 2) for a_, b in zip(marks[:-1], marks[1:])],

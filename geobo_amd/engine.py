@@ -575,6 +575,15 @@ class PosteriorEngine(RowFormMixin):
         self._rowsrc, self._Aedge, self._Arows = {}, {}, {}
         self._lattice_plan = None      # host analysis of the survey geometry + its device copies: part of the operator build
 
+    def release(self):
+        """Give the device memory back (workspaces, transform buffers, operators, eigen-data); the engine rebuilds what the next
+        step needs.  bench.py --check: the ranks free their share before rank 0 runs the 1-rank comparison on the same device."""
+        self.clear_operators()
+        self._ws, self._spectral, self._gram, self._gens, self._fullrows = {}, None, None, {}, {}
+        self._xyz = None
+        self.last = None
+        torch.cuda.empty_cache()
+
     # ---- stages ------------------------------------------------------------------------------------------------
     def _tick(self, name, t0=None):
         if not self.profile:

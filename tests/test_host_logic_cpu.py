@@ -174,3 +174,67 @@ def test_lattice_gram_form_decision_table():
     assert lattice_gram_form(True, True, 4, 64 * 48, c0, c1, plane, 64 * 48 * 64) is None         # 12 planes: not a multiple of 16
     assert lattice_gram_form(True, False, 3, 64 * 48, 0, 64 * 16 * 64, plane, 64 * 48 * 64) == "rows"
     assert lattice_gram_form(True, False, 5, 64 * 48 + 5, 0, 0, plane, 1) is None                 # Ms / G not a multiple of 128
+
+
+def test_route_table():
+    """geobo_amd/plan.py: the one pure function behind every shape / rank-count / precision decision of the engine -- every
+    BASELINE.json configuration x world in {1, 2, 4, 8}, the environment overrides, and the notes a user gets when a faster family
+    steps aside for a shape reason."""
+    from geobo_amd.plan import plan_route
+    fam = lambda *a, **k: plan_route(*a, **k).family
+    # config 1 (16^3, exp) and config 2 (32^3): no fused kernels, below the size where the batched-GEMM forms of the row algorithm pay
+    for n in (16, 32):
+        for w in (1, 2, 4, 8):
+            r = plan_route(n, n, n, world=w)
+            assert r.spectral and r.family == "columns" and not r.rows and r.exchange == (w >= 4) and "no fused kernels" in r.note
+    assert dict(plan_route(32, 32, 32).kernels)["xz"] == "pair"
+    # configs 3 / 4 (64^3 fp64): one rank on the fused kernels with A K materialised, from two ranks sharded by sensor rows
+    r = plan_route(64, 64, 64, operators="auto")
+    assert r.family == "single" and r.single and not r.rows and r.note == "" and dict(r.kernels) == dict(xz="fold", y="toeplitz", gram="fused", ss="fused")
+    for w in (2, 4, 8):
+        r = plan_route(64, 64, 64, world=w, rank=w - 1)
+        assert r.family == "rows" and r.rows and not r.single and r.exchange and r.exchange_without_rows == (w >= 4)
+    assert fam(64, 48, 64) == "single" and fam(64, 48, 64, world=4) == "rows"
+    # fp32 tables / streamed operators no longer force column shards: the row form carries them (config 5's modes at 64^3)
+    assert fam(64, 64, 64, world=8, assembly="f32") == "rows" and fam(64, 64, 64, assembly="f32") == "rows"
+    assert fam(64, 64, 64, world=4, operators="streamed") == "rows"
+    # config 5 (128^3 x 3, fp32 assembly): row form on the batched-GEMM kernels; operator rows are generated per batch where a rank's
+    # share cannot be resident
+    for w in (1, 2, 4, 8):
+        r = plan_route(128, 128, 128, world=w, assembly="f32", operators="auto")
+        assert r.family == "rows" and dict(r.kernels) == dict(xz="gemm", y="toeplitz", gram="gemm", ss="stored")
+        assert (r.operators == "streamed") == (w < 8)
+    assert plan_route(128, 128, 128, world=8, assembly="f32", operators="streamed").operators == "streamed"
+    assert fam(96, 96, 96) == "rows" and dict(plan_route(96, 96, 96).kernels)["y"] == "spectrum"
+    # shapes the spectral route does not take, and padded sensor rows
+    r = plan_route(25, 16, 16)
+    assert not r.spectral and r.family == "columns" and "not multiples of 16" in r.note
+    r = plan_route(64, 16, 16 * 20)          # nx * ny = 1024 (fine), planes 64 x 320 ...
+    assert r.spectral
+    r = plan_route(48, 16, 64)               # nx * ny = 768 = 3 * 256: unpadded
+    assert r.spectral and r.family == "columns"
+    r = plan_route(16, 24 * 2, 16)           # nx * ny = 768
+    assert r.spectral
+    r = plan_route(80, 16, 16)               # nx * ny = 1280 = 5 * 256
+    assert r.spectral and r.family == "columns"
+    r = plan_route(144, 16, 144)             # nx * ny = 2304 = 9 * 256, N = 331776 >= 2^18, planes 144 x 144: rows
+    assert r.family == "rows"
+    r = plan_route(112, 48, 112)             # nx * ny = 5376 = 21 * 256
+    assert r.family == "rows"
+    r = plan_route(112, 16, 112, world=1)    # nx * ny = 1792 = 7 * 256 but N = 200704 < 2^18
+    assert r.family == "columns" and "below" in r.note
+    r = plan_route(16, 16, 16 * 1024)        # padded? nx * ny = 256: fine; planes 16 x 16384
+    assert r.spectral
+    r = plan_route(96, 88 + 8, 96, world=7)  # 9216 sensor rows do not divide over 7 ranks
+    assert r.family == "columns" and ("do not divide" in r.note or not r.spectral)
+    # environment overrides go INTO the planner
+    assert fam(64, 64, 64, env={"GEOBO_POSTERIOR": "dense"}) == "columns"
+    assert fam(64, 64, 64, world=4, env={"GEOBO_POSTERIOR": "dense"}) == "columns"
+    assert fam(64, 64, 64, world=4, env={"GEOBO_SPECTRAL_EXCHANGE": "0"}) == "columns"
+    assert fam(64, 64, 64, world=2, env={"GEOBO_ROWS": "0"}) == "columns"
+    assert fam(64, 64, 64, env={"GEOBO_ROWS": "1"}) == "rows" and fam(16, 16, 16, env={"GEOBO_ROWS": "1"}) == "rows"
+    assert fam(64, 64, 64, env={"GEOBO_XZ_FOLD": "0"}) == "columns"          # without the radix-2 kernels one rank has no fused reduction ...
+    assert fam(64, 64, 64, env={"GEOBO_AKA_LATTICE": "0"}) == "single"
+    assert fam(64, 64, 64, world=2, env={"GEOBO_AKA_LATTICE": "0"}) == "columns"
+    assert not plan_route(64, 64, 64, method="dense").spectral
+    assert "spectral/rows" in plan_route(64, 64, 64, world=8).describe()
