@@ -316,7 +316,7 @@ extern "C" int geobo_toeplitz_y(int ny, int64_t C, int64_t plane, int64_t R, int
   if (nprop < 1 || nprop > 2 || R <= 0 || y0 < 0 || y1 > ny || y1 <= y0 || plane < C) return GEOBO_E_ARG;
   if (C <= 0 || C % 64 || (plane & 1) || (int64_t)ny * plane * 8 >= (1ll << 31)) return GEOBO_E_ALIGN;
   hipStream_t st = (hipStream_t)stream;
-  if (ny == 128) {
+  if (ny > 64) {
     const double* tabs[3] = {tab0, nprop == 2 ? tab1 : nullptr, nullptr};
     double* outs[3] = {out0, nprop == 2 ? out1 : nullptr, nullptr};
     return geobo_toeplitz_y3(ny, C, plane, R, nprop, in, tabs, outs, y0, y1, stream);
@@ -340,7 +340,7 @@ extern "C" int geobo_toeplitz_y3(int ny, int64_t C, int64_t plane, int64_t R, in
     if (!tabs[j] || !outs[j]) return GEOBO_E_ARG;
   if (R <= 0 || y0 < 0 || y1 > ny || y1 <= y0 || plane < C) return GEOBO_E_ARG;
   if (C <= 0 || C % 64 || (plane & 1) || (int64_t)ny * plane * 8 >= (1ll << 31)) return GEOBO_E_ALIGN;
-  if (ny != 128) {
+  if (ny <= 64) {
     // shorter axes: the register-table kernel, two property blocks per sweep
     for (int j = 0; j < nprop; j += 2) {
       const int n = nprop - j >= 2 ? 2 : 1;
@@ -353,5 +353,11 @@ extern "C" int geobo_toeplitz_y3(int ny, int64_t C, int64_t plane, int64_t R, in
   ToeplitzWinArgs g;
   g.in = in; g.C = C; g.S = plane; g.R = R; g.nprop = nprop; g.y0 = y0; g.y1 = y1;
   for (int j = 0; j < 3; ++j) { g.tab[j] = tabs[j < nprop ? j : 0]; g.out[j] = outs[j < nprop ? j : 0]; }
-  return launch_win<128, 16>(g, (hipStream_t)stream);
+  switch (ny) {     // the windowed kernel: a lane's half of the inputs + 16 outputs = a window of ny/2 + 15 table values in registers
+    case 128: return launch_win<128, 16>(g, (hipStream_t)stream);
+    case 112: return launch_win<112, 16>(g, (hipStream_t)stream);
+    case 96: return launch_win<96, 16>(g, (hipStream_t)stream);
+    case 80: return launch_win<80, 16>(g, (hipStream_t)stream);
+    default: return GEOBO_E_UNSUPPORTED;   // other y extents: carry y through the spectrum instead (spectral.py)
+  }
 }

@@ -471,7 +471,7 @@ def a_sens_lattice_stencil(ws, nx, ny, nz):
     return ws[np_:np_ + (2 * ny - 3) * (2 * nx - 1) * nz].view(2 * ny - 3, 2 * nx - 1, nz)
 
 
-TOEPLITZ_NY = (16, 32, 48, 64, 128)      # y extents geobo_toeplitz_y / _y3 are instantiated for
+TOEPLITZ_NY = (16, 32, 48, 64, 80, 96, 112, 128)      # y extents geobo_toeplitz_y / _y3 are instantiated for
 
 
 def toeplitz_y(ny, C, R, src, tabs, outs, y0=0, y1=None, plane=None):

@@ -22,7 +22,7 @@ from dataclasses import asdict, dataclass
 PAD_M, PAD_N = 256, 128
 XZ2D_SHAPES = ((48, 64), (64, 64), (64, 32))      # fused (x, z) transform instances (hip.XZ2D_SHAPES)
 XZ2D_FOLD_N = (64,)                               # radix-2 instances (hip.XZ2D_FOLD_N)
-TOEPLITZ_NY = (16, 32, 48, 64, 128)               # Toeplitz y-stage instances (hip.TOEPLITZ_NY)
+TOEPLITZ_NY = (16, 32, 48, 64, 80, 96, 112, 128)               # Toeplitz y-stage instances (hip.TOEPLITZ_NY)
 ROWS_MIN_VOXELS = 1 << 18                         # batched-GEMM forms of the row algorithm pay from 64^3 voxels ...
 ROWS_MIN_PLANE = 96 * 96                          # ... and (x, z) planes that fill the 128 x 128 GEMM tiles
 

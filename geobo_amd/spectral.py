@@ -168,7 +168,7 @@ class SpectralProduct:
         if self.kernel_timer is None:
             return fn()
         # (one name per kernel symbol: single-block launches run toeplitz_y_kernel<ny, 2>, the others <ny, 1>)
-        name = "kernel:toeplitz_y" if len(tabs) >= 2 or ny == 128 else "kernel:toeplitz_y_single"
+        name = "kernel:toeplitz_y" if len(tabs) >= 2 or ny > 64 else "kernel:toeplitz_y_single"
         return self.kernel_timer(name, 8.0 * R * C * (ny + len(tabs) * (y1 - y0)), fn)
 
     def buf(self, name, n):

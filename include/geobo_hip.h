@@ -305,13 +305,14 @@ int geobo_xcorr_reduce_fold(int n, int64_t rows, int planes, const double* in, i
  * in: [R][ny][plane]; tab_j: [ny][C]; out_j: [R][y1-y0][plane]; plane >= C is the stride between the y-planes of in and out in
  * doubles (even): with plane == C a power of two (16384 at 64^3) the ny planes a lane walks sit on the same HBM channels, which
  * costs a quarter of the bandwidth (profiles/r03_hbm_copy_runs.txt) -- callers pad it.  nprop = 1 or 2 property blocks per
- * sweep (tab1/out1 unused for 1).  ny in {16, 32, 48, 64} (GEOBO_E_UNSUPPORTED otherwise), C % 64 == 0, ny*plane*8 < 2^31. */
+ * sweep (tab1/out1 unused for 1).  ny in {16, 32, 48, 64} run here; {80, 96, 112, 128} are forwarded to geobo_toeplitz_y3
+ * (GEOBO_E_UNSUPPORTED otherwise), C % 64 == 0, ny*plane*8 < 2^31. */
 int geobo_toeplitz_y(int ny, int64_t C, int64_t plane, int64_t R, int nprop, const double* in, const double* tab0, const double* tab1,
                      double* out0, double* out1, int y0, int y1, void* stream);
 
 /* The same stage for up to THREE property blocks per sweep of the input (tabs / outs: HOST arrays of nprop device pointers) and
- * for ny = 128 (BASELINE config 5, 128^3 x 3 properties): there the ny table values of a mode no longer fit a lane's registers; a
- * lane owns one mode, one half of the inputs and a chunk of 16 outputs, whose distances form a window of 79 table values with
+ * for ny in {80, 96, 112, 128} (128: BASELINE config 5, 128^3 x 3 properties): there the ny table values of a mode no longer fit a
+ * lane's registers; a lane owns one mode, one half of the inputs and a chunk of 16 outputs, whose distances form a window of ny/2 + 15 table values with
  * static register indices; the input row is re-read once per 16-output chunk (one chunk for the 16-plane slab of an 8-rank shard).
  * ny in {16, 32, 48, 64} is forwarded to geobo_toeplitz_y two blocks at a time. */
 int geobo_toeplitz_y3(int ny, int64_t C, int64_t plane, int64_t R, int nprop, const double* in, const double* const* tabs,

@@ -205,7 +205,8 @@ def test_route_table():
         assert r.family == "rows" and dict(r.kernels) == dict(xz="gemm", y="toeplitz", gram="gemm", ss="stored")
         assert (r.operators == "streamed") == (w < 8)
     assert plan_route(128, 128, 128, world=8, assembly="f32", operators="streamed").operators == "streamed"
-    assert fam(96, 96, 96) == "rows" and dict(plan_route(96, 96, 96).kernels)["y"] == "spectrum"
+    assert fam(96, 96, 96) == "rows" and dict(plan_route(96, 96, 96).kernels)["y"] == "toeplitz"
+    assert dict(plan_route(144, 144, 144).kernels)["y"] == "spectrum"
     # shapes the spectral route does not take, and padded sensor rows
     r = plan_route(25, 16, 16)
     assert not r.spectral and r.family == "columns" and "not multiples of 16" in r.note

@@ -964,12 +964,14 @@ def test_row_sharded_lattice_gram_matches_the_single_rank_AkA():
     assert d <= 1e-12 * ref.abs().max().item(), d
 
 
-@pytest.mark.parametrize("dims", [(48, 32, 64), (64, 48, 64), (32, 16, 64), (16, 80, 16), (64, 64, 64), (16, 128, 16), (64, 128, 64)])
+@pytest.mark.parametrize("dims", [(48, 32, 64), (64, 48, 64), (32, 16, 64), (16, 80, 16), (64, 64, 64), (16, 128, 16), (64, 128, 64), (16, 96, 32),
+                                  (32, 112, 16), (16, 144, 16)])
 @pytest.mark.parametrize("kern,cross", [("matern32", True), ("sparse", False)])
 def test_spectral_product_matches_lattice_contraction_on_non_cubic_grids(dims, kern, cross):
     """Every kernel combination of the spectral route against the dense lattice-table contraction (geobo_ak_fused_grid) on
     random operator rows: fused (x,z) transform for nx = 48 / 64 with nz = 64, batched-GEMM passes otherwise; Toeplitz y
-    stage for ny <= 64 and for ny = 128 (windowed kernel), y through the spectrum for ny = 80; one to three property blocks per sweep."""
+    stage for ny <= 64 and for ny = 80 / 96 / 112 / 128 (windowed kernel), y through the spectrum for ny = 144; one to three property
+    blocks per sweep."""
     from geobo_amd import hip
     from geobo_amd.spectral import SpectralProduct
     nx, ny, nz = dims
@@ -979,7 +981,7 @@ def test_spectral_product_matches_lattice_contraction_on_non_cubic_grids(dims, k
     A = torch.zeros((rows, N + 16), dtype=torch.float64, device="cuda")[:, :N]
     A[:37] = (torch.rand((37, N), generator=g, dtype=torch.float64) * 2 - 1).cuda()
     sp = SpectralProduct(nx, ny, nz, "cuda")
-    assert sp.fused_xz == ((nx, nz) in ((48, 64), (64, 64))) and sp.dense_y == (ny in (16, 32, 48, 64, 128))
+    assert sp.fused_xz == ((nx, nz) in ((48, 64), (64, 64))) and sp.dense_y == (ny in (16, 32, 48, 64, 80, 96, 112, 128))
     kid = hip.kernel_id(kern, cross)
     tabs = [hip.cov_table(kid, nx, ny, nz, 100.0, 90.0, 110.0, l1, l2, w, 1.3, "cuda")
             for l1, l2, w in ((210.0, 170.0, 0.7), (260.0, 240.0, 1.0), (150.0, 300.0, 0.4))]
