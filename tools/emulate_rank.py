@@ -100,14 +100,14 @@ def main():
         # bytes this rank SENDS per collective (fp64)
         a2a_per_peer = rows_r * P_c * nc * 8.0 if (eng.exchange and not rowp) else 0.0   # one operator, one destination
         a2a_total = 2 * (G - 1) * a2a_per_peer                                       # both operators, all peers
-        if eng.exchange and eng._row_gram():
+        if rowp or (eng.exchange and eng._row_gram()):
             aka_bytes_in = (G - 1) * rows_r * (3.0 if rowp else 4.0) * Ms_pad * 8.0   # all-gather of row blocks: what a rank receives
             aka_kind = "all_gather of AkA row blocks"
         else:
             aka_bytes_in = 2.0 * (G - 1) / G * true_AkA.numel() * 8.0                # ring all-reduce: 2 (G-1)/G S per rank
             aka_kind = "all_reduce of the partial AkA"
         slices = 0.0 if rowp else (G - 1) * P_c * nc * 8.0 * 2                        # mu and var slices received
-        allred = 2.0 * P_c * N * 8.0 if rowp else 0.0                                 # partial means and sums of squares
+        allred = 1.0 * P_c * N * 8.0 if rowp else 0.0                                 # partial sums of squares (every rank forms the mean whole)
         pred = {}
         for label, link in (("153 GB/s per link (task statement)", 153e9), ("64 GB/s per link and direction (conservative)", 64e9)):
             links = min(G - 1, 7)
@@ -121,7 +121,8 @@ def main():
             pred[label] = dict(all_to_all_ms=round(t_a2a, 2), aka_collective_ms=round(t_aka, 2), slices_or_all_reduce_ms=round(t_sl, 2),
                                step_ms_no_overlap=round(ms + t_a2a + t_aka + t_sl, 1), step_ms=round(ms + exposed, 1),
                                speedup_vs_one_rank=round(ms1 / (ms + exposed), 2))
-        out["ranks"][str(G)] = dict(rank=r, row_exchange=bool(eng.exchange and not rowp), row_posterior=rowp, row_gram=bool(eng._row_gram()),
+        out["ranks"][str(G)] = dict(rank=r, route=eng.route.describe(), row_exchange=bool(eng.exchange and not rowp), row_posterior=rowp,
+                                    row_gram=bool(rowp or eng._row_gram()),
                                     compute_ms_per_step_measured=round(ms, 2), stage_ms_measured=st,
                                     replicated_ms=round(st.get("potrf_inv", 0.0), 2),
                                     bytes_sent_all_to_all=a2a_total, aka_collective=aka_kind, bytes_received_aka=aka_bytes_in,
