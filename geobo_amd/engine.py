@@ -23,13 +23,12 @@ HBM layout (all fp64, row-major, zero padded -- include/geobo_hip.h "PADDING CON
     AkA/L      M_pad x M_pad             M_pad = pad256(2*Ms_pad + M_d); padding rows carry identity
     Linv       M_pad x M_pad
 
-Multi-GPU (one process per GPU, torch.distributed/RCCL).  Lattice survey, fp64, resident operators (round 3): sharded by ROWS -- a
-rank owns Ms / G sensor rows of each operator: its rows of A K over all voxels, its row blocks of AkA (all-gather), its rows of
-Linv A3 (one all-reduce of the partial means and sums of squares); no column shard of anything (_assemble_rows, _posterior_rows).
-Otherwise voxel COLUMNS of A K / V are sharded in units of 128 (= y-slabs of the cube): 1-2 ranks with replicated forward transforms
-and one all-reduce of the partial AkA, from 4 ranks with row-sharded transforms and one all-to-all of A K block-columns per
-operator; mu / var slices by one all-gather.
-DESIGN.md section 7.
+Which family a step runs in -- "single" (one rank, fused n = 64 kernels, transposed.py), "rows" (sharded by sensor rows over world >= 1
+ranks, chunked, any grid of the spectral route: rowform.py) or "columns" (voxel-column shards, fused reduction, row exchange from 4
+ranks: this file + columnform.py) -- is decided by plan.plan_route (pure, CPU-tested) and confirmed when the operators are built
+(lattice survey, even stencils).  Multi-GPU: one process per GPU, torch.distributed / RCCL; row form: one all-gather of AkA row blocks +
+one all-reduce of the partial sums of squares; column form: all-reduce of the partial AkA or all-to-all of A K block columns, mu / var
+slices by one all-gather.  DESIGN.md sections 2 and 7.
 """
 import math
 import os
@@ -40,7 +39,10 @@ import torch
 
 from . import geometry, hip
 from .plan import plan_route
+from .columnform import ColumnExchangeMixin
 from .rowform import RowFormMixin
+from .operators import StreamedOperator
+from .transposed import TransposedPosteriorMixin
 from .sharding import (EmulatedGroup, allreduce_sum_, assemble_columns, backend_of, exchange_blocks, exchange_blocks_finish,
                        exchange_blocks_start, gather_rows, gather_slices, shard_columns)
 
@@ -115,63 +117,7 @@ def _on_device(fn):
     return wrapper
 
 
-class StreamedOperator:
-    """A forward operator that is never resident: its rows (all voxels of a batch of sensors) or its column slabs (one y-range
-    of every sensor) are generated on demand straight from the survey geometry -- on a lattice survey by one contiguous copy
-    per (sensor, y-slab) out of the stencil table Q (geobo_a_sens_lattice), otherwise by the direct kernel.  What BASELINE
-    config 5 needs: at 128^3 one operator is 275 GB (SURVEY.md section 8 size table)."""
-
-    def __init__(self, eng, func, Bv, mul, div, locd, axes_dev, plan, lws):
-        self.eng, self.func, self.Bv, self.mul, self.div = eng, func, Bv, mul, div
-        self.locd, self.axes_dev, self.plan, self.lws = locd, axes_dev, plan, lws
-        self.lattice = None     # spectral.LatticeRows: the transform reads the rows as windows of the stencil table (keep_stencil)
-
-    def keep_stencil(self, name):
-        """Lattice survey: keep this operator's stencil table Q (63 MB at 64^3; the lattice workspace is shared between the
-        operators) and its two 1e6-padded boundary slabs for every sensor, and describe the rows as windows of Q -- the forward
-        transform then reads the table, which stays in cache, and no operator row is ever written or read."""
-        from .spectral import LatticeRows
-        e = self.eng
-        nx, ny, nz, plane = e.nx, e.ny, e.nz, e.nx * e.nz
-        nqx = 2 * nx - 1
-        Q = e._workspace("lattice_Q_" + name, (2 * ny - 3, nqx, nz))
-        Q.copy_(hip.a_sens_lattice_stencil(self.lws, nx, ny, nz))
-        row_off = (((ny - 2 - self.plan["jy"].to(torch.int64)) * nqx + (nx - 1 - self.plan["jx"].to(torch.int64))) * nz).contiguous()
-        E2 = e._workspace2d("Aedge_" + name, e.Ms_pad, 2 * plane)
-        if e.Ms_pad > e.Ms:
-            E2[e.Ms:].zero_()
-        xed, yed, zed = self.axes_dev
-        for k, iy in enumerate((0, ny - 1)):
-            hip.a_sens(self.func, self.Bv, self.locd, nx, ny, nz, xed, yed, zed, self.mul, self.div, E2[:, k * plane:(k + 1) * plane], iy, iy + 1,
-                       plan=self.plan, ws=self.lws, col_origin=iy * plane)
-        self.edge = E2
-        self.lattice = LatticeRows(Q.view(-1), row_off, nqx * nz, E2)
-
-    def rows_into(self, buf, r0, R):
-        """buf[:R, :N_pad] <- operator rows r0 .. r0+R-1 (voxel padding columns zero)."""
-        e = self.eng
-        out = buf[:R, :e.N_pad]
-        if e.N_pad > e.N:
-            out[:, e.N:].zero_()
-        xed, yed, zed = self.axes_dev
-        hip.a_sens(self.func, self.Bv, self.locd[r0:r0 + R].contiguous(), e.nx, e.ny, e.nz, xed, yed, zed, self.mul, self.div, out,
-                   plan=self.plan, rows=slice(r0, r0 + R), ws=self.lws)
-        return out
-
-    def slab_into(self, buf, iy0, iy1):
-        """buf[:Ms_pad, :(iy1-iy0)*nx*nz] <- columns of the y-slabs iy0 .. iy1-1 for every sensor (rows >= Ms zero)."""
-        e = self.eng
-        w = (iy1 - iy0) * e.nx * e.nz
-        out = buf[:e.Ms_pad, :w]
-        if e.Ms_pad > e.Ms:
-            out[e.Ms:].zero_()
-        xed, yed, zed = self.axes_dev
-        hip.a_sens(self.func, self.Bv, self.locd, e.nx, e.ny, e.nz, xed, yed, zed, self.mul, self.div, out, iy0, iy1,
-                   plan=self.plan, ws=self.lws, col_origin=iy0 * e.nx * e.nz)
-        return out
-
-
-class PosteriorEngine(RowFormMixin):
+class PosteriorEngine(RowFormMixin, TransposedPosteriorMixin, ColumnExchangeMixin):
     def __init__(self, settings, device=None, rank=0, world=1, group=None, profile=False, method="auto", assembly="f64",
                  operators="resident"):
         """assembly "f32": covariance tables rounded through fp32 and A K kept in fp32 in HBM (BASELINE config 5, "fp32 kernel
@@ -708,130 +654,6 @@ class PosteriorEngine(RowFormMixin):
                             hip.convert(dst[jj], outs[jj][r0:r0 + R])
             self._timed("spectral_product", fl, batches, valu=fv)
 
-    def _assemble_AK_spectral_exchange(self, AK, lengths, W, name, amp, props):
-        """Row-sharded spectral product + all-to-all (multi-GPU): rank r transforms sensor rows [r*Ms/G, (r+1)*Ms/G) of both
-        operators for every voxel, cropping the backward passes once per destination y-slab straight into the send buffer of
-        the operator, [dest][block][row][col]; one all_to_all_single over xGMI per operator (the first one runs under the second
-        operator's transforms); the received blocks are this rank's columns of every sensor row."""
-        if self.f32 or self.streamed:
-            return self._exchange_chunked(AK, lengths, W, name, amp, props)
-        self._finish_exchange()          # (an exchange left over by a call that failed between its start and its factorisation)
-        # one exchange per operator: the gravity rows travel while the magnetic rows are being transformed
-        sends, pending = [], []
-        for s_, func in ((0, "grav"), (1, "magn")):
-            send = self._exchange_send(s_, func, lengths, W, name, amp, props)
-            sends.append(send)
-            out = self._workspace("xchg_recv_%d" % s_, tuple(send.shape)) if backend_of(self._xgroup) == "nccl" else None
-            if self.async_exchange:
-                pending.append(exchange_blocks_start(send, self.world, self._xgroup, out=out))
-            else:
-                pending.append((self._timed("xgmi_all_to_all", 0.0, lambda: exchange_blocks(send, self.world, self._xgroup)), None))
-        self._keep_full_rows(sends, props)
-        self._pending_exchange = (AK, pending, props)
-        if not self._row_gram():
-            self._finish_exchange()      # AkA by the GEMM reads the received columns of A K
-
-    def _finish_exchange(self):
-        """Wait for the row exchange and put the received blocks into A K.  With the row-sharded lattice Gram nothing reads those
-        columns before the posterior reduction (AkA comes from this rank's own rows, kept from the send buffers), so posterior()
-        calls this after the factorisation: the all-to-all runs under the Gram, the all-gather and the Cholesky."""
-        if self._pending_exchange is None:
-            return
-        AK, pending, props = self._pending_exchange
-        self._pending_exchange = None
-        for s_, (recv, work) in enumerate(pending):
-            self._timed("xgmi_all_to_all", 0.0, lambda: exchange_blocks_finish(work))
-            self._exchange_place(AK, recv, props, s_)
-
-    def _exchange_chunked(self, AK, lengths, W, name, amp, props):
-        """The row exchange for the large-cube modes (fp32 assembly and / or streamed operators, BASELINE config 5): the rank's
-        sensor rows go through the transform in chunks of a few row batches; each chunk is cropped per destination into a send
-        buffer of ~1.5 GB (fp32 in the fp32 mode: converted from an fp64 scratch of one batch), exchanged by its own
-        all_to_all_single and written straight into the A K shard -- no rank-sized send / receive buffers (3 x 104 GB at 128^3)."""
-        sp, nc, G = self._spectral, self.nc, self.world
-        plane = self.nx * self.nz
-        rows_r, P_c, Rb = self.Ms // G, len(props), self._spectral.R
-        esize = 4 if self.f32 else 8
-        Rc = Rb * max(1, int((3 << 29) // (G * P_c * Rb * nc * esize)))
-        send = self._workspace("xchg_send_chunk", (G, P_c, Rc, nc), dtype=hip.F32 if self.f32 else F64)
-        scr = self._workspace("xchg_scratch64", (G, P_c, Rb, nc)) if self.f32 else None
-        slabs_of = [tuple(c // plane for c in shard_columns(self.N_pad, G, d)) for d in range(G)]
-        self._fullrows = {}
-        for s_, func in ((0, "grav"), (1, "magn")):
-            lams = [sp.eigenvalues(self._cov_table(hip.kernel_id(name, s_ != j), lengths[j], lengths[s_], W[s_][j], amp)) for j in props]
-            A = [v for k, v in self._A.items() if k[0] == func][0]
-            streamed = isinstance(A, StreamedOperator)
-            abuf = self._op_rows_buffer() if streamed else None
-            for r0 in range(0, rows_r, Rc):
-                R = min(Rc, rows_r - r0)
-
-                def transform():
-                    for rb in range(0, R, Rb):
-                        n = min(Rb, R - rb)
-                        g0 = self.rank * rows_r + r0 + rb                 # first sensor row of this batch
-                        src = A.rows_into(abuf, g0, n) if streamed else self._Arows[func][r0 + rb:r0 + rb + n]
-                        dst = scr if self.f32 else send[:, :, rb:rb + Rb]
-                        sp.product(src, n, lams, None, slabs=[(slabs_of[d][0], slabs_of[d][1], [dst[d, jj] for jj in range(P_c)])
-                                                              for d in range(G)])
-                        if self.f32:
-                            for d in range(G):
-                                for jj in range(P_c):
-                                    hip.convert(scr[d, jj, :n], send[d, jj, rb:rb + n])
-                self._timed("spectral_product", sp.flops(R, P_c, self.ny), transform, valu=sp.flops_valu(R, P_c))
-                recv = self._timed("xgmi_all_to_all", 0.0, lambda: exchange_blocks(send.view(G, -1), self.world, self.group))
-                for srcr in range(G):
-                    blk = recv[srcr].view(P_c, Rc, nc)
-                    a0 = s_ * self.Ms_pad + srcr * rows_r + r0
-                    for jj in range(P_c):
-                        AK[a0:a0 + R, jj * nc:(jj + 1) * nc].copy_(blk[jj, :R])
-
-    def _row_gram(self):
-        """True when AkA is assembled from row blocks: row exchange + lattice Gram available for both operators."""
-        return self.exchange and all(self._lam.get(f) is not None for f in ("grav", "magn"))
-
-    def _keep_full_rows(self, sends, props):
-        """This rank's own sensor rows of A K over ALL voxels (block columns 0 and 1), gathered from the per-destination slabs of
-        the two send buffers: the input of the row-sharded lattice Gram."""
-        self._fullrows = {}
-        if not self._row_gram():
-            return
-        G, nc = self.world, self.nc
-        rows_r, P_c = self.Ms // G, len(props)
-        for s_ in (0, 1):
-            v = sends[s_].view(G, P_c, rows_r, nc)
-            for sp_ in (0, 1):
-                full = self._workspace2d("fullrows_%d%d" % (s_, sp_), rows_r, G * nc)
-                for d in range(G):
-                    full[:, d * nc:(d + 1) * nc].copy_(v[d, props.index(sp_)])
-                self._fullrows[(s_, sp_)] = full
-
-    def _exchange_send(self, s_, func, lengths, W, name, amp, props):
-        """Send buffer of one operator, (G, P_c * rows_r * nc): [destination][block][row][col] -- this rank's sensor rows of A_s K,
-        every voxel, cropped per destination y-slab by the backward passes themselves."""
-        sp, nc, G = self._spectral, self.nc, self.world
-        plane = self.nx * self.nz
-        rows_r, P_c = self.Ms // G, len(props)
-        send = self._workspace("xchg_send_%d" % s_, (G, P_c * rows_r * nc))
-        slabs_of = [tuple(c // plane for c in shard_columns(self.N_pad, G, d)) for d in range(G)]
-        lams = []
-        for j in props:
-            tab = self._cov_table(hip.kernel_id(name, s_ != j), lengths[j], lengths[s_], W[s_][j], amp)
-            lams.append(sp.eigenvalues(tab))
-        slabs = [(slabs_of[d][0], slabs_of[d][1], [send[d].view(P_c, rows_r, nc)[jj] for jj in range(P_c)]) for d in range(G)]
-        Ar = self._Arows[func]
-        self._timed("spectral_product", sp.flops(rows_r, P_c, self.ny), lambda: sp.product(Ar, rows_r, lams, None, slabs=slabs),
-                    valu=sp.flops_valu(rows_r, P_c))
-        return send
-
-    def _exchange_place(self, AK, recv, props, s_):
-        G, nc = self.world, self.nc
-        rows_r, P_c = self.Ms // G, len(props)
-        for src in range(G):
-            blocks = recv[src].view(P_c, rows_r, nc)
-            r0 = s_ * self.Ms_pad + src * rows_r
-            for jj in range(P_c):
-                AK[r0:r0 + rows_r, jj * nc:(jj + 1) * nc].copy_(blocks[jj])
-
     def _edge_spectrum(self, func, k, ycols):
         """Spectrum of boundary slab k (0: iy = 0, 1: iy = ny - 1) of operator `func` for the lattice Gram's x-correlation; built once
         per operator build (clear_operators drops it) from the slab's columns of the operator."""
@@ -958,47 +780,6 @@ class PosteriorEngine(RowFormMixin):
         allreduce_sum_(AkA, self.world, self.group)
         return self._finish_AkA(AkA, M_pad, sel_t, lengths, name, amp, gp_sigma)
 
-    def _sym_ok(self, A_g, A_m):
-        """The symmetric plan of A K / AkA (see _assemble_AK): the step will run in the transposed order (_zpath_static_ok) and AkA is
-        the lattice Gram for both operators, boundary slabs through their spectra."""
-        if not self._zpath_static_ok():
-            return False
-        return (self._gram is not None and self._gram.edge_supported() and self.Ms_pad == self.nx * self.ny
-                and all(self._lam.get(f) is not None and self._lam[f][0] is A for f, A in (("grav", A_g), ("magn", A_m))))
-
-    def _assemble_AkA_sym(self, AkA, AK, M_pad, A_g, A_m, sel_t, lengths, name, amp, gp_sigma, props):
-        """AkA on one device from the blocks of A K the symmetric plan keeps, row block by row block through the lattice Gram:
-        [grav rows -> grav columns], [grav rows -> magn columns] (transposed into the lower-left block, which is what the
-        factorisation reads), [magn rows -> magn columns], drill rows -> both.  A quarter of the Gram's and of A K's work less than the
-        block-column form, which computes the lower-left block from A_m K_10 as well."""
-        gram, pl, ny, Msp, nc = self._gram, self.nx * self.nz, self.ny, self.Ms_pad, self.nc
-        Md, off_d = 0 if sel_t is None else sel_t.numel(), 2 * self.Ms_pad
-        lam = {0: self._lam["grav"][1], 1: self._lam["magn"][1]}
-        ops = {0: A_g, 1: A_m}
-
-        def edge_cols(sp_, k, iy):
-            A = ops[sp_]
-            if isinstance(A, StreamedOperator):
-                return A.edge[:, k * pl:(k + 1) * pl] if A.lattice is not None else A.slab_into(self._workspace2d("op_slab", Msp, pl), iy, iy + 1)
-            return A[:, iy * pl:(iy + 1) * pl]
-
-        def rows_times_AT(X, nrows, sp_, out):
-            gram.gram_rows(X, nrows, lam[sp_], out, 0, ny)
-            for k, iy in enumerate((0, ny - 1)):
-                gram.edge_rows(X[:, iy * pl:], nrows, self._edge_spectrum(("grav", "magn")[sp_], k, edge_cols(sp_, k, iy)), out)
-        blk = lambda r0, j: AK[r0:, props.index(j) * nc:(props.index(j) + 1) * nc]
-
-        def run():
-            rows_times_AT(blk(0, 0), self.Ms, 0, AkA[0:, 0:Msp])
-            rows_times_AT(blk(0, 1), self.Ms, 1, AkA[0:, Msp:2 * Msp])
-            rows_times_AT(blk(Msp, 1), self.Ms, 1, AkA[Msp:, Msp:2 * Msp])
-            AkA[Msp:2 * Msp, :Msp] = AkA[:Msp, Msp:2 * Msp].t()
-            if Md:
-                rows_times_AT(blk(off_d, 0), Md, 0, AkA[off_d:, 0:Msp])
-                rows_times_AT(blk(off_d, 1), Md, 1, AkA[off_d:, Msp:2 * Msp])
-        self._timed("aka_lattice", gram.flops(3 * self.Ms + 2 * Md, ny), run)
-        return self._finish_AkA(AkA, M_pad, sel_t, lengths, name, amp, gp_sigma)
-
     def _finish_AkA(self, AkA, M_pad, sel_t, lengths, name, amp, gp_sigma):
         """Drill columns by symmetry, the drill-drill block, the noise variances on the diagonal (identity on the padding)."""
         xyz = self.grid_points()
@@ -1023,176 +804,6 @@ class PosteriorEngine(RowFormMixin):
         if len(y_d):
             y[2 * self.Ms_pad:2 * self.Ms_pad + len(y_d)] = y_d
         return hip.to_dev(y, self.device)
-
-    def _zpath_static_ok(self):
-        """The one-rank transposed posterior on the fused kernels (plan.Route.single): one rank, fp64 A K, the radix-2 transform kernels
-        and the Toeplitz y stage of this grid, unpadded sensor rows and voxel columns."""
-        if not self.route.single or self.exchange:
-            return False
-        self._spectral_product()
-        return True
-
-    def _zpath_ok(self, AK, props, A_g, A_m):
-        """... and the covariance generators of the last A K assembly."""
-        return (self._zpath_static_ok() and AK is not None and AK.dtype == F64
-                and all((s_, j) in self._gens for s_ in (0, 1) for j in props))
-
-    def _resident_operator(self, A, func):
-        """A materialised copy of a forward operator that the route so far only kept implicitly (stencil table + boundary slabs)."""
-        if not isinstance(A, StreamedOperator):
-            return A
-        R = self._workspace2d("A_" + func, self.Ms_pad, self.N_pad)
-        xed, yed, zed = A.axes_dev
-        hip.a_sens(A.func, A.Bv, A.locd, self.nx, self.ny, self.nz, xed, yed, zed, A.mul, A.div, R, plan=A.plan, ws=A.lws)
-        return R
-
-    def _lattice_Z(self, Lview, nrows, func, A, out, zx=False, edge=None):
-        """out[r, :N] = sum_c Lview[r, c] A[c, :]  for a lattice-survey operator, without touching A: interior slabs through the stencil
-        table's eigen-data, the two boundary slabs through their x-DFT spectra (lattice_gram.apply_transpose / edge_apply_transpose)."""
-        gram, pl, ny = self._gram, self.nx * self.nz, self.ny
-        lam = self._lam[func][1]
-        hit = self._lamW.get((func, zx))
-        if hit is None or hit[0] is not lam:
-            hit = self._lamW[(func, zx)] = (lam, gram.transpose_tables3(lam) if zx else gram.transpose_tables(lam))
-        if zx:
-            gram.apply_transpose_zx(Lview, nrows, hit[1], out)      # rows as [iy][iz][ix]
-        else:
-            gram.apply_transpose(Lview, nrows, hit[1], out)
-        for k, iy in enumerate((0, ny - 1)):
-            if edge is not None:                      # (row form: the two boundary slabs of every sensor, engine.operator)
-                ycols = edge[k]
-            elif isinstance(A, StreamedOperator) and A.lattice is not None:
-                ycols = A.edge[:, k * pl:(k + 1) * pl]
-            elif isinstance(A, StreamedOperator):
-                ycols = A.slab_into(self._workspace2d("op_slab", self.Ms_pad, pl), iy, iy + 1)
-            else:
-                ycols = A[:, iy * pl:(iy + 1) * pl]
-            key = (func, k)
-            vt = self._edgeVt.get(key)
-            if vt is None or vt[0] != ycols.data_ptr():
-                vt = self._edgeVt[key] = (ycols.data_ptr(), gram.edge_eigen_t(ycols))
-            gram.edge_apply_transpose(Lview, nrows, vt[1], out[:, iy * pl:(iy + 1) * pl], zx=zx)
-
-    def _posterior_zpath(self, Linv, AK, u, A_g, A_m, sel_t, lengths, W, name, amp, props, M_pad):
-        """Posterior mean and variance in the TRANSPOSED order (round 3).  V = L^-1 (A3 K) is (L^-1 A3) K as well, and A3 is block
-        diagonal: applying L^-1 to the forward operators costs M x Ms x N per operator -- independent of the number of property blocks
-        and only over the operator's own columns of L^-1 -- where applying it to A K costs M^2 / 2 x N per property block:
-            Z_g = Linv[:, grav columns] A_g,   Z_m = Linv[:, magn columns] A_m                (fp64 MFMA GEMMs, triangular X: 1.8e13 flop
-                                                                                               at 64^3 instead of 3.6e13)
-            V_j = Z_g K_0j + Z_m K_1j  (+ the drill term in the last rows only: L^-1 is lower triangular)
-        and the covariance products run through the same spectral kernels as A K, with the inverse transform squaring and summing
-        its output planes over the rows instead of storing them (geobo_xz2d_fold_inv_ss): V is never written.  The mean needs no V
-        at all: mu = (A K)^T (L^-T u), two weighted column sums.  Same arithmetic up to summation order (inversion.py:114-117)."""
-        sp, N, Msp, P_c, Md = self._spectral, self.N, self.Ms_pad, len(props), 0 if sel_t is None else sel_t.numel()
-        nx, ny, nz = self.nx, self.ny, self.nz
-        cws = self._workspace("colgemv_ws", (max(hip.colgemv_ws_doubles(M_pad, M_pad), hip.colgemv_ws_doubles(Msp, self.N_pad)),))
-        w = self._timed("posterior_mean", 0.0, lambda: hip.colgemv(Linv, u, ws=cws))
-        Zg, Zm = self._workspace2d("Zg", 2 * Msp, N), self._workspace2d("Zm", Msp, N)
-        # Z = L^-1[:, operator columns] A: on a lattice survey a (y, x) convolution of every row's sensor image with the operator's
-        # stencil table (lattice_gram.apply_transpose: 2e8 flop per row), otherwise two triangular MFMA GEMMs (2.1e9 flop per row)
-        lat = (self._gram is not None and self._gram.edge_supported() and Msp == nx * ny and os.environ.get("GEOBO_Z_LATTICE", "1") != "0"
-               and all(self._lam.get(f) is not None and self._lam[f][0] is A for f, A in (("grav", A_g), ("magn", A_m))))
-        if lat:
-            gram = self._gram
-            fl = 3 * Msp * (gram.flops(1, ny) + 2 * 3 * 2.0 * 128 * 128 * 64)
-
-            zx = gram.zx_supported()          # rows of Z as [iy][iz][ix]: the fused inverse transform writes them, the products below follow
-
-            def zlattice():
-                self._lattice_Z(Linv[:2 * Msp, :Msp], 2 * Msp, "grav", A_g, Zg, zx=zx)
-                self._lattice_Z(Linv[Msp:2 * Msp, Msp:2 * Msp], Msp, "magn", A_m, Zm, zx=zx)
-            self._timed("posterior_zlattice", fl, zlattice)
-            Ag = Am = None
-            vec_of = lambda func, wv, out: self._lattice_Z(wv.view(1, -1), 1, func, A_g if func == "grav" else A_m, out)
-        else:
-            Ag = self._timed("a_sens_grav", 0.0, lambda: self._resident_operator(A_g, "grav"))
-            Am = self._timed("a_sens_magn", 0.0, lambda: self._resident_operator(A_m, "magn"))
-            tri = sum(min(256 * (bi + 1), Msp) for bi in range(Msp // 256)) * 256.0      # executed k-extent x rows of a triangular block
-            fl = 2.0 * N * (2 * tri + 1.0 * Msp * Msp)
-            alg = 2.0 * N * (2 * (Msp * (Msp + 1) / 2.0) + 1.0 * Msp * Msp)
-
-            def zgemm():
-                hip.gemm_nn(Linv[:2 * Msp, :Msp], Ag[:Msp, :N], Zg, x_lower=True)
-                hip.gemm_nn(Linv[Msp:2 * Msp, Msp:2 * Msp], Am[:Msp, :N], Zm, x_lower=True)
-            self._timed("posterior_zgemm", fl, zgemm, alg=alg)
-            vec_of = lambda func, wv, out: hip.colgemv((Ag if func == "grav" else Am)[:Msp, :N], wv, out=out[0], ws=cws)
-        mu_l = self._timed("posterior_mean", 0.0, lambda: self._mean_rows(w, sel_t, lengths, W, name, amp, props, vec_of)).reshape(-1)
-        slots = hip.xz2d_fold_inv_ss_slots(nx, sp.R, ny)
-        ss = [self._workspace("post_ss_%d" % jj, (slots, ny, nx * nz)) for jj in range(P_c)]
-        for t in ss:
-            t.zero_()
-        gens_g, gens_m = [self._gens[(0, j)] for j in props], [self._gens[(1, j)] for j in props]
-        zx = lat and zx
-        swap = (lambda g: g.view(ny, sp.Px, sp.Pz).transpose(1, 2).contiguous().view(-1)) if zx else (lambda g: g)   # tables of transposed planes
-        tg, tm = [swap(g) for g in gens_g], [swap(g) for g in gens_m]
-        self._timed("posterior_spectral", sp.flops_ss(Msp, Msp, P_c), lambda: sp.reduce_ss(Zg, 2 * Msp, tg, Zm, Msp, tm, ss),
-                    valu=3.0 * Msp * P_c * 2.0 * ny * ny * sp.Px * sp.Pz)
-        if zx:
-            ssum = torch.stack([t.sum(0).view(ny, nz, nx).transpose(1, 2).reshape(-1) for t in ss])   # planes came out as [iz][ix]
-        else:
-            ssum = torch.stack([t.sum(0).reshape(-1) for t in ss])                        # (P_c, N), voxel order (iy, ix, iz)
-        if Md:
-            ssum = ssum + self._timed("posterior_drill_rows", 0.0, lambda: self._drill_rows_ss(
-                Linv, 0, Md, sel_t, lengths, W, name, amp, props, gens_g, gens_m,
-                (lambda Lv, n, func, out: self._lattice_Z(Lv, n, func, A_g if func == "grav" else A_m, out)) if lat else None, Ag, Am))
-        return mu_l, (amp * 1.0 - ssum).reshape(-1)
-
-    def _mean_rows(self, w, sel_t, lengths, W, name, amp, props, vec_of):
-        """Posterior mean (P_c, N):  mu_j = (A3 K)[:, block j]^T w  re-associated as  K_.j (A3^T w)  -- the covariance blocks are
-        symmetric, so three N-vectors (A_g^T w_g, A_m^T w_m, the drill weights scattered to their voxels) go through the covariance
-        product as ONE row each (0.3 ms) where the weighted column sums of A K read all of it (35 GB at 64^3: 6 ms).
-        vec_of(func, weights, out (1 x N)): out = A_func^T weights.  w = L^-T u (inversion.py:105,115)."""
-        sp, N, Msp, P_c = self._spectral, self.N, self.Ms_pad, len(props)
-        Md = 0 if sel_t is None else sel_t.numel()
-        V = self._workspace2d("mean_rows", 4, N)
-        vec_of("grav", w[:Msp], V[0:1])
-        vec_of("magn", w[Msp:2 * Msp], V[1:2])
-        terms = [(V[0:1], 0), (V[1:2], 1)]
-        if Md:
-            V[2].zero_()
-            V[2][sel_t] = w[2 * Msp:2 * Msp + Md]
-            terms.append((V[2:3], 2))
-        mu = torch.zeros((P_c, N), dtype=F64, device=self.device)
-        tmp = [self._workspace2d("mean_tmp_%d" % jj, 2, N) for jj in range(P_c)]
-        for rows, s_ in terms:
-            gens = [self._gens[(s_, j)] if s_ < 2 else
-                    sp.eigenvalues(self._cov_table(hip.kernel_id(name, s_ != j), lengths[j], lengths[s_], W[s_][j], amp)) for j in props]
-            sp.product(rows, 1, gens, tmp)
-            for jj in range(P_c):
-                mu[jj].add_(tmp[jj][0])
-        return mu
-
-    def _drill_rows_ss(self, Linv, d0, nd, sel_t, lengths, W, name, amp, props, gens_g, gens_m, lattice_Z, Ag, Am):
-        """(P_c, N) sums of squares of V = L^-1 (A3 K) over the drill rows d0 .. d0 + nd of the row block behind the sensor rows:
-        L^-1 is lower triangular, so only THESE rows see the drill columns.  Tiles of up to 128 rows through the storing covariance
-        product, three terms (gravity, magnetic, drill block rows of K), squared and summed here.  lattice_Z(Lview, n, func, out):
-        rows of L^-1 A on a lattice survey; None: MFMA GEMMs against the resident operators Ag / Am (whole 128-row tiles)."""
-        sp, N, Msp, P_c, Md, T = self._spectral, self.N, self.Ms_pad, len(props), sel_t.numel(), 128
-        Zgd, Zmd, Zdd = (self._workspace2d(nm, T, N) for nm in ("Zg_d", "Zm_d", "Zd_d"))
-        Vd = [self._workspace2d("Vd_%d" % jj, T, N) for jj in range(P_c)]
-        tmp = [self._workspace2d("Vt_%d" % jj, T, N) for jj in range(P_c)]
-        gens_d = [sp.eigenvalues(self._cov_table(hip.kernel_id(name, 2 != j), lengths[j], lengths[2], W[2][j], amp)) for j in props]
-        acc = torch.zeros((P_c, N), dtype=F64, device=self.device)
-        for c0 in range(d0, d0 + nd, T):
-            n = min(T, d0 + nd - c0)
-            b0 = 2 * Msp + c0
-            if lattice_Z is not None:
-                lattice_Z(Linv[b0:b0 + n, :Msp], n, "grav", Zgd)
-                lattice_Z(Linv[b0:b0 + n, Msp:2 * Msp], n, "magn", Zmd)
-            else:
-                nt = min(T, Linv.shape[0] - b0)          # (M_pad is a multiple of 256: whole tiles unless the caller's share starts mid-tile)
-                hip.gemm_nn(Linv[b0:b0 + nt, :Msp], Ag[:Msp, :N], Zgd)
-                hip.gemm_nn(Linv[b0:b0 + nt, Msp:2 * Msp], Am[:Msp, :N], Zmd)
-            Zdd[:n].zero_()
-            Zdd[:n, sel_t] = Linv[b0:b0 + n, 2 * Msp:2 * Msp + Md]
-            sp.product(Zgd, n, gens_g, Vd)
-            for Zx, gx in ((Zmd, gens_m), (Zdd, gens_d)):
-                sp.product(Zx, n, gx, tmp)
-                for jj in range(P_c):
-                    Vd[jj][:n].add_(tmp[jj][:n])
-            for jj in range(P_c):
-                acc[jj].add_((Vd[jj][:n] ** 2).sum(0))
-        return acc
 
     def _results_to_host(self, mu, var, props, queued=None):
         """(P_c N) device mean and variance, complete on this rank -> the reference's two (3N,) property-major host vectors (NaN: blocks
@@ -1313,6 +924,8 @@ class PosteriorEngine(RowFormMixin):
                                        self.N_pad, self.world, to_host=self._to_host)
                 out["mu"], out["var"] = mu, var
             self._tick("d2h", t)
+        # AK_complete False: the symmetric plan leaves the blocks (magn rows, block 0) and (sensor rows, block 2) unwritten (the tests'
+        # oracle contacts read the assembled blocks); None in the row form
         self.last = dict(L=L, Linv=Linv, u=u, AK=AK, AK_complete=AK is not None and not self._ak_sym, props=props, sel=sel)
         return out
 
@@ -1322,8 +935,10 @@ class PosteriorEngine(RowFormMixin):
         the device (A K, L^-1) -- what `predict3(full_cov=True)` returns.  Small cubes only: 9 N^2 doubles are built on the
         device and copied to the host, exactly the object the matrix-free path exists to avoid."""
         last = getattr(self, "last", None)
-        if (last is None or tuple(last["props"]) != (0, 1, 2) or self.world != 1 or not last.get("AK_complete", True)
-                or last["AK"].dtype != F64):
+        if last is not None and not last.get("AK_complete", True):
+            raise RuntimeError("full covariance needs A K from the last posterior(), and this step kept only the blocks AkA needs "
+                               "(symmetric / row form of the transposed order): rerun with GEOBO_POSTERIOR=dense for predict3(full_cov=True)")
+        if last is None or tuple(last["props"]) != (0, 1, 2) or self.world != 1 or last["AK"].dtype != F64:
             raise RuntimeError("full covariance needs a single-rank fp64 posterior() with all three property blocks")
         n3 = 3 * self.N_pad
         if n3 * n3 * 8 * 2 > limit_bytes:
