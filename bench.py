@@ -378,13 +378,15 @@ def main():
         d["flop"] += fl
         d["alg"] += alg
         d["valu"] += valu
-    single = [k for k in stages if k in ("ak_fused_grid", "ak_fused", "posterior_reduce", "posterior_zgemm", "aka_gemm_nt", "kernel:toeplitz_y")]
+    single = [k for k in stages if k in ("ak_fused_grid", "ak_fused", "posterior_reduce", "posterior_zgemm", "aka_gemm_nt", "kernel:toeplitz_y", "kernel:toeplitz_y2t")]
     dom = max(single, key=lambda k: stages[k]["seconds"]) if single else None
     kernel_names = {"ak_fused_grid": "geobo_ak_fused_grid (gemm_f64_kernel<4,2,TAB>)", "ak_fused": "geobo_ak_fused (gemm_f64_kernel<4,2,GEN>)",
                     "posterior_reduce": "geobo_posterior_reduce (gemm_f64_kernel<4,2,NN,REDUCE>)",
                     "posterior_zgemm": "geobo_gemm_nn, triangular X: Z = L^-1[:, operator columns] A (gemm_f64_kernel<4,2,NN>; two launches per step)",
                     "kernel:toeplitz_y": "geobo_toeplitz_y (toeplitz_y_kernel<64, 1>: the launches with two property blocks per read of the "
                                          "spectrum): y stage of the covariance products (A K and V = (L^-1 A) K)",
+                    "kernel:toeplitz_y2t": "geobo_toeplitz_y2t (toeplitz_y2_kernel<64>: the two-term rows of the transposed posterior, V = Z_g K_0j + "
+                                           "Z_m K_1j for two property blocks in one pass over both input spectra)",
                     "aka_gemm_nt": "geobo_gemm_nt (gemm_f64_kernel<4,2,NT>)"}
 
     coll_names = {"xgmi_all_gather": "all_gather", "xgmi_all_reduce": "all_reduce", "xgmi_all_to_all": "all_to_all"}
@@ -425,13 +427,14 @@ def main():
         F_valu = sum(d["valu"] for d in mfma.values()) / a.steps
         step_ms = sorted(1e3 * (b - a_) for a_, b in zip(marks[:-1], marks[1:]))
         roof = None
-        if dom == "kernel:toeplitz_y":
+        if dom in ("kernel:toeplitz_y", "kernel:toeplitz_y2t"):
             # HBM / fp64-VALU co-limited stream kernel: algorithmic bytes (spectrum read once + one output slab per property block)
             d = stages[dom]
             calls = d["calls"]
             mean_s = d["seconds"] / calls
             by = d["alg"] / calls
-            vflop = 2.0 * eng.ny * (by / 8.0) * (2.0 / 3.0)      # FMA flop of the mean launch: ny per output element, two of the three streams are outputs
+            # FMA flop of the mean launch: ny per output element and term (one-term launches: two of the three streams are outputs)
+            vflop = d["valu"] / calls if d["valu"] > 0 else 2.0 * eng.ny * (by / 8.0) * (2.0 / 3.0)
             traffic, tsrc = None, None
             try:
                 p = json.load(open(os.path.join(ROOT, "profiles", PMC_FILES["toeplitz_y"])))
@@ -448,7 +451,9 @@ def main():
                     "traffic_source": None if tsrc is None else tsrc + " (committed rocprofv3 --pmc passes of the same kernel: FETCH_SIZE x2 + "
                     "WRITE_SIZE, scaled by the algorithmic bytes; not collected in this run)",
                     "launches_timed": calls, "bytes_per_launch": by, "bytes_per_launch_is": "algorithmic: the batch's (x, z)-spectrum read once "
-                    "(8 B x rows x ny x 4 nx nz) + one output slab per property block",
+                    "(8 B x rows x ny x 4 nx nz; both terms' spectra for the two-term kernel) + one output slab per property block",
+                    "other_y_stage_kernels_ms_per_step": {k: round(1e3 * stages[k]["seconds"] / a.steps, 2) for k in stages
+                                                          if k.startswith("kernel:toeplitz") and k != dom},
                     "mean_launch_s": mean_s, "median_launch_s": sorted(d["durs"])[calls // 2],
                     "co_limit": {"what": "fp64 VALU: one mode per lane, ny^2 FMA per mode and block (no matrix operand is shared between modes)",
                                  "achieved_TFLOPs_fp64_valu": vflop / mean_s / 1e12, "peak_TFLOPs": FP64_MATRIX_PEAK_TFLOPS},

@@ -166,6 +166,114 @@ __global__ void __launch_bounds__(256, 2) toeplitz_y_kernel(ToeplitzArgs g) {
   }
 }
 
+// ---- two-term rows (round 4): V = Z_g K_0j + Z_m K_1j in ONE pass -------------------------------------------------------------------
+// The rows of the transposed posterior behind the gravity block are sums of two covariance products (engine._posterior_zpath).  As two
+// launches of the kernel above each term writes its own output spectrum (2 x 4.3 GB per 256-row batch at 64^3) and the inverse
+// transform reads both.  Here one workgroup of EIGHT waves -- (term, property block, half of the outputs) -- shares the two input rows
+// of a sensor row; the four waves of the second term hand their 32 partial sums per lane to their partners through the input buffer
+// that has just been consumed (all of it is dead after the row's barrier: 4 waves x 32 x 512 B = the 64 KiB of the two staged rows), the
+// partners add and store ONE output per property block.  Same FMAs as before (the stage is bound by the fp64 VALU either way); what
+// goes away is one output stream of the y stage and one input stream of the inverse transform.  LDS: 2 stages x 2 terms x NY x 512 B
+// = 128 KiB, one workgroup per CU (the same eight waves per CU as two workgroups of the kernel above).
+struct Toeplitz2Args {
+  const double* in[2];        // [R][NY][S] per term
+  const double* tab[2][2];    // [term][block]: [NY][C]
+  double* out[2];             // [R][NY][S] per property block
+  int64_t C, S, R;
+};
+
+template <int NY>
+__global__ void __launch_bounds__(512, 1) toeplitz_y2_kernel(Toeplitz2Args g) {
+  constexpr int OC = NY / 2;
+  extern __shared__ __attribute__((aligned(16))) double xs2_dyn[];          // [2 stages][2 terms][NY][64]
+  double (*xs)[2][NY][64] = reinterpret_cast<double (*)[2][NY][64]>(xs2_dyn);
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int term = w >> 2, prop = (w >> 1) & 1, half = w & 1;
+  const unsigned lane8 = (unsigned)lane * 8u;
+  const int64_t C = g.S, c0 = (int64_t)blockIdx.x * 64;
+  const int C8 = (int)(C * 8);
+  double t[NY];
+  {
+    const int T8 = (int)(g.C * 8);
+    const rsrc_t tr = make_rsrc(g.tab[term][prop] + c0, NY * T8);
+#pragma unroll
+    for (int d = 0; d < NY; ++d) t[d] = ld_lane(tr, lane8, d * T8);
+  }
+  int64_t r = blockIdx.y;
+  if (r >= g.R) return;
+  const int64_t rstep = gridDim.y, rowlen = (int64_t)NY * C;
+  double* po = g.out[prop] + c0 + r * rowlen;
+  const double* ps0 = g.in[0] + r * rowlen + c0;
+  const double* ps1 = g.in[1] + r * rowlen + c0;
+  const int64_t dma_lane = (int64_t)(lane >> 5) * C + (lane & 31) * 2;   // one DMA instruction moves two y-planes of 64 modes
+  auto stage = [&](const double* row0, const double* row1, int b) {
+    for (int i = w; i < NY / 2; i += 8) {
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(row0 + (int64_t)(2 * i) * C + dma_lane), (lds_ptr_t)&xs[b][0][2 * i][0], 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(row1 + (int64_t)(2 * i) * C + dma_lane), (lds_ptr_t)&xs[b][1][2 * i][0], 16, 0, 0);
+    }
+  };
+  stage(ps0, ps1, 0);
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  const int xstep = half ? -512 : 512;
+  const int ysgn = half ? -1 : 1, ybase = half ? NY - 1 : 0;
+  int b = 0;
+  for (; r < g.R; r += rstep) {
+    const bool more = r + rstep < g.R;
+    if (more) {
+      ps0 += rstep * rowlen;
+      ps1 += rstep * rowlen;
+      stage(ps0, ps1, b ^ 1);
+    }
+    double acc[OC], xb[2][GX];
+    const unsigned xaddr = (unsigned)(uintptr_t)(lds_ptr_t)&xs[b][term][half ? NY - 1 : 0][0] + lane8;
+    toeplitz_group<NY, OC, 0>(t, acc, xb, xaddr, xstep);
+#pragma unroll
+    for (int o = 0; o < OC; ++o) asm volatile("" : "+v"(acc[o]));
+    __builtin_amdgcn_s_waitcnt(vmcnt_only(0));      // this wave's share of the next rows has landed (and last row's stores are out)
+    __builtin_amdgcn_s_barrier();                   // (1) every wave is done reading the two rows of stage b: their 64 KiB are free
+    // exchange area = stage b, [pair = 2 prop + half][o][lane]
+    double* const ex = &xs[b][0][0][0] + (size_t)((2 * prop + half) * OC) * 64 + lane;
+    if (term == 1) {
+#pragma unroll
+      for (int o = 0; o < OC; ++o) ex[o * 64] = acc[o];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                   // (2) the second term's partial sums are in LDS
+    if (term == 0) {
+#pragma unroll
+      for (int o = 0; o < OC; ++o) acc[o] += ex[o * 64];
+      const rsrc_t dst = make_rsrc(po, NY * C8);
+      int pitch = C8;
+      asm volatile("" : "+s"(pitch));
+#pragma unroll
+      for (int o = 0; o < OC; ++o) st_lane(dst, lane8, (ybase + ysgn * o) * pitch, acc[o]);
+    }
+    po += rstep * rowlen;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                   // (3) the exchange has been read: stage b may be refilled by the next iteration
+    b ^= 1;
+  }
+}
+
+template <int NY>
+int launch2(const Toeplitz2Args& g, hipStream_t st) {
+  constexpr size_t lds = (size_t)2 * 2 * NY * 64 * sizeof(double);
+  auto kern = toeplitz_y2_kernel<NY>;
+  static std::atomic<uint64_t> attr_done{0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return GEOBO_E_LAUNCH;
+  if (!((attr_done.load(std::memory_order_acquire) >> dev) & 1)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return GEOBO_E_LAUNCH;
+    attr_done.fetch_or((uint64_t)1 << dev, std::memory_order_release);
+  }
+  int64_t gy = g.R < 2 ? g.R : 2;      // one workgroup per CU: 256 column blocks x 2 at 64^3 = two rounds of the chip
+  while ((g.C / 64) * gy < 512 && gy < g.R) ++gy;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(g.C / 64), (unsigned)gy), dim3(512), lds, st, g);
+  return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
+}
+
 // ---- long y axes (NY = 128: the 128^3 configuration): the NY table values of a lane no longer fit its registers ---------------
 // A lane owns ONE mode and ONE HALF of the inputs (lanes 0-31: y' < NY/2, lanes 32-63 the same 32 modes with y' >= NY/2) and a chunk of
 // OC consecutive outputs o = ob .. ob+OC-1.  The distances d = o - y' it meets form a window of NY/2 + OC - 1 consecutive values, so
@@ -330,6 +438,22 @@ extern "C" int geobo_toeplitz_y(int ny, int64_t C, int64_t plane, int64_t R, int
     case 48: return launch<48>(g, st);
     case 64: return launch<64>(g, st);
     default: return GEOBO_E_UNSUPPORTED;  // other y extents: carry y through the spectrum instead (spectral.py)
+  }
+}
+
+extern "C" int geobo_toeplitz_y2t(int ny, int64_t C, int64_t plane, int64_t R, const double* in_g, const double* in_m, const double* tab_g0,
+                                  const double* tab_g1, const double* tab_m0, const double* tab_m1, double* out0, double* out1, void* stream) {
+  if (!in_g || !in_m || !tab_g0 || !tab_g1 || !tab_m0 || !tab_m1 || !out0 || !out1) return GEOBO_E_ARG;
+  if (R <= 0 || plane < C) return GEOBO_E_ARG;
+  if (C <= 0 || C % 64 || (plane & 1) || (int64_t)ny * plane * 8 >= (1ll << 31)) return GEOBO_E_ALIGN;
+  Toeplitz2Args g;
+  g.in[0] = in_g; g.in[1] = in_m; g.tab[0][0] = tab_g0; g.tab[0][1] = tab_g1; g.tab[1][0] = tab_m0; g.tab[1][1] = tab_m1;
+  g.out[0] = out0; g.out[1] = out1; g.C = C; g.S = plane; g.R = R;
+  switch (ny) {
+    case 64: return launch2<64>(g, (hipStream_t)stream);
+    case 48: return launch2<48>(g, (hipStream_t)stream);
+    case 32: return launch2<32>(g, (hipStream_t)stream);
+    default: return GEOBO_E_UNSUPPORTED;
   }
 }
 

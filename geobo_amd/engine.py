@@ -423,7 +423,7 @@ class PosteriorEngine(RowFormMixin, TransposedPosteriorMixin, ColumnExchangeMixi
         if self._spectral is None:
             self._spectral = SpectralProduct(self.nx, self.ny, self.nz, self.device)
         self._spectral.kernel_timer = None if (self.kernel_events is None or os.environ.get("GEOBO_KERNEL_TIMER", "1") == "0") else (
-            lambda name, by, fn: self._timed(name, 0.0, fn, alg=by))
+            lambda name, by, fn, valu=0.0: self._timed(name, 0.0, fn, alg=by, valu=valu))
         return self._spectral
 
     def _timed(self, name, flops, fn, alg=0.0, valu=0.0):

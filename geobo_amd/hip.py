@@ -488,6 +488,19 @@ def toeplitz_y(ny, C, R, src, tabs, outs, y0=0, y1=None, plane=None):
                                      int(y0), int(y1), _stream()), "geobo_toeplitz_y3")
 
 
+TOEPLITZ_Y2T_NY = (32, 48, 64)      # y extents of the two-term kernel
+
+
+def toeplitz_y2t(ny, C, R, src_g, src_m, tabs_g, tabs_m, outs, plane=None):
+    """outs[j][r, y, c] = sum_y' tabs_g[j][|y - y'|, c] src_g[r, y', c] + tabs_m[j][|y - y'|, c] src_m[r, y', c],  j = 0, 1
+    (geobo_toeplitz_y2t: the two-term rows of the transposed posterior in one pass)."""
+    lib = require_gpu()
+    assert len(tabs_g) == 2 and len(tabs_m) == 2 and len(outs) == 2
+    _lib.check(lib.geobo_toeplitz_y2t(int(ny), int(C), int(C if plane is None else plane), int(R), _p(_chk(src_g, "src_g")), _p(_chk(src_m, "src_m")),
+                                      _p(_chk(tabs_g[0], "tab")), _p(_chk(tabs_g[1], "tab")), _p(_chk(tabs_m[0], "tab")), _p(_chk(tabs_m[1], "tab")),
+                                      _p(_chk(outs[0], "out")), _p(_chk(outs[1], "out")), _stream()), "geobo_toeplitz_y2t")
+
+
 class PotrfContext:
     """Fork streams / events of geobo_potrf_inv on the device that is current at construction (owned by the caller: one per
     engine; never shared between concurrent factorisations)."""

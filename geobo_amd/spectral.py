@@ -407,6 +407,16 @@ class SpectralProduct:
             for j in range(0, P_c, 2):
                 js = list(range(j, min(j + 2, P_c)))
                 sg = [self.buf(("S", "S1")[i], Rb * ny * Cp) for i in range(len(js))]
+                if two and len(js) == 2 and ny in hip.TOEPLITZ_Y2T_NY and os.environ.get("GEOBO_Y2T", "1") != "0":
+                    # both terms in ONE y-stage pass (geobo_toeplitz_y2t): one output spectrum per block, one input of the inverse
+                    fn = lambda: hip.toeplitz_y2t(ny, C, Rb, t2g, t2m, [gens_g[jj] for jj in js], [gens_m[jj] for jj in js], sg, plane=Cp)
+                    if self.kernel_timer is None:
+                        fn()
+                    else:
+                        self.kernel_timer("kernel:toeplitz_y2t", 8.0 * Rb * C * (2 * ny + 2 * ny), fn, valu=2.0 * (2 * ny) * ny * C * Rb * 2)
+                    for i, jj in enumerate(js):
+                        hip.xz2d_fold_inv_ss(nx, Rb, ny, sg[i], ny * Cp, Cp, self.F["x"], self.F["z"], ss[jj])
+                    continue
                 self._ystage(ny, C, Rb, t2g, [gens_g[jj] for jj in js], sg, 0, ny, Cp)
                 sm = None
                 if two:

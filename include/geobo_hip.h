@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GEOBO_VERSION 203 /* 201: flag word of geobo_gemm_nt, (64, 32) instance of geobo_xz2d, workspace layout of geobo_potrf_inv; 202: geobo_ymul, geobo_xz2d_fold_lattice; 203: geobo_sumsq_accum, geobo_lamdot_z */
+#define GEOBO_VERSION 203 /* 201: flag word of geobo_gemm_nt, (64, 32) instance of geobo_xz2d, workspace layout of geobo_potrf_inv; 202: geobo_ymul, geobo_xz2d_fold_lattice; 203: geobo_sumsq_accum, geobo_lamdot_z, geobo_toeplitz_y2t */
 
 #define GEOBO_PAD_M 256 /* row padding of M-like dimensions (observation rows)            */
 #define GEOBO_PAD_N 128 /* padding of voxel-like dimensions (columns / contraction index) */
@@ -309,6 +309,15 @@ int geobo_xcorr_reduce_fold(int n, int64_t rows, int planes, const double* in, i
  * (GEOBO_E_UNSUPPORTED otherwise), C % 64 == 0, ny*plane*8 < 2^31. */
 int geobo_toeplitz_y(int ny, int64_t C, int64_t plane, int64_t R, int nprop, const double* in, const double* tab0, const double* tab1,
                      double* out0, double* out1, int y0, int y1, void* stream);
+
+/* The same stage for rows that are the SUM of two covariance products (the rows of the transposed posterior behind the gravity block,
+ * V = Z_g K_0j + Z_m K_1j, inversion.py:114-117 re-associated), two property blocks per sweep, full height:
+ *     out_j[r][y][c] = sum_{y'} tab_gj[|y - y'|][c] * in_g[r][y'][c] + tab_mj[|y - y'|][c] * in_m[r][y'][c],   j = 0, 1
+ * One workgroup of eight waves (term, block, half of the outputs) shares both input rows; the second term's partial sums reach their
+ * partners through the consumed input buffer in LDS: one output stream per block instead of two (and one input stream less for the
+ * inverse transform that follows).  ny in {32, 48, 64} (GEOBO_E_UNSUPPORTED otherwise), C % 64 == 0, plane >= C even. */
+int geobo_toeplitz_y2t(int ny, int64_t C, int64_t plane, int64_t R, const double* in_g, const double* in_m, const double* tab_g0,
+                       const double* tab_g1, const double* tab_m0, const double* tab_m1, double* out0, double* out1, void* stream);
 
 /* The same stage for up to THREE property blocks per sweep of the input (tabs / outs: HOST arrays of nprop device pointers) and
  * for ny in {80, 96, 112, 128} (128: BASELINE config 5, 128^3 x 3 properties): there the ny table values of a mode no longer fit a

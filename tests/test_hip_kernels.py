@@ -406,6 +406,37 @@ def test_toeplitz_y_matches_torch(hip, ny, C, R, nprop, y0, y1):
         assert torch.equal(outp[j][:, :, :C], outs[j]) and bool((outp[j][:, :, C:] == 7.0).all())
 
 
+@pytest.mark.parametrize("ny,C,R", [(64, 256, 5), (64, 16384, 37), (48, 128, 9), (32, 1024, 70), (64, 128, 1)])
+def test_toeplitz_y2t_matches_torch(hip, ny, C, R):
+    # two-term rows in one pass: out_j = T(tab_gj) in_g + T(tab_mj) in_m for two property blocks; many rows per workgroup (the LDS
+    # exchange through the consumed input stage, three barriers per row) and a padded plane stride
+    src_g, src_m = _rand((R, ny, C), 31), _rand((R, ny, C), 32)
+    tg, tm = [_rand((ny, C), 33 + j) for j in range(2)], [_rand((ny, C), 35 + j) for j in range(2)]
+    outs = [torch.full((R, ny, C), float("nan"), dtype=torch.float64, device="cuda") for _ in range(2)]
+    hip.toeplitz_y2t(ny, C, R, src_g.reshape(-1), src_m.reshape(-1), [t.reshape(-1) for t in tg], [t.reshape(-1) for t in tm],
+                     [o.reshape(-1) for o in outs])
+    torch.cuda.synchronize()
+    idx = (torch.arange(ny)[:, None] - torch.arange(ny)[None, :]).abs().cuda()
+    for j in range(2):
+        ref = torch.einsum("ypc,rpc->ryc", tg[j][idx], src_g) + torch.einsum("ypc,rpc->ryc", tm[j][idx], src_m)
+        assert normwise(outs[j].cpu().numpy(), ref.cpu().numpy()) < 1e-14
+    # against the two one-term launches it replaces (same FMAs per term, one more addition)
+    a = [torch.empty((R, ny, C), dtype=torch.float64, device="cuda") for _ in range(2)]
+    b = [torch.empty((R, ny, C), dtype=torch.float64, device="cuda") for _ in range(2)]
+    hip.toeplitz_y(ny, C, R, src_g.reshape(-1), [t.reshape(-1) for t in tg], [o.reshape(-1) for o in a])
+    hip.toeplitz_y(ny, C, R, src_m.reshape(-1), [t.reshape(-1) for t in tm], [o.reshape(-1) for o in b])
+    for j in range(2):
+        assert torch.equal(outs[j], a[j] + b[j])
+    S = C + 256
+    gp, mp = (torch.full((R, ny, S), float("nan"), dtype=torch.float64, device="cuda") for _ in range(2))
+    gp[:, :, :C], mp[:, :, :C] = src_g, src_m
+    outp = [torch.full((R, ny, S), 7.0, dtype=torch.float64, device="cuda") for _ in range(2)]
+    hip.toeplitz_y2t(ny, C, R, gp.reshape(-1), mp.reshape(-1), [t.reshape(-1) for t in tg], [t.reshape(-1) for t in tm],
+                     [o.reshape(-1) for o in outp], plane=S)
+    for j in range(2):
+        assert torch.equal(outp[j][:, :, :C], outs[j]) and bool((outp[j][:, :, C:] == 7.0).all())
+
+
 @pytest.mark.parametrize("nx,nz,rows,ppr", [(48, 64, 3, 37), (64, 64, 3, 37), (64, 64, 4, 800), (48, 64, 7, 500), (64, 32, 3, 37),
                                             (64, 32, 5, 900)])
 @pytest.mark.parametrize("inverse", [False, True])
