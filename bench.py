@@ -93,7 +93,7 @@ def synthetic_inputs(inv, md):
 
 
 PMC_FILES = {"ak_fused_grid": "r01_pmc_ak_fused_grid_v2.json", "posterior_reduce": "r03_pmc_posterior_reduce.json",
-             "k_block_grid": "r03_pmc_k_block_grid_f64.json", "toeplitz_y": "r03_pmc_toeplitz_y.json"}
+             "k_block_grid": "r03_pmc_k_block_grid_f64.json", "toeplitz_y": "r04_pmc_toeplitz_y.json", "toeplitz_y2t": "r04_pmc_toeplitz_y2t.json"}
 GPU_DENSE_ROUTE = "profiles/r01_bench64_dense.json"   # builder-run bench line of `--method dense` (same algorithm as the CPU sample)
 
 
@@ -436,12 +436,14 @@ def main():
             # FMA flop of the mean launch: ny per output element and term (one-term launches: two of the three streams are outputs)
             vflop = d["valu"] / calls if d["valu"] > 0 else 2.0 * eng.ny * (by / 8.0) * (2.0 / 3.0)
             traffic, tsrc = None, None
-            try:
-                p = json.load(open(os.path.join(ROOT, "profiles", PMC_FILES["toeplitz_y"])))
-                traffic = p["derived"]["hbm_bytes_per_launch_corrected"] * by / p["derived"]["algorithmic_bytes"]
-                tsrc = "profiles/" + PMC_FILES["toeplitz_y"]
-            except Exception:
-                pass
+            for pf in (PMC_FILES[dom.split(":")[1]], PMC_FILES[dom.split(":")[1]].replace("r04_", "r03_")):
+                try:
+                    p = json.load(open(os.path.join(ROOT, "profiles", pf)))
+                    traffic = p["derived"]["hbm_bytes_per_launch_corrected"] * by / p["derived"]["algorithmic_bytes"]
+                    tsrc = "profiles/" + pf
+                    break
+                except Exception:
+                    pass
             roof = {"bound": "hbm", "kernel": kernel_names[dom], "achieved": by / mean_s / 1e9, "peak": 8000.0, "unit": "GB/s",
                     "frac": by / mean_s / 8e12, "frac_fp64_valu": vflop / mean_s / 1e12 / FP64_MATRIX_PEAK_TFLOPS,
                     "bound_note": "HBM and the fp64 VALU limit this kernel together (8 flop per byte): `frac` is the HBM side as the contract asks, "

@@ -4,6 +4,7 @@
 R=${1:-r04}
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 ROOT=$(pwd)
+python tools/pmc_collect.py toeplitz2t > /dev/null 2>&1; cp gpurun_out/pmc_toeplitz_y2t.json gpurun_out/${R}_pmc_toeplitz_y2t.json; python tools/pmc_collect.py toeplitz > /dev/null 2>&1; cp gpurun_out/pmc_toeplitz_y.json gpurun_out/${R}_pmc_toeplitz_y.json
 python bench.py --steps 20 --warmup 5 > gpurun_out/${R}_bench64_spectral.json 2> gpurun_out/${R}_bench64.err
 (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_b && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu > $ROOT/gpurun_out/${R}_bench64_spectral_under_rocprof.json 2>/dev/null; cp $(find /tmp/prof_b -name "*kernel_stats.csv" | head -1) $ROOT/gpurun_out/${R}_bench64_spectral_kernel_stats.csv)
 python bench.py --size 32 --kernel exp --drill 0 --steps 20 --warmup 3 --no-cpu > gpurun_out/${R}_bench32_config2.json 2>/dev/null

@@ -33,6 +33,13 @@ if which in ("all", "toeplitz"):
     outs = [torch.empty(R * n * C, dtype=torch.float64, device=dev) for _ in range(2)]
     timed("toeplitz_y", R * C * 2.0 * n * n * 2, R * n * C * 8.0 * 3, lambda: hip.toeplitz_y(n, C, R, src, tabs, outs))
     del src, tabs, outs
+if which in ("all", "toeplitz2t"):
+    C = P * P
+    src_g, src_m = rnd(R * n * C), rnd(R * n * C)
+    tg, tm = [rnd(n * C), rnd(n * C)], [rnd(n * C), rnd(n * C)]
+    outs = [torch.empty(R * n * C, dtype=torch.float64, device=dev) for _ in range(2)]
+    timed("toeplitz_y2t", R * C * 2.0 * n * n * 4, R * n * C * 8.0 * 4, lambda: hip.toeplitz_y2t(n, C, R, src_g, src_m, tg, tm, outs))
+    del src_g, src_m, tg, tm, outs
 if which in ("all", "xcorr"):
     src = rnd(R, P * n * n)
     lam = rnd(P * n * P)
