@@ -51,6 +51,7 @@ SIGNATURES = {
                                     _i64, _dp, _sz, _dp]),
     "geobo_xz2d": (_int, [_int, _int, _int, _i64, _int, _dp, _i64, _i64, _dp, _i64, _dp, _i64, _dp, _i64, _i64, _dp]),
     "geobo_xz2d_fold": (_int, [_int, _int, _i64, _int, _dp, _i64, _i64, _dp, _dp, _dp, _i64, _i64, _dp]),
+    "geobo_xz2d_fold_quad": (_int, [_int, _int, _i64, _int, _dp, _i64, _i64, _dp, _dp, _dp, _i64, _i64, _dp]),
     "geobo_xcorr_reduce_fold": (_int, [_int, _i64, _int, _dp, _i64, _i64, _dp, _dp, _dp, _i64, _i64, _dp]),
     "geobo_xz2d_fold_lattice": (_int, [_int, _i64, _int, _dp, _dp, _i64, _dp, _i64, _dp, _dp, _dp, _i64, _i64, _dp]),
     "geobo_xz2d_fold_inv_ss_slots": (_int, [_int, _i64, _int]),

@@ -51,6 +51,14 @@ struct FoldArgs {
   // the terms, the second runs once); nothing is stored per plane -- every workgroup keeps sum_r X_r[y]^2 for its fixed y in
   // registers and adds it to ss + (slot*ppr + y)*n*n at the end (slot = blockIdx.x / ppr; the grid is a multiple of ppr)
   const double* in2; int64_t in2_row, r2_first; double* ss;
+  // QUAD form (geobo_xz2d_fold_quad; n = 32 planes on the n = 64 kernels): a 2N x 2N / N x N "plane" of the kernel is a 2 x 2 arrangement
+  // of four consecutive planes of half the extent -- [[y, y+1], [y+2, y+3]] -- and the folded matrices are those of diag(G32, G32):
+  // four independent transforms per kernel plane (half of the MFMAs meet zero blocks; the passes are HBM bound either way).  Memory
+  // rows are half as long; the right half of a kernel row and the bottom half of the rows live in other planes:
+  //   byte offset of element (row i, 16-byte slot s) = i * rowB + (i >= rows / 2 ? botB : 0) + (s % hs) * 16 + (s / hs) * halfB
+  // with hs = slots per memory row.  Dense planes: rowB = the full row, halfB = rowB / 2, botB = 0.
+  int in_rowB, in_halfB, in_botB;        // input side (bytes)
+  int out_rowB, out_halfB, out_botB;     // output side (bytes; the inverse's output row stride stays out_rs)
 };
 
 constexpr int vmcnt_imm(int v) { return (v & 15) | (7 << 4) | (15 << 8) | ((v >> 4) << 14); }
@@ -90,9 +98,12 @@ struct FwdCfg {
   static_assert(N == 64 && ND >= 1 && RT >= RING - 1 && RT % RING == 0 && N / 16 == NW, "shape");
 };
 
-template <int N>
+template <int N, bool QUAD>
 __global__ void __launch_bounds__(256, 2) xz_fold_fwd_kernel(FoldArgs g) {
   constexpr int RING = 4;
+  // dense planes: compile-time strides (the runtime form costs the n = 64 pipeline ~0.7 % of a 64^3 step: A/B on one box)
+  const int in_rowB = QUAD ? g.in_rowB : N * 8, in_halfB = QUAD ? g.in_halfB : N * 4, in_botB = QUAD ? g.in_botB : 0;
+  const int out_rowB = QUAD ? g.out_rowB : 2 * N * 8, out_halfB = QUAD ? g.out_halfB : N * 8, out_botB = QUAD ? g.out_botB : 0;
   using K = FwdCfg<N, RING>;
   constexpr int RT = K::RT, KP = K::KP, MT = K::MT, H = N / 2;
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -134,8 +145,10 @@ __global__ void __launch_bounds__(256, 2) xz_fold_fwd_kernel(FoldArgs g) {
 #pragma unroll
   for (int j = 0; j < K::ND; ++j) {
     const int row = (w + K::NW * j) * K::RPI + drow;          // LDS row of the chunk <- memory row rowperm(row)
-    doff[j] = rowperm(row) * K::ROWB + ((dpos ^ (row & 15)) << 4);
+    const int sl = dpos ^ (row & 15);                         // 16-byte slot of the kernel row (LPR slots; the right half may be another plane)
+    doff[j] = rowperm(row) * in_rowB + ((sl & (K::LPR / 2 - 1)) << 4) + (sl / (K::LPR / 2)) * in_halfB;
   }
+  const int in_chunkB = 16 * in_rowB;
   auto plane_ptr = [&](int64_t p) {
     const int64_t r = p / g.ppr;
     const int y = (int)(p % g.ppr);
@@ -149,13 +162,15 @@ __global__ void __launch_bounds__(256, 2) xz_fold_fwd_kernel(FoldArgs g) {
   auto stage = [&](const char* plane, int c, int slot) {
 #pragma unroll
     for (int j = 0; j < K::ND; ++j)
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)(plane + c * K::CHB + doff[j]), (lds_ptr_t)(ring + slot * K::CHB + (w + K::NW * j) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(plane + c * in_chunkB + (c >= K::RT / 2 ? in_botB : 0) + doff[j]),
+                                       (lds_ptr_t)(ring + slot * K::CHB + (w + K::NW * j) * 1024), 16, 0, 0);
   };
   const char* cur = plane_ptr(first);
   __syncthreads();                                            // Fx image visible
 #pragma unroll
   for (int c = 0; c < RING - 1; ++c) stage(cur, c, c);
-  const unsigned soff = (unsigned)(q * 2 * (2 * N) * 8 + 2 * (16 * w + lr) * 8);   // this lane's byte offset inside an output plane
+  // this lane's byte offset inside an output plane: rows 2 q (+ 1), columns 2 (16 w + lr) (+ 1) -- waves 2, 3 write the right half
+  const unsigned soff = (unsigned)(q * 2 * out_rowB + ((2 * (16 * w + lr)) & (N - 1)) * 8 + (w >> 1) * out_halfB);
   bool warm = false;
   for (int64_t p = first; p < g.nplanes; p += pstep) {
     const int64_t pn = p + pstep < g.nplanes ? p + pstep : p;
@@ -217,9 +232,9 @@ __global__ void __launch_bounds__(256, 2) xz_fold_fwd_kernel(FoldArgs g) {
         // base row bx = 16 m + 4 r + q: output rows 2 bx (E2 + O2) and 2 bx + 1 (E2 - O2), columns (2b, 2b+1)
         const v2d plus = (v2d){e2[m][0][r] + o2[m][0][r], e2[m][1][r] + o2[m][1][r]};
         const v2d minus = (v2d){e2[m][0][r] - o2[m][0][r], e2[m][1][r] - o2[m][1][r]};
-        char* const rowp = op + (size_t)(2 * (16 * m + 4 * r)) * (2 * N) * 8;
+        char* const rowp = op + (size_t)(2 * (16 * m + 4 * r)) * out_rowB + (m >= MT / 2 ? out_botB : 0);
         *reinterpret_cast<v2d*>(rowp) = plus;
-        *reinterpret_cast<v2d*>(rowp + (2 * N) * 8) = minus;
+        *reinterpret_cast<v2d*>(rowp + out_rowB) = minus;
       }
     warm = true;
     cur = nxt;
@@ -269,9 +284,11 @@ struct InvCfg {
 // W = Lambda[iz] * lhat_r never exists in memory).  MUL stages its chunks through registers instead of LDS-DMA: every thread loads
 // its 4 x 16 bytes of both factors two chunks ahead (two register sets), multiplies and writes the ring slot itself; the chunk
 // barrier waits for those LDS writes only.
-template <int N, int MODE>
+template <int N, int MODE, bool QUAD>
 __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
   constexpr bool RED = MODE == 1, MUL = MODE == 2;
+  const int in_rowB = QUAD ? g.in_rowB : 2 * N * 8, in_halfB = QUAD ? g.in_halfB : N * 8, in_botB = QUAD ? g.in_botB : 0;
+  const int out_halfB = QUAD ? g.out_halfB : N * 4, out_botB = QUAD ? g.out_botB : 0;
   constexpr int RING = 3;
   using K = InvCfg<N, RING>;
   constexpr int RT = K::RT, KP = K::KP, MT = K::MT, H = N / 2;
@@ -306,7 +323,9 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
 #pragma unroll
     for (int j = 0; j < K::ND; ++j) {
       const int row = w + K::NW * j;                          // one 1-KiB row per DMA instruction
-      const char* src = reinterpret_cast<const char*>(plane) + (int64_t)(16 * c + rowperm(row)) * K::ROWB + ((lane ^ (row & 15)) << 4);
+      const int sl = lane ^ (row & 15);
+      const char* src = reinterpret_cast<const char*>(plane) + (int64_t)(16 * c + rowperm(row)) * in_rowB + (c >= RT / 2 ? in_botB : 0) +
+                        ((sl & 31) << 4) + (sl >> 5) * in_halfB;
       __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(ring + slot * K::CHB + row * 1024), 16, 0, 0);
     }
   };
@@ -451,15 +470,17 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
     } else {
       if constexpr (MUL) fetch(curA, curB, 2);                // (curA / curB already name the next plane)
       else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
-      double* const op = g.out + (p / g.ppr) * g.out_row + (p % g.ppr) * g.out_plane + 2 * (16 * jt + lr) + par;
+      // columns 2 (16 jt + lr) + par: wave pair jt = 1 writes the right half (another plane in the quad form); rows >= N / 2 the bottom half
+      double* const op = g.out + (p / g.ppr) * g.out_row + (p % g.ppr) * g.out_plane + 2 * lr + par + jt * (out_halfB >> 3);
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const v4d ev = xe[m][0] + xe[m][1], od = xo[m][0] + xo[m][1];
+        double* const om = op + (m >= MT / 2 ? (out_botB >> 3) : 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int j = 16 * m + q + 4 * r;                   // output rows 2j (even) and 2j+1 (odd)
-          op[(int64_t)(2 * j) * g.out_rs] = ev[r];
-          op[(int64_t)(2 * j + 1) * g.out_rs] = od[r];
+          om[(int64_t)(2 * j) * g.out_rs] = ev[r];
+          om[(int64_t)(2 * j + 1) * g.out_rs] = od[r];
         }
       }
     }
@@ -605,10 +626,10 @@ __global__ void __launch_bounds__(512, 2) xcorr_fold_kernel(XCFArgs g) {
   }
 }
 
-template <int N>
+template <int N, bool QUAD = false>
 int launch_fwd(const FoldArgs& g, hipStream_t st) {
   using K = FwdCfg<N, 4>;
-  auto kern = xz_fold_fwd_kernel<N>;
+  auto kern = xz_fold_fwd_kernel<N, QUAD>;
   static std::atomic<uint64_t> attr_done{0};
   if (int rc = ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), K::LDS)) return rc;
   const int64_t nwg = g.nplanes < 2048 ? g.nplanes : 2048;   // persistent, two workgroups per CU resident
@@ -616,11 +637,11 @@ int launch_fwd(const FoldArgs& g, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
 }
 
-template <int N, int MODE>
+template <int N, int MODE, bool QUAD = false>
 int launch_inv(const FoldArgs& g, hipStream_t st) {
   using K = InvCfg<N, 3>;
   constexpr bool RED = MODE == 1;
-  auto kern = xz_fold_inv_kernel<N, MODE>;
+  auto kern = xz_fold_inv_kernel<N, MODE, QUAD>;
   static std::atomic<uint64_t> attr_done{0};
   if (int rc = ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), K::LDS)) return rc;
   int64_t nwg = g.nplanes < 2048 ? g.nplanes : 2048;
@@ -629,6 +650,10 @@ int launch_inv(const FoldArgs& g, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), K::LDS, st, g);
   return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
 }
+
+// dense planes: the right half of a row and the bottom rows follow in place
+void dense_fwd(FoldArgs& g, int n) { g.in_rowB = n * 8; g.in_halfB = n * 4; g.in_botB = 0; g.out_rowB = 2 * n * 8; g.out_halfB = n * 8; g.out_botB = 0; }
+void dense_inv(FoldArgs& g, int n) { g.in_rowB = 2 * n * 8; g.in_halfB = n * 8; g.in_botB = 0; g.out_rowB = 0; g.out_halfB = n * 4; g.out_botB = 0; }
 
 }  // namespace
 
@@ -666,7 +691,35 @@ extern "C" int geobo_xz2d_fold(int inverse, int n, int64_t rows, int planes_per_
   g.Fz = Fz; g.Fx = Fx; g.ppr = planes_per_row; g.nplanes = rows * planes_per_row; g.out_rs = n;
   g.row_off = nullptr; g.edge = nullptr; g.edge_row = 0;
   g.in2 = nullptr; g.in2_row = 0; g.r2_first = 0; g.ss = nullptr;
+  if (inverse) dense_inv(g, 64); else dense_fwd(g, 64);
   return inverse ? launch_inv<64, 0>(g, (hipStream_t)stream) : launch_fwd<64>(g, (hipStream_t)stream);
+}
+
+extern "C" int geobo_xz2d_fold_quad(int inverse, int n, int64_t rows, int groups_per_row, const double* in, int64_t in_row, int64_t in_plane,
+                                    const double* Fx, const double* Fz, double* out, int64_t out_row, int64_t out_plane, void* stream) {
+  if (!in || !out || !Fx || !Fz) return GEOBO_E_ARG;
+  if (rows <= 0 || groups_per_row <= 0) return GEOBO_OK;
+  if ((in_row & 1) || (in_plane & 1) || (out_row & 1) || (out_plane & 1) || ((uintptr_t)in & 15) || ((uintptr_t)out & 15) ||
+      ((uintptr_t)Fx & 15) || ((uintptr_t)Fz & 15))
+    return GEOBO_E_ALIGN;
+  if (n != 32 || in_plane * 8 >= (1ll << 29) || out_plane * 8 >= (1ll << 29)) return GEOBO_E_UNSUPPORTED;
+  // a kernel plane = the planes y .. y+3 of a group as [[y, y+1], [y+2, y+3]]; in_plane / out_plane: stride of ONE small plane
+  const int N = 64, h = N / 2;
+  FoldArgs g;
+  g.in = in; g.in_row = in_row; g.in_plane = 4 * in_plane; g.out = out; g.out_row = out_row; g.out_plane = 4 * out_plane;
+  g.Fz = Fz; g.Fx = Fx; g.ppr = groups_per_row; g.nplanes = rows * groups_per_row;
+  g.row_off = nullptr; g.edge = nullptr; g.edge_row = 0;
+  g.in2 = nullptr; g.in2_row = 0; g.r2_first = 0; g.ss = nullptr;
+  if (!inverse) {       // four h x h planes in, four N x N planes out
+    g.out_rs = N;
+    g.in_rowB = h * 8; g.in_halfB = (int)(in_plane * 8); g.in_botB = (int)(2 * in_plane * 8) - h * h * 8;
+    g.out_rowB = N * 8; g.out_halfB = (int)(out_plane * 8); g.out_botB = (int)(2 * out_plane * 8) - N * N * 8;
+    return launch_fwd<64, true>(g, (hipStream_t)stream);
+  }
+  g.out_rs = h;           // four N x N planes in, four h x h planes out
+  g.in_rowB = N * 8; g.in_halfB = (int)(in_plane * 8); g.in_botB = (int)(2 * in_plane * 8) - N * N * 8;
+  g.out_rowB = 0; g.out_halfB = (int)(out_plane * 8); g.out_botB = (int)(2 * out_plane * 8) - h * h * 8;
+  return launch_inv<64, 0, true>(g, (hipStream_t)stream);
 }
 
 extern "C" int geobo_xz2d_fold_lattice(int n, int64_t rows, int planes_per_row, const double* Q, const int64_t* row_off,
@@ -684,6 +737,7 @@ extern "C" int geobo_xz2d_fold_lattice(int n, int64_t rows, int planes_per_row, 
   g.Fz = Fz; g.Fx = Fx; g.ppr = planes_per_row; g.nplanes = rows * planes_per_row; g.out_rs = n;
   g.row_off = row_off; g.edge = edge; g.edge_row = edge_row;
   g.in2 = nullptr; g.in2_row = 0; g.r2_first = 0; g.ss = nullptr;
+  dense_fwd(g, 64);
   return launch_fwd<64>(g, (hipStream_t)stream);
 }
 
@@ -709,6 +763,7 @@ extern "C" int geobo_xz2d_fold_inv_ss(int n, int64_t rows, int planes_per_row, c
   g.Fz = Fz; g.Fx = Fx; g.ppr = planes_per_row; g.nplanes = rows * planes_per_row;
   g.row_off = nullptr; g.edge = nullptr; g.edge_row = 0;
   g.in2 = in2; g.in2_row = in2_row; g.r2_first = in2 ? r2_first : rows; g.ss = ss;
+  dense_inv(g, 64);
   return launch_inv<64, 1>(g, (hipStream_t)stream);
 }
 
@@ -725,6 +780,7 @@ extern "C" int geobo_xz2d_fold_inv_strided(int n, int64_t rows, int planes_per_r
   g.Fz = Fz; g.Fx = Fx; g.ppr = planes_per_row; g.nplanes = rows * planes_per_row;
   g.row_off = nullptr; g.edge = nullptr; g.edge_row = 0;
   g.in2 = nullptr; g.in2_row = 0; g.r2_first = 0; g.ss = nullptr;
+  dense_inv(g, 64);
   return launch_inv<64, 0>(g, (hipStream_t)stream);
 }
 
@@ -742,5 +798,6 @@ extern "C" int geobo_xz2d_fold_inv_mul(int n, int64_t rows, int planes_per_row, 
   g.Fz = Fz; g.Fx = Fx; g.ppr = planes_per_row; g.nplanes = rows * planes_per_row;
   g.row_off = nullptr; g.edge = nullptr; g.edge_row = 0;
   g.in2 = b; g.in2_row = b_row; g.r2_first = 0; g.ss = nullptr;
+  dense_inv(g, 64);
   return launch_inv<64, 2>(g, (hipStream_t)stream);
 }

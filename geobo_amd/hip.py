@@ -405,6 +405,15 @@ def xz2d_fold(inverse, n, rows, ppr, src, in_row, in_plane, Fx, Fz, out, out_row
                "geobo_xz2d_fold")
 
 
+def xz2d_fold_quad(inverse, n, rows, groups, src, in_row, in_plane, Fx, Fz, out, out_row, out_plane):
+    """geobo_xz2d_fold for n = 32 planes, four consecutive planes of a row per kernel plane (geobo_xz2d_fold_quad); Fx / Fz: folded
+    matrices of diag(G_32, G_32), shape (64, 32, 2)."""
+    lib = require_gpu()
+    _lib.check(lib.geobo_xz2d_fold_quad(1 if inverse else 0, int(n), int(rows), int(groups), _p(_chk(src, "src")), int(in_row), int(in_plane),
+                                        _p(_chk(Fx, "Fx")), _p(_chk(Fz, "Fz")), _p(_chk(out, "out")), int(out_row), int(out_plane), _stream()),
+               "geobo_xz2d_fold_quad")
+
+
 def xz2d_fold_inv_ss_slots(n, rows, ppr):
     return _lib.load().geobo_xz2d_fold_inv_ss_slots(int(n), int(rows), int(ppr))
 

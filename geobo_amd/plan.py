@@ -116,7 +116,8 @@ def plan_route(nx, ny, nz, world=1, rank=0, assembly="f64", operators="resident"
     if family == "rows" and not streamed and rows_r * N_pad * 8 > (40 << 30):
         ops = "streamed"
         notes.append("operator rows of a rank (%.0f GB) are generated per batch instead of being resident" % (rows_r * N_pad * 8 / 1e9))
-    kernels = (("xz", "fold" if (fused_xz and fold) else "fused" if fused_xz else "pair" if pair_xz else "gemm"),
+    quad_xz = pair_xz and ny % 4 == 0 and on("GEOBO_XZ_FOLD") and 64 in XZ2D_FOLD_N and on("GEOBO_XZ_QUAD")
+    kernels = (("xz", "fold" if (fused_xz and fold) else "fused" if fused_xz else "quad" if quad_xz else "pair" if pair_xz else "gemm"),
                ("y", "toeplitz" if dense_y else "spectrum"),
                ("gram", ("fused" if gram_fast else "gemm") if (family in ("rows", "single") and gram_ok) else "per-step"),
                ("ss", ("fused" if fused_ss else "stored") if family in ("rows", "single") else "reduction"))

@@ -135,6 +135,16 @@ class SpectralProduct:
         # is row-wise anyway, the x step spends half its MFMAs on the zero blocks (cheap next to two GEMM passes through HBM)
         self.pair_xz = ((nx, nz) == (32, 32) and (64, 32) in hip.XZ2D_SHAPES and ny % 2 == 0
                         and os.environ.get("GEOBO_SPECTRAL_FUSED_XZ", "1") != "0")
+        # 32 x 32 planes, better: FOUR consecutive y-planes as one 64 x 64 plane of the radix-2 kernels with the folded matrices of
+        # diag(G32, G32) (geobo_xz2d_fold_quad): no zero blocks in z, folded in both axes, four waves per workgroup
+        self.quad_xz = ((nx, nz) == (32, 32) and ny % 4 == 0 and 64 in hip.XZ2D_FOLD_N and self.fold
+                        and os.environ.get("GEOBO_XZ_QUAD", "1") != "0" and os.environ.get("GEOBO_SPECTRAL_FUSED_XZ", "1") != "0")
+        if self.quad_xz:
+            fe, fo = folded_matrices(32)
+            fq = np.zeros((64, 32, 2))
+            fq[:32, :16, 0], fq[:32, :16, 1] = fe, fo
+            fq[32:, 16:, 0], fq[32:, 16:, 1] = fe, fo
+            self.Fq = dev(fq)
         self._pairs = {}
         # plane stride of the (x, z)-spectrum work buffers [row][y][Px*Pz].  Px*Pz is a power of two at 64^3 (16384 doubles =
         # 128 KiB); a bare copy with the y stage's access pattern (512-byte runs, one per plane) streams 3.95 TB/s at that stride and
@@ -207,6 +217,10 @@ class SpectralProduct:
             else:
                 hip.xz2d(False, nx, nz, R, ny, src, lds, nx * nz, M["x"], M["z"], t2, ny * Cp, Cp)
             return t2
+        if self.quad_xz and M is self.G:
+            t2 = self.buf(out_name, R * ny * Px * Pz)
+            hip.xz2d_fold_quad(False, nx, R, ny // 4, src, lds, nx * nz, self.Fq, self.Fq, t2, ny * Px * Pz, Px * Pz)
+            return t2
         if self.pair_xz:
             t2 = self.buf(out_name, R * ny * Px * Pz)
             hip.xz2d(False, 2 * nx, nz, R, ny // 2, src, lds, 2 * nx * nz, self._paired(M["x"], Px, nx), M["z"], t2, ny * Px * Pz,
@@ -251,6 +265,11 @@ class SpectralProduct:
                     hip.xz2d(True, nx, nz, R, yb - ya, u2[(ya - ylo) * Cp:], Ly * Cp, Cp, self.GT["x"], self.GT["z"],
                              out, ldo, nx * nz)
             return
+        if self.quad_xz and all((yb - ya) % 4 == 0 for ya, yb, _, _ in targets):
+            for ya, yb, out, ldo in targets:
+                hip.xz2d_fold_quad(True, nx, R, (yb - ya) // 4, u2[(ya - ylo) * Px * Pz:], Ly * Px * Pz, Px * Pz, self.Fq, self.Fq,
+                                   out, ldo, nx * nz)
+            return
         if self.pair_xz and all((yb - ya) % 2 == 0 for ya, yb, _, _ in targets):
             for ya, yb, out, ldo in targets:
                 hip.xz2d(True, 2 * nx, nz, R, (yb - ya) // 2, u2[(ya - ylo) * Px * Pz:], Ly * Px * Pz, 2 * Px * Pz,
@@ -270,7 +289,10 @@ class SpectralProduct:
         pn = hip.pad_n
         fwd = 2.0 * (ny * nx * pn(Pz) * nz + ny * pn(Px) * pn(Pz) * nx)
         bwd = 2.0 * (slab * pn(nx) * pn(Pz) * Px + pn(slab * nx) * pn(nz) * Pz)
-        if self.pair_xz:                            # diag(Mx, Mx) on stacked plane pairs: the x steps run over the zero blocks too
+        if self.quad_xz:                            # four planes per 64-point radix-2 plane: folded, both axes over the zero blocks
+            fwd = 0.25 * ny * (64.0 * 64 * 128 + 128.0 * 64 * 128)
+            bwd = 0.25 * slab * (128.0 * 128 * 64 + 64.0 * 128 * 64)
+        elif self.pair_xz:                          # diag(Mx, Mx) on stacked plane pairs: the x steps run over the zero blocks too
             fwd += 2.0 * ny * Px * Pz * nx
             bwd += 2.0 * slab * nx * Pz * Px
         if self.fused_xz and self.fold and "x" in self.F and nx == nz:

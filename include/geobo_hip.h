@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GEOBO_VERSION 203 /* 201: flag word of geobo_gemm_nt, (64, 32) instance of geobo_xz2d, workspace layout of geobo_potrf_inv; 202: geobo_ymul, geobo_xz2d_fold_lattice; 203: geobo_sumsq_accum, geobo_lamdot_z, geobo_toeplitz_y2t */
+#define GEOBO_VERSION 203 /* 201: flag word of geobo_gemm_nt, (64, 32) instance of geobo_xz2d, workspace layout of geobo_potrf_inv; 202: geobo_ymul, geobo_xz2d_fold_lattice; 203: geobo_sumsq_accum, geobo_lamdot_z, geobo_toeplitz_y2t, geobo_xz2d_fold_quad */
 
 #define GEOBO_PAD_M 256 /* row padding of M-like dimensions (observation rows)            */
 #define GEOBO_PAD_N 128 /* padding of voxel-like dimensions (columns / contraction index) */
@@ -282,6 +282,15 @@ int geobo_xz2d_fold_inv_strided(int n, int64_t rows, int planes_per_row, const d
 int geobo_xz2d_fold_inv_mul(int n, int64_t rows, int planes_per_row, const double* a, int64_t a_plane, const double* b, int64_t b_row,
                             const double* Fx, const double* Fz, double* out, int64_t out_row, int64_t out_plane,
                             int64_t out_rowstride, void* stream);
+
+/* geobo_xz2d_fold for planes of HALF the extent (n = 32) on the n = 64 kernels: a group of four consecutive planes y .. y+3 of a row is one
+ * kernel plane [[y, y+1], [y+2, y+3]] (the kernel reads / writes half-length memory rows; right half and bottom rows come from the
+ * neighbouring planes), Fx / Fz are the folded matrices of diag(G_32, G_32) ((64, 32, 2)): four independent transforms per kernel
+ * plane, half of the MFMAs on zero blocks -- the passes are HBM bound either way (config 2's 32^3 grid: 0.55 / 0.8 ms per 2048 rows where
+ * the stacked-pair form of geobo_xz2d took 1.2 / 3.4).  in_plane / out_plane: stride between consecutive SMALL planes of a row
+ * (inverse = 0: n x n in, 2n x 2n out; inverse = 1 the other way round); groups_per_row = planes per row / 4.  n = 32. */
+int geobo_xz2d_fold_quad(int inverse, int n, int64_t rows, int groups_per_row, const double* in, int64_t in_row, int64_t in_plane,
+                         const double* Fx, const double* Fz, double* out, int64_t out_row, int64_t out_plane, void* stream);
 
 int geobo_xz2d_fold_inv_ss_slots(int n, int64_t rows, int planes_per_row);
 int geobo_xz2d_fold_inv_ss(int n, int64_t rows, int planes_per_row, const double* in, int64_t in_row, int64_t in_plane,

@@ -187,7 +187,7 @@ def test_route_table():
         for w in (1, 2, 4, 8):
             r = plan_route(n, n, n, world=w)
             assert r.spectral and r.family == "columns" and not r.rows and r.exchange == (w >= 4) and "no fused kernels" in r.note
-    assert dict(plan_route(32, 32, 32).kernels)["xz"] == "pair"
+    assert dict(plan_route(32, 32, 32).kernels)["xz"] == "quad" and dict(plan_route(32, 32, 32, env={"GEOBO_XZ_QUAD": "0"}).kernels)["xz"] == "pair"
     # configs 3 / 4 (64^3 fp64): one rank on the fused kernels with A K materialised, from two ranks sharded by sensor rows
     r = plan_route(64, 64, 64, operators="auto")
     assert r.family == "single" and r.single and not r.rows and r.note == "" and dict(r.kernels) == dict(xz="fold", y="toeplitz", gram="fused", ss="fused")

@@ -965,7 +965,7 @@ def test_row_sharded_lattice_gram_matches_the_single_rank_AkA():
 
 
 @pytest.mark.parametrize("dims", [(48, 32, 64), (64, 48, 64), (32, 16, 64), (16, 80, 16), (64, 64, 64), (16, 128, 16), (64, 128, 64), (16, 96, 32),
-                                  (32, 112, 16), (16, 144, 16)])
+                                  (32, 112, 16), (16, 144, 16), (32, 32, 32), (32, 16, 32)])
 @pytest.mark.parametrize("kern,cross", [("matern32", True), ("sparse", False)])
 def test_spectral_product_matches_lattice_contraction_on_non_cubic_grids(dims, kern, cross):
     """Every kernel combination of the spectral route against the dense lattice-table contraction (geobo_ak_fused_grid) on
