@@ -135,8 +135,8 @@ def test_large_cube_modes_on_the_row_exchange_path(assembly, operators, size, tm
     """BASELINE config 5's modes (fp32 assembly, streamed operators) with 4 ranks: chunked row exchange (each chunk of sensor rows
     transformed, cropped per destination, exchanged by its own all-to-all and written straight into the A K shard), N/G-deep AkA
     panels, sharded posterior -- against the 1-rank run of the same mode (gloo transport on this box's one device)."""
-    # 64 x 48 x 64: the lattice Gram is instantiated there but a rank's slab (12 planes) is no multiple of 16 and the chunked exchange
-    # keeps no full rows -- AkA must fall back to the N/G-deep panels (round-2 advisory: it died in gram_rows' assertion)
+    # 64 x 48 x 64 with fp32 assembly: since round 4 the ROW form carries it (fp32-rounded covariance tables, no A K shard at all); the
+    # 32^3 cases stay on the chunked exchange (the planner keeps small grids without fused kernels in the column form)
     one = _run_ranks(1, "gloo", str(tmp_path / "m1.npz"), size, (assembly, operators))
     four = _run_ranks(4, "gloo", str(tmp_path / "m4.npz"), size, (assembly, operators))
     assert int(four["world"]) == 4 and bool(four["exchange"])
@@ -146,6 +146,23 @@ def test_large_cube_modes_on_the_row_exchange_path(assembly, operators, size, tm
             assert np.isnan(a).all()
         else:
             assert normwise(a, b) <= tol
+
+
+@pytest.mark.parametrize("size,world,assembly,operators,env", [("64x48x64", 4, "f32", "streamed", {}), ("32", 2, "f64", "resident", {"GEOBO_ROWS": "1"}),
+                                                              ("32", 4, "f32", "streamed", {"GEOBO_ROWS": "1", "GEOBO_ROW_CHUNK": "256"})])
+def test_row_form_under_real_collectives(size, world, assembly, operators, env, tmp_path):
+    """Round 4: the row form with fp32-rounded tables / streamed operators (config 5's modes) and on a grid without fused kernels
+    (32^3, forced: batched-GEMM stand-ins, chunked) -- all-gather of AkA row blocks, all-reduce of the partial sums of squares and the
+    rank-agreement check over gloo on this box's one device, against the 1-rank run of the same mode."""
+    one = _run_ranks(1, "gloo", str(tmp_path / "q1.npz"), size, (assembly, operators), env_extra=env)
+    many = _run_ranks(world, "gloo", str(tmp_path / "qN.npz"), size, (assembly, operators), env_extra=env)
+    assert int(many["world"]) == world and bool(many["rowpath"]) and bool(one["rowpath"])
+    for a, b in zip(many["cubes"], one["cubes"]):
+        if np.isnan(b).all():
+            assert np.isnan(a).all()
+        else:
+            assert normwise(a, b) <= 1e-10
+    assert abs(float(many["logl"]) - float(one["logl"])) <= 1e-10 * abs(float(one["logl"]))
 
 
 def test_emulated_ranks_partial_posteriors_add_up():
