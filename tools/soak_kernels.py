@@ -22,6 +22,11 @@ def soak(seed=0, seconds=None, iters=60, verbose=True):
     Gf = hip.to_dev(forward_matrix(n))
     GfT = Gf.t().contiguous()
     Ff = hip.to_dev(np.stack(folded_matrices(n), axis=2))
+    G32 = hip.to_dev(forward_matrix(32))
+    fe32, fo32 = folded_matrices(32)
+    fq = np.zeros((64, 32, 2))
+    fq[:32, :16, 0], fq[:32, :16, 1], fq[32:, 16:, 0], fq[32:, 16:, 1] = fe32, fo32, fe32, fo32
+    Fq = hip.to_dev(fq)
     bad = 0
     t0 = time.time()
     it = 0
@@ -117,6 +122,32 @@ def soak(seed=0, seconds=None, iters=60, verbose=True):
         e = (ss.sum(0) - refs_).abs().max().item() / refs_.abs().max().item()
         if not e < 1e-12:
             bad += 1; print("fold_inv_ss rows=%d ppr=%d r2=%d err %.3e" % (rows2, ppr2, r2, e), flush=True)
+        # ---- round 4: the two-term y stage (eight waves, partial sums exchanged through the consumed LDS stage) ---------------------
+        nyt = int(rng.choice([32, 48, 64]))
+        Ct, Rt = 64 * int(rng.integers(1, 7)), int(rng.integers(1, 40))
+        sg_, sm_ = rnd(Rt, nyt, Ct), rnd(Rt, nyt, Ct)
+        tg_, tm_ = [rnd(nyt, Ct), rnd(nyt, Ct)], [rnd(nyt, Ct), rnd(nyt, Ct)]
+        o2 = [torch.empty((Rt, nyt, Ct), dtype=torch.float64, device="cuda") for _ in range(2)]
+        hip.toeplitz_y2t(nyt, Ct, Rt, sg_.reshape(-1), sm_.reshape(-1), [t.reshape(-1) for t in tg_], [t.reshape(-1) for t in tm_],
+                         [o.reshape(-1) for o in o2])
+        idt = (torch.arange(nyt)[:, None] - torch.arange(nyt)[None, :]).abs().cuda()
+        for j in range(2):
+            ref = torch.einsum("ypc,rpc->ryc", tg_[j][idt], sg_) + torch.einsum("ypc,rpc->ryc", tm_[j][idt], sm_)
+            e = (o2[j] - ref).abs().max().item() / ref.abs().max().item()
+            if not e < 1e-13:
+                bad += 1; print("toeplitz_y2t ny=%d R=%d C=%d err %.3e" % (nyt, Rt, Ct, e), flush=True)
+        # ---- round 4: 32 x 32 planes four at a time on the n = 64 radix-2 kernels ---------------------------------------------------
+        rq, gq = int(rng.integers(1, 30)), int(rng.integers(1, 12))
+        for inverse in (False, True):
+            iq, oq = (64, 32) if inverse else (32, 64)
+            srcq = rnd(rq, 4 * gq * iq * iq + 16)
+            outq = torch.empty((rq, 4 * gq * oq * oq), dtype=torch.float64, device="cuda")
+            hip.xz2d_fold_quad(inverse, 32, rq, gq, srcq, srcq.stride(0), iq * iq, Fq, Fq, outq, outq.stride(0), oq * oq)
+            Mq = G32.t().contiguous() if inverse else G32
+            ref = torch.einsum("ai,rpik,bk->rpab", Mq, srcq[:, :4 * gq * iq * iq].reshape(rq, 4 * gq, iq, iq), Mq)
+            e = (outq.reshape(rq, 4 * gq, oq, oq) - ref).abs().max().item() / ref.abs().max().item()
+            if not e < 1e-13:
+                bad += 1; print("xz2d_fold_quad inverse=%s rows=%d groups=%d err %.3e" % (inverse, rq, gq, e), flush=True)
     if verbose:
         print("soak: %d iterations, %d mismatches" % (it, bad))
     return it, bad
