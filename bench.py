@@ -374,13 +374,15 @@ def main():
     # per-stage / per-kernel device time from HIP events recorded on the launch stream (torch's current stream)
     stages = {}
     for name, fl, alg, valu, e0, e1 in ev:
-        d = stages.setdefault(name, dict(calls=0, seconds=0.0, flop=0.0, alg=0.0, valu=0.0, durs=[]))
+        d = stages.setdefault(name, dict(calls=0, seconds=0.0, flop=0.0, alg=0.0, bytes=0.0, valu=0.0, durs=[]))
         d["calls"] += 1
         sec = e0.elapsed_time(e1) * 1e-3
         d["seconds"] += sec
         d["durs"].append(sec)
         d["flop"] += fl
-        d["alg"] += alg
+        # per-kernel events ("kernel:...") carry algorithmic BYTES in the event's third slot, stage events algorithmic FLOP: kept apart
+        # so that no sum over stages can mix the two units
+        d["bytes" if name.startswith("kernel:") else "alg"] += alg
         d["valu"] += valu
     single = [k for k in stages if k in ("ak_fused_grid", "ak_fused", "posterior_reduce", "posterior_zgemm", "aka_gemm_nt", "kernel:toeplitz_y", "kernel:toeplitz_y2t")]
     dom = max(single, key=lambda k: stages[k]["seconds"]) if single else None
@@ -436,7 +438,7 @@ def main():
             d = stages[dom]
             calls = d["calls"]
             mean_s = d["seconds"] / calls
-            by = d["alg"] / calls
+            by = d["bytes"] / calls
             # FMA flop of the mean launch: ny per output element and term (one-term launches: two of the three streams are outputs)
             vflop = d["valu"] / calls if d["valu"] > 0 else 2.0 * eng.ny * (by / 8.0) * (2.0 / 3.0)
             traffic, tsrc = None, None
@@ -452,7 +454,7 @@ def main():
             ytab = {}
             for k, v in stages.items():
                 if k.startswith("kernel:toeplitz"):
-                    c_, m_, b_ = v["calls"], v["seconds"] / v["calls"], v["alg"] / v["calls"]
+                    c_, m_, b_ = v["calls"], v["seconds"] / v["calls"], v["bytes"] / v["calls"]
                     vf = v["valu"] / c_ if v["valu"] > 0 else 2.0 * eng.ny * (b_ / 8.0) * (2.0 / 3.0 if k == "kernel:toeplitz_y" else 0.5)
                     ytab[k.split(":")[1]] = {"ms_per_step": round(1e3 * v["seconds"] / a.steps, 2), "launches_per_step": c_ / a.steps,
                                              "mean_launch_ms": round(1e3 * m_, 4), "frac_hbm_8TBps": round(b_ / m_ / 8e12, 3),

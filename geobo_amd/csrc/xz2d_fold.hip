@@ -242,6 +242,15 @@ __global__ void __launch_bounds__(256, 2) xz_fold_fwd_kernel(FoldArgs g) {
 }
 
 // ---- inverse: S (2N x 2N) -> X (N x N) -------------------------------------------------------------------------------------
+template <int OFF>
+__device__ __forceinline__ void lds_read_b128(v2d& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int CNT>
+__device__ __forceinline__ void wait_lgkmcnt(v2d& d) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(d) : "n"(CNT));
+}
+
 template <int KP, int T>
 __device__ __forceinline__ void inv_step1(v2d (&a)[KP], const double (&gz)[KP], double sgn, v4d (&d)[4]) {
   asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a[T]) : "n"(KP - 1 - T));
@@ -309,6 +318,14 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
 #pragma unroll
   for (int t = 0; t < KP; ++t) gz[t] = g.Fz[(((int64_t)(4 * t + q) * H + 16 * jt + lr) << 1) + par];
   const double sgn = par ? -1.0 : 1.0;
+  // step-2 fragments (Fe_x, Fo_x)[bx = 8 rt + 4 h + q][j = 16 m + lr]: row j of the image, slot bx ^ (j & 15) = 16 (rt >> 1) +
+  // [(8 (rt & 1) + 4 h + q) ^ lr]  ->  faddr[rt & 1][h] + m * 16 * N * 16 + (rt >> 1) * 256  (one per-lane VGPR + an immediate)
+  unsigned faddr[2][2];
+#pragma unroll
+  for (int r1 = 0; r1 < 2; ++r1)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      faddr[r1][h] = (unsigned)(uintptr_t)(lds_ptr_t)mxf + lr * (N * 16) + (((8 * r1 + 4 * h + q) ^ lr) << 4);
 
   const int64_t first = blockIdx.x, pstep = gridDim.x;
   if (first >= g.nplanes) return;
@@ -387,21 +404,27 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
   for (int m = 0; m < MT; ++m) sse[m] = sso[m] = (v4d){0., 0., 0., 0.};
   for (int64_t p = first; p < g.nplanes; p += pstep) {
     const int nt = nterms(p);
-    v4d t1[RT];                                               // T[row position][this wave's 16 z outputs], summed over the terms
+    // Output tiles of the plane (even / odd output rows x two accumulator chains), carried across the chunks: every 16-row chunk goes
+    // through BOTH contractions before the next one is touched (round 4; like the forward kernel).  With step 2 as one burst of 64
+    // MFMAs at the end of the plane the chunk stream ran dry behind every plane (only RING - 1 chunks of the next plane are requested
+    // during the burst): 55-64 % MFMA busy.  Terms of a two-term row simply accumulate (both contractions are linear).
+    v4d xe[MT][2], xo[MT][2];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) xe[m][0] = xe[m][1] = xo[m][0] = xo[m][1] = (v4d){0., 0., 0., 0.};
     for (int term = 0; term < nt; ++term) {
     const bool last_term = term + 1 == nt;
     const int64_t pn = last_term ? (p + pstep < g.nplanes ? p + pstep : p) : p;
     const double* nxt = MUL ? nullptr : plane_ptr(pn, last_term ? 0 : term + 1);
     const rsrc_t nxtA = planeA(MUL ? pn : 0), nxtB = planeB(MUL ? pn : 0);
-#pragma unroll
-    for (int c = 0; c < RT; ++c) {
+    static_for<0, RT>([&](auto cc) {
+      constexpr int c = decltype(cc)::value;
       if constexpr (MUL) {
         commit(c + 1, (slot0 + c + 1) % RING);                // chunk c + 1 (fetched during chunk c - 2): its slot was last read at c - 2
         // the ring writes must have landed, the staged loads of chunk c + 2 must NOT be waited for (__syncthreads drains vmcnt too)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (c + 3 < RT) fetch(curA, curB, c + 3);             // into the set the commit has just freed
         else if (c + 3 < RT + 2) fetch(nxtA, nxtB, c + 3 - RT);
-        // (chunk 2 of the next plane is fetched behind step 2: a second set of 16 registers does not fit beside T and the output tiles)
+        // (chunk 2 of the next plane is fetched behind the plane's stores: a second set of 16 registers does not fit beside the tiles)
       } else {
       // (reduction form: no stores inside the loop, hence no drain before them -- every chunk takes the counted wait)
       if (RED || !(c <= RING - 2 && warm)) __builtin_amdgcn_s_waitcnt(vmcnt_imm((RING - 2) * K::ND));
@@ -435,31 +458,31 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
       inv_step1<KP, 0>(a, gz, sgn, d);
       tc = (d[0] + d[1]) + (d[2] + d[3]);
       }
-      t1[c] = (RED && term > 0) ? t1[c] + tc : tc;
-    }
+      // ---- step 2 on the chunk's rows: row pairs (2 bx, 2 bx + 1) sit in registers (2h, 2h+1): U = sum, V = difference; even output
+      //      rows from U with Fe_x, odd ones from V with Fo_x.  The fragment reads are issued behind step 1's (their latency runs under
+      //      the tail of its MFMAs) and are inline asm: for LDS reads it can see the compiler drains every outstanding LDS-DMA first.
+      static_for<0, 2>([&](auto hh) {
+        constexpr int h = decltype(hh)::value;
+        v2d f[MT];                                                // (per h: the second pair's reads run under the first pair's MFMAs)
+        static_for<0, MT>([&](auto mm) {
+          constexpr int m = decltype(mm)::value;
+          lds_read_b128<m * 16 * N * 16 + (c >> 1) * 256>(f[m], faddr[c & 1][h]);
+        });
+        const double u = tc[2 * h] + tc[2 * h + 1], v = tc[2 * h] - tc[2 * h + 1];
+        static_for<0, MT>([&](auto mm) {
+          constexpr int m = decltype(mm)::value;
+          wait_lgkmcnt<MT - 1 - m>(f[m]);
+          xe[m][h] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[m].x, u, xe[m][h], 0, 0, 0);
+          xo[m][h] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[m].y, v, xo[m][h], 0, 0, 0);
+        });
+      });
+    });
     warm = true;
     slot0 = (slot0 + RT) % RING;
     cur = nxt;
     curA = nxtA;
     curB = nxtB;
     }   // terms
-    // ---- step 2: row pairs (2 bx, 2 bx+1) sit in registers (2h, 2h+1): U = sum, V = difference; even output rows from U with
-    //      Fe_x, odd output rows from V with Fo_x; A = (Fe_x, Fo_x)[bx = 8 rt + 4 h + q][j = 16 m + lr] from one b128 read ------
-    v4d xe[MT][2], xo[MT][2];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) xe[m][0] = xe[m][1] = xo[m][0] = xo[m][1] = (v4d){0., 0., 0., 0.};
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const double u = t1[rt][2 * h] + t1[rt][2 * h + 1], v = t1[rt][2 * h] - t1[rt][2 * h + 1];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          const v2d f = *reinterpret_cast<const v2d*>(mxf + (((16 * m + lr) * N + ((8 * rt + 4 * h + q) ^ lr)) << 1));
-          xe[m][h] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.x, u, xe[m][h], 0, 0, 0);
-          xo[m][h] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.y, v, xo[m][h], 0, 0, 0);
-        }
-      }
     if constexpr (RED) {
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
@@ -471,16 +494,18 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
       if constexpr (MUL) fetch(curA, curB, 2);                // (curA / curB already name the next plane)
       else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
       // columns 2 (16 jt + lr) + par: wave pair jt = 1 writes the right half (another plane in the quad form); rows >= N / 2 the bottom half
-      double* const op = g.out + (p / g.ppr) * g.out_row + (p % g.ppr) * g.out_plane + 2 * lr + par + jt * (out_halfB >> 3);
+      int64_t ors = g.out_rs;
+      asm volatile("" : "+s"(ors));                           // (per plane: keeps the 16 store offsets from being hoisted into 32 live VGPRs)
+      double* const op = g.out + (p / g.ppr) * g.out_row + (p % g.ppr) * g.out_plane + 2 * lr + par + jt * (out_halfB >> 3) + 2 * q * ors;
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const v4d ev = xe[m][0] + xe[m][1], od = xo[m][0] + xo[m][1];
         double* const om = op + (m >= MT / 2 ? (out_botB >> 3) : 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int j = 16 * m + q + 4 * r;                   // output rows 2j (even) and 2j+1 (odd)
-          om[(int64_t)(2 * j) * g.out_rs] = ev[r];
-          om[(int64_t)(2 * j + 1) * g.out_rs] = od[r];
+          const int j0 = 16 * m + 4 * r;                      // output rows 2 (j0 + q) (even) and + 1 (odd): the lane part sits in op
+          om[(int64_t)(2 * j0) * ors] = ev[r];
+          om[(int64_t)(2 * j0 + 1) * ors] = od[r];
         }
       }
     }

@@ -924,9 +924,10 @@ class PosteriorEngine(RowFormMixin, TransposedPosteriorMixin, ColumnExchangeMixi
                                        self.N_pad, self.world, to_host=self._to_host)
                 out["mu"], out["var"] = mu, var
             self._tick("d2h", t)
-        # AK_complete False: the symmetric plan leaves the blocks (magn rows, block 0) and (sensor rows, block 2) unwritten (the tests'
-        # oracle contacts read the assembled blocks); None in the row form
-        self.last = dict(L=L, Linv=Linv, u=u, AK=AK, AK_complete=AK is not None and not self._ak_sym, props=props, sel=sel)
+        # A K is published only when it is whole; the symmetric plan leaves the blocks (magn rows, block 0) and (sensor rows, block 2)
+        # unwritten: that buffer goes under AK_partial (the tests' oracle contacts read its assembled blocks); the row form has none
+        whole = AK is not None and not self._ak_sym
+        self.last = dict(L=L, Linv=Linv, u=u, AK=AK if whole else None, AK_partial=None if whole else AK, AK_complete=whole, props=props, sel=sel)
         return out
 
     @_on_device

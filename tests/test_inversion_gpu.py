@@ -782,7 +782,7 @@ def _independent_checks_64(inv, s, G, Ag_o, Am_o, sens, lengths, W, what):
     Lt = torch.tril(L)
     sel = inv._sel
     off = {0: 0, 1: eng.Ms_pad, 2: 2 * eng.Ms_pad}
-    AK = eng.last["AK"]
+    AK = eng.last["AK"] if eng.last["AK"] is not None else eng.last["AK_partial"]
     for s_, A_o, gs in ((0, Ag_o, 0.1), (1, Am_o, 0.1)):
         for k in (1, 4):
             r = sens[k]
