@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <stdint.h>
+#include <stdlib.h>
 #include "geobo_hip.h"
 
 namespace {
@@ -280,15 +281,17 @@ int launch2(const Toeplitz2Args& g, hipStream_t st) {
 //     acc[oo] += t[oo - i + NY/2 - 1] * x[i]        (i: input inside the half, oo: output inside the chunk)
 // has static register indices into a window of 79 table values (NY = 128, OC = 16) loaded once per workgroup with |d| folded in at
 // load time; the two halves of a mode meet in one __shfl_xor(.., 32) per output -- no second LDS buffer, no second barrier.
-// Workgroup = 2 * nprop waves (property block, 32-mode group) sharing one input row at a time through the same LDS-DMA ring as above
-// (2 x NY x 512 B = 128 KiB: one workgroup per CU); grid = (64-mode blocks, output chunks, row groups).  Each output chunk re-reads
-// the input row: one chunk for a rank's 16-plane slab of the 8-rank run, NY / OC for a full-height product.
+// Workgroup = 2 * nprop * cw waves (output chunk, property block, 32-mode group) sharing one input row at a time through the same
+// LDS-DMA ring as above (2 x NY x 512 B = 128 KiB: one workgroup per CU); grid = (64-mode blocks, groups of cw output chunks, row
+// groups).  cw = the output chunks that fit eight waves (4 for one property block, 2 for two, 1 for three): with one chunk per
+// workgroup (round 3) a one-block launch ran TWO waves per CU and a full-height product staged every input row NY / OC = 8 times;
+// with cw chunks it is eight waves and NY / (OC cw) stagings.
 struct ToeplitzWinArgs {
   const double* in;       // [R][NY][S]
   const double* tab[3];   // [NY][C] per property block
   double* out[3];         // [R][y1-y0][S] per property block
   int64_t C, S, R;
-  int nprop, y0, y1;
+  int nprop, y0, y1, cw;
 };
 
 template <int NH, int OC, int G>
@@ -314,18 +317,19 @@ __device__ __forceinline__ void toeplitz_win_group(const double (&t)[NH + OC - 1
 }
 
 template <int NY, int OC>
-__global__ void __launch_bounds__(384, 1) toeplitz_y_win_kernel(ToeplitzWinArgs g) {
+__global__ void __launch_bounds__(512, 1) toeplitz_y_win_kernel(ToeplitzWinArgs g) {
   constexpr int NH = NY / 2, WIN = NH + OC - 1;
   static_assert(GX == 4 && NH % GX == 0 && NH * 512 < 65536, "shape");
   extern __shared__ __attribute__((aligned(16))) double xs_dyn[];      // [2][NY][64]
   double (*xs)[NY][64] = reinterpret_cast<double (*)[NY][64]>(xs_dyn);
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nw = 2 * g.nprop;
-  const int prop = w >> 1, mg = w & 1, h = lane >> 5;
+  const int nw = 2 * g.nprop * g.cw;
+  const int prop = (w >> 1) % g.nprop, ck = (w >> 1) / g.nprop, mg = w & 1, h = lane >> 5;
   const int mode = 32 * mg + (lane & 31);                                // this lane's mode inside the 64-mode block
   const int64_t S = g.S, c0 = (int64_t)blockIdx.x * 64;
   const int S8 = (int)(S * 8), out_bytes = (g.y1 - g.y0) * S8;
-  const int ob = g.y0 + OC * (int)blockIdx.y;                            // first output of this workgroup's chunk
+  const int ob = g.y0 + OC * ((int)blockIdx.y * g.cw + ck);              // first output of this wave's chunk (may lie behind y1:
+                                                                         // such a wave only helps staging the rows)
   double t[WIN];
   {
     const int dmin = ob - (NH * h + NH - 1);
@@ -399,9 +403,26 @@ int launch_win(const ToeplitzWinArgs& g, hipStream_t st) {
     attr_done.fetch_or((uint64_t)1 << dev, std::memory_order_release);
   }
   const int nchunks = (g.y1 - g.y0 + OC - 1) / OC;
+  if (g.nprop == 3 && nchunks >= 2 && !getenv("GEOBO_TOEPLITZ_WIN_CW")) {
+    // three blocks are six waves with ONE chunk each; as 2 + 1 blocks every launch has eight waves and two / four chunks per
+    // staged row (measured at ny = 128: 6.5 ms against 3.7 + 1.8)
+    ToeplitzWinArgs a2 = g, a1 = g;
+    a2.nprop = 2;
+    a1.nprop = 1; a1.tab[0] = g.tab[2]; a1.out[0] = g.out[2];
+    const int rc = launch_win<NY, OC>(a2, st);
+    return rc ? rc : launch_win<NY, OC>(a1, st);
+  }
+  ToeplitzWinArgs a = g;
+  a.cw = g.nprop == 1 ? 4 : g.nprop == 2 ? 2 : 1;  // eight waves (256 VGPRs each: the table window alone is 158)
+  if (a.cw > nchunks) a.cw = nchunks;
+  if (const char* e = getenv("GEOBO_TOEPLITZ_WIN_CW")) {   // A/B runs: 1 = one chunk per workgroup (round 3)
+    const int v = atoi(e);
+    if (v >= 1 && 2 * g.nprop * v <= 8) a.cw = v < nchunks ? v : nchunks;
+  }
+  const int ngroups = (nchunks + a.cw - 1) / a.cw;
   int64_t gz = 1;                                   // one workgroup per CU: a few waves of workgroups, each sweeping R / gz rows
-  while ((g.C / 64) * nchunks * gz < 1024 && gz < g.R) ++gz;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(g.C / 64), (unsigned)nchunks, (unsigned)gz), dim3(128 * g.nprop), lds, st, g);
+  while ((g.C / 64) * ngroups * gz < 1024 && gz < g.R) ++gz;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(g.C / 64), (unsigned)ngroups, (unsigned)gz), dim3(128 * g.nprop * a.cw), lds, st, a);
   return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
 }
 

@@ -1,14 +1,17 @@
-"""Warm timing of the y-stage kernels at the 64^3 batch shape (256 rows): 40 back-to-back launches each, HIP events around the lot.
-    python tools/time_toeplitz.py"""
+"""Warm timing of the y-stage kernels at the 64^3 batch shape (256 rows) or, with an argument, at n^3 (n = 128: 32 rows of 64 MB, the
+windowed kernel; GEOBO_TOEPLITZ_WIN_CW=1 in the environment = one output chunk per workgroup, round 3): 40 back-to-back launches each,
+HIP events around the lot.
+    python tools/time_toeplitz.py [n]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from geobo_amd import hip
-n, R, C = 64, 256, 128 * 128
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+R, C = (256 if n <= 64 else 32), 4 * n * n
 rnd = lambda *shape: torch.rand(shape, dtype=torch.float64, device="cuda") * 2 - 1
 src, src2 = rnd(R * n * C), rnd(R * n * C)
 tabs = [rnd(n * C) for _ in range(4)]
-outs = [torch.empty(R * n * C, dtype=torch.float64, device="cuda") for _ in range(2)]
+outs = [torch.empty(R * n * C, dtype=torch.float64, device="cuda") for _ in range(3)]
 def timed(name, flop, by, f, reps=40):
     for _ in range(5): f()
     torch.cuda.synchronize()
@@ -18,6 +21,10 @@ def timed(name, flop, by, f, reps=40):
     e1.record(); torch.cuda.synchronize()
     t = e0.elapsed_time(e1) * 1e-3 / reps
     print("%-22s %.4f ms  %.1f TF/s fp64 FMA (%.2f of 78.6)  %.2f TB/s (%.2f of 8)" % (name, t * 1e3, flop / t / 1e12, flop / t / 78.6e12, by / t / 1e12, by / t / 8e12), flush=True)
-timed("toeplitz_y 2 blocks", R * C * 2.0 * n * n * 2, R * n * C * 8.0 * 3, lambda: hip.toeplitz_y(n, C, R, src, tabs[:2], outs))
+timed("toeplitz_y 2 blocks", R * C * 2.0 * n * n * 2, R * n * C * 8.0 * 3, lambda: hip.toeplitz_y(n, C, R, src, tabs[:2], outs[:2]))
 timed("toeplitz_y 1 block", R * C * 2.0 * n * n, R * n * C * 8.0 * 2, lambda: hip.toeplitz_y(n, C, R, src, tabs[:1], outs[:1]))
-timed("toeplitz_y2t", R * C * 2.0 * n * n * 4, R * n * C * 8.0 * 4, lambda: hip.toeplitz_y2t(n, C, R, src, src2, tabs[:2], tabs[2:], outs))
+if n > 64:
+    timed("toeplitz_y 3 blocks", R * C * 2.0 * n * n * 3, R * n * C * 8.0 * 4, lambda: hip.toeplitz_y(n, C, R, src, tabs[:3], outs))
+    timed("toeplitz_y 1 block, 16-plane slab", R * C * 2.0 * n * 16, R * C * 8.0 * (n + 16), lambda: hip.toeplitz_y(n, C, R, src, tabs[:1], outs[:1], 16, 32))
+    sys.exit(0)
+timed("toeplitz_y2t", R * C * 2.0 * n * n * 4, R * n * C * 8.0 * 4, lambda: hip.toeplitz_y2t(n, C, R, src, src2, tabs[:2], tabs[2:], outs[:2]))
