@@ -316,7 +316,7 @@ __device__ __forceinline__ void toeplitz_win_group(const double (&t)[NH + OC - 1
   if constexpr (G + 1 < NGX) toeplitz_win_group<NH, OC, G + 1>(t, acc, xb, xaddr);
 }
 
-template <int NY, int OC>
+template <int NY, int OC, bool ACC>
 __global__ void __launch_bounds__(512, 1) toeplitz_y_win_kernel(ToeplitzWinArgs g) {
   constexpr int NH = NY / 2, WIN = NH + OC - 1;
   static_assert(GX == 4 && NH % GX == 0 && NH * 512 < 65536, "shape");
@@ -380,6 +380,13 @@ __global__ void __launch_bounds__(512, 1) toeplitz_y_win_kernel(ToeplitzWinArgs 
       const rsrc_t dst = make_rsrc(po, out_bytes);
       int n = nout, pitch = S8;
       asm volatile("" : "+s"(n), "+s"(pitch));
+      if constexpr (ACC) {     // out += ...: the second term of a two-term row adds into the first term's spectrum (geobo_toeplitz_y3_add)
+        double prev[OC];
+#pragma unroll
+        for (int o = 0; o < OC; ++o) prev[o] = (o < n) ? ld_lane(dst, lane8, o * pitch) : 0.0;
+#pragma unroll
+        for (int o = 0; o < OC; ++o) acc[o] += prev[o];
+      }
 #pragma unroll
       for (int o = 0; o < OC; ++o)
         if (o < n) st_lane(dst, lane8, o * pitch, acc[o]);
@@ -390,10 +397,10 @@ __global__ void __launch_bounds__(512, 1) toeplitz_y_win_kernel(ToeplitzWinArgs 
   }
 }
 
-template <int NY, int OC>
+template <int NY, int OC, bool ACC = false>
 int launch_win(const ToeplitzWinArgs& g, hipStream_t st) {
   constexpr size_t lds = (size_t)2 * NY * 64 * sizeof(double);
-  auto kern = toeplitz_y_win_kernel<NY, OC>;
+  auto kern = toeplitz_y_win_kernel<NY, OC, ACC>;
   static std::atomic<uint64_t> attr_done{0};      // per-device "large-LDS attribute set" bits (include/geobo_hip.h, conventions)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return GEOBO_E_LAUNCH;
@@ -409,8 +416,8 @@ int launch_win(const ToeplitzWinArgs& g, hipStream_t st) {
     ToeplitzWinArgs a2 = g, a1 = g;
     a2.nprop = 2;
     a1.nprop = 1; a1.tab[0] = g.tab[2]; a1.out[0] = g.out[2];
-    const int rc = launch_win<NY, OC>(a2, st);
-    return rc ? rc : launch_win<NY, OC>(a1, st);
+    const int rc = launch_win<NY, OC, ACC>(a2, st);
+    return rc ? rc : launch_win<NY, OC, ACC>(a1, st);
   }
   ToeplitzWinArgs a = g;
   a.cw = g.nprop == 1 ? 4 : g.nprop == 2 ? 2 : 1;  // eight waves (256 VGPRs each: the table window alone is 158)
@@ -478,6 +485,33 @@ extern "C" int geobo_toeplitz_y2t(int ny, int64_t C, int64_t plane, int64_t R, c
   }
 }
 
+namespace {
+template <bool ACC>
+int launch_win_by_ny(int ny, const ToeplitzWinArgs& g, hipStream_t st) {
+  switch (ny) {     // the windowed kernel: a lane's half of the inputs + 16 outputs = a window of ny/2 + 15 table values in registers
+    case 128: return launch_win<128, 16, ACC>(g, st);
+    case 112: return launch_win<112, 16, ACC>(g, st);
+    case 96: return launch_win<96, 16, ACC>(g, st);
+    case 80: return launch_win<80, 16, ACC>(g, st);
+    default: return GEOBO_E_UNSUPPORTED;   // other y extents: carry y through the spectrum instead (spectral.py)
+  }
+}
+}  // namespace
+
+extern "C" int geobo_toeplitz_y3_add(int ny, int64_t C, int64_t plane, int64_t R, int nprop, const double* in, const double* const* tabs,
+                                     double* const* outs, int y0, int y1, void* stream) {
+  if (!in || !tabs || !outs || nprop < 1 || nprop > 3) return GEOBO_E_ARG;
+  for (int j = 0; j < nprop; ++j)
+    if (!tabs[j] || !outs[j]) return GEOBO_E_ARG;
+  if (R <= 0 || y0 < 0 || y1 > ny || y1 <= y0 || plane < C) return GEOBO_E_ARG;
+  if (C <= 0 || C % 64 || (plane & 1) || (int64_t)ny * plane * 8 >= (1ll << 31)) return GEOBO_E_ALIGN;
+  if (ny <= 64) return GEOBO_E_UNSUPPORTED;   // (the register-table kernel has the two-term form geobo_toeplitz_y2t instead)
+  ToeplitzWinArgs g;
+  g.in = in; g.C = C; g.S = plane; g.R = R; g.nprop = nprop; g.y0 = y0; g.y1 = y1;
+  for (int j = 0; j < 3; ++j) { g.tab[j] = tabs[j < nprop ? j : 0]; g.out[j] = outs[j < nprop ? j : 0]; }
+  return launch_win_by_ny<true>(ny, g, (hipStream_t)stream);
+}
+
 extern "C" int geobo_toeplitz_y3(int ny, int64_t C, int64_t plane, int64_t R, int nprop, const double* in, const double* const* tabs,
                                  double* const* outs, int y0, int y1, void* stream) {
   if (!in || !tabs || !outs || nprop < 1 || nprop > 3) return GEOBO_E_ARG;
@@ -498,11 +532,5 @@ extern "C" int geobo_toeplitz_y3(int ny, int64_t C, int64_t plane, int64_t R, in
   ToeplitzWinArgs g;
   g.in = in; g.C = C; g.S = plane; g.R = R; g.nprop = nprop; g.y0 = y0; g.y1 = y1;
   for (int j = 0; j < 3; ++j) { g.tab[j] = tabs[j < nprop ? j : 0]; g.out[j] = outs[j < nprop ? j : 0]; }
-  switch (ny) {     // the windowed kernel: a lane's half of the inputs + 16 outputs = a window of ny/2 + 15 table values in registers
-    case 128: return launch_win<128, 16>(g, (hipStream_t)stream);
-    case 112: return launch_win<112, 16>(g, (hipStream_t)stream);
-    case 96: return launch_win<96, 16>(g, (hipStream_t)stream);
-    case 80: return launch_win<80, 16>(g, (hipStream_t)stream);
-    default: return GEOBO_E_UNSUPPORTED;   // other y extents: carry y through the spectrum instead (spectral.py)
-  }
+  return launch_win_by_ny<false>(ny, g, (hipStream_t)stream);
 }

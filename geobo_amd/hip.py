@@ -483,9 +483,13 @@ def a_sens_lattice_stencil(ws, nx, ny, nz):
 TOEPLITZ_NY = (16, 32, 48, 64, 80, 96, 112, 128)      # y extents geobo_toeplitz_y / _y3 are instantiated for
 
 
-def toeplitz_y(ny, C, R, src, tabs, outs, y0=0, y1=None, plane=None):
+TOEPLITZ_ADD_NY = (80, 96, 112, 128)      # y extents of the accumulating form (geobo_toeplitz_y3_add)
+
+
+def toeplitz_y(ny, C, R, src, tabs, outs, y0=0, y1=None, plane=None, accumulate=False):
     """outs[j][r, y - y0, c] = sum_y' tabs[j][|y - y'|, c] * src[r, y', c]  (geobo_toeplitz_y3); 1 to 3 property blocks per sweep.
-    plane: stride in doubles between the y-planes of src and outs (default C: dense)."""
+    plane: stride in doubles between the y-planes of src and outs (default C: dense).  accumulate: outs[j] += (geobo_toeplitz_y3_add,
+    ny in TOEPLITZ_ADD_NY)."""
     lib = require_gpu()
     y1 = ny if y1 is None else y1
     n = len(tabs)
@@ -493,8 +497,8 @@ def toeplitz_y(ny, C, R, src, tabs, outs, y0=0, y1=None, plane=None):
     import ctypes                    # (the argument C -- modes per plane -- shadows the module alias here)
     tp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in (_chk(t, "tab") for t in tabs)])
     op = (ctypes.c_void_p * n)(*[o.data_ptr() for o in (_chk(o, "out") for o in outs)])
-    _lib.check(lib.geobo_toeplitz_y3(int(ny), int(C), int(C if plane is None else plane), int(R), n, _p(_chk(src, "src")), tp, op,
-                                     int(y0), int(y1), _stream()), "geobo_toeplitz_y3")
+    fn, name = (lib.geobo_toeplitz_y3_add, "geobo_toeplitz_y3_add") if accumulate else (lib.geobo_toeplitz_y3, "geobo_toeplitz_y3")
+    _lib.check(fn(int(ny), int(C), int(C if plane is None else plane), int(R), n, _p(_chk(src, "src")), tp, op, int(y0), int(y1), _stream()), name)
 
 
 TOEPLITZ_Y2T_NY = (32, 48, 64)      # y extents of the two-term kernel

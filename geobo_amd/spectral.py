@@ -171,15 +171,15 @@ class SpectralProduct:
         self._bufs = {}
         self.kernel_timer = None     # callable(name, algorithmic_bytes, fn) -> fn(): the engine's HIP-event bracket for single kernels
 
-    def _ystage(self, ny, C, R, src, tabs, outs, y0, y1, plane):
+    def _ystage(self, ny, C, R, src, tabs, outs, y0, y1, plane, accumulate=False):
         """geobo_toeplitz_y launch, bracketed for the bench's per-kernel roofline when a timer is set: algorithmic bytes = the rows'
-        (x, z)-spectrum read once + one output slab per property block."""
-        fn = lambda: hip.toeplitz_y(ny, C, R, src, tabs, outs, y0, y1, plane=plane)
+        (x, z)-spectrum read once + one output slab per property block (read as well when the launch accumulates)."""
+        fn = lambda: hip.toeplitz_y(ny, C, R, src, tabs, outs, y0, y1, plane=plane, accumulate=accumulate)
         if self.kernel_timer is None:
             return fn()
         # (one name per kernel symbol: single-block launches run toeplitz_y_kernel<ny, 2>, the others <ny, 1>)
         name = "kernel:toeplitz_y" if len(tabs) >= 2 or ny > 64 else "kernel:toeplitz_y_single"
-        return self.kernel_timer(name, 8.0 * R * C * (ny + len(tabs) * (y1 - y0)), fn)
+        return self.kernel_timer(name, 8.0 * R * C * (ny + (2 if accumulate else 1) * len(tabs) * (y1 - y0)), fn)
 
     def buf(self, name, n):
         b = self._bufs.get(name)
@@ -409,10 +409,27 @@ class SpectralProduct:
         starts = list(range(0, min(m_first, Mg), R)) + list(range(m_first, Mg, R))
         if not self.fused_ss():
             N = self.N
+            add_y = self.dense_y and ny in hip.TOEPLITZ_ADD_NY and os.environ.get("GEOBO_Y_ADD", "1") != "0"
             for r0 in starts:
                 two = r0 >= m_first
                 Rb = min(R, (Mg if two else min(m_first, Mg)) - r0)
                 vg = [self.buf("SSV%d" % jj, R * N)[:R * N].view(R, N) for jj in range(P_c)]
+                if two and add_y:
+                    # both terms meet in the (x, z)-spectrum: the second y stage adds into the first one's output, ONE inverse
+                    # transform per block instead of two (what geobo_toeplitz_y2t does for the register-table kernel)
+                    Cq = Cp if self.fused_xz else C
+                    t2g = self.forward_zx(Zg[r0:], Rb, self.G, src_row_stride=Zg.stride(0), out_name="T2")
+                    t2m = self.forward_zx(Zm[r0 - m_first:], Rb, self.G, src_row_stride=Zm.stride(0), out_name="T2b")
+                    for j in range(0, P_c, 3):
+                        js = list(range(j, min(j + 3, P_c)))
+                        u2 = [self.buf(("S", "S1", "S2")[i], Rb * ny * Cq) for i in range(len(js))]
+                        self._ystage(ny, C, Rb, t2g, [gens_g[jj] for jj in js], u2, 0, ny, Cq)
+                        self._ystage(ny, C, Rb, t2m, [gens_m[jj] for jj in js], u2, 0, ny, Cq, accumulate=True)
+                        for i, jj in enumerate(js):
+                            self.backward_xz(u2[i], Rb, 0, ny, [(0, ny, vg[jj], vg[jj].stride(0))])
+                    for jj in range(P_c):
+                        hip.sumsq_accum(vg[jj], None, Rb, ss[jj].view(ss[jj].shape[0], -1))
+                    continue
                 self.product(Zg[r0:], Rb, gens_g, vg)
                 vm = None
                 if two:

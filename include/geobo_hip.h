@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GEOBO_VERSION 203 /* 201: flag word of geobo_gemm_nt, (64, 32) instance of geobo_xz2d, workspace layout of geobo_potrf_inv; 202: geobo_ymul, geobo_xz2d_fold_lattice; 203: geobo_sumsq_accum, geobo_lamdot_z, geobo_toeplitz_y2t, geobo_xz2d_fold_quad */
+#define GEOBO_VERSION 204 /* 201: flag word of geobo_gemm_nt, (64, 32) instance of geobo_xz2d, workspace layout of geobo_potrf_inv; 202: geobo_ymul, geobo_xz2d_fold_lattice; 203: geobo_sumsq_accum, geobo_lamdot_z, geobo_toeplitz_y2t, geobo_xz2d_fold_quad; 204: geobo_toeplitz_y3_add */
 
 #define GEOBO_PAD_M 256 /* row padding of M-like dimensions (observation rows)            */
 #define GEOBO_PAD_N 128 /* padding of voxel-like dimensions (columns / contraction index) */
@@ -331,10 +331,16 @@ int geobo_toeplitz_y2t(int ny, int64_t C, int64_t plane, int64_t R, const double
 /* The same stage for up to THREE property blocks per sweep of the input (tabs / outs: HOST arrays of nprop device pointers) and
  * for ny in {80, 96, 112, 128} (128: BASELINE config 5, 128^3 x 3 properties): there the ny table values of a mode no longer fit a
  * lane's registers; a lane owns one mode, one half of the inputs and a chunk of 16 outputs, whose distances form a window of ny/2 + 15 table values with
- * static register indices; the input row is re-read once per 16-output chunk (one chunk for the 16-plane slab of an 8-rank shard).
+ * static register indices; a workgroup of eight waves shares one staged input row between 4 / 2 / 1 output chunks (1 / 2 / 3 blocks;
+ * three blocks run as 2 + 1), so a full-height product stages every row ny / (16 x chunks) times.
  * ny in {16, 32, 48, 64} is forwarded to geobo_toeplitz_y two blocks at a time. */
 int geobo_toeplitz_y3(int ny, int64_t C, int64_t plane, int64_t R, int nprop, const double* in, const double* const* tabs,
                       double* const* outs, int y0, int y1, void* stream);
+/* outs[j] += (the same sums): the second term of a two-term row V = Z_g K_0j + Z_m K_1j adds into the first term's spectrum, so that
+ * ONE inverse transform per block follows (shape-independent form of the transposed posterior; what geobo_toeplitz_y2t does for
+ * ny <= 64).  ny in {80, 96, 112, 128}; GEOBO_E_UNSUPPORTED otherwise. */
+int geobo_toeplitz_y3_add(int ny, int64_t C, int64_t plane, int64_t R, int nprop, const double* in, const double* const* tabs,
+                          double* const* outs, int y0, int y1, void* stream);
 
 /* In-place lower Cholesky of the (m x m, ld) matrix A, m % 256 == 0 (padding rows/cols = identity);
  * scipy.linalg.cholesky(AkA, lower=True), inversion.py:100.  Also writes Linv = L^-1 (m x m, ldi; lower,

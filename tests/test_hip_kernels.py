@@ -381,7 +381,12 @@ def test_gemm_nt_splitk_matches_torch(hip):
 @pytest.mark.parametrize("ny,C,R,nprop,y0,y1", [(16, 64, 3, 1, 0, 16), (32, 128, 5, 2, 0, 32), (48, 64, 4, 2, 16, 32),
                                                  (64, 256, 9, 2, 0, 64), (64, 128, 2, 1, 32, 64), (64, 64, 3, 3, 0, 64),
                                                  (128, 64, 3, 3, 0, 16), (128, 128, 5, 3, 16, 32), (128, 64, 2, 1, 100, 128),
-                                                 (128, 64, 4, 2, 0, 128), (128, 192, 3, 3, 40, 70), (128, 64, 7, 3, 112, 128)])
+                                                 (128, 64, 4, 2, 0, 128), (128, 192, 3, 3, 40, 70), (128, 64, 7, 3, 112, 128),
+                                                 # several output chunks per workgroup (windowed kernel): 8 chunks / 4 per workgroup;
+                                                 # 7 chunks (one wave pair without outputs); 6 chunks / 2; three blocks as 2 + 1 over
+                                                 # 5 chunks; a slab that ends inside a chunk
+                                                 (128, 64, 3, 1, 0, 128), (112, 64, 3, 1, 0, 112), (96, 128, 4, 2, 0, 96),
+                                                 (80, 64, 2, 3, 0, 80), (112, 64, 2, 2, 16, 100)])
 def test_toeplitz_y_matches_torch(hip, ny, C, R, nprop, y0, y1):
     # out_j[r, y - y0, c] = sum_y' tab_j[|y - y'|, c] in[r, y', c]: the per-mode symmetric Toeplitz blocks of K_sj
     src = _rand((R, ny, C), 11)
@@ -404,6 +409,29 @@ def test_toeplitz_y_matches_torch(hip, ny, C, R, nprop, y0, y1):
     hip.toeplitz_y(ny, C, R, srcp.reshape(-1), [t.reshape(-1) for t in tabs], [o.reshape(-1) for o in outp], y0, y1, plane=S)
     for j in range(nprop):
         assert torch.equal(outp[j][:, :, :C], outs[j]) and bool((outp[j][:, :, C:] == 7.0).all())
+
+
+@pytest.mark.parametrize("ny,C,R,nprop,y0,y1", [(128, 64, 3, 3, 0, 128), (128, 128, 2, 1, 0, 128), (96, 64, 4, 2, 0, 96), (112, 64, 2, 2, 16, 100),
+                                                 (80, 64, 3, 3, 0, 80)])
+def test_toeplitz_y_accumulating_form(hip, ny, C, R, nprop, y0, y1):
+    # geobo_toeplitz_y3_add: the second term of a two-term row adds into the first term's output -- bit for bit the sum of the two
+    # stand-alone launches (one more addition per output), rows outside the slab and the padding between planes untouched
+    S = C + 64
+    src_g, src_m = (torch.full((R, ny, S), float("nan"), dtype=torch.float64, device="cuda") for _ in range(2))
+    src_g[:, :, :C], src_m[:, :, :C] = _rand((R, ny, C), 41), _rand((R, ny, C), 42)
+    tg, tm = [_rand((ny, C), 43 + j) for j in range(nprop)], [_rand((ny, C), 47 + j) for j in range(nprop)]
+    mk = lambda: [torch.full((R, y1 - y0, S), 7.0, dtype=torch.float64, device="cuda") for _ in range(nprop)]
+    a, b, both = mk(), mk(), mk()
+    flat = lambda ts: [t.reshape(-1) for t in ts]
+    hip.toeplitz_y(ny, C, R, src_g.reshape(-1), flat(tg), flat(a), y0, y1, plane=S)
+    hip.toeplitz_y(ny, C, R, src_m.reshape(-1), flat(tm), flat(b), y0, y1, plane=S)
+    hip.toeplitz_y(ny, C, R, src_g.reshape(-1), flat(tg), flat(both), y0, y1, plane=S)
+    hip.toeplitz_y(ny, C, R, src_m.reshape(-1), flat(tm), flat(both), y0, y1, plane=S, accumulate=True)
+    torch.cuda.synchronize()
+    for j in range(nprop):
+        assert torch.equal(both[j][:, :, :C], a[j][:, :, :C] + b[j][:, :, :C]) and bool((both[j][:, :, C:] == 7.0).all())
+    with pytest.raises(RuntimeError):
+        hip.toeplitz_y(64, C, R, src_g.reshape(-1), flat(tg[:1]), flat(both[:1]), 0, 64, plane=S, accumulate=True)    # ny <= 64: unsupported
 
 
 @pytest.mark.parametrize("ny,C,R", [(64, 256, 5), (64, 16384, 37), (48, 128, 9), (32, 1024, 70), (64, 128, 1)])
