@@ -43,7 +43,7 @@ def test_host_side_helpers(lib):
     lib.geobo_pad_n.argtypes = [ctypes.c_int64]
     lib.geobo_potrf_ws_bytes.restype = ctypes.c_size_t
     lib.geobo_potrf_ws_bytes.argtypes = [ctypes.c_int64]
-    assert lib.geobo_version() == 203
+    assert lib.geobo_version() == 204
     assert lib.geobo_pad_m(8242) == 8448 and lib.geobo_pad_m(256) == 256 and lib.geobo_pad_m(1) == 256
     assert lib.geobo_pad_n(480) == 512 and lib.geobo_pad_n(262144) == 262144
     # 66 blocks of 128: spine nodes (0, 34), (34, 50), (50, 58) and the last segment (58, 66); per node its T (rows behind mid x its
