@@ -162,9 +162,10 @@ class SpectralProduct:
             rows_per_batch = int(os.environ["GEOBO_SPECTRAL_ROWS"])
         if rows_per_batch is None:
             per_row = (ny * self.Cp if self.dense_y else self.P3) * 8
-            # ~3 GB per work buffer; ny = 128 (67 MB of spectrum per row): 24 rows -- measured on the 128^3 rank step: 12 rows 10.3 s
-            # (launch bound), 24: 6.1 s, 48: 6.3 s, 96: 6.7 s, 192: 8.3 s (the batch's intermediates fall out of the caches)
-            cap = (3 << 30) if ny <= 64 else (13 << 27)
+            # ~3 GB per work buffer; ny = 128 (67 MB of spectrum per row): 48 rows.  Measured on the 128^3 rank step with the round-4 y
+            # stage (several output chunks per staged row), A K -> AkA + posterior: 16 rows 1.69 + 2.94 s, 24: 1.62 + 2.92, 32: 1.58 + 2.82,
+            # 48: 1.55 + 2.78, 64: 1.58 + 2.77, 96: 1.53 + 2.76, 128: 1.50 + 2.75 (flat from 48; 108 / 117 / 127 / 146 GB peak)
+            cap = 3 << 30
             rows_per_batch = max(1, min(256 if self.dense_y else 128, cap // per_row))
         g = 128 // math.gcd(nx * ny, 128)
         self.R = max(g, rows_per_batch // g * g)

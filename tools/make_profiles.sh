@@ -10,3 +10,6 @@ python bench.py --steps 20 --warmup 5 > gpurun_out/${R}_bench64_spectral.json 2>
 python bench.py --size 32 --kernel exp --drill 0 --steps 20 --warmup 3 --no-cpu > gpurun_out/${R}_bench32_config2.json 2>/dev/null
 (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_c && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c -- python $ROOT/tests/dryrun_config5.py --size 128 --world 8 --rank 0 --no-oracle > $ROOT/gpurun_out/${R}_config5_rank0_under_rocprof.json 2>/dev/null; cp $(find /tmp/prof_c -name "*kernel_stats.csv" | head -1) $ROOT/gpurun_out/${R}_config5_rank0_kernel_stats.csv)
 for m in 8448 2048; do for mode in blocked column; do echo "GEOBO_POTF2=$mode: $(GEOBO_POTF2=$mode python tools/run_potrf_once.py $m ctx | tail -1)"; done; done > gpurun_out/${R}_potrf_blocked_vs_column.txt 2>&1
+python tests/dryrun_config5.py --size 128 --world 8 --rank 0 > gpurun_out/${R}_config5_rank0_of_8_rowform.json 2> gpurun_out/${R}_config5_rank0.err
+python bench.py --size 96 --steps 2 --warmup 1 --no-cpu > gpurun_out/${R}_bench96_one_gpu.json 2>/dev/null
+python bench.py --size 128 --props 3 --assembly f32 --steps 1 --warmup 1 --no-cpu > gpurun_out/${R}_bench128x3_f32_one_gpu.json 2>/dev/null
