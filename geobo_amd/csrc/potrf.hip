@@ -413,7 +413,7 @@ int64_t scratch_blocks(int n) {   // 128 x 128 blocks of T scratch a serial subt
 }
 
 // right spine of the tree over nb blocks: nodes d < depth with (lo, mid); the last segment [lo[depth], nb) is a plain subtree
-constexpr int MAX_SPINE = 8, SPINE_LEAF = 8;
+constexpr int MAX_SPINE = 8, SPINE_LEAF = 4;   // (leaf 8 -> 4: M = 2048 2.75 -> 2.45 ms, nothing at 4224 / 8448; 2: slower from 4224)
 struct Spine {
   int depth; int lo[MAX_SPINE + 1], mid[MAX_SPINE];
   int64_t t_off[MAX_SPINE], s_off[MAX_SPINE], leaf_off, total;   // offsets into the workspace, in doubles
