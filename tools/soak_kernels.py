@@ -148,6 +148,25 @@ def soak(seed=0, seconds=None, iters=60, verbose=True):
             e = (outq.reshape(rq, 4 * gq, oq, oq) - ref).abs().max().item() / ref.abs().max().item()
             if not e < 1e-13:
                 bad += 1; print("xz2d_fold_quad inverse=%s rows=%d groups=%d err %.3e" % (inverse, rq, gq, e), flush=True)
+        # ---- round 4: the windowed y stage (ny > 64) with several output chunks per workgroup, slabs ending inside a chunk, three blocks
+        #      as 2 + 1, and the accumulating form (second term of a two-term row) --------------------------------------------------
+        nyw = int(rng.choice([80, 96, 112, 128]))
+        Cw, Rw, npw = 64 * int(rng.integers(1, 4)), int(rng.integers(1, 9)), int(rng.integers(1, 4))
+        ya = int(rng.integers(0, nyw - 1)); yb = int(rng.integers(ya + 1, nyw + 1))
+        if rng.integers(0, 2):
+            ya, yb = 0, nyw
+        sw, sw2 = rnd(Rw, nyw, Cw), rnd(Rw, nyw, Cw)
+        tw, tw2 = [rnd(nyw, Cw) for _ in range(npw)], [rnd(nyw, Cw) for _ in range(npw)]
+        ow = [torch.full((Rw, yb - ya, Cw), float("nan"), dtype=torch.float64, device="cuda") for _ in range(npw)]
+        flat = lambda ts: [t.reshape(-1) for t in ts]
+        hip.toeplitz_y(nyw, Cw, Rw, sw.reshape(-1), flat(tw), flat(ow), ya, yb)
+        hip.toeplitz_y(nyw, Cw, Rw, sw2.reshape(-1), flat(tw2), flat(ow), ya, yb, accumulate=True)
+        idw = (torch.arange(nyw)[:, None] - torch.arange(nyw)[None, :]).abs().cuda()
+        for j in range(npw):
+            ref = (torch.einsum("ypc,rpc->ryc", tw[j][idw], sw) + torch.einsum("ypc,rpc->ryc", tw2[j][idw], sw2))[:, ya:yb]
+            e = (ow[j] - ref).abs().max().item() / ref.abs().max().item()
+            if not e < 1e-13:
+                bad += 1; print("toeplitz windowed ny=%d R=%d C=%d blocks=%d slab [%d, %d) err %.3e" % (nyw, Rw, Cw, npw, ya, yb, e), flush=True)
     if verbose:
         print("soak: %d iterations, %d mismatches" % (it, bad))
     return it, bad
