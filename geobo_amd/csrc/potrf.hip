@@ -8,7 +8,8 @@
 //                     straight into the diagonal block of Linv);
 //   panel solve       P = A[k+1:,k] * (L_kk^-1)^T           -> geobo_gemm_nt on the fp64 MFMA core (in place)
 //   trailing update   A[k+1:,k+1:] -= P P^T (lower tiles)   -> geobo_gemm_nt, lower_only
-// L^-1 is then assembled by recursive halving, two MFMA GEMMs per merge:
+// L^-1 is assembled by recursive halving, two MFMA GEMMs per merge, every node queued on a worker stream as soon as the columns of L
+// it reads are final (the EAGER tree below):
 //   Linv[hi,lo] = -Linv[hi,hi] * (L[hi,lo] * Linv[lo,lo]).
 #include <hip/hip_runtime.h>
 #include <new>
@@ -359,16 +360,10 @@ __global__ void __launch_bounds__(256) logl_stats_kernel(int64_t m, const double
 
 // L^-1 by recursive halving, two MFMA GEMMs per merge:
 //   node [lo, hi) split at mid:   T = L[mid:hi, lo:mid] * Linv[lo:mid, lo:mid],   Linv[mid:hi, lo:mid] = -Linv[mid:hi, mid:hi] * T.
-// The merges near the leaves are a handful of tiles each (the latency of ONE tile's k sweep, whatever the chip could do in
-// parallel), so the tree is not built after the factorisation but UNDER it (with a fork context): along the right spine
-//   [0, nb) -> [mid_0, nb) -> [mid_1, nb) -> ...
-// the left child [lo_d, mid_d) of spine node d only needs columns < mid_d of L, which are final once the factorisation has
-// passed step mid_d - 1.  At that point a worker stream of the context inverts the left child (serial recursion: dozens of
-// launches of a few tiles each, which fit between the factorisation's own kernels).  What remains after the last panel is the
-// short last spine segment and the two GEMMs of every spine node's merge: T_d = L[mid_d:nb, lo_d:mid_d] * Linv[lo_d:mid_d, lo_d:mid_d]
-// on the workers, all spine nodes at once, and Linv[mid_d:nb, lo_d:mid_d] = -Linv[mid_d:nb, mid_d:nb] * T_d, deepest first.
+// (rounds 2-3 launched the left child of every node of the right spine as one serial recursion when the factorisation passed its last
+//  column and kept the rest for the end; round 4 schedules every node on its own: see the EAGER tree below.)
 struct InvCtx {
-  const double* L; int64_t ld; double* Linv; int64_t ldi; double* T; hipStream_t st;
+  const double* L; int64_t ld; double* Linv; int64_t ldi; hipStream_t st;
 };
 
 int split_point(int lo, int hi) {
@@ -393,61 +388,43 @@ int merge_T(const InvCtx& c, int lo, int mid, int hi, const double* T) {
                        c.st);
 }
 
-// whole subtree [lo, hi) on c.st, scratch c.T (>= scratch_blocks(hi - lo) * NB^2 doubles: every T is consumed before the next)
-int build_inverse(const InvCtx& c, int lo, int hi) {
-  if (hi - lo <= 1) return GEOBO_OK;
+// EAGER tree (round 4).  Measured: the factorisation loop alone takes 11.2 ms at M = 8448 and the call 17.2 -- the L^-1 tree, two thirds
+// of it the serial inversion of the root's left child (128 launches of a few tiles each) queued at the half-way point, was the critical
+// path of the second half.  Every node [lo, mid, hi) of the tree needs
+//     T      = L[mid:hi, lo:mid] * Linv[lo:mid, lo:mid]       -- final once the factorisation has passed block mid - 1 and the left child is merged
+//     merge:   Linv[mid:hi, lo:mid] = -Linv[mid:hi, mid:hi] * T -- once block hi - 1 is through and the right child is merged
+// so after block c of the factorisation a worker stream receives, in post-order, the merges of all nodes with hi = c + 1 and then the T
+// products of all nodes with mid = c + 1 (in-order stream: children before parents).  The work is spread along the loop, every node has its
+// own T buffer, and what is left behind the last diagonal block is the right spine's merges.  Same GEMMs per node as the serial recursion:
+// identical bits.
+constexpr int MAX_NODES = 2048;
+struct TreeNode { int lo, mid, hi; int64_t t_off; };
+struct TreePlan { int n; int64_t total; TreeNode node[MAX_NODES]; };
+void plan_tree_rec(int lo, int hi, TreePlan& p) {
+  if (hi - lo <= 1 || p.n >= MAX_NODES) return;
   const int mid = split_point(lo, hi);
-  int rc = build_inverse(c, lo, mid);
-  if (rc) return rc;
-  rc = build_inverse(c, mid, hi);
-  if (rc) return rc;
-  rc = form_T(c, lo, mid, hi, c.T);
-  if (rc) return rc;
-  return merge_T(c, lo, mid, hi, c.T);
+  plan_tree_rec(lo, mid, p);
+  plan_tree_rec(mid, hi, p);
+  if (p.n >= MAX_NODES) return;
+  p.node[p.n++] = TreeNode{lo, mid, hi, p.total};
+  p.total += (int64_t)(hi - mid) * (mid - lo) * NB * NB;
 }
-
-int64_t scratch_blocks(int n) {   // 128 x 128 blocks of T scratch a serial subtree of n blocks needs (its root's T is the largest)
-  if (n <= 1) return 0;
-  const int mid = split_point(0, n);
-  return (int64_t)(n - mid) * mid;
-}
-
-// right spine of the tree over nb blocks: nodes d < depth with (lo, mid); the last segment [lo[depth], nb) is a plain subtree
-constexpr int MAX_SPINE = 8, SPINE_LEAF = 4;   // (leaf 8 -> 4: M = 2048 2.75 -> 2.45 ms, nothing at 4224 / 8448; 2: slower from 4224)
-struct Spine {
-  int depth; int lo[MAX_SPINE + 1], mid[MAX_SPINE];
-  int64_t t_off[MAX_SPINE], s_off[MAX_SPINE], leaf_off, total;   // offsets into the workspace, in doubles
-};
-Spine plan_spine(int nb) {
-  Spine sp;
-  sp.depth = 0;
-  int lo = 0;
-  int64_t off = 0;
-  while (nb - lo > SPINE_LEAF && sp.depth < MAX_SPINE) {
-    const int mid = split_point(lo, nb), d = sp.depth++;
-    sp.lo[d] = lo; sp.mid[d] = mid;
-    sp.t_off[d] = off; off += (int64_t)(nb - mid) * (mid - lo) * NB * NB;
-    sp.s_off[d] = off; off += scratch_blocks(mid - lo) * NB * NB;
-    lo = mid;
-  }
-  sp.lo[sp.depth] = lo;
-  sp.leaf_off = off; off += scratch_blocks(nb - lo) * NB * NB;
-  sp.total = off;
-  return sp;
+int64_t tree_doubles(int nb) {      // = sum over the nodes of (hi - mid)(mid - lo) blocks: closed recursion, no plan needed
+  if (nb <= 1) return 0;
+  const int mid = split_point(0, nb);
+  return (int64_t)(nb - mid) * mid * NB * NB + tree_doubles(mid) + tree_doubles(nb - mid);
 }
 
 // Fork context (geobo_potrf_ctx_create): three streams + a few events on the device that was current at creation, owned by
 // the caller.  Nothing here is process-global: two engines (or two devices, or two threads) each bring their own.
-constexpr int NEV = 8 + 2 * MAX_SPINE;   // 2 x 4 for the look-ahead rings of the factorisation, 2 per spine node of the L^-1 tree
+constexpr int NEV = 8 + 5;   // 2 x 4 for the look-ahead rings of the factorisation, 4 + 1 for the L^-1 tree (step ring, join)
 struct PotrfCtx { int dev; hipStream_t s[3]; hipEvent_t ev[NEV]; };
 
 }  // namespace
 
 extern "C" size_t geobo_potrf_ws_bytes(int64_t m) {
   const int64_t nb = (m + NB - 1) / NB;
-  const Spine sp = plan_spine((int)nb);          // every spine node's T and its worker's scratch side by side (they overlap in time)
-  const int64_t serial = scratch_blocks((int)nb) * NB * NB;
-  return (size_t)(sp.total > serial ? sp.total : serial) * sizeof(double);
+  return (size_t)tree_doubles((int)nb) * sizeof(double);      // one T buffer per node of the L^-1 tree
 }
 
 extern "C" int geobo_potrf_ctx_create(void** ctx) {
@@ -502,16 +479,35 @@ extern "C" int geobo_potrf_inv(int64_t m, double* A, int64_t ld, double* Linv, i
   hipStream_t side = pc ? pc->s[0] : st;
   const hipEvent_t* Pev = pc ? pc->ev : nullptr;
   const hipEvent_t* Bev = pc ? pc->ev + 4 : nullptr;
-  const hipEvent_t* Sev = pc ? pc->ev + 8 : nullptr;     // spine node d: [2d] factorisation passed mid_d, [2d+1] its T_d is ready
+  const hipEvent_t* Sev = pc ? pc->ev + 8 : nullptr;     // L^-1 tree: [c & 3] block c is through, [4] the worker has finished
   const int nb = (int)(m / NB);
-  Spine sp = plan_spine(nb);
-  if (!pc) { sp.depth = 0; sp.lo[0] = 0; sp.leaf_off = 0; }   // no workers: the whole tree after the factorisation, on the caller's stream
+  if (nb - 1 > MAX_NODES) return GEOBO_E_ARG;
   InvCtx ic;
   ic.L = A; ic.ld = ld; ic.Linv = Linv; ic.ldi = ldi;
   double* const wsd = (double*)ws;
-  int next_spine = 0;                                    // spine nodes are passed in order: mid_0 < mid_1 < ...
-  bool t0_early = false;
-  constexpr int T0_LEAD = 4;
+  TreePlan tp;
+  tp.n = 0; tp.total = 0;
+  plan_tree_rec(0, nb, tp);
+  hipStream_t wtree = pc ? pc->s[1] : st;
+  // after block c (diagonal block factorised, panel below it solved): merges with hi = c + 1, then T products with mid = c + 1
+  auto tree_after_step = [&](int c) -> int {
+    if (tp.n == 0) return GEOBO_OK;
+    bool any = false;
+    for (int i = 0; i < tp.n && !any; ++i) any = tp.node[i].hi == c + 1 || tp.node[i].mid == c + 1;
+    if (!any) return GEOBO_OK;
+    if (pc && (hipEventRecord(Sev[c & 3], st) != hipSuccess || hipStreamWaitEvent(wtree, Sev[c & 3], 0) != hipSuccess)) return GEOBO_E_LAUNCH;
+    InvCtx tc = ic;
+    tc.st = wtree;
+    for (int i = 0; i < tp.n; ++i) {
+      const TreeNode& nd = tp.node[i];
+      if (nd.hi == c + 1) { const int rc = merge_T(tc, nd.lo, nd.mid, nd.hi, wsd + nd.t_off); if (rc) return rc; }
+    }
+    for (int i = 0; i < tp.n; ++i) {
+      const TreeNode& nd = tp.node[i];
+      if (nd.mid == c + 1) { const int rc = form_T(tc, nd.lo, nd.mid, nd.hi, wsd + nd.t_off); if (rc) return rc; }
+    }
+    return GEOBO_OK;
+  };
   // TWO-LEVEL blocking (round 3): outer panels of OB x 128 columns.  A panel is factorised by the 128-block steps above restricted
   // to the panel's own columns (diagonal block, panel solve, update of the panel columns to the right of it: tall and narrow, a
   // few tens of microseconds), and the trailing matrix receives ONE rank-(OB x 128) update per panel instead of OB rank-128 ones:
@@ -546,29 +542,16 @@ extern "C" int geobo_potrf_inv(int64_t m, double* A, int64_t ld, double* Linv, i
       else hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(256), 0, st, A + kb * ld + kb, ld, Linv + kb * ldi + kb, ldi, (int)kb, info);
       if (hipGetLastError() != hipSuccess) return GEOBO_E_LAUNCH;
       const int64_t rem = m - kb - NB;
-      if (rem <= 0) continue;
+      if (rem <= 0) {
+        const int rt = tree_after_step(step);
+        if (rt) return rt;
+        continue;
+      }
       double* P = A + (kb + NB) * ld + kb;
       int rc = geobo_gemm_nt(rem, NB, NB, 1.0, P, ld, Linv + kb * ldi + kb, ldi, 0.0, P, ld, crit, 0, stream);
       if (rc) return rc;
-      if (next_spine < sp.depth && step + 1 == sp.mid[next_spine]) {
-        // columns < mid_d of L are final: a worker inverts the spine node's left child under the rest of the loop
-        const int d = next_spine++;
-        hipStream_t wk = pc->s[1 + (d & 1)];
-        if (hipEventRecord(Sev[2 * d], st) != hipSuccess || hipStreamWaitEvent(wk, Sev[2 * d], 0) != hipSuccess) return GEOBO_E_LAUNCH;
-        ic.st = wk; ic.T = wsd + sp.s_off[d];
-        rc = build_inverse(ic, sp.lo[d], sp.mid[d]);
-        if (rc) return rc;
-      }
-      if (next_spine > 0 && !t0_early && step + 1 >= nb - T0_LEAD) {
-        // the root's T product starts under the LAST few steps (their bulk updates are a handful of tiles): 18.1 -> 17.5 ms;
-        // any earlier and its long tiles cost the critical path more than they hide (see below)
-        ic.st = pc->s[1];
-        if (hipEventRecord(Sev[0], st) != hipSuccess || hipStreamWaitEvent(ic.st, Sev[0], 0) != hipSuccess) return GEOBO_E_LAUNCH;
-        rc = form_T(ic, sp.lo[0], sp.mid[0], nb, wsd + sp.t_off[0]);
-        if (rc) return rc;
-        if (hipEventRecord(Sev[1], ic.st) != hipSuccess) return GEOBO_E_LAUNCH;
-        t0_early = true;
-      }
+      rc = tree_after_step(step);
+      if (rc) return rc;
       const int64_t cols_left = k0 + W - (kb + NB);
       if (cols_left > 0) {   // the panel's own columns to the right of this block: rows >= kb + NB, lower tiles from the diagonal on
         rc = geobo_gemm_nt(rem, cols_left, NB, -1.0, P, ld, P, ld, 1.0, A + (kb + NB) * ld + (kb + NB), ld, GEOBO_GEMM_LOWER_ONLY | crit, 0, stream);
@@ -604,25 +587,8 @@ extern "C" int geobo_potrf_inv(int64_t m, double* A, int64_t ld, double* Linv, i
     k0 += W;
   }
   if (pc && last_b >= 0 && hipStreamWaitEvent(st, Bev[last_b & 3], 0) != hipSuccess) return GEOBO_E_LAUNCH;
-  // the other T products (hundreds of long tiles) wait for the end of the loop: under it they cost the critical path more than
-  // they hide (measured 18.9 against 17.9 ms, also in chunks and on 128-row tiles) -- one worker per spine node, concurrently
-  for (int d = t0_early ? 1 : 0; d < sp.depth; ++d) {
-    ic.st = pc->s[1 + (d & 1)];
-    // not before the factorisation is through (the event of the node's start is free again: its wait was captured at the time)
-    if (hipEventRecord(Sev[2 * d], st) != hipSuccess || hipStreamWaitEvent(ic.st, Sev[2 * d], 0) != hipSuccess) return GEOBO_E_LAUNCH;
-    int rc = form_T(ic, sp.lo[d], sp.mid[d], nb, wsd + sp.t_off[d]);
-    if (rc) return rc;
-    if (hipEventRecord(Sev[2 * d + 1], ic.st) != hipSuccess) return GEOBO_E_LAUNCH;
-  }
-  // what is left: the last spine segment, then the second GEMM of every spine node's merge, deepest first
-  ic.st = st; ic.T = wsd + sp.leaf_off;
-  int rc = build_inverse(ic, sp.lo[sp.depth], nb);
-  if (rc) return rc;
-  for (int d = sp.depth - 1; d >= 0; --d) {
-    if (hipStreamWaitEvent(st, Sev[2 * d + 1], 0) != hipSuccess) return GEOBO_E_LAUNCH;
-    rc = merge_T(ic, sp.lo[d], sp.mid[d], nb, wsd + sp.t_off[d]);
-    if (rc) return rc;
-  }
+  // everything is queued; what is left on the worker behind the last diagonal block are the merges of the tree's right spine
+  if (pc && tp.n > 0 && (hipEventRecord(Sev[4], wtree) != hipSuccess || hipStreamWaitEvent(st, Sev[4], 0) != hipSuccess)) return GEOBO_E_LAUNCH;
   return GEOBO_OK;
 }
 

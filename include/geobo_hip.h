@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GEOBO_VERSION 204 /* 201: flag word of geobo_gemm_nt, (64, 32) instance of geobo_xz2d, workspace layout of geobo_potrf_inv; 202: geobo_ymul, geobo_xz2d_fold_lattice; 203: geobo_sumsq_accum, geobo_lamdot_z, geobo_toeplitz_y2t, geobo_xz2d_fold_quad; 204: geobo_toeplitz_y3_add */
+#define GEOBO_VERSION 205 /* 201: flag word of geobo_gemm_nt, (64, 32) instance of geobo_xz2d, workspace layout of geobo_potrf_inv; 202: geobo_ymul, geobo_xz2d_fold_lattice; 203: geobo_sumsq_accum, geobo_lamdot_z, geobo_toeplitz_y2t, geobo_xz2d_fold_quad; 204: geobo_toeplitz_y3_add; 205: workspace layout of geobo_potrf_inv (one T buffer per tree node) */
 
 #define GEOBO_PAD_M 256 /* row padding of M-like dimensions (observation rows)            */
 #define GEOBO_PAD_N 128 /* padding of voxel-like dimensions (columns / contraction index) */
@@ -349,8 +349,8 @@ int geobo_toeplitz_y3_add(int ny, int64_t C, int64_t plane, int64_t R, int nprop
  * ws: workspace of geobo_potrf_ws_bytes(m) bytes.
  * ctx: fork context or NULL.  With a context (three internal streams, ordered after / before `stream` by events) the
  * trailing update of every step runs one step behind on the first stream (look-ahead), and the L^-1 tree -- dozens of small
- * merges -- is built under the factorisation: the left child of every node on the tree's right spine only needs finished
- * columns of L and is inverted by the other two streams as soon as the loop has passed it (27 -> 18.5 ms at m = 8448).
+ * merges -- is built under the factorisation: every node's two GEMMs are queued on the second stream as soon as the columns of L
+ * they read are final (27 -> 17 ms at m = 8448; one T buffer per node in ws).
  * A context is made ONCE at set-up time (geobo_potrf_ctx_create: the only entry points of this library that
  * create runtime objects, never called from a launch path), belongs to the device that was current then, and serves one
  * factorisation at a time: concurrent factorisations (other streams, other threads, other devices) each bring their own.

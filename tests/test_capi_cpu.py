@@ -43,13 +43,20 @@ def test_host_side_helpers(lib):
     lib.geobo_pad_n.argtypes = [ctypes.c_int64]
     lib.geobo_potrf_ws_bytes.restype = ctypes.c_size_t
     lib.geobo_potrf_ws_bytes.argtypes = [ctypes.c_int64]
-    assert lib.geobo_version() == 204
+    assert lib.geobo_version() == 205
     assert lib.geobo_pad_m(8242) == 8448 and lib.geobo_pad_m(256) == 256 and lib.geobo_pad_m(1) == 256
     assert lib.geobo_pad_n(480) == 512 and lib.geobo_pad_n(262144) == 262144
-    # 66 blocks of 128: spine nodes (0, 34), (34, 50), (50, 58) and the last segment (58, 66); per node its T (rows behind mid x its
-    # left child) and the scratch of the worker that inverts the left child -- 1088 + 288, 256 + 64, 64 + 16, and 16 for the segment
-    assert lib.geobo_potrf_ws_bytes(8448) == 1792 * 128 * 128 * 8
-    assert lib.geobo_potrf_ws_bytes(1024) == 16 * 128 * 128 * 8      # 8 blocks: no spine, the serial tree's largest T (4 x 4 blocks)
+    # one T buffer per node [lo, mid, hi) of the L^-1 tree, (hi - mid) x (mid - lo) blocks of 128 x 128; split on even block counts
+    def tree_blocks(n):
+        if n <= 1:
+            return 0
+        mid = n // 2
+        if n > 2 and mid & 1:
+            mid += 1
+        return (n - mid) * mid + tree_blocks(mid) + tree_blocks(n - mid)
+    assert tree_blocks(8) == 16 + 2 * 4 + 4 * 1 and tree_blocks(66) == 2145
+    for m in (256, 1024, 2048, 8448, 33024):
+        assert lib.geobo_potrf_ws_bytes(m) == tree_blocks(m // 128) * 128 * 128 * 8
 
 
 def test_argument_validation_without_gpu(lib):
