@@ -16,7 +16,6 @@
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <stdint.h>
-#include <stdlib.h>
 #include "geobo_hip.h"
 
 namespace {
@@ -410,7 +409,7 @@ int launch_win(const ToeplitzWinArgs& g, hipStream_t st) {
     attr_done.fetch_or((uint64_t)1 << dev, std::memory_order_release);
   }
   const int nchunks = (g.y1 - g.y0 + OC - 1) / OC;
-  if (g.nprop == 3 && nchunks >= 2 && !getenv("GEOBO_TOEPLITZ_WIN_CW")) {
+  if (g.nprop == 3 && nchunks >= 2) {
     // three blocks are six waves with ONE chunk each; as 2 + 1 blocks every launch has eight waves and two / four chunks per
     // staged row (measured at ny = 128: 6.5 ms against 3.7 + 1.8)
     ToeplitzWinArgs a2 = g, a1 = g;
@@ -422,10 +421,6 @@ int launch_win(const ToeplitzWinArgs& g, hipStream_t st) {
   ToeplitzWinArgs a = g;
   a.cw = g.nprop == 1 ? 4 : g.nprop == 2 ? 2 : 1;  // eight waves (256 VGPRs each: the table window alone is 158)
   if (a.cw > nchunks) a.cw = nchunks;
-  if (const char* e = getenv("GEOBO_TOEPLITZ_WIN_CW")) {   // A/B runs: 1 = one chunk per workgroup (round 3)
-    const int v = atoi(e);
-    if (v >= 1 && 2 * g.nprop * v <= 8) a.cw = v < nchunks ? v : nchunks;
-  }
   const int ngroups = (nchunks + a.cw - 1) / a.cw;
   int64_t gz = 1;                                   // one workgroup per CU: a few waves of workgroups, each sweeping R / gz rows
   while ((g.C / 64) * ngroups * gz < 1024 && gz < g.R) ++gz;

@@ -1,5 +1,5 @@
 """Warm timing of the y-stage kernels at the 64^3 batch shape (256 rows) or, with an argument, at n^3 (n = 128: 32 rows of 64 MB, the
-windowed kernel; GEOBO_TOEPLITZ_WIN_CW=1 in the environment = one output chunk per workgroup, round 3): 40 back-to-back launches each,
+windowed kernel): 40 back-to-back launches each,
 HIP events around the lot.
     python tools/time_toeplitz.py [n]"""
 import os, sys
