@@ -104,8 +104,9 @@ def plan_route(nx, ny, nz, world=1, rank=0, assembly="f64", operators="resident"
         if not unpadded:
             notes.append("nx*ny = %d is not a multiple of %d (padded sensor rows): fused reduction L^-1 (A K) instead of the transposed order" % (Ms, PAD_M))
         elif not pays:
-            notes.append("no fused kernels for %d x %d x %d and the grid is below %d voxels / %d-mode planes: N-deep Gram and fused reduction "
-                         "(2-6x the work of the structured forms)" % (nx, ny, nz, ROWS_MIN_VOXELS, ROWS_MIN_PLANE))
+            notes.append("no fused kernels for %d x %d x %d, and the batched-GEMM forms of the structured algorithm pay from %d voxels with "
+                         "(x, z) planes of %d modes (here %d and %d): N-deep Gram and fused reduction (2-6x the work of the structured "
+                         "forms)" % (nx, ny, nz, ROWS_MIN_VOXELS, ROWS_MIN_PLANE, N, plane))
         elif world > 1 and Ms % world:
             notes.append("%d sensor rows do not divide over %d ranks: column shards" % (Ms, world))
     if not spectral and method == "auto" and (nx % 16 or ny % 16 or nz % 16):

@@ -70,10 +70,12 @@ def test_row_form_32_against_oracle_vectors(name, kern, operators, monkeypatch):
 
 
 @pytest.mark.parametrize("dims,kern,props,md", [((48, 32, 64), "matern32", (0, 1, 2), 20), ((32, 48, 16), "exp", (0, 1), 0),
-                                               ((16, 80, 32), "sparse", (0, 1, 2), 7), ((64, 48, 64), "matern32", (0, 1), 50)])
+                                               ((16, 80, 32), "sparse", (0, 1, 2), 7), ((64, 48, 64), "matern32", (0, 1), 50),
+                                               ((64, 80, 64), "matern32", (0, 1), 20)])
 def test_row_form_matches_the_column_form(dims, kern, props, md, monkeypatch):
-    """Non-cubic grids (fused (x, z) kernels with batched-GEMM Gram; y through the spectrum at ny = 80; the all-fused 64 x 48 x 64 shape
-    whose default is the one-rank materialised form): the row form against whatever the planner picks without it."""
+    """Non-cubic grids (fused (x, z) kernels with batched-GEMM Gram; the windowed y stage at ny = 80, with the batched-GEMM transforms
+    and -- 64 x 80 x 64 -- with the radix-2 ones, where the two-term rows add in a padded-stride spectrum; the all-fused 64 x 48 x 64
+    shape whose default is the one-rank materialised form): the row form against whatever the planner picks without it."""
     import bench
     from geobo_amd.inversion import Inversion
     nx, ny, nz = dims
