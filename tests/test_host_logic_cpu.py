@@ -223,7 +223,7 @@ def test_route_table():
     r = plan_route(112, 48, 112)             # nx * ny = 5376 = 21 * 256
     assert r.family == "rows"
     r = plan_route(112, 16, 112, world=1)    # nx * ny = 1792 = 7 * 256 but N = 200704 < 2^18
-    assert r.family == "columns" and "below" in r.note
+    assert r.family == "columns" and "pay from 262144 voxels" in r.note and "here 200704 and 12544" in r.note
     r = plan_route(16, 16, 16 * 1024)        # padded? nx * ny = 256: fine; planes 16 x 16384
     assert r.spectral
     r = plan_route(96, 88 + 8, 96, world=7)  # 9216 sensor rows do not divide over 7 ranks
