@@ -25,6 +25,10 @@ XZ2D_FOLD_N = (64,)                               # radix-2 instances (hip.XZ2D_
 TOEPLITZ_NY = (16, 32, 48, 64, 80, 96, 112, 128)               # Toeplitz y-stage instances (hip.TOEPLITZ_NY)
 ROWS_MIN_VOXELS = 1 << 18                         # batched-GEMM forms of the row algorithm pay from 64^3 voxels ...
 ROWS_MIN_PLANE = 96 * 96                          # ... and (x, z) planes that fill the 128 x 128 GEMM tiles
+ROWS_MIN_VOXELS_FUSED = 1 << 17                   # with fused / four-plane (x, z) kernels and the Toeplitz y stage: from 2^17 voxels.  Measured
+                                                  # (row form / column form, ms per step, one MI355X): 64x32x64 107 / 138, 32x128x32 379 / 482,
+                                                  # 64x64x32 369 / 484, 48x64x64 341 / 424, 64x80x64 877 / 1736, 64x128x64 2365 / 6670 (50 / 235 GB);
+                                                  # below: 64x32x32 101 / 80, 48x32x64 89 / 69, 32x64x32 87 / 77, 64x16x64 35 / 33
 
 
 def _pad(v, m):
@@ -87,14 +91,16 @@ def plan_route(nx, ny, nz, world=1, rank=0, assembly="f64", operators="resident"
     fused_ss = fused_xz and fold and dense_y and ny <= 64
     transposed = env.get("GEOBO_POSTERIOR", "zpath") == "zpath"
     unpadded = Ms == Ms_pad and N == N_pad
-    single = world == 1 and not f32 and spectral and unpadded and transposed and fused_ss
     gram_ok = lattice_gram_supported(nx, ny, nz) and on("GEOBO_AKA_LATTICE")
     gram_fast = lattice_gram_fast(nx, ny, nz)
+    single = world == 1 and not f32 and spectral and unpadded and transposed and fused_ss
+    quad_xz = pair_xz and ny % 4 == 0 and on("GEOBO_XZ_FOLD") and 64 in XZ2D_FOLD_N and on("GEOBO_XZ_QUAD")
     rows_mode = env.get("GEOBO_ROWS", "auto")           # "0": never; "1": wherever it is possible; "auto": where it pays
-    pays = (gram_fast and fused_ss) or (N >= ROWS_MIN_VOXELS and plane >= ROWS_MIN_PLANE)
+    pays = ((gram_fast and fused_ss) or ((fused_xz or quad_xz) and dense_y and N >= ROWS_MIN_VOXELS_FUSED)
+            or (N >= ROWS_MIN_VOXELS and plane >= ROWS_MIN_PLANE))
     xmode = env.get("GEOBO_SPECTRAL_EXCHANGE", "auto")    # "0": replicated forward transforms, column shards (also switches the row form off for N > 1)
     rows = (spectral and unpadded and Ms % world == 0 and gram_ok and transposed and on("GEOBO_Z_LATTICE") and rows_mode != "0"
-            and (pays or rows_mode == "1") and not (single and rows_mode != "1") and (world == 1 or xmode != "0" or rows_mode == "1"))
+            and (pays or rows_mode == "1") and not (single and gram_fast and rows_mode != "1") and (world == 1 or xmode != "0" or rows_mode == "1"))
     ncs = {shard_columns(N_pad, world, r)[1] - shard_columns(N_pad, world, r)[0] for r in range(world)}
     xbase = spectral and world > 1 and Ms % world == 0 and len(ncs) == 1 and xmode != "0"
     exchange_without_rows = xbase and (world >= 4 or xmode == "1")
@@ -104,9 +110,11 @@ def plan_route(nx, ny, nz, world=1, rank=0, assembly="f64", operators="resident"
         if not unpadded:
             notes.append("nx*ny = %d is not a multiple of %d (padded sensor rows): fused reduction L^-1 (A K) instead of the transposed order" % (Ms, PAD_M))
         elif not pays:
-            notes.append("no fused kernels for %d x %d x %d, and the batched-GEMM forms of the structured algorithm pay from %d voxels with "
-                         "(x, z) planes of %d modes (here %d and %d): N-deep Gram and fused reduction (2-6x the work of the structured "
-                         "forms)" % (nx, ny, nz, ROWS_MIN_VOXELS, ROWS_MIN_PLANE, N, plane))
+            notes.append("the structured algorithm pays from %d voxels with fused (x, z) kernels and from %d voxels with (x, z) planes of %d "
+                         "modes on the batched-GEMM forms (here %d x %d x %d: %d voxels, %d modes, %s (x, z) kernels): N-deep Gram and fused "
+                         "reduction (2-6x the work of the structured forms at larger sizes)"
+                         % (ROWS_MIN_VOXELS_FUSED, ROWS_MIN_VOXELS, ROWS_MIN_PLANE, nx, ny, nz, N, plane,
+                            "fused" if (fused_xz or quad_xz) else "no fused"))
         elif world > 1 and Ms % world:
             notes.append("%d sensor rows do not divide over %d ranks: column shards" % (Ms, world))
     if not spectral and method == "auto" and (nx % 16 or ny % 16 or nz % 16):
@@ -117,7 +125,6 @@ def plan_route(nx, ny, nz, world=1, rank=0, assembly="f64", operators="resident"
     if family == "rows" and not streamed and rows_r * N_pad * 8 > (40 << 30):
         ops = "streamed"
         notes.append("operator rows of a rank (%.0f GB) are generated per batch instead of being resident" % (rows_r * N_pad * 8 / 1e9))
-    quad_xz = pair_xz and ny % 4 == 0 and on("GEOBO_XZ_FOLD") and 64 in XZ2D_FOLD_N and on("GEOBO_XZ_QUAD")
     kernels = (("xz", "fold" if (fused_xz and fold) else "fused" if fused_xz else "quad" if quad_xz else "pair" if pair_xz else "gemm"),
                ("y", "toeplitz" if dense_y else "spectrum"),
                ("gram", ("fused" if gram_fast else "gemm") if (family in ("rows", "single") and gram_ok) else "per-step"),

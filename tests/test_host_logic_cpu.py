@@ -186,7 +186,7 @@ def test_route_table():
     for n in (16, 32):
         for w in (1, 2, 4, 8):
             r = plan_route(n, n, n, world=w)
-            assert r.spectral and r.family == "columns" and not r.rows and r.exchange == (w >= 4) and "no fused kernels" in r.note
+            assert r.spectral and r.family == "columns" and not r.rows and r.exchange == (w >= 4) and "structured algorithm pays from" in r.note
     assert dict(plan_route(32, 32, 32).kernels)["xz"] == "quad" and dict(plan_route(32, 32, 32, env={"GEOBO_XZ_QUAD": "0"}).kernels)["xz"] == "pair"
     # configs 3 / 4 (64^3 fp64): one rank on the fused kernels with A K materialised, from two ranks sharded by sensor rows
     r = plan_route(64, 64, 64, operators="auto")
@@ -195,6 +195,13 @@ def test_route_table():
         r = plan_route(64, 64, 64, world=w, rank=w - 1)
         assert r.family == "rows" and r.rows and not r.single and r.exchange and r.exchange_without_rows == (w >= 4)
     assert fam(64, 48, 64) == "single" and fam(64, 48, 64, world=4) == "rows"
+    # fused / four-plane (x, z) kernels with another y extent: the row form from 2^17 voxels (measured; the materialised one-rank form
+    # keeps the two shapes with a fused lattice Gram); smaller grids stay where they were
+    for g in ((64, 32, 64), (64, 80, 64), (64, 128, 64), (48, 64, 64), (64, 64, 32), (32, 128, 32)):
+        assert fam(*g) == "rows" and fam(*g, world=4) == "rows", g
+    for g in ((64, 32, 32), (48, 32, 64), (32, 64, 32)):
+        assert fam(*g) == "columns", g
+    assert fam(64, 16, 64) == "single"            # (transposed posterior on the materialised A K with Z by GEMM: 33 ms, row form 35)
     # fp32 tables / streamed operators no longer force column shards: the row form carries them (config 5's modes at 64^3)
     assert fam(64, 64, 64, world=8, assembly="f32") == "rows" and fam(64, 64, 64, assembly="f32") == "rows"
     assert fam(64, 64, 64, world=4, operators="streamed") == "rows"
@@ -223,7 +230,7 @@ def test_route_table():
     r = plan_route(112, 48, 112)             # nx * ny = 5376 = 21 * 256
     assert r.family == "rows"
     r = plan_route(112, 16, 112, world=1)    # nx * ny = 1792 = 7 * 256 but N = 200704 < 2^18
-    assert r.family == "columns" and "pay from 262144 voxels" in r.note and "here 200704 and 12544" in r.note
+    assert r.family == "columns" and "here 112 x 16 x 112: 200704 voxels, 12544 modes, no fused" in r.note
     r = plan_route(16, 16, 16 * 1024)        # padded? nx * ny = 256: fine; planes 16 x 16384
     assert r.spectral
     r = plan_route(96, 88 + 8, 96, world=7)  # 9216 sensor rows do not divide over 7 ranks
@@ -234,7 +241,8 @@ def test_route_table():
     assert fam(64, 64, 64, world=4, env={"GEOBO_SPECTRAL_EXCHANGE": "0"}) == "columns"
     assert fam(64, 64, 64, world=2, env={"GEOBO_ROWS": "0"}) == "columns"
     assert fam(64, 64, 64, env={"GEOBO_ROWS": "1"}) == "rows" and fam(16, 16, 16, env={"GEOBO_ROWS": "1"}) == "rows"
-    assert fam(64, 64, 64, env={"GEOBO_XZ_FOLD": "0"}) == "columns"          # without the radix-2 kernels one rank has no fused reduction ...
+    r = plan_route(64, 64, 64, env={"GEOBO_XZ_FOLD": "0"})                   # without the radix-2 kernels: no fused reduction, so not the
+    assert r.family == "rows" and dict(r.kernels)["xz"] == "fused" and dict(r.kernels)["ss"] == "stored"   # materialised form; the row form on xz2d
     assert fam(64, 64, 64, env={"GEOBO_AKA_LATTICE": "0"}) == "single"
     assert fam(64, 64, 64, world=2, env={"GEOBO_AKA_LATTICE": "0"}) == "columns"
     assert not plan_route(64, 64, 64, method="dense").spectral

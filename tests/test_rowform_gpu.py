@@ -81,6 +81,7 @@ def test_row_form_matches_the_column_form(dims, kern, props, md, monkeypatch):
     nx, ny, nz = dims
     s = settings_for(nx, ny, nz, kernelfunc=kern)
     lengths = np.array([200.0, 202.0, 204.0])
+    monkeypatch.setenv("GEOBO_ROWS", "0")          # (the planner itself picks the row form for the larger of these grids)
     ref = Inversion(settings=s, props=props)
     grav, mag, loc, drill0 = bench.synthetic_inputs(ref, md)
     ref.gp_length = lengths.copy()
