@@ -25,6 +25,11 @@ XZ2D_FOLD_N = (64,)                               # radix-2 instances (hip.XZ2D_
 TOEPLITZ_NY = (16, 32, 48, 64, 80, 96, 112, 128)               # Toeplitz y-stage instances (hip.TOEPLITZ_NY)
 ROWS_MIN_VOXELS = 1 << 18                         # batched-GEMM forms of the row algorithm pay from 64^3 voxels ...
 ROWS_MIN_PLANE = 96 * 96                          # ... and (x, z) planes that fill the 128 x 128 GEMM tiles
+ROWS_MIN_VOXELS_MID, ROWS_MIN_PLANE_MID = 3 << 17, 64 * 64   # ... or from 393 216 voxels with planes of 4096 modes: 80^3 3345 / 4733 ms (52 / 183 GB),
+                                                  # 80x64x80 2026 / 2503; at the old threshold 96x32x96 786 / 741; below: 80x32x80 528 / 414, 112x16x112 290 / 212,
+                                                  # 16x128x128 462 / 367 (2048-mode planes), 48^3 237 / 188, 32x32x128 100 / 63
+COLUMN_FORM_MAX_BYTES = 160 << 30                 # a two-property A K of the column form beyond this does not fit beside its workspaces (80x128x80:
+                                                  # 272 GB, out of memory; row form 8.8 s in 63 GB)
 ROWS_MIN_VOXELS_FUSED = 1 << 17                   # with fused / four-plane (x, z) kernels and the Toeplitz y stage: from 2^17 voxels.  Measured
                                                   # (row form / column form, ms per step, one MI355X): 64x32x64 107 / 138, 32x128x32 379 / 482,
                                                   # 64x64x32 369 / 484, 48x64x64 341 / 424, 64x80x64 877 / 1736, 64x128x64 2365 / 6670 (50 / 235 GB);
@@ -96,8 +101,10 @@ def plan_route(nx, ny, nz, world=1, rank=0, assembly="f64", operators="resident"
     single = world == 1 and not f32 and spectral and unpadded and transposed and fused_ss
     quad_xz = pair_xz and ny % 4 == 0 and on("GEOBO_XZ_FOLD") and 64 in XZ2D_FOLD_N and on("GEOBO_XZ_QUAD")
     rows_mode = env.get("GEOBO_ROWS", "auto")           # "0": never; "1": wherever it is possible; "auto": where it pays
+    column_ak_bytes = (2 * Ms_pad + PAD_M) * 2 * N_pad * 8 // max(world, 1)
     pays = ((gram_fast and fused_ss) or ((fused_xz or quad_xz) and dense_y and N >= ROWS_MIN_VOXELS_FUSED)
-            or (N >= ROWS_MIN_VOXELS and plane >= ROWS_MIN_PLANE))
+            or (N >= ROWS_MIN_VOXELS and plane >= ROWS_MIN_PLANE) or (N >= ROWS_MIN_VOXELS_MID and plane >= ROWS_MIN_PLANE_MID)
+            or column_ak_bytes > COLUMN_FORM_MAX_BYTES)
     xmode = env.get("GEOBO_SPECTRAL_EXCHANGE", "auto")    # "0": replicated forward transforms, column shards (also switches the row form off for N > 1)
     rows = (spectral and unpadded and Ms % world == 0 and gram_ok and transposed and on("GEOBO_Z_LATTICE") and rows_mode != "0"
             and (pays or rows_mode == "1") and not (single and gram_fast and rows_mode != "1") and (world == 1 or xmode != "0" or rows_mode == "1"))
@@ -111,9 +118,9 @@ def plan_route(nx, ny, nz, world=1, rank=0, assembly="f64", operators="resident"
             notes.append("nx*ny = %d is not a multiple of %d (padded sensor rows): fused reduction L^-1 (A K) instead of the transposed order" % (Ms, PAD_M))
         elif not pays:
             notes.append("the structured algorithm pays from %d voxels with fused (x, z) kernels and from %d voxels with (x, z) planes of %d "
-                         "modes on the batched-GEMM forms (here %d x %d x %d: %d voxels, %d modes, %s (x, z) kernels): N-deep Gram and fused "
-                         "reduction (2-6x the work of the structured forms at larger sizes)"
-                         % (ROWS_MIN_VOXELS_FUSED, ROWS_MIN_VOXELS, ROWS_MIN_PLANE, nx, ny, nz, N, plane,
+                         "modes (%d with %d) on the batched-GEMM forms (here %d x %d x %d: %d voxels, %d modes, %s (x, z) kernels): N-deep Gram "
+                         "and fused reduction (2-6x the work of the structured forms at larger sizes)"
+                         % (ROWS_MIN_VOXELS_FUSED, ROWS_MIN_VOXELS, ROWS_MIN_PLANE, ROWS_MIN_VOXELS_MID, ROWS_MIN_PLANE_MID, nx, ny, nz, N, plane,
                             "fused" if (fused_xz or quad_xz) else "no fused"))
         elif world > 1 and Ms % world:
             notes.append("%d sensor rows do not divide over %d ranks: column shards" % (Ms, world))

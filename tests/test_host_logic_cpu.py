@@ -202,6 +202,13 @@ def test_route_table():
     for g in ((64, 32, 32), (48, 32, 64), (32, 64, 32)):
         assert fam(*g) == "columns", g
     assert fam(64, 16, 64) == "single"            # (transposed posterior on the materialised A K with Z by GEMM: 33 ms, row form 35)
+    # batched-GEMM (x, z) passes: from 2^18 voxels with 96 x 96 planes, from 393 216 voxels with 64 x 64 planes, or where the column form's
+    # A K cannot fit
+    for g in ((80, 80, 80), (80, 64, 80), (96, 32, 96), (80, 128, 80)):
+        assert fam(*g) == "rows", g
+    for g in ((80, 32, 80), (112, 16, 112), (16, 128, 128), (48, 48, 48), (32, 32, 128)):
+        assert fam(*g) == "columns", g
+    assert fam(16, 512, 128) == "rows" and fam(16, 512, 128, world=8) == "columns"      # 2^20 voxels, 2048-mode planes: only the memory rule
     # fp32 tables / streamed operators no longer force column shards: the row form carries them (config 5's modes at 64^3)
     assert fam(64, 64, 64, world=8, assembly="f32") == "rows" and fam(64, 64, 64, assembly="f32") == "rows"
     assert fam(64, 64, 64, world=4, operators="streamed") == "rows"
