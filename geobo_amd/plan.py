@@ -93,7 +93,7 @@ def plan_route(nx, ny, nz, world=1, rank=0, assembly="f64", operators="resident"
     pair_xz = (nx, nz) == (32, 32) and (64, 32) in XZ2D_SHAPES and ny % 2 == 0 and on("GEOBO_SPECTRAL_FUSED_XZ")
     fold = on("GEOBO_XZ_FOLD") and nx == nz and nx in XZ2D_FOLD_N
     dense_y = ny in TOEPLITZ_NY and on("GEOBO_SPECTRAL_DENSE_Y")
-    fused_ss = fused_xz and fold and dense_y and ny <= 64
+    fused_ss = fused_xz and fold and dense_y          # (any Toeplitz ny: the reduction in the inverse transform takes any plane count)
     transposed = env.get("GEOBO_POSTERIOR", "zpath") == "zpath"
     unpadded = Ms == Ms_pad and N == N_pad
     gram_ok = lattice_gram_supported(nx, ny, nz) and on("GEOBO_AKA_LATTICE")

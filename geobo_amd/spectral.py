@@ -388,7 +388,7 @@ class SpectralProduct:
     def fused_ss(self):
         """True where the inverse transform itself squares and sums its output planes (geobo_xz2d_fold_inv_ss: the radix-2 kernels of
         nx = nz = 64 with the Toeplitz y stage); elsewhere reduce_ss stores a batch of V rows and geobo_sumsq_accum reduces it."""
-        return self.fused_xz and self.fold and self.nx == self.nz and "x" in self.F and self.dense_y and self.ny <= 64
+        return self.fused_xz and self.fold and self.nx == self.nz and "x" in self.F and self.dense_y
 
     GENERIC_SS_SLOTS = 8
 
@@ -459,12 +459,14 @@ class SpectralProduct:
                     continue
                 self._ystage(ny, C, Rb, t2g, [gens_g[jj] for jj in js], sg, 0, ny, Cp)
                 sm = None
-                if two:
+                if two and ny in hip.TOEPLITZ_ADD_NY and os.environ.get("GEOBO_Y_ADD", "1") != "0":
+                    self._ystage(ny, C, Rb, t2m, [gens_m[jj] for jj in js], sg, 0, ny, Cp, accumulate=True)     # the terms meet in the spectrum
+                elif two:
                     sm = [self.buf(("Sb", "S1b")[i], Rb * ny * Cp) for i in range(len(js))]
                     self._ystage(ny, C, Rb, t2m, [gens_m[jj] for jj in js], sm, 0, ny, Cp)
                 for i, jj in enumerate(js):
                     hip.xz2d_fold_inv_ss(nx, Rb, ny, sg[i], ny * Cp, Cp, self.F["x"], self.F["z"], ss[jj],
-                                         src2=sm[i] if two else None, in2_row=ny * Cp, r2_first=0)
+                                         src2=sm[i] if sm is not None else None, in2_row=ny * Cp, r2_first=0)
 
     def flops_ss(self, rows_one, rows_two, nblocks):
         """Executed flop of reduce_ss: rows_one one-term rows, rows_two two-term rows (forward + y stage per term, one second
