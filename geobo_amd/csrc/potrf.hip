@@ -12,6 +12,7 @@
 // it reads are final (the EAGER tree below):
 //   Linv[hi,lo] = -Linv[hi,hi] * (L[hi,lo] * Linv[lo,lo]).
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <new>
 #include <stdint.h>
 #include <stdlib.h>
@@ -150,6 +151,15 @@ __device__ __forceinline__ void sfor(F&& f) {
 }
 
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+// result stores of the diagonal-block kernel: plain as a kernel of its own; write-through (agent-scope relaxed atomic = `sc1`) inside
+// the persistent tile-DAG kernel below, where another workgroup on another XCD reads them within the same launch
+template <bool PUB>
+__device__ __forceinline__ void stg(double* p, double v) {
+  if constexpr (PUB) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *p = v;
+}
 
 __device__ __forceinline__ double rdlane(double v, int lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
@@ -164,7 +174,7 @@ template <int W> struct Own {
   static constexpr int slot(int i, int c) { return c == W ? i - W : N0 + (i - W - 4); }   // valid for c in {W, W+4}, i >= c
 };
 
-template <int W>
+template <int W, bool PUB>
 __device__ __forceinline__ void potf2b_body(double* __restrict__ A, int64_t ld, double* __restrict__ Linv, int64_t ldi, int kb_global,
                                             int* __restrict__ info, double (&pan)[2][NB][PS], double (&xss)[4][16][PS],
                                             double (&bc)[4][2][16]) {
@@ -237,7 +247,7 @@ __device__ __forceinline__ void potf2b_body(double* __restrict__ A, int64_t ld, 
     for (int r = 0; r < 4; ++r) xss[W][q4 + 4 * r][lr] = xt[r];      // row-major X_ss, this wave's own copy
     if constexpr (s % 4 == W) {                                // L_ss to memory (upper part zero) by the column's owner
 #pragma unroll
-      for (int r = 0; r < 4; ++r) A[(int64_t)(16 * s + q4 + 4 * r) * ld + 16 * s + lr] = (lr <= q4 + 4 * r) ? t[r] : 0.0;
+      for (int r = 0; r < 4; ++r) stg<PUB>(A + (int64_t)(16 * s + q4 + 4 * r) * ld + 16 * s + lr, (lr <= q4 + 4 * r) ? t[r] : 0.0);
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);                        // lgkmcnt(0): this wave's xss copy is written (wave-local: no barrier)
     // MFMA fragments of X_ss: A[i = lr][k = 4 t + q4] (also B[k][j] = X_ss^T: the same addresses)
@@ -269,7 +279,7 @@ __device__ __forceinline__ void potf2b_body(double* __restrict__ A, int64_t ld, 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           pan[buf][16 * i + q4 + 4 * r][lr] = acc[r];
-          A[(int64_t)(16 * i + q4 + 4 * r) * ld + 16 * s + lr] = acc[r];
+          stg<PUB>(A + (int64_t)(16 * i + q4 + 4 * r) * ld + 16 * s + lr, acc[r]);
         }
       }
     });
@@ -298,12 +308,12 @@ __device__ __forceinline__ void potf2b_body(double* __restrict__ A, int64_t ld, 
   sfor<0, NT>([&](auto qq) {
     constexpr int q = decltype(qq)::value, i = O::row(q), c = O::col(q);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Linv[(int64_t)(16 * i + q4 + 4 * r) * ldi + 16 * c + lr] = y[q][r];
+    for (int r = 0; r < 4; ++r) stg<PUB>(Linv + (int64_t)(16 * i + q4 + 4 * r) * ldi + 16 * c + lr, y[q][r]);
     if constexpr (i > c) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        A[(int64_t)(16 * c + q4 + 4 * r) * ld + 16 * i + lr] = 0.0;        // mirror tile (c, i): strictly above the diagonal
-        Linv[(int64_t)(16 * c + q4 + 4 * r) * ldi + 16 * i + lr] = 0.0;
+        stg<PUB>(A + (int64_t)(16 * c + q4 + 4 * r) * ld + 16 * i + lr, 0.0);        // mirror tile (c, i): strictly above the diagonal
+        stg<PUB>(Linv + (int64_t)(16 * c + q4 + 4 * r) * ldi + 16 * i + lr, 0.0);
       }
     }
   });
@@ -316,10 +326,342 @@ __global__ void __launch_bounds__(256) potf2b_inv_kernel(double* __restrict__ A,
   __shared__ double bc[4][2][16];
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   switch (w) {     // four specialisations: the tile lists differ per wave, every register index is static; all hit the same barriers
-    case 0: potf2b_body<0>(A, ld, Linv, ldi, kb_global, info, pan, xss, bc); break;
-    case 1: potf2b_body<1>(A, ld, Linv, ldi, kb_global, info, pan, xss, bc); break;
-    case 2: potf2b_body<2>(A, ld, Linv, ldi, kb_global, info, pan, xss, bc); break;
-    default: potf2b_body<3>(A, ld, Linv, ldi, kb_global, info, pan, xss, bc); break;
+    case 0: potf2b_body<0, false>(A, ld, Linv, ldi, kb_global, info, pan, xss, bc); break;
+    case 1: potf2b_body<1, false>(A, ld, Linv, ldi, kb_global, info, pan, xss, bc); break;
+    case 2: potf2b_body<2, false>(A, ld, Linv, ldi, kb_global, info, pan, xss, bc); break;
+    default: potf2b_body<3, false>(A, ld, Linv, ldi, kb_global, info, pan, xss, bc); break;
+  }
+}
+
+// ---- persistent tile-DAG factorisation + inverse (round 5) ------------------------------------------------------------------------
+// ONE launch, one 256-thread workgroup per CU, no host-side schedule: the 128 x 128 tiles of L and of X = L^-1 are tasks of a
+// dependency graph, drawn IN ORDER from one global counter (a task only ever depends on tasks with a smaller index, so whatever is
+// claimed can always finish: no residency assumption, no deadlock), synchronised through agent-scope counters in global memory.
+//   Cholesky tile (i, j), i >= j  (LEFT-looking: the tile is accumulated in registers over the whole contraction, C is touched once
+//   instead of once per 128 columns -- the rank-128 trailing updates of the stream schedule moved 16 flop per byte of C):
+//       S = A_ij - sum_{k<j} L_ik L_jk^T ;   i == j:  L_jj = chol(S), D_j = L_jj^-1 (potf2b_body) ;   i > j:  L_ij = S D_j^T
+//   inverse tile (i, c), c < i  (forward substitution by block rows, so that row i of X follows row i of L):
+//       X_ic = -D_i sum_{k=c}^{i-1} L_ik X_kc ,   X_cc = D_c
+// A task waits (one lane polls, relaxed agent-scope loads + s_sleep; one agent-scope acquire after the match; barrier) only where its
+// next 128 columns of the contraction are not final yet, runs the contraction over everything that is (LDS-DMA ring + fp64 MFMA, as in
+// gemm_f64.hip), and publishes its tile with write-through stores, a per-wave vmcnt(0) drain, a barrier and ONE flag store
+// (MI355X_MICROARCH.md "inter-workgroup visibility", form R1).  Task order: column step s = the tiles (s..nb-1, s) of L, diagonal first,
+// then row s - XD of X (its inputs were final XD steps ago: filler work under the latency chain diag -> sub-diagonal tile -> next diag).
+// Summation order is fixed by the tile, not by timing: bit-reproducible.  Every spin is bounded (abort flag + wall-clock limit).
+constexpr int DBK = 16, DXS = 16, DNST = 3;
+constexpr int DXBUF = NB * DXS;                  // X chunk [128 rows][16 k], 128-byte rows, XOR-swizzled 16-byte slots
+constexpr int DYS_NN = NB + 4;                   // row stride of a [16 k][128 cols] chunk (the X_kc operand of the inverse tiles)
+constexpr int DYBUF = DBK * DYS_NN;              // >= NB * DXS: also holds a [128 cols][16 k] chunk
+constexpr int DSTAGE = DXBUF + DYBUF;
+constexpr int DAG_LDS_DOUBLES = DNST * DSTAGE;   // 99 840 bytes: one workgroup per CU
+constexpr size_t DAG_LDS_BYTES = (size_t)DAG_LDS_DOUBLES * sizeof(double) + 64;
+constexpr int DAG_CTL = 16;                      // control words in front of the counters: [0] task head, [1] abort
+constexpr int DAG_XDELAY = 6;
+
+struct DagArgs {
+  double* A; int64_t ld; double* Linv; int64_t ldi; int* info;
+  int* ctl;          // [0] head, [1] abort, [DAG_CTL .. +nb) rows of L final up to (count), then nb x nb flags of X
+  int nb, xdelay;
+};
+
+__device__ __forceinline__ int dswz(int row) {
+  const int p = (row >> 1) & 7;
+  return (p & 1) | (((p >> 2) & 1) * 6);
+}
+__device__ __forceinline__ int ld_flag(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_flag(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// bounded spin of ONE lane: true = give up (someone aborted, or this lane did after ~4 s of wall clock: 100 MHz counter)
+struct Spin {
+  unsigned n = 0; uint64_t t0 = 0;
+  __device__ __forceinline__ bool fail(int* ctl, int* info) {
+    __builtin_amdgcn_s_sleep(4);
+    if ((++n & 255u) != 0) return false;
+    if (ld_flag(ctl + 1)) return true;
+    const uint64_t t = wall_clock64();
+    if (t0 == 0) { t0 = t; return false; }
+    if (t - t0 < 400000000ull) return false;
+    st_flag(ctl + 1, 1);
+    if (*info == 0) *info = -7;
+    return true;
+  }
+};
+
+// acc += X[128 rows][klen] * Y^T (NT: Y [128 cols][klen], both k-contiguous) or X * Y (NN: Y [klen][128 cols]); klen % 16 == 0.
+// The 3-stage LDS-DMA ring and the fragment rotation of gemm_f64.hip, 2 x 2 waves of 64 x 64.
+template <bool NN>
+__device__ __forceinline__ void dag_segment(v4d (&acc)[4][4], const double* Xp, int64_t ldx, const double* Yp, int64_t ldy, int klen,
+                                            double* smem) {
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1, lr = lane & 15, lg = lane >> 4, srow = tid >> 3;
+  const char* const Xb = reinterpret_cast<const char*>(Xp);
+  const char* const Yb = reinterpret_cast<const char*>(Yp);
+  int64_t xsrc[4], ysrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = i * 32 + srow;
+    xsrc[i] = ((int64_t)row * ldx + 2 * ((tid & 7) ^ dswz(row))) * 8;
+    ysrc[i] = NN ? ((int64_t)(i * 4 + wave) * ldy + 2 * lane) * 8 : ((int64_t)row * ldy + 2 * ((tid & 7) ^ dswz(row))) * 8;
+  }
+  auto stage = [&](int k0, int st) {
+    double* const xs = smem + st * DSTAGE;
+    double* const ys = xs + DXBUF;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(Xb + xsrc[i] + (int64_t)k0 * 8), (lds_ptr_t)(xs + (i * 32 + wave * 8) * DXS), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if constexpr (NN)
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(Yb + ysrc[i] + (int64_t)k0 * ldy * 8), (lds_ptr_t)(ys + (i * 4 + wave) * DYS_NN), 16, 0, 0);
+      else
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(Yb + ysrc[i] + (int64_t)k0 * 8), (lds_ptr_t)(ys + (i * 32 + wave * 8) * DXS), 16, 0, 0);
+    }
+  };
+  const int xoff0 = 2 * ((2 * lg + 0) ^ dswz(lr)), xoff1 = 2 * ((2 * lg + 1) ^ dswz(lr));
+  const double* const xfrag = smem + (wm * 64 + lr) * DXS;
+  const double* const yfrag = smem + DXBUF + (NN ? (wn * 64 + lr) : (wn * 64 + lr) * DXS);
+  auto read_half = [&](int st, int h, v2d (&av)[4], v2d (&bv)[4]) {
+    const double* xb = xfrag + st * DSTAGE + (h ? xoff1 : xoff0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) av[m] = *reinterpret_cast<const v2d*>(xb + m * 16 * DXS);
+    if constexpr (NN) {
+      const double* yb = yfrag + st * DSTAGE + (4 * lg + 2 * h) * DYS_NN;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) { bv[n][0] = yb[n * 16]; bv[n][1] = yb[DYS_NN + n * 16]; }
+    } else {
+      const double* yb = yfrag + st * DSTAGE + (h ? xoff1 : xoff0);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) bv[n] = *reinterpret_cast<const v2d*>(yb + n * 16 * DXS);
+    }
+  };
+  stage(0, 0);
+  stage(klen > DBK ? DBK : 0, 1);
+  __syncthreads();
+  int s0 = 0, s1 = 1, s2 = 2;
+  v2d a0[4], b0[4], a1[4], b1[4];
+  read_half(0, 0, a0, b0);
+  for (int k0 = 0; k0 < klen; k0 += DBK) {
+    int kn = k0 + 2 * DBK;
+    if (kn >= klen) kn = klen - DBK;          // the tail re-stages the last chunk instead of branching
+    stage(kn, s2);
+    read_half(s0, 1, a1, b1);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t == 2) read_half(s1, 0, a0, b0);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(t < 2 ? a0[m][t & 1] : a1[m][t & 1], t < 2 ? b0[n][t & 1] : b1[n][t & 1],
+                                                           acc[m][n], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x126, 4, 0);
+    }
+    __syncthreads();
+    const int ts = s0; s0 = s1; s1 = s2; s2 = ts;
+  }
+}
+
+// tile <-> accumulators (D layout of v_mfma_f64_16x16x4: col = lane & 15, row = (lane >> 4) + 4 reg)
+template <bool PUB>
+__device__ __forceinline__ void dag_store(const v4d (&acc)[4][4], double* T, int64_t ld, double sgn) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* const tw = T + (int64_t)((wave >> 1) * 64 + (lane >> 4)) * ld + (wave & 1) * 64 + (lane & 15);
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) stg<PUB>(tw + (int64_t)(m * 16 + 4 * r) * ld + n * 16, sgn * acc[m][n][r]);
+}
+__device__ __forceinline__ void dag_load_neg(v4d (&acc)[4][4], const double* T, int64_t ld) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const double* const tw = T + (int64_t)((wave >> 1) * 64 + (lane >> 4)) * ld + (wave & 1) * 64 + (lane & 15);
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[m][n][r] = -tw[(int64_t)(m * 16 + 4 * r) * ld + n * 16];
+}
+__device__ __forceinline__ void dag_zero(v4d (&acc)[4][4]) {
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = (v4d){0., 0., 0., 0.};
+}
+// every wave has stored write-through: drain, meet, ONE flag store
+__device__ __forceinline__ void dag_publish(int* flag, int value) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) st_flag(flag, value);
+}
+// broadcast of a value found by thread 0 (which has also issued the agent-scope acquire): all threads return it
+__device__ __forceinline__ int dag_bcast(int* sh, int v) {
+  if (threadIdx.x == 0) sh[0] = v;
+  __syncthreads();
+  const int r = sh[0];
+  __syncthreads();
+  return r;
+}
+
+__global__ void __launch_bounds__(256) potrf_dag_kernel(const DagArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  int* const sh = reinterpret_cast<int*>(smem + DAG_LDS_DOUBLES);
+  int* const ready = a.ctl + DAG_CTL;
+  int* const xflag = ready + a.nb;
+  const int nb = a.nb, XD = a.xdelay, total = nb * nb;
+  const int tid = threadIdx.x;
+  int cur_s = 0, cur_base = 0;     // claimed indices grow: decode incrementally
+  auto step_tasks = [&](int s) { return (s < nb ? nb - s : 0) + ((s >= XD && s - XD < nb) ? s - XD : 0); };
+  for (;;) {
+    v4d acc[4][4];
+    int t = 0;
+    if (tid == 0) t = atomicAdd(a.ctl, 1);
+    t = dag_bcast(sh, t);
+    if (t >= total) return;
+    while (t >= cur_base + step_tasks(cur_s)) { cur_base += step_tasks(cur_s); ++cur_s; }
+    const int r = t - cur_base, nchol = cur_s < nb ? nb - cur_s : 0;
+    if (r < nchol) {
+      // ---------------- tile (i, j) of L ----------------
+      const int j = cur_s, i = cur_s + r;
+      double* const Tij = a.A + (int64_t)i * NB * a.ld + (int64_t)j * NB;
+      dag_load_neg(acc, Tij, a.ld);
+      int have = 0;
+      bool fin = false;
+      for (;;) {
+        const double *Xp, *Yp;
+        int64_t ldy;
+        int klen;
+        if (have < j) {
+          int f = 0;
+          if (tid == 0) {
+            Spin sp;
+            for (;;) {
+              const int ri = ld_flag(ready + i), rj = (i == j) ? ri : ld_flag(ready + j);
+              f = ri < rj ? ri : rj;
+              if (f > j) f = j;
+              if (f > have) break;
+              if (sp.fail(a.ctl, a.info)) { f = -1; break; }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          }
+          f = dag_bcast(sh, f);
+          if (f < 0) return;
+          Xp = a.A + (int64_t)i * NB * a.ld + (int64_t)have * NB;
+          Yp = a.A + (int64_t)j * NB * a.ld + (int64_t)have * NB;
+          ldy = a.ld;
+          klen = (f - have) * NB;
+          have = f;
+        } else {
+          if (i == j) break;
+          // S is complete: park it in the tile's own place, then L_ij = S D_j^T as one more contraction (X = S from memory)
+          dag_store<false>(acc, Tij, a.ld, -1.0);
+          int ok = 1;
+          if (tid == 0) {
+            Spin sp;
+            while (ld_flag(ready + j) < j + 1)
+              if (sp.fail(a.ctl, a.info)) { ok = 0; break; }
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          ok = dag_bcast(sh, ok);
+          if (!ok) return;
+          dag_zero(acc);
+          Xp = Tij;
+          Yp = a.Linv + (int64_t)j * NB * a.ldi + (int64_t)j * NB;
+          ldy = a.ldi;
+          klen = NB;
+          fin = true;
+        }
+        dag_segment<false>(acc, Xp, a.ld, Yp, ldy, klen, smem);
+        if (fin) break;
+      }
+      if (i == j) {
+        dag_store<false>(acc, Tij, a.ld, -1.0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads();
+        double (&pan)[2][NB][PS] = *reinterpret_cast<double (*)[2][NB][PS]>(smem);
+        double (&xss)[4][16][PS] = *reinterpret_cast<double (*)[4][16][PS]>(smem + 2 * NB * PS);
+        double (&bc)[4][2][16] = *reinterpret_cast<double (*)[4][2][16]>(smem + 2 * NB * PS + 4 * 16 * PS);
+        double* const Djj = a.Linv + (int64_t)j * NB * a.ldi + (int64_t)j * NB;
+        switch (__builtin_amdgcn_readfirstlane(tid >> 6)) {
+          case 0: potf2b_body<0, true>(Tij, a.ld, Djj, a.ldi, j * NB, a.info, pan, xss, bc); break;
+          case 1: potf2b_body<1, true>(Tij, a.ld, Djj, a.ldi, j * NB, a.info, pan, xss, bc); break;
+          case 2: potf2b_body<2, true>(Tij, a.ld, Djj, a.ldi, j * NB, a.info, pan, xss, bc); break;
+          default: potf2b_body<3, true>(Tij, a.ld, Djj, a.ldi, j * NB, a.info, pan, xss, bc); break;
+        }
+        dag_publish(ready + j, j + 1);
+      } else {
+        dag_store<true>(acc, Tij, a.ld, 1.0);
+        dag_publish(ready + i, j + 1);
+      }
+    } else {
+      // ---------------- tile (i, c) of X = L^-1 ----------------
+      const int i = cur_s - XD, c = r - nchol;
+      double* const Tic = a.Linv + (int64_t)i * NB * a.ldi + (int64_t)c * NB;
+      dag_zero(acc);
+      int have = c;
+      bool fin = false;
+      for (;;) {
+        const double *Xp, *Yp;
+        int64_t ldx;
+        int klen;
+        if (have < i) {
+          int f = 0;
+          if (tid < 64) {       // wave 0: lane l looks at contraction block have + l
+            Spin sp;
+            const int k = have + tid;
+            for (;;) {
+              int okl = 0;
+              if (k < i) okl = (k == c) ? (ld_flag(ready + c) >= c + 1) : (ld_flag(xflag + (int64_t)k * nb + c) != 0);
+              // row i of L (and D_i for the last step) must be final as well
+              const int li = ld_flag(ready + i) >= i + 1;
+              const unsigned long long m = __ballot(okl && li);
+              f = m == ~0ull ? 64 : __builtin_ctzll(~m);
+              if (f > 0) break;
+              if (sp.fail(a.ctl, a.info)) { f = -1; break; }
+            }
+            f = __builtin_amdgcn_readfirstlane(f);
+            if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          }
+          f = dag_bcast(sh, f);
+          if (f < 0) return;
+          Xp = a.A + (int64_t)i * NB * a.ld + (int64_t)have * NB;
+          ldx = a.ld;
+          Yp = a.Linv + (int64_t)have * NB * a.ldi + (int64_t)c * NB;
+          klen = f * NB;
+          have += f;
+        } else {
+          // X_ic = -D_i S: S parked in the tile's own place, one more contraction with X = D_i, Y = S
+          dag_store<false>(acc, Tic, a.ldi, 1.0);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          __syncthreads();
+          dag_zero(acc);
+          Xp = a.Linv + (int64_t)i * NB * a.ldi + (int64_t)i * NB;
+          ldx = a.ldi;
+          Yp = Tic;
+          klen = NB;
+          fin = true;
+        }
+        dag_segment<true>(acc, Xp, ldx, Yp, a.ldi, klen, smem);
+        if (fin) break;
+      }
+      dag_store<true>(acc, Tic, a.ldi, -1.0);
+      {   // the mirror tile (c, i) of the result is zero (nothing reads it inside the launch)
+        double* const Z = a.Linv + (int64_t)c * NB * a.ldi + (int64_t)i * NB;
+        for (int e = tid; e < NB * NB / 2; e += 256) *reinterpret_cast<v2d*>(Z + (int64_t)(e >> 6) * a.ldi + 2 * (e & 63)) = (v2d){0., 0.};
+      }
+      dag_publish(xflag + (int64_t)i * nb + c, 1);
+    }
   }
 }
 
@@ -420,11 +762,37 @@ int64_t tree_doubles(int nb) {      // = sum over the nodes of (hi - mid)(mid - 
 constexpr int NEV = 8 + 5;   // 2 x 4 for the look-ahead rings of the factorisation, 4 + 1 for the L^-1 tree (step ring, join)
 struct PotrfCtx { int dev; hipStream_t s[3]; hipEvent_t ev[NEV]; };
 
+size_t dag_ctl_bytes(int64_t nb) { return (size_t)(DAG_CTL + nb + nb * nb) * sizeof(int); }
+
+// one persistent launch (the tile DAG above): counters zeroed on the stream, grid = one workgroup per CU
+int potrf_inv_dag(int64_t m, double* A, int64_t ld, double* Linv, int64_t ldi, int* info, int* ctl, hipStream_t st) {
+  static std::atomic<uint64_t> attr_done{0};   // opt-in to > 64 KiB dynamic LDS, once per DEVICE (idempotent; as in gemm_f64.hip)
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return GEOBO_E_LAUNCH;
+  if (!((attr_done.load(std::memory_order_acquire) >> dev) & 1)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_dag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)DAG_LDS_BYTES) != hipSuccess)
+      return GEOBO_E_LAUNCH;
+    attr_done.fetch_or((uint64_t)1 << dev, std::memory_order_release);
+  }
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return GEOBO_E_LAUNCH;
+  const int nb = (int)(m / NB);
+  if (hipMemsetAsync(ctl, 0, dag_ctl_bytes(nb), st) != hipSuccess) return GEOBO_E_LAUNCH;
+  DagArgs a;
+  a.A = A; a.ld = ld; a.Linv = Linv; a.ldi = ldi; a.info = info; a.ctl = ctl; a.nb = nb;
+  a.xdelay = DAG_XDELAY;
+  if (const char* e = getenv("GEOBO_POTRF_XDELAY")) { const int v = atoi(e); if (v >= 0 && v <= 64) a.xdelay = v; }
+  int grid = cus < nb * nb ? cus : nb * nb;
+  hipLaunchKernelGGL(potrf_dag_kernel, dim3(grid), dim3(256), DAG_LDS_BYTES, st, a);
+  return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
+}
+
 }  // namespace
 
 extern "C" size_t geobo_potrf_ws_bytes(int64_t m) {
   const int64_t nb = (m + NB - 1) / NB;
-  return (size_t)tree_doubles((int)nb) * sizeof(double);      // one T buffer per node of the L^-1 tree
+  // one T buffer per node of the L^-1 tree (stream schedule), then the counters of the tile DAG
+  return (size_t)tree_doubles((int)nb) * sizeof(double) + dag_ctl_bytes(nb);
 }
 
 extern "C" int geobo_potrf_ctx_create(void** ctx) {
@@ -465,6 +833,14 @@ extern "C" int geobo_potrf_inv(int64_t m, double* A, int64_t ld, double* Linv, i
   if (ws_bytes < geobo_potrf_ws_bytes(m)) return GEOBO_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(info, 0, sizeof(int), st) != hipSuccess) return GEOBO_E_LAUNCH;
+  // From m = 1024: the persistent tile DAG (one launch; every tile of Linv is written by it, no memset).  Below -- the tiny grids of
+  // optimize_gp's search, see the note at blocked_potf2 -- and with GEOBO_POTRF=streams: the stream schedule that follows.
+  bool dag = m >= 1024;
+  if (const char* e = getenv("GEOBO_POTRF")) dag = e[0] == 'd';
+  if (dag) {
+    const int64_t nbd = m / NB;
+    return potrf_inv_dag(m, A, ld, Linv, ldi, info, reinterpret_cast<int*>((char*)ws + (size_t)tree_doubles((int)nbd) * sizeof(double)), st);
+  }
   if (hipMemset2DAsync(Linv, (size_t)ldi * sizeof(double), 0, (size_t)m * sizeof(double), (size_t)m, st) != hipSuccess)
     return GEOBO_E_LAUNCH;
   // Right-looking factorisation with ONE STEP OF LOOK-AHEAD when a fork context is given.  The trailing update of step c is

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GEOBO_VERSION 205 /* 201: flag word of geobo_gemm_nt, (64, 32) instance of geobo_xz2d, workspace layout of geobo_potrf_inv; 202: geobo_ymul, geobo_xz2d_fold_lattice; 203: geobo_sumsq_accum, geobo_lamdot_z, geobo_toeplitz_y2t, geobo_xz2d_fold_quad; 204: geobo_toeplitz_y3_add; 205: workspace layout of geobo_potrf_inv (one T buffer per tree node) */
+#define GEOBO_VERSION 206 /* 201: flag word of geobo_gemm_nt, (64, 32) instance of geobo_xz2d, workspace layout of geobo_potrf_inv; 202: geobo_ymul, geobo_xz2d_fold_lattice; 203: geobo_sumsq_accum, geobo_lamdot_z, geobo_toeplitz_y2t, geobo_xz2d_fold_quad; 204: geobo_toeplitz_y3_add; 205: workspace layout of geobo_potrf_inv (one T buffer per tree node); 206: geobo_potrf_inv as one persistent tile-DAG launch from m = 1024 (workspace: + counters) */
 
 #define GEOBO_PAD_M 256 /* row padding of M-like dimensions (observation rows)            */
 #define GEOBO_PAD_N 128 /* padding of voxel-like dimensions (columns / contraction index) */
@@ -347,6 +347,11 @@ int geobo_toeplitz_y3_add(int ny, int64_t C, int64_t plane, int64_t R, int nprop
  * upper part zeroed), used instead of the two solve_triangular calls (inversion.py:105,114).
  * info (device int32): 0 ok, j>0 = first non-positive / NaN pivot (1-based), like LAPACK dpotrf.
  * ws: workspace of geobo_potrf_ws_bytes(m) bytes.
+ * From m = 1024 the call is ONE persistent launch (round 5, potrf.hip "tile DAG"): one 256-thread workgroup per CU draws the 128 x 128
+ * tiles of L (left-looking: a tile is accumulated in registers over its whole contraction) and of L^-1 (forward substitution by block
+ * rows) in dependency order from a global counter and synchronises through agent-scope counters in ws; every spin is bounded -- info
+ * = -7 reports a scheduler time-out (never seen; the result is then undefined).  ctx is not used by that form.  Below m = 1024, or
+ * with GEOBO_POTRF=streams in the environment, the stream schedule of rounds 2-4 runs:
  * ctx: fork context or NULL.  With a context (three internal streams, ordered after / before `stream` by events) the
  * trailing update of every step runs one step behind on the first stream (look-ahead), and the L^-1 tree -- dozens of small
  * merges -- is built under the factorisation: every node's two GEMMs are queued on the second stream as soon as the columns of L

@@ -17,7 +17,9 @@ Two forms of the posterior are provided:
   * `posterior_dense`   -- reference-shaped (materialises D2, the 3N x 3N prior and the full
                            posterior covariance exactly like inversion.py:77-122); usable to ~20^3;
   * `posterior_blocked` -- the same mathematics, matrix-free and column-blocked (never holds K);
-                           this is the bridge to 32^3 and the `cpu_baseline` "port" that bench.py times.
+                           this is the bridge to 32^3 and the `cpu_baseline` "port" that bench.py times;
+  * `posterior_fft`     -- `posterior_blocked` with the sensor rows of A K by FFT convolution on the regular grid
+                           (`ak_rows_fft`): whole-cube goldens at 64 x 48 x 64 (tests/golden/make_oracle64.py).
 
 Conventions (SURVEY.md section 8): grid nx,ny,nz; flat voxel index p = (iy*nx + ix)*nz + iz;
 property blocks 0 = density (gravity rows), 1 = magnetic susceptibility (magnetic rows),
@@ -352,7 +354,7 @@ def posterior_blocked(P3, A_g, A_m, sel, y, lengths, W, name, gp_sigma, gp_amp=1
 
 
 def cubing(grid: Grid, gravfield, magfield, drillfield, sensor_locations, drilldata0, gp_length=None,
-           dense=False, props=(0, 1, 2), A=None, block=2048, gp_amp=1.0):
+           dense=False, props=(0, 1, 2), A=None, block=2048, gp_amp=1.0, fft=False, workers=1):
     """inversion.py:182-248 -- z-score the data (population std), build operators, posterior,
     reshape to (3, ny, nx, nz), scale by the data std / std^2 (means are NOT added back).
 
@@ -379,6 +381,9 @@ def cubing(grid: Grid, gravfield, magfield, drillfield, sensor_locations, drilld
     W = weight_matrix(grid.gp_coeff)
     if dense:
         r = posterior_dense(P3, A_g, A_m, sel, y, lengths, W, grid.kernelfunc, grid.gp_err, gp_amp=gp_amp)
+    elif fft:
+        r = posterior_fft(grid, P3, A_g, A_m, sel, y, lengths, W, grid.kernelfunc, grid.gp_err, gp_amp=gp_amp, props=props,
+                          workers=workers)
     else:
         r = posterior_blocked(P3, A_g, A_m, sel, y, lengths, W, grid.kernelfunc, grid.gp_err, gp_amp=gp_amp, props=props,
                               block=block)
@@ -423,6 +428,90 @@ def ak_row_fft(grid: Grid, a_row, name, lengths, W, s, j, gp_amp=1.0):
     apad[:ny, :nx, :nz] = np.asarray(a_row).reshape(ny, nx, nz)
     w = np.fft.irfftn(np.fft.rfftn(apad) * np.fft.rfftn(kpad), s=shape, axes=(0, 1, 2))
     return w[:ny, :nx, :nz].reshape(-1)
+
+
+def _lattice_spectrum(grid: Grid, name, lengths, W, s, j, gp_amp):
+    """rfftn of block (s, j) of the prior on the index-difference lattice, zero-padded to (2ny, 2nx, 2nz) with offset 0 at index 0
+    (the kernel half of `ak_row_fft`, same arithmetic)."""
+    from scipy import fft as sfft
+    ny, nx, nz = grid.ny, grid.nx, grid.nz
+    dy = np.arange(-(ny - 1), ny) * grid.sy
+    dx = np.arange(-(nx - 1), nx) * grid.sx
+    dz = np.arange(-(nz - 1), nz) * grid.sz
+    d2 = 0 + (dx[None, :, None]) ** 2 + (dy[:, None, None]) ** 2 + (dz[None, None, :]) ** 2
+    kk = gp_amp * k_block(name, d2, lengths, W, s, j)
+    shape = (2 * ny, 2 * nx, 2 * nz)
+    kpad = np.zeros(shape)
+    kpad[:2 * ny - 1, :2 * nx - 1, :2 * nz - 1] = kk
+    kpad = np.roll(kpad, (-(ny - 1), -(nx - 1), -(nz - 1)), axis=(0, 1, 2))
+    return sfft.rfftn(kpad)
+
+
+def ak_rows_fft(grid: Grid, A_rows, name, lengths, W, s, js, gp_amp=1.0, workers=1, batch=16, out=None):
+    """Rows of A K_sj for a stack of operator rows (R, N) and every block j in `js`: `ak_row_fft` with the row's forward
+    transform shared between the blocks and the kernel spectra computed once (scipy's pocketfft, double precision, `workers`
+    threads over the batch).  Returns {j: (R, N)} (or fills `out[j]`).  Pinned to `ak_row_fft` / the direct contraction in
+    tests/test_oracle_golden.py."""
+    from scipy import fft as sfft
+    ny, nx, nz = grid.ny, grid.nx, grid.nz
+    shape = (2 * ny, 2 * nx, 2 * nz)
+    spec = {j: _lattice_spectrum(grid, name, lengths, W, s, j, gp_amp) for j in js}
+    A_rows = np.asarray(A_rows)
+    R = A_rows.shape[0]
+    res = out if out is not None else {j: np.empty((R, grid.N)) for j in js}
+    for r0 in range(0, R, batch):
+        r1 = min(R, r0 + batch)
+        apad = np.zeros((r1 - r0,) + shape)
+        apad[:, :ny, :nx, :nz] = A_rows[r0:r1].reshape(r1 - r0, ny, nx, nz)
+        fa = sfft.rfftn(apad, axes=(1, 2, 3), workers=workers)
+        for j in js:
+            w = sfft.irfftn(fa * spec[j][None], s=shape, axes=(1, 2, 3), workers=workers)
+            res[j][r0:r1] = w[:, :ny, :nx, :nz].reshape(r1 - r0, -1)
+    return res
+
+
+def posterior_fft(grid: Grid, P3, A_g, A_m, sel, y, lengths, W, name, gp_sigma, gp_amp=1.0, props=(0, 1, 2), workers=1,
+                  block=8192, log=None):
+    """`posterior_blocked` with the sensor rows of A K formed by FFT convolution on the grid of calcGridPoints3D (`ak_rows_fft`)
+    instead of the column-blocked contraction: the form of inversion.py:77-122 that reaches 64 x 48 x 64 on a CPU (whole-cube
+    goldens for the grids on which the radix-2 / lattice kernels of the HIP path run).  Same AkA, Cholesky (scipy), V = L^-1 (A K)
+    column-blocked, mu and var as `posterior_blocked`; checked against it in tests/test_oracle_golden.py."""
+    N = P3.shape[0]
+    mg, mm, md = A_g.shape[0], A_m.shape[0], len(sel)
+    M = mg + mm + md
+    say = log if log is not None else (lambda *a: None)
+    AK = {j: np.empty((M, N)) for j in props}
+    for s, A, r0 in ((0, A_g, 0), (1, A_m, mg)):
+        ak_rows_fft(grid, A, name, lengths, W, s, props, gp_amp=gp_amp, workers=workers,
+                    out={j: AK[j][r0:r0 + A.shape[0]] for j in props})
+        say("A K rows of operator %d" % s)
+    if md:
+        D2s = sqdist(P3[sel], P3)                       # (md, N): rows p = drilled voxels
+        for j in props:
+            AK[j][mg + mm:] = gp_amp * k_block(name, D2s, lengths, W, 2, j)
+    if 0 not in props or 1 not in props:
+        raise ValueError("property blocks 0 and 1 required")
+    AkA = np.zeros((M, M))
+    AkA[:, :mg] = AK[0] @ A_g.T
+    AkA[:, mg:mg + mm] = AK[1] @ A_m.T
+    if md:
+        AkA[:mg + mm, mg + mm:] = AkA[mg + mm:, :mg + mm].T
+        AkA[mg + mm:, mg + mm:] = gp_amp * k_block(name, sqdist(P3[sel]), lengths, W, 2, 2)
+    AkA = AkA + np.diag(_noise(gp_sigma, mg, mm, md) ** 2)
+    say("AkA")
+    L = cholesky(AkA, lower=True)
+    u = solve_triangular(L, y, lower=True)
+    logl = -0.5 * (u @ u + np.log(np.diag(L) ** 2).sum() + N * np.log(2 * np.pi))
+    mu = np.full(3 * N, np.nan)
+    var = np.full(3 * N, np.nan)
+    for j in props:
+        for c0 in range(0, N, block):
+            c1 = min(N, c0 + block)
+            V = solve_triangular(L, AK[j][:, c0:c1], lower=True)
+            mu[j * N + c0:j * N + c1] = V.T @ u
+            var[j * N + c0:j * N + c1] = gp_amp * 1.0 - np.einsum("mq,mq->q", V, V)
+        say("posterior of block %d" % j)
+    return dict(mu=mu, var=var, logl=logl, AkA=AkA, L=L, u=u)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -43,7 +43,7 @@ def test_host_side_helpers(lib):
     lib.geobo_pad_n.argtypes = [ctypes.c_int64]
     lib.geobo_potrf_ws_bytes.restype = ctypes.c_size_t
     lib.geobo_potrf_ws_bytes.argtypes = [ctypes.c_int64]
-    assert lib.geobo_version() == 205
+    assert lib.geobo_version() == 206
     assert lib.geobo_pad_m(8242) == 8448 and lib.geobo_pad_m(256) == 256 and lib.geobo_pad_m(1) == 256
     assert lib.geobo_pad_n(480) == 512 and lib.geobo_pad_n(262144) == 262144
     # one T buffer per node [lo, mid, hi) of the L^-1 tree, (hi - mid) x (mid - lo) blocks of 128 x 128; split on even block counts
@@ -55,8 +55,10 @@ def test_host_side_helpers(lib):
             mid += 1
         return (n - mid) * mid + tree_blocks(mid) + tree_blocks(n - mid)
     assert tree_blocks(8) == 16 + 2 * 4 + 4 * 1 and tree_blocks(66) == 2145
+    # ... followed by the counters of the persistent tile-DAG kernel: 16 control words, nb row counters, nb x nb tile flags
     for m in (256, 1024, 2048, 8448, 33024):
-        assert lib.geobo_potrf_ws_bytes(m) == tree_blocks(m // 128) * 128 * 128 * 8
+        nb = m // 128
+        assert lib.geobo_potrf_ws_bytes(m) == tree_blocks(nb) * 128 * 128 * 8 + 4 * (16 + nb + nb * nb)
 
 
 def test_argument_validation_without_gpu(lib):

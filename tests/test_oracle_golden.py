@@ -164,6 +164,34 @@ def test_ak_row_fft_equals_direct_contraction(kern):
         assert np.abs(got - ref).max() <= 1e-13 * np.abs(ref).max()
 
 
+def test_ak_rows_fft_equals_ak_row_fft():
+    """The batched form behind the whole-cube 64 x 48 x 64 goldens: same numbers as the single-row form (and hence as the direct
+    contraction, above), forward transform shared between the blocks."""
+    G = O.Grid(nx=7, ny=5, nz=6, xmax=700., ymax=450., zLcube=660., kernelfunc="matern32")
+    lengths = np.array([200., 204., 230.])
+    W = O.weight_matrix([0.7, 0.3, 0.2])
+    A = np.random.default_rng(4).standard_normal((5, G.N))
+    got = O.ak_rows_fft(G, A, "matern32", lengths, W, 1, (0, 1, 2), gp_amp=1.3, workers=2, batch=2)
+    for j in (0, 1, 2):
+        for r in range(5):
+            ref = O.ak_row_fft(G, A[r], "matern32", lengths, W, 1, j, gp_amp=1.3)
+            assert np.abs(got[j][r] - ref).max() <= 1e-14 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("name,dims,kern", [("tiny_matern32", (10, 8, 6), "matern32"), ("tiny_sparse", (10, 8, 6), "sparse"),
+                                            ("cube16_exp", (16, 16, 16), "exp")])
+def test_posterior_fft_matches_the_reference(name, dims, kern):
+    """`cubing(fft=True)` -- the form that produced tests/golden/oracle64x48_matern32.npz -- against the reference's own cubes."""
+    f = load_golden(name + ".npz")
+    G = _grid_for(f, *dims, kern)
+    d0 = f["drilldata0"]
+    r = O.cubing(G, f["gravfield"], f["magfield"], d0[d0 != 0], f["sensor_locations"], d0, gp_length=f["gp_length_in"].copy(),
+                 fft=True, workers=2)
+    errs = [normwise(a, b) for a, b in zip(r["cubes"], f["cubes"]) if not np.isnan(b).all()]
+    assert max(errs) < 1e-10, errs
+    assert abs(r["logl"] - float(f["logl"])) < 1e-9 * abs(float(f["logl"]))
+
+
 def test_F4_forward_model_known_answer():
     f = load_golden("forward_kat.npz")
     G = O.Grid(nx=25, ny=16, nz=16, xmax=3050, ymax=1952, zLcube=800.)
