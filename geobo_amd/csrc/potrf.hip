@@ -312,7 +312,9 @@ __device__ __forceinline__ void potf2b_body(double* __restrict__ A, int64_t ld, 
     if constexpr (i > c) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        stg<PUB>(A + (int64_t)(16 * c + q4 + 4 * r) * ld + 16 * i + lr, 0.0);        // mirror tile (c, i): strictly above the diagonal
+        // mirror tile (c, i): strictly above the diagonal.  Inside the tile DAG the zeros of D_j ARE read by other workgroups (the
+        // whole 128 x 128 tile is the operand of L_ij = S D_j^T): published like the rest; the zeros of L_jj are read by no one
+        A[(int64_t)(16 * c + q4 + 4 * r) * ld + 16 * i + lr] = 0.0;
         stg<PUB>(Linv + (int64_t)(16 * c + q4 + 4 * r) * ldi + 16 * i + lr, 0.0);
       }
     }
@@ -357,6 +359,17 @@ constexpr int DAG_LDS_DOUBLES = DNST * DSTAGE;   // 99 840 bytes: one workgroup 
 constexpr size_t DAG_LDS_BYTES = (size_t)DAG_LDS_DOUBLES * sizeof(double) + 64;
 constexpr int DAG_CTL = 16;                      // control words in front of the counters: [0] task head, [1] abort
 constexpr int DAG_XDELAY = 6;
+
+// -DGEOBO_DAG_TRACE (tools/potrf_dag_trace.py builds it): every task logs 8 x int64 behind the counters --
+// [0] (type << 40 | i << 20 | j), [1] workgroup << 8 | XCC, [2] claimed, [3] contraction complete, [4] last dependency seen,
+// [5] published (100 MHz wall clock), [6] ticks spent polling, [7] segments run
+#ifdef GEOBO_DAG_TRACE
+#define DAG_T(slot, val) do { if (threadIdx.x == 0) trace[(slot)] = (val); } while (0)
+#define DAG_NOW() ((long long)wall_clock64())
+#else
+#define DAG_T(slot, val) do { } while (0)
+#define DAG_NOW() 0ll
+#endif
 
 struct DagArgs {
   double* A; int64_t ld; double* Linv; int64_t ldi; int* info;
@@ -511,6 +524,20 @@ __device__ __forceinline__ int dag_bcast(int* sh, int v) {
   return r;
 }
 
+// the diagonal block as a function of its own: inlined into the task loop its 230 + 100 registers (four wave specialisations) spilled
+// (640 scratch accesses on the latency chain: 135 us per block instead of 49)
+__device__ __noinline__ void potf2b_dag(double* T, int64_t ld, double* D, int64_t ldi, int kb_global, int* info, double* smem) {
+  double (&pan)[2][NB][PS] = *reinterpret_cast<double (*)[2][NB][PS]>(smem);
+  double (&xss)[4][16][PS] = *reinterpret_cast<double (*)[4][16][PS]>(smem + 2 * NB * PS);
+  double (&bc)[4][2][16] = *reinterpret_cast<double (*)[4][2][16]>(smem + 2 * NB * PS + 4 * 16 * PS);
+  switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
+    case 0: potf2b_body<0, true>(T, ld, D, ldi, kb_global, info, pan, xss, bc); break;
+    case 1: potf2b_body<1, true>(T, ld, D, ldi, kb_global, info, pan, xss, bc); break;
+    case 2: potf2b_body<2, true>(T, ld, D, ldi, kb_global, info, pan, xss, bc); break;
+    default: potf2b_body<3, true>(T, ld, D, ldi, kb_global, info, pan, xss, bc); break;
+  }
+}
+
 __global__ void __launch_bounds__(256) potrf_dag_kernel(const DagArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   int* const sh = reinterpret_cast<int*>(smem + DAG_LDS_DOUBLES);
@@ -526,12 +553,20 @@ __global__ void __launch_bounds__(256) potrf_dag_kernel(const DagArgs a) {
     if (tid == 0) t = atomicAdd(a.ctl, 1);
     t = dag_bcast(sh, t);
     if (t >= total) return;
+#ifdef GEOBO_DAG_TRACE
+    long long* const trace = reinterpret_cast<long long*>((reinterpret_cast<uintptr_t>(xflag + (int64_t)nb * nb) + 7) & ~(uintptr_t)7) + (int64_t)t * 8;
+    long long t_poll = 0, t_p0 = 0;
+    int n_seg = 0;
+    DAG_T(1, ((long long)blockIdx.x << 8) | (__builtin_amdgcn_s_getreg(6164) & 7));   // hwreg(HW_REG_XCC_ID = 20, 0, 4)
+    DAG_T(2, DAG_NOW());
+#endif
     while (t >= cur_base + step_tasks(cur_s)) { cur_base += step_tasks(cur_s); ++cur_s; }
     const int r = t - cur_base, nchol = cur_s < nb ? nb - cur_s : 0;
     if (r < nchol) {
       // ---------------- tile (i, j) of L ----------------
       const int j = cur_s, i = cur_s + r;
       double* const Tij = a.A + (int64_t)i * NB * a.ld + (int64_t)j * NB;
+      DAG_T(0, (0ll << 40) | ((long long)i << 20) | j);
       dag_load_neg(acc, Tij, a.ld);
       int have = 0;
       bool fin = false;
@@ -543,6 +578,9 @@ __global__ void __launch_bounds__(256) potrf_dag_kernel(const DagArgs a) {
           int f = 0;
           if (tid == 0) {
             Spin sp;
+#ifdef GEOBO_DAG_TRACE
+            t_p0 = DAG_NOW();
+#endif
             for (;;) {
               const int ri = ld_flag(ready + i), rj = (i == j) ? ri : ld_flag(ready + j);
               f = ri < rj ? ri : rj;
@@ -551,6 +589,9 @@ __global__ void __launch_bounds__(256) potrf_dag_kernel(const DagArgs a) {
               if (sp.fail(a.ctl, a.info)) { f = -1; break; }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#ifdef GEOBO_DAG_TRACE
+            t_poll += DAG_NOW() - t_p0;
+#endif
           }
           f = dag_bcast(sh, f);
           if (f < 0) return;
@@ -560,7 +601,8 @@ __global__ void __launch_bounds__(256) potrf_dag_kernel(const DagArgs a) {
           klen = (f - have) * NB;
           have = f;
         } else {
-          if (i == j) break;
+          if (i == j) { DAG_T(1, (DAG_NOW() << 16) | ((long long)blockIdx.x << 8)); break; }
+          DAG_T(3, DAG_NOW());
           // S is complete: park it in the tile's own place, then L_ij = S D_j^T as one more contraction (X = S from memory)
           dag_store<false>(acc, Tij, a.ld, -1.0);
           int ok = 1;
@@ -573,6 +615,7 @@ __global__ void __launch_bounds__(256) potrf_dag_kernel(const DagArgs a) {
           if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
           ok = dag_bcast(sh, ok);
           if (!ok) return;
+          DAG_T(4, DAG_NOW());
           dag_zero(acc);
           Xp = Tij;
           Yp = a.Linv + (int64_t)j * NB * a.ldi + (int64_t)j * NB;
@@ -581,6 +624,9 @@ __global__ void __launch_bounds__(256) potrf_dag_kernel(const DagArgs a) {
           fin = true;
         }
         dag_segment<false>(acc, Xp, a.ld, Yp, ldy, klen, smem);
+#ifdef GEOBO_DAG_TRACE
+        ++n_seg;
+#endif
         if (fin) break;
       }
       if (i == j) {
@@ -588,25 +634,21 @@ __global__ void __launch_bounds__(256) potrf_dag_kernel(const DagArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __syncthreads();
-        double (&pan)[2][NB][PS] = *reinterpret_cast<double (*)[2][NB][PS]>(smem);
-        double (&xss)[4][16][PS] = *reinterpret_cast<double (*)[4][16][PS]>(smem + 2 * NB * PS);
-        double (&bc)[4][2][16] = *reinterpret_cast<double (*)[4][2][16]>(smem + 2 * NB * PS + 4 * 16 * PS);
-        double* const Djj = a.Linv + (int64_t)j * NB * a.ldi + (int64_t)j * NB;
-        switch (__builtin_amdgcn_readfirstlane(tid >> 6)) {
-          case 0: potf2b_body<0, true>(Tij, a.ld, Djj, a.ldi, j * NB, a.info, pan, xss, bc); break;
-          case 1: potf2b_body<1, true>(Tij, a.ld, Djj, a.ldi, j * NB, a.info, pan, xss, bc); break;
-          case 2: potf2b_body<2, true>(Tij, a.ld, Djj, a.ldi, j * NB, a.info, pan, xss, bc); break;
-          default: potf2b_body<3, true>(Tij, a.ld, Djj, a.ldi, j * NB, a.info, pan, xss, bc); break;
-        }
+        DAG_T(3, DAG_NOW());      // (diagonal tasks: [3] = S parked and visible, [4] = factorised and inverted)
+        potf2b_dag(Tij, a.ld, a.Linv + (int64_t)j * NB * a.ldi + (int64_t)j * NB, a.ldi, j * NB, a.info, smem);
+        DAG_T(4, DAG_NOW());
         dag_publish(ready + j, j + 1);
+        DAG_T(5, DAG_NOW()); DAG_T(6, t_poll); DAG_T(7, n_seg);
       } else {
         dag_store<true>(acc, Tij, a.ld, 1.0);
         dag_publish(ready + i, j + 1);
+        DAG_T(5, DAG_NOW()); DAG_T(6, t_poll); DAG_T(7, n_seg);
       }
     } else {
       // ---------------- tile (i, c) of X = L^-1 ----------------
       const int i = cur_s - XD, c = r - nchol;
       double* const Tic = a.Linv + (int64_t)i * NB * a.ldi + (int64_t)c * NB;
+      DAG_T(0, (1ll << 40) | ((long long)i << 20) | c);
       dag_zero(acc);
       int have = c;
       bool fin = false;
@@ -619,6 +661,9 @@ __global__ void __launch_bounds__(256) potrf_dag_kernel(const DagArgs a) {
           if (tid < 64) {       // wave 0: lane l looks at contraction block have + l
             Spin sp;
             const int k = have + tid;
+#ifdef GEOBO_DAG_TRACE
+            t_p0 = DAG_NOW();
+#endif
             for (;;) {
               int okl = 0;
               if (k < i) okl = (k == c) ? (ld_flag(ready + c) >= c + 1) : (ld_flag(xflag + (int64_t)k * nb + c) != 0);
@@ -631,6 +676,9 @@ __global__ void __launch_bounds__(256) potrf_dag_kernel(const DagArgs a) {
             }
             f = __builtin_amdgcn_readfirstlane(f);
             if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#ifdef GEOBO_DAG_TRACE
+            t_poll += DAG_NOW() - t_p0;
+#endif
           }
           f = dag_bcast(sh, f);
           if (f < 0) return;
@@ -641,6 +689,7 @@ __global__ void __launch_bounds__(256) potrf_dag_kernel(const DagArgs a) {
           have += f;
         } else {
           // X_ic = -D_i S: S parked in the tile's own place, one more contraction with X = D_i, Y = S
+          DAG_T(3, DAG_NOW()); DAG_T(4, DAG_NOW());
           dag_store<false>(acc, Tic, a.ldi, 1.0);
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -653,6 +702,9 @@ __global__ void __launch_bounds__(256) potrf_dag_kernel(const DagArgs a) {
           fin = true;
         }
         dag_segment<true>(acc, Xp, ldx, Yp, a.ldi, klen, smem);
+#ifdef GEOBO_DAG_TRACE
+        ++n_seg;
+#endif
         if (fin) break;
       }
       dag_store<true>(acc, Tic, a.ldi, -1.0);
@@ -661,6 +713,7 @@ __global__ void __launch_bounds__(256) potrf_dag_kernel(const DagArgs a) {
         for (int e = tid; e < NB * NB / 2; e += 256) *reinterpret_cast<v2d*>(Z + (int64_t)(e >> 6) * a.ldi + 2 * (e & 63)) = (v2d){0., 0.};
       }
       dag_publish(xflag + (int64_t)i * nb + c, 1);
+      DAG_T(5, DAG_NOW()); DAG_T(6, t_poll); DAG_T(7, n_seg);
     }
   }
 }
@@ -762,7 +815,13 @@ int64_t tree_doubles(int nb) {      // = sum over the nodes of (hi - mid)(mid - 
 constexpr int NEV = 8 + 5;   // 2 x 4 for the look-ahead rings of the factorisation, 4 + 1 for the L^-1 tree (step ring, join)
 struct PotrfCtx { int dev; hipStream_t s[3]; hipEvent_t ev[NEV]; };
 
-size_t dag_ctl_bytes(int64_t nb) { return (size_t)(DAG_CTL + nb + nb * nb) * sizeof(int); }
+size_t dag_ctl_bytes(int64_t nb) {
+#ifdef GEOBO_DAG_TRACE
+  return (size_t)(DAG_CTL + nb + nb * nb + 2) * sizeof(int) + (size_t)nb * nb * 8 * sizeof(long long);
+#else
+  return (size_t)(DAG_CTL + nb + nb * nb) * sizeof(int);
+#endif
+}
 
 // one persistent launch (the tile DAG above): counters zeroed on the stream, grid = one workgroup per CU
 int potrf_inv_dag(int64_t m, double* A, int64_t ld, double* Linv, int64_t ldi, int* info, int* ctl, hipStream_t st) {
