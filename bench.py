@@ -315,9 +315,16 @@ def main():
     torch.cuda.set_device(local)
     dist = None
     ranks_reported = 1
-    if world > 1:
+    # one rank: a process group exists only when a launcher started us (WORLD_SIZE=1 under torch.distributed.run) or with --check, which
+    # then pushes the row form's collectives through the backend with one rank (RCCL for "nccl": the one-GPU stand-in for a node)
+    if world > 1 or a.check or "WORLD_SIZE" in os.environ:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(so.getsockname()[1])
         dist.init_process_group(backend=a.backend, rank=rank, world_size=world)
         ones = torch.ones(1, dtype=torch.float64, device="cuda")
         dist.all_reduce(ones)                      # the rank count the backend itself reports (RCCL for "nccl")
@@ -405,6 +412,25 @@ def main():
         dist.all_gather_object(colls, my_coll)
     check = None
     operators_in_use = sorted({"streamed" if type(v).__name__ == "StreamedOperator" else "resident" for v in inv.engine._A.values()})
+    if a.check and world == 1:
+        # the multi-rank form of this step on the one rank there is -- row form forced, its all-gather / all-reduce / agreement issued
+        # through the backend (sharding._live) -- against the cubes of the timed steps (a second engine beside the timed one: 2 x 50 GB)
+        os.environ["GEOBO_ROWS"] = "1"
+        solo = Inversion(settings=s, props=(0, 1, 2)[:a.props], rank=0, world=1, device="cuda:%d" % local, method=a.method,
+                         assembly=a.assembly, operators=a.operators)
+        os.environ.pop("GEOBO_ROWS")
+        solo.engine.force_collectives = True
+        solo.engine.kernel_events = []
+        solo.gp_length = (gp_length.copy() if gp_length is not None else s.gp_lengthscale * np.asarray([s.xvoxsize] * 3))
+        ref = solo.cubing(grav, mag, drill0[drill0 != 0], loc, drill0)
+        idx = (0, 1, 3, 4) if a.props == 2 else range(6)
+        evs = [(e[0], e[4].elapsed_time(e[5])) for e in solo.engine.kernel_events if e[0] in coll_names]
+        check = {"what": "row form forced on the one rank, collectives through backend '%s' with world size 1" % a.backend,
+                 "max_normwise_diff_vs_timed_steps": max(float(np.abs(cubes[i] - ref[i]).max() / np.abs(ref[i]).max()) for i in idx),
+                 "cube_checksums_row_form": [float(np.abs(ref[i]).sum()) for i in idx], "route_row_form": solo.engine.route.describe(),
+                 "family_of_the_check_step": solo.engine.step_route, "collective_ms": {coll_names[k]: round(v, 3) for k, v in evs},
+                 "logl_diff": float(abs(inv.logl - solo.logl))}
+        del solo
     if a.check and world > 1:
         inv.engine.release()                   # (dry runs put all ranks on one device: make room for the 1-rank engine)
         dist.barrier()
@@ -508,7 +534,7 @@ def main():
                        "N_voxels": N, "M_rows": M, "props_out": p_out, "parallelism": ("sensor-row shards x%d" if eng._rowpath else "voxel-column shards x%d") % world,
                        "route": eng.route.describe(), "route_family_of_the_steps": eng.step_route, "route_note": eng.route.note or None,
                        "collective_ms_per_step": colls, "stage_ms_per_step_by_rank": tables, "check_vs_1_rank": check,
-                       "backend": a.backend if world > 1 else None, "ranks_reported_by_backend": ranks_reported,
+                       "backend": a.backend if dist is not None else None, "ranks_reported_by_backend": ranks_reported,
                        "method": "spectral" if inv.engine.use_spectral else "dense", "assembly": a.assembly, "operators": a.operators,
                        "operators_in_use": operators_in_use,
                        "row_exchange": bool(inv.engine.exchange and not inv.engine._rowpath), "row_posterior": bool(inv.engine._rowpath),

@@ -950,47 +950,54 @@ extern "C" int geobo_potrf_inv(int64_t m, double* A, int64_t ld, double* Linv, i
   // 128 columns at M = 8448); at rank 512 it is a matrix-pipe-bound GEMM again.  The look-ahead is the same, one level up:
   //     caller's stream:  [wait (b)_(K-2)] factorise panel K -> event P_K;  [wait (b)_(K-1)] (a)_K = the next panel's columns
   //     side stream:      [wait P_K] (b)_K = everything right of the next panel -> event B_K
-  // OB = 1 is the round-2 schedule exactly (GEOBO_POTRF_OB, for A/B runs).  Fixed summation orders for a given OB: ranks that
+  // OB = 1 is the round-2 schedule exactly.  Fixed summation orders for a given OB: ranks that
   // factorise the same matrix get the same bits.  Measured (tools/run_potrf_once.py): M = 33024 (128^3 x 3 properties) 547 -> 408 ms
   // with OB = 4; M = 8448 17.5 -> 18.2 ms -- there the loop is bound by the chain potf2 (98 us) -> panel solve -> panel update of
   // every 128 columns, not by the trailing update, and the longer (a) of a 512-wide panel sits on that chain.  Hence by size:
   // diagonal blocks: the blocked kernel (49 us alone on the chip against 66) from m = 1024; below that -- the tiny grids on which
   // optimize_gp's SHGO / SLSQP search runs, whose forward differences (h = 1.5e-8) amplify last-bit differences of the objective into
   // a different path through a flat valley -- the column kernel, whose rounding the reference-optimum fixture was recorded against.
-  // GEOBO_POTF2=column / blocked forces one (A/B runs).
-  bool blocked_potf2 = m >= 1024;
-  if (const char* e = getenv("GEOBO_POTF2")) blocked_potf2 = e[0] != 'c';
-  int OB = nb >= 96 ? 4 : 1;
-  if (const char* e = getenv("GEOBO_POTRF_OB")) { const int v = atoi(e); if (v >= 1 && v <= 16) OB = v; }
+  const bool blocked_potf2 = m >= 1024;
+  const int OB = nb >= 96 ? 4 : 1;
+  // Error paths (round-4 advisory): once a tree GEMM or a look-ahead update is queued on a context stream, a non-OK return must not leave
+  // that work running behind the caller's back (a retry with jitter on `stream` would race with GEMMs still writing Linv and the T
+  // buffers): every early return below first makes `stream` wait for both context streams.
+  auto fail = [&](int rc) -> int {
+    if (pc) {
+      if (hipEventRecord(Sev[4], wtree) == hipSuccess) (void)hipStreamWaitEvent(st, Sev[4], 0);
+      if (hipEventRecord(Bev[0], side) == hipSuccess) (void)hipStreamWaitEvent(st, Bev[0], 0);
+    }
+    return rc;
+  };
   int step = 0, ostep = 0, last_b = -1, prev_b = -1;   // step: global 128-block index; outer steps whose (b) was launched most recently
   if (pc) {   // the side stream starts after everything already queued on the caller's stream (the memsets above, the producer of A)
-    if (hipEventRecord(Pev[3], st) != hipSuccess || hipStreamWaitEvent(side, Pev[3], 0) != hipSuccess) return GEOBO_E_LAUNCH;
+    if (hipEventRecord(Pev[3], st) != hipSuccess || hipStreamWaitEvent(side, Pev[3], 0) != hipSuccess) return fail(GEOBO_E_LAUNCH);
   }
   // panel and (a) are short and run next to (b) of the previous step: 128-row tiles find room as soon as HALF a CU drains
   // (a 512-thread workgroup waits for a whole CU: behind 256-thread (b) tiles that only happens when (b) ends)
   const int crit = pc ? GEOBO_GEMM_SMALL_TILES : 0;
   for (int64_t k0 = 0; k0 < m; ++ostep) {
     const int64_t W = (m - k0) < (int64_t)OB * NB ? (m - k0) : (int64_t)OB * NB;
-    if (pc && prev_b >= 0 && hipStreamWaitEvent(st, Bev[prev_b & 3], 0) != hipSuccess) return GEOBO_E_LAUNCH;
+    if (pc && prev_b >= 0 && hipStreamWaitEvent(st, Bev[prev_b & 3], 0) != hipSuccess) return fail(GEOBO_E_LAUNCH);
     for (int64_t kb = k0; kb < k0 + W; kb += NB, ++step) {
       if (blocked_potf2) hipLaunchKernelGGL(potf2b_inv_kernel, dim3(1), dim3(256), 0, st, A + kb * ld + kb, ld, Linv + kb * ldi + kb, ldi, (int)kb, info);
       else hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(256), 0, st, A + kb * ld + kb, ld, Linv + kb * ldi + kb, ldi, (int)kb, info);
-      if (hipGetLastError() != hipSuccess) return GEOBO_E_LAUNCH;
+      if (hipGetLastError() != hipSuccess) return fail(GEOBO_E_LAUNCH);
       const int64_t rem = m - kb - NB;
       if (rem <= 0) {
         const int rt = tree_after_step(step);
-        if (rt) return rt;
+        if (rt) return fail(rt);
         continue;
       }
       double* P = A + (kb + NB) * ld + kb;
       int rc = geobo_gemm_nt(rem, NB, NB, 1.0, P, ld, Linv + kb * ldi + kb, ldi, 0.0, P, ld, crit, 0, stream);
-      if (rc) return rc;
+      if (rc) return fail(rc);
       rc = tree_after_step(step);
-      if (rc) return rc;
+      if (rc) return fail(rc);
       const int64_t cols_left = k0 + W - (kb + NB);
       if (cols_left > 0) {   // the panel's own columns to the right of this block: rows >= kb + NB, lower tiles from the diagonal on
         rc = geobo_gemm_nt(rem, cols_left, NB, -1.0, P, ld, P, ld, 1.0, A + (kb + NB) * ld + (kb + NB), ld, GEOBO_GEMM_LOWER_ONLY | crit, 0, stream);
-        if (rc) return rc;
+        if (rc) return fail(rc);
       }
     }
     const int64_t remo = m - k0 - W;   // rows / columns behind the panel
@@ -999,29 +1006,29 @@ extern "C" int geobo_potrf_inv(int64_t m, double* A, int64_t ld, double* Linv, i
       double* C0 = A + (k0 + W) * ld + (k0 + W);
       if (!pc) {
         int rc = geobo_gemm_nt(remo, remo, W, -1.0, Pp, ld, Pp, ld, 1.0, C0, ld, GEOBO_GEMM_LOWER_ONLY, 0, stream);
-        if (rc) return rc;
+        if (rc) return fail(rc);
       } else {
-        if (hipEventRecord(Pev[ostep & 3], st) != hipSuccess) return GEOBO_E_LAUNCH;
-        if (last_b >= 0 && hipStreamWaitEvent(st, Bev[last_b & 3], 0) != hipSuccess) return GEOBO_E_LAUNCH;
+        if (hipEventRecord(Pev[ostep & 3], st) != hipSuccess) return fail(GEOBO_E_LAUNCH);
+        if (last_b >= 0 && hipStreamWaitEvent(st, Bev[last_b & 3], 0) != hipSuccess) return fail(GEOBO_E_LAUNCH);
         const int64_t Wn = remo < (int64_t)OB * NB ? remo : (int64_t)OB * NB;
         // (a)_K: the next panel's columns, rows >= its diagonal
         int rc = geobo_gemm_nt(remo, Wn, W, -1.0, Pp, ld, Pp, ld, 1.0, C0, ld, (OB > 1 ? GEOBO_GEMM_LOWER_ONLY : 0) | crit, 0, stream);
-        if (rc) return rc;
+        if (rc) return fail(rc);
         prev_b = last_b;
         if (remo > Wn) {
           // (b)_K: columns behind the next panel, lower tiles
-          if (hipStreamWaitEvent(side, Pev[ostep & 3], 0) != hipSuccess) return GEOBO_E_LAUNCH;
+          if (hipStreamWaitEvent(side, Pev[ostep & 3], 0) != hipSuccess) return fail(GEOBO_E_LAUNCH);
           double* P2 = Pp + Wn * ld;
           rc = geobo_gemm_nt(remo - Wn, remo - Wn, W, -1.0, P2, ld, P2, ld, 1.0, C0 + Wn * ld + Wn, ld, GEOBO_GEMM_LOWER_ONLY, 0, side);
-          if (rc) return rc;
-          if (hipEventRecord(Bev[ostep & 3], side) != hipSuccess) return GEOBO_E_LAUNCH;
+          if (rc) return fail(rc);
+          if (hipEventRecord(Bev[ostep & 3], side) != hipSuccess) return fail(GEOBO_E_LAUNCH);
           last_b = ostep;
         }
       }
     }
     k0 += W;
   }
-  if (pc && last_b >= 0 && hipStreamWaitEvent(st, Bev[last_b & 3], 0) != hipSuccess) return GEOBO_E_LAUNCH;
+  if (pc && last_b >= 0 && hipStreamWaitEvent(st, Bev[last_b & 3], 0) != hipSuccess) return fail(GEOBO_E_LAUNCH);
   // everything is queued; what is left on the worker behind the last diagonal block are the merges of the tree's right spine
   if (pc && tp.n > 0 && (hipEventRecord(Sev[4], wtree) != hipSuccess || hipStreamWaitEvent(st, Sev[4], 0) != hipSuccess)) return GEOBO_E_LAUNCH;
   return GEOBO_OK;

@@ -206,6 +206,9 @@ class PosteriorEngine(RowFormMixin, TransposedPosteriorMixin, ColumnExchangeMixi
         self._Arows, self._Aedge, self._fullrows, self._rowsrc, self._op_args = {}, {}, {}, {}, {}
         self._slab_ops = set()      # data pointers of operators that hold only this rank's column slab
         self._potrf_ctx = None
+        # one-rank runs issue no collective; bench.py --gpus 1 --check and the RCCL test set this so that the row form's all-gather,
+        # all-reduce and agreement go through the backend with one rank (sharding._live)
+        self.force_collectives = os.environ.get("GEOBO_FORCE_COLLECTIVES", "0") == "1"
         self.kernel_events = None  # set to [] to record (name, flops, start, stop) HIP events per fused launch
         self.aka_hook = None       # callable(AkA) run between the assembly of AkA and its factorisation (emulation tool only)
 
@@ -243,7 +246,7 @@ class PosteriorEngine(RowFormMixin, TransposedPosteriorMixin, ColumnExchangeMixi
         xe, ye, ze = self.node_axes() if axes is None else axes
         # survey on the cube's own x-y lattice (the reference's workflow): translation-invariant stencil, ~2000x fewer potentials
         plan = None
-        if os.environ.get("GEOBO_A_SENS_LATTICE", "1") != "0":
+        if True:      # (the lattice analysis is always attempted; a survey off the lattice gets plan = None)
             pkey = (loc.tobytes(), xe.tobytes(), ye.tobytes(), ze.tobytes())
             if self._lattice_plan is None or self._lattice_plan[0] != pkey:
                 self._lattice_plan = (pkey, hip.lattice_plan(loc, xe, ye, ze, self.nx, self.ny, self.nz, self.device))
@@ -324,8 +327,7 @@ class PosteriorEngine(RowFormMixin, TransposedPosteriorMixin, ColumnExchangeMixi
                 from .spectral import SpectralProduct
                 if self._spectral is None and self.use_spectral:
                     self._spectral = SpectralProduct(self.nx, self.ny, self.nz, self.device)
-                if (self.use_spectral and self._spectral.lattice_feed and not self.f32
-                        and os.environ.get("GEOBO_LATTICE_FEED", "1") != "0"):
+                if self.use_spectral and self._spectral.lattice_feed and not self.f32:
                     self._timed("a_sens_" + func, 0.0, lambda: A.keep_stencil(func))
             self._lam[func] = None if lam is None else (A, lam)
             if rows_mode:
@@ -394,6 +396,10 @@ class PosteriorEngine(RowFormMixin, TransposedPosteriorMixin, ColumnExchangeMixi
         """The row form is impossible for this survey / field: operator builds and steps take the column form (with the all-to-all only
         where it pays without the row posterior: from 4 ranks) until an operator build with another survey / field lifts the denial.
         Operators already built for the row form are dropped (posterior() rebuilds them from the recorded arguments)."""
+        if self.route.rows_mandatory:
+            # (round-4 advisory) the column form's A K does not fit this device: say so instead of running into the allocator
+            raise RuntimeError("the row form is the only one that fits this grid (a materialised A K would take %.0f GB per rank) and it "
+                               "cannot run here: %s" % (self.route.ak_bytes / 1e9, why))
         self._deny[what] = (key, why)
         self.exchange = self.route.exchange_without_rows
         self._A = {k: v for k, v in self._A.items() if not k[5]}
@@ -407,7 +413,7 @@ class PosteriorEngine(RowFormMixin, TransposedPosteriorMixin, ColumnExchangeMixi
         """operators="auto": True when neither the transforms nor AkA need a materialised operator."""
         if plan is None or self.world != 1 or self.f32 or not self.use_spectral or not plan["rowmajor"]:
             return False
-        if os.environ.get("GEOBO_LATTICE_FEED", "1") == "0" or os.environ.get("GEOBO_AKA_LATTICE", "1") == "0":
+        if os.environ.get("GEOBO_AKA_LATTICE", "1") == "0":
             return False
         from .lattice_gram import LatticeGram
         from .spectral import SpectralProduct
@@ -422,7 +428,7 @@ class PosteriorEngine(RowFormMixin, TransposedPosteriorMixin, ColumnExchangeMixi
         from .spectral import SpectralProduct
         if self._spectral is None:
             self._spectral = SpectralProduct(self.nx, self.ny, self.nz, self.device)
-        self._spectral.kernel_timer = None if (self.kernel_events is None or os.environ.get("GEOBO_KERNEL_TIMER", "1") == "0") else (
+        self._spectral.kernel_timer = None if self.kernel_events is None else (
             lambda name, by, fn, valu=0.0: self._timed(name, 0.0, fn, alg=by, valu=valu))
         return self._spectral
 
@@ -560,6 +566,9 @@ class PosteriorEngine(RowFormMixin, TransposedPosteriorMixin, ColumnExchangeMixi
                 self._rowpath = True
                 self._fullrows = {}
                 return None, M_pad
+        if self.route.rows_mandatory and self.use_spectral:
+            raise RuntimeError("A K of this grid would take %.0f GB on this rank and only the row form avoids it (%s)"
+                               % (self.route.ak_bytes / 1e9, self.route.note or "GEOBO_ROWS=0 / GEOBO_POSTERIOR=dense switch it off"))
         AK = self._workspace2d("AK", M_pad, len(props) * nc, dtype=hip.F32 if self.f32 else F64)
         # every sensor/drill row is overwritten below; only the padding must be defined: rows behind each row block
         # (zero, so that AkA / V get zero rows) and voxel columns >= N of the last shard (finite: they meet zero A columns)

@@ -15,8 +15,8 @@ F64 = torch.float64
 
 KERNEL_IDS = {"d2": 0, "exp": 1, "exp_x": 2, "matern32": 3, "matern32_x": 4, "sparse": 5, "sparse_x": 6}
 FUNC_IDS = {"grav": 0, "magn": 1}
-PAD_M = 256
-PAD_N = 128
+# kernel-instance tables and padding units: ONE definition (plan.py, which decides routes from them on the CPU); re-exported here
+from .plan import PAD_M, PAD_N, TOEPLITZ_NY, XZ2D_FOLD_N, XZ2D_SHAPES  # noqa: E402,F401
 
 
 def kernel_id(name, cross):
@@ -355,10 +355,21 @@ def gemm_nn(X, Y, C_, alpha=1.0, beta=0.0, x_lower=False, y_lower=False):
 
 def gemm_batched(y_is_kn, m, n, k, X, ldx, strideX, Y, ldy, strideY, C_, ldc, strideC, m_valid, n_valid, batch, alpha=1.0,
                  beta=0.0):
-    """Raw batched GEMM (see include/geobo_hip.h); X/Y/C are tensors whose data_ptr is the batch-0 origin."""
+    """Raw batched GEMM (see include/geobo_hip.h); X/Y/C are tensors whose data_ptr is the batch-0 origin.
+    m, n are COMPUTE extents (multiples of 128: the MFMA tiles run without edge predication on their loads; only the stores look at
+    m_valid / n_valid), so operand tiles may overhang the valid rows -- by contract into slack of the same allocation.  That contract
+    is checked here (round 5: a per-slot operand of the boundary-slab convolution overhung its tensor by 64 KB at nz = 16, which only
+    aborted once an unmapped page happened to follow it)."""
     lib = require_gpu()
     done = 0
     esz = 8
+    for T, lead, stride, rows, cols, what in ((X, ldx, strideX, m, k, "X"),
+                                              (Y, ldy, strideY, k if y_is_kn else n, n if y_is_kn else k, "Y")):
+        last = (batch - 1) * int(stride) + (int(rows) - 1) * int(lead) + int(cols)
+        room = T.untyped_storage().nbytes() // T.element_size() - T.storage_offset()
+        if last > room:
+            raise ValueError("geobo_gemm_batched: operand %s (%d x %d, ld %d, batch %d x stride %d) reads %d elements past its allocation"
+                             % (what, rows, cols, lead, batch, stride, last - room))
     while done < batch:                      # gridDim.y limit
         nb = min(batch - done, 65535)
         _lib.check(lib.geobo_gemm_batched(1 if y_is_kn else 0, int(m), int(n), int(k), float(alpha),
@@ -383,7 +394,7 @@ def scale_broadcast2(a, b0, b1, out0, out1):
                                           _p(out0), _p(out1), _stream()), "geobo_scale_broadcast2")
 
 
-XZ2D_SHAPES = ((48, 64), (64, 64), (64, 32))      # (nx, nz) the fused (x, z) transform kernel is instantiated for
+# XZ2D_SHAPES (plan.py): (nx, nz) the fused (x, z) transform kernel is instantiated for
 
 
 def xz2d(inverse, nx, nz, rows, ppr, src, in_row, in_plane, Mx, Mz, out, out_row, out_plane):
@@ -394,7 +405,7 @@ def xz2d(inverse, nx, nz, rows, ppr, src, in_row, in_plane, Mx, Mz, out, out_row
                               _p(_chk(out, "out")), int(out_row), int(out_plane), _stream()), "geobo_xz2d")
 
 
-XZ2D_FOLD_N = (64,)      # extents the radix-2 kernels are instantiated for (both axes equal)
+# XZ2D_FOLD_N (plan.py): extents the radix-2 kernels are instantiated for (both axes equal)
 
 
 def xz2d_fold(inverse, n, rows, ppr, src, in_row, in_plane, Fx, Fz, out, out_row, out_plane):
@@ -480,7 +491,7 @@ def a_sens_lattice_stencil(ws, nx, ny, nz):
     return ws[np_:np_ + (2 * ny - 3) * (2 * nx - 1) * nz].view(2 * ny - 3, 2 * nx - 1, nz)
 
 
-TOEPLITZ_NY = (16, 32, 48, 64, 80, 96, 112, 128)      # y extents geobo_toeplitz_y / _y3 are instantiated for
+# TOEPLITZ_NY (plan.py): y extents geobo_toeplitz_y / _y3 are instantiated for
 
 
 TOEPLITZ_ADD_NY = (80, 96, 112, 128)      # y extents of the accumulating form (geobo_toeplitz_y3_add)

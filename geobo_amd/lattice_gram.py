@@ -51,7 +51,7 @@ class LatticeGram:
         # D = Gx X for a whole batch (Py Px nz doubles per row: 67 MB at 128^3), ~2 GB per buffer
         per_row = self.Py * self.Px * self.nz * 8
         dflt = 256 if self.fast(self.nx, self.ny, self.nz) else max(8, min(256, (2 << 30) // per_row))
-        self.R = int(os.environ.get("GEOBO_GRAM_ROWS", str(dflt)))
+        self.R = dflt
         # rows per batch of the transposed application (W = Lambda * lhat is Px nz Py doubles per row: 8.4 MB at 64^3, 67 MB at 128^3)
         self.Rz = self.R if self.fast(self.nx, self.ny, self.nz) else max(8, min(256, (2 << 30) // per_row))
         self.J = (self.ny + 63) // 64 * 64                          # jy slots of the boundary-slab spectra (whole 64-row halves of a GEMM tile)
@@ -79,7 +79,7 @@ class LatticeGram:
         return self._edge_c
 
     def edge_supported(self):
-        return os.environ.get("GEOBO_GRAM_EDGE_SPECTRAL", "1") != "0"
+        return True
 
     def edge_eigen(self, E):
         """Spectrum of one boundary slab of an operator.  E: (>= ny*nx rows) x (nx*nz) view of the slab's columns, row (jy, jx),
@@ -227,14 +227,18 @@ class LatticeGram:
         (same transforms Kc, Ks of the slab's x-Toeplitz stencil as edge_eigen; the convolution theorem instead of the correlation's)."""
         nx, ny, nz, J = self.nx, self.ny, self.nz, self.J
         Kc_s, Ks_s, K64 = self._edge_spectra(E)                                      # [slot][jy][iz], [slot][jy][iz], [jy][iz]
-        # (one spare slot of zeros: the compute rows of the per-slot GEMM, pad128(2 nz), may overhang the last slot)
-        Vt = torch.zeros((nx + 1, 2, nz, 2, J), dtype=F64, device=self.device)       # [slot][C | S][iz][cos | sin][jy (J slots)]
+        # (spare slots of zeros behind the last one: the compute rows of the per-slot GEMM, pad128(2 nz), overhang it by pad128(2 nz) - 2 nz
+        #  rows -- THREE slots at nz = 16; with the one spare slot of rounds 3-4 the last slot's operand tile read 64 KB past the
+        #  allocation there: harmless values, never stored, but an unmapped page behind the tensor aborts the process -- found in round 5
+        #  when a larger Cholesky workspace moved the allocations of the 16^3 row-form tests)
+        spare = (hip.pad_n(2 * nz) - 2 * nz + 2 * nz - 1) // (2 * nz)
+        Vt = torch.zeros((nx + max(spare, 1), 2, nz, 2, J), dtype=F64, device=self.device)       # [slot][C | S][iz][cos | sin][jy (J slots)]
         Kc_t, Ks_t = Kc_s.transpose(1, 2), Ks_s.transpose(1, 2)                      # [slot][iz][jy]
         Vt[1:nx, 0, :, 0, :ny], Vt[1:nx, 0, :, 1, :ny] = Kc_t[1:], -Ks_t[1:]         # Outc = Lc Kc - Ls Ks
         Vt[1:nx, 1, :, 0, :ny], Vt[1:nx, 1, :, 1, :ny] = Ks_t[1:], Kc_t[1:]          # Outs = Lc Ks + Ls Kc
         Vt[0, 0, :, 0, :ny] = Kc_t[0]                                                # frequency 0
         Vt[0, 1, :, 1, :ny] = K64.t()                                                # frequency nx
-        return Vt.view(nx + 1, 2 * nz, 2 * J)
+        return Vt.view(-1, 2 * nz, 2 * J)
 
     def edge_apply_transpose(self, Lrows, nrows, Vt, out, zx=False):
         """out[r, (ix, iz)] = sum_(jy, jx) Lrows[r, jy*nx+jx] kappa_jy(ix - jx, iz)  for r < nrows: one boundary slab of L^-1 A.
@@ -267,14 +271,17 @@ class LatticeGram:
 
     @staticmethod
     def fast(nx, ny, nz):
-        """Grids whose x step and back-transform run on the fused kernels (geobo_xcorr_reduce(_fold), geobo_xz2d(_fold))."""
-        return nx == 64 and nz == 64 and ny in (48, 64)
+        """Grids whose x step and back-transform run on the fused kernels (geobo_xcorr_reduce(_fold), geobo_xz2d(_fold)): the planner's
+        table (plan.lattice_gram_fast) is the one definition."""
+        from .plan import lattice_gram_fast
+        return lattice_gram_fast(nx, ny, nz)
 
     @staticmethod
     def supported(nx, ny, nz):
         """Any grid of the spectral route (extents in multiples of 16): the stages without a fused instance for the extent run as
-        batched MFMA GEMMs + geobo_lamdot_z."""
-        return nx % 16 == 0 and ny % 16 == 0 and nz % 16 == 0 and ny >= 16
+        batched MFMA GEMMs + geobo_lamdot_z (plan.lattice_gram_supported)."""
+        from .plan import lattice_gram_supported
+        return lattice_gram_supported(nx, ny, nz)
 
     def eigen(self, Q, tol=1e-11):
         """Lambda^T[ky][z][kx] / (Py Px) from the stencil table Q[(2ny-3)][(2nx-1)][nz]; None if Q is not even in both offsets."""
@@ -322,7 +329,7 @@ class LatticeGram:
         for r0 in range(0, nrows, self.R):
             R = min(self.R, nrows - r0)
             y1b = sp.buf("LG_Y1", R * Py * plane)
-            if (Py, Ly) in hip.YMUL_SHAPES and plane % 64 == 0 and os.environ.get("GEOBO_GRAM_YMUL", "1") != "0":
+            if (Py, Ly) in hip.YMUL_SHAPES and plane % 64 == 0:
                 hip.ymul(Py, Ly, plane, R, gy, X[r0:], X.stride(0), y1b, Py * plane)      # G_y in registers, rows streamed once
             else:
                 hip.gemm_batched(True, hip.pad_n(Py), hip.pad_n(plane), Ly, gy, ny, 0, X[r0:], plane, X.stride(0), y1b, plane,

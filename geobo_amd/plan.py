@@ -56,6 +56,8 @@ class Route:
     operators: str          # "resident" | "streamed" | "auto" as requested, resolved to "streamed" where residency cannot fit
     kernels: tuple          # (("xz", ...), ("y", ...), ("gram", ...), ("ss", ...)): which implementation carries each stage
     note: str               # why a faster family stepped aside for this shape ("" when nothing did)
+    ak_bytes: int = 0       # what a materialised A K (column form / one-rank fused form) of this rank would take
+    rows_mandatory: bool = False   # ak_bytes > COLUMN_FORM_MAX_BYTES: only the row form fits; a denied row form is an error, not a fallback
 
     def describe(self):
         k = dict(self.kernels)
@@ -84,11 +86,13 @@ def plan_route(nx, ny, nz, world=1, rank=0, assembly="f64", operators="resident"
     N, Ms = nx * ny * nz, nx * ny
     N_pad, Ms_pad = _pad(N, PAD_N), _pad(Ms, PAD_M)
     plane = nx * nz
-    c0, c1 = shard_columns(N_pad, world, rank)
     f32, streamed = assembly == "f32", operators == "streamed"
     notes = []
-    spectral = (method in ("auto", "spectral") and nx % 16 == 0 and ny % 16 == 0 and nz % 16 == 0 and N == N_pad
-                and c0 % plane == 0 and c1 % plane == 0 and c1 > c0)
+    # slab alignment is decided over ALL ranks' shards (round-4 advisory: decided per rank, 16^3 on 3 / 5 / 6 / 7 ranks gave some ranks
+    # the spectral route and others the dense one -- same collectives, different arithmetic and bench lines per rank)
+    shards = [shard_columns(N_pad, world, r) for r in range(world)]
+    aligned = all(c0 % plane == 0 and c1 % plane == 0 and c1 > c0 for c0, c1 in shards)
+    spectral = (method in ("auto", "spectral") and nx % 16 == 0 and ny % 16 == 0 and nz % 16 == 0 and N == N_pad and aligned)
     fused_xz = (nx, nz) in XZ2D_SHAPES and on("GEOBO_SPECTRAL_FUSED_XZ")
     pair_xz = (nx, nz) == (32, 32) and (64, 32) in XZ2D_SHAPES and ny % 2 == 0 and on("GEOBO_SPECTRAL_FUSED_XZ")
     fold = on("GEOBO_XZ_FOLD") and nx == nz and nx in XZ2D_FOLD_N
@@ -136,5 +140,9 @@ def plan_route(nx, ny, nz, world=1, rank=0, assembly="f64", operators="resident"
                ("y", "toeplitz" if dense_y else "spectrum"),
                ("gram", ("fused" if gram_fast else "gemm") if (family in ("rows", "single") and gram_ok) else "per-step"),
                ("ss", ("fused" if fused_ss else "stored") if family in ("rows", "single") else "reduction"))
+    if column_ak_bytes > COLUMN_FORM_MAX_BYTES and family != "rows":
+        notes.append("a materialised A K of this grid takes %.0f GB per rank (limit %.0f): only the row form fits, and it is %s"
+                     % (column_ak_bytes / 1e9, COLUMN_FORM_MAX_BYTES / 1e9, "switched off (GEOBO_ROWS=0)" if rows_mode == "0" else "not available here"))
     return Route(spectral=spectral, family=family, rows=rows, single=single, exchange=exchange, exchange_without_rows=exchange_without_rows,
-                 operators=ops, kernels=kernels, note="; ".join(notes))
+                 operators=ops, kernels=kernels, note="; ".join(notes), ak_bytes=int(column_ak_bytes),
+                 rows_mandatory=bool(column_ak_bytes > COLUMN_FORM_MAX_BYTES))

@@ -24,7 +24,7 @@ import os
 import torch
 
 from . import hip
-from .sharding import EmulatedGroup, allreduce_sum_, gather_rows
+from .sharding import EmulatedGroup, agree, allreduce_sum_, gather_rows
 
 F64 = hip.F64
 ROW_SCRATCH_BYTES = 8 << 30       # per stage: the chunk's A K blocks (stage 1) / rows of Z (stage 3)
@@ -35,7 +35,7 @@ class RowFormMixin:
     def _rows_chunk(self, nblocks):
         """Rows per chunk: `nblocks` row blocks of N doubles each inside the scratch budget, whole transform batches."""
         sp = self._spectral
-        budget = int(os.environ.get("GEOBO_ROW_SCRATCH_GB", "0")) << 30 or ROW_SCRATCH_BYTES
+        budget = ROW_SCRATCH_BYTES
         ck = int(os.environ.get("GEOBO_ROW_CHUNK", "0")) or max(1, budget // (nblocks * self.N * 8))      # (GEOBO_ROW_CHUNK: tests)
         return max(sp.R, ck // sp.R * sp.R)
 
@@ -66,15 +66,9 @@ class RowFormMixin:
         return True
 
     def _rows_agree(self, flag):
-        """Every rank must take the same form (a rank-divergent decision would deadlock in the first collective): one 4-byte MIN."""
-        if self.world > 1 and not isinstance(self.group, EmulatedGroup) and torch.distributed.is_available() and torch.distributed.is_initialized():
-            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=self.device)
-            lo, hi = t.clone(), t.clone()
-            torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN, group=self.group)
-            torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX, group=self.group)
-            if int(lo.item()) != int(hi.item()):
-                raise RuntimeError("ranks disagree on the row form of this step (rank %d: %s): operators were built differently" % (self.rank, flag))
-        return flag
+        """Every rank must take the same form (a rank-divergent decision would deadlock in the first collective): `sharding.agree`,
+        one all-reduce and one read-back; the answer only changes when operators are (re)built, which is where this is called."""
+        return agree(flag, self.world, self.group, self.device, force=self.force_collectives)
 
     # ---- A K -> AkA ------------------------------------------------------------------------------------------------------------------
     def _rows_times_AT(self, X, nrows, sp_, out):
@@ -148,7 +142,7 @@ class RowFormMixin:
     def _assemble_AkA_rows(self, AkA, M_pad, sel_t, lengths, name, amp, gp_sigma, props):
         """AkA from row blocks: local correlation of this rank's sensor rows, one all-gather."""
         loc, drill = self._rows_aka_local(props, sel_t, lengths, self._W, name, amp)
-        allrows = self._timed("xgmi_all_gather", 0.0, lambda: gather_rows(loc, self.world, self.group))
+        allrows = self._timed("xgmi_all_gather", 0.0, lambda: gather_rows(loc, self.world, self.group, force=self.force_collectives))
         self._rows_aka_place(AkA, allrows, drill, sel_t)
         return self._finish_AkA(AkA, M_pad, sel_t, lengths, name, amp, gp_sigma)
 
@@ -216,5 +210,5 @@ class RowFormMixin:
                 for jj in range(P_c):
                     ssq[jj].add_(part[jj])
             self._timed("posterior_drill_rows", 0.0, drill_rows)
-        self._timed("xgmi_all_reduce", 0.0, lambda: allreduce_sum_(ssq, G, self.group))
+        self._timed("xgmi_all_reduce", 0.0, lambda: allreduce_sum_(ssq, G, self.group, force=self.force_collectives))
         return mu, amp * 1.0 - ssq

@@ -40,11 +40,36 @@ def shard_columns(n_pad, world, rank):
     return u0 * PAD_N, u1 * PAD_N
 
 
-def allreduce_sum_(t, world, group=None):
-    """In-place sum over ranks of the partial AkA."""
-    if world > 1 and not isinstance(group, EmulatedGroup):
+def _live(world, group, force):
+    """Does a collective go to the backend?  Not under an EmulatedGroup; with one rank only when `force` is set AND a process group
+    exists (bench.py --gpus 1 --check and the `-m gpu` RCCL test: the same calls a rank of N > 1 makes, issued through RCCL with one
+    rank, so that library load, fp64 support and stream semantics are exercised on a one-GPU box)."""
+    if isinstance(group, EmulatedGroup):
+        return False
+    if world > 1:
+        return True
+    return bool(force) and torch.distributed.is_available() and torch.distributed.is_initialized()
+
+
+def allreduce_sum_(t, world, group=None, force=False):
+    """In-place sum over ranks (partial AkA of the column form; partial sums of squares of the row form)."""
+    if _live(world, group, force):
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=group)
     return t
+
+
+def agree(flag, world, group=None, device=None, force=False):
+    """Every rank must take the same form of a step (a rank-divergent decision would deadlock in the first collective).  ONE
+    all-reduce (MIN over [flag, -flag] gives the minimum and minus the maximum) and one read-back; raises when ranks differ."""
+    if not _live(world, group, force):
+        return flag
+    v = 1 if flag else 0
+    t = torch.tensor([v, -v], dtype=torch.int32, device=device)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN, group=group)
+    lo, neg_hi = (int(x) for x in t.tolist())
+    if lo != -neg_hi:
+        raise RuntimeError("ranks disagree on the form of this step (this rank: %s): operators were built differently" % bool(flag))
+    return flag
 
 
 def gather_slices(t, nblocks, n_pad, world, group=None):
@@ -66,11 +91,11 @@ def gather_slices(t, nblocks, n_pad, world, group=None):
     return [o[:n] for o, n in zip(outs, sizes)]
 
 
-def gather_rows(local, world, group=None):
+def gather_rows(local, world, group=None, force=False):
     """All-gather of equal row blocks: `local` (any shape, contiguous) of every rank -> tensor (world, *local.shape).
     Used by the row-sharded lattice Gram: every rank correlates its own sensor rows of A K with the stencil table, so AkA
     arrives as row blocks (0.57 GB in total at 64^3) instead of as partial sums that need an all-reduce."""
-    if world == 1:
+    if world == 1 and not _live(world, group, force):
         return local.unsqueeze(0)
     import torch.distributed as dist
     local = local.contiguous()

@@ -111,7 +111,7 @@ class LatticeRows:
 class SpectralProduct:
     """AK rows by the real-DFT route for one grid; holds the transform matrices and the work buffers."""
 
-    def __init__(self, nx, ny, nz, device, rows_per_batch=None):
+    def __init__(self, nx, ny, nz, device, rows_per_batch=None, plane_pad=0):
         if nx % 16 or ny % 16 or nz % 16:
             raise ValueError("spectral path needs grid extents that are multiples of 16")
         self.nx, self.ny, self.nz = nx, ny, nz
@@ -151,15 +151,13 @@ class SpectralProduct:
         # 5.2 TB/s with 2 KiB of padding (tools/hbm_copy_runs.hip, profiles/r03_hbm_copy_runs.txt) -- but the kernels of this
         # pipeline do not move: toeplitz_y 1.514 / 1.506 ms, inverse transform 0.372 / 0.375 ms, forward 0.571 / 0.573 ms with / without
         # the padding (profiles/r03_spectral_plane_pad_ab.txt): they are held by the fp64 VALU / the matrix pipe at the clock a
-        # memory-bound launch runs at, not by channel aliasing.  The stride stays a parameter (GEOBO_SPECTRAL_PLANE_PAD, doubles);
-        # default dense.  Fused kernels only: they take explicit row / plane strides.
+        # memory-bound launch runs at, not by channel aliasing.  The stride stays a parameter (`plane_pad`, doubles; the A/B switch
+        # of round 3 is retired); default dense.  Fused kernels only: they take explicit row / plane strides.
         C = self.Px * self.Pz
-        pad = int(os.environ.get("GEOBO_SPECTRAL_PLANE_PAD", "0"))
+        pad = int(plane_pad)
         self.Cp = C + pad if (self.fused_xz and self.dense_y and C % 2048 == 0 and pad > 0) else C
         # operator rows fed straight from a lattice survey's stencil table (LatticeRows): needs the radix-2 forward kernel
         self.lattice_feed = self.fused_xz and self.fold and nx == nz and "x" in self.F and ny >= 3 and self.dense_y
-        if rows_per_batch is None and os.environ.get("GEOBO_SPECTRAL_ROWS"):
-            rows_per_batch = int(os.environ["GEOBO_SPECTRAL_ROWS"])
         if rows_per_batch is None:
             per_row = (ny * self.Cp if self.dense_y else self.P3) * 8
             # ~3 GB per work buffer; ny = 128 (67 MB of spectrum per row): 48 rows.  Measured on the 128^3 rank step with the round-4 y
@@ -410,7 +408,7 @@ class SpectralProduct:
         starts = list(range(0, min(m_first, Mg), R)) + list(range(m_first, Mg, R))
         if not self.fused_ss():
             N = self.N
-            add_y = self.dense_y and ny in hip.TOEPLITZ_ADD_NY and os.environ.get("GEOBO_Y_ADD", "1") != "0"
+            add_y = self.dense_y and ny in hip.TOEPLITZ_ADD_NY
             for r0 in starts:
                 two = r0 >= m_first
                 Rb = min(R, (Mg if two else min(m_first, Mg)) - r0)
@@ -447,7 +445,7 @@ class SpectralProduct:
             for j in range(0, P_c, 2):
                 js = list(range(j, min(j + 2, P_c)))
                 sg = [self.buf(("S", "S1")[i], Rb * ny * Cp) for i in range(len(js))]
-                if two and len(js) == 2 and ny in hip.TOEPLITZ_Y2T_NY and os.environ.get("GEOBO_Y2T", "1") != "0":
+                if two and len(js) == 2 and ny in hip.TOEPLITZ_Y2T_NY:
                     # both terms in ONE y-stage pass (geobo_toeplitz_y2t): one output spectrum per block, one input of the inverse
                     fn = lambda: hip.toeplitz_y2t(ny, C, Rb, t2g, t2m, [gens_g[jj] for jj in js], [gens_m[jj] for jj in js], sg, plane=Cp)
                     if self.kernel_timer is None:
@@ -459,7 +457,7 @@ class SpectralProduct:
                     continue
                 self._ystage(ny, C, Rb, t2g, [gens_g[jj] for jj in js], sg, 0, ny, Cp)
                 sm = None
-                if two and ny in hip.TOEPLITZ_ADD_NY and os.environ.get("GEOBO_Y_ADD", "1") != "0":
+                if two and ny in hip.TOEPLITZ_ADD_NY:
                     self._ystage(ny, C, Rb, t2m, [gens_m[jj] for jj in js], sg, 0, ny, Cp, accumulate=True)     # the terms meet in the spectrum
                 elif two:
                     sm = [self.buf(("Sb", "S1b")[i], Rb * ny * Cp) for i in range(len(js))]

@@ -254,3 +254,38 @@ def test_route_table():
     assert fam(64, 64, 64, world=2, env={"GEOBO_AKA_LATTICE": "0"}) == "columns"
     assert not plan_route(64, 64, 64, method="dense").spectral
     assert "spectral/rows" in plan_route(64, 64, 64, world=8).describe()
+
+
+def test_planner_and_kernel_wrappers_share_one_instance_table():
+    """Round-4 advisory: plan.py carried its own copies of the kernel-instance tables.  They are now defined once (plan.py) and
+    re-exported by hip.py / LatticeGram; this pins that."""
+    from geobo_amd import hip, plan
+    from geobo_amd.lattice_gram import LatticeGram
+    assert hip.XZ2D_SHAPES is plan.XZ2D_SHAPES and hip.XZ2D_FOLD_N is plan.XZ2D_FOLD_N and hip.TOEPLITZ_NY is plan.TOEPLITZ_NY
+    assert (hip.PAD_M, hip.PAD_N) == (plan.PAD_M, plan.PAD_N) == (256, 128)
+    for dims in ((64, 64, 64), (64, 48, 64), (64, 32, 64), (32, 32, 32), (48, 64, 64), (128, 128, 128), (20, 16, 16)):
+        assert LatticeGram.fast(*dims) == plan.lattice_gram_fast(*dims)
+        assert LatticeGram.supported(*dims) == plan.lattice_gram_supported(*dims)
+
+
+def test_every_rank_plans_the_same_route():
+    """Round-4 advisory: slab alignment used to be decided from the calling rank's own shard, so e.g. 16^3 on 3, 5, 6 or 7 ranks gave
+    some ranks the spectral route and others the dense one.  The decision is over all shards now: one route per (grid, world)."""
+    from geobo_amd.plan import plan_route
+    for n in range(16, 145, 16):
+        for dims in ((n, n, n), (n, 16, n), (16, n, 32)):
+            for world in range(1, 9):
+                routes = {plan_route(*dims, world=world, rank=r).describe() + str(plan_route(*dims, world=world, rank=r).spectral)
+                          for r in range(world)}
+                assert len(routes) == 1, (dims, world, routes)
+
+
+def test_mandatory_row_form_is_flagged():
+    """Round-4 advisory: where the column form's A K cannot fit (80 x 128 x 80: 272 GB) the planner says that only the row form
+    fits, so that the engine raises with the reason instead of running into the allocator when that form is denied or switched off."""
+    from geobo_amd.plan import plan_route
+    r = plan_route(80, 128, 80)
+    assert r.family == "rows" and r.rows_mandatory and r.ak_bytes > 160 << 30
+    off = plan_route(80, 128, 80, env={"GEOBO_ROWS": "0"})
+    assert off.family != "rows" and off.rows_mandatory and "only the row form fits" in off.note
+    assert not plan_route(64, 64, 64).rows_mandatory and not plan_route(128, 128, 128, world=8, assembly="f32").rows_mandatory

@@ -30,6 +30,33 @@ def _run_ranks(n, backend, out, size="32", extra=(), env_extra=None):
     return dict(np.load(out))
 
 
+def test_rccl_with_one_rank(tmp_path):
+    """RCCL itself, on the one device every box has ("RCCL path exercised with world size 1"): backend "nccl" with one
+    rank, every collective of the multi-GPU forms through `geobo_amd.sharding` on device tensors -- all_gather_into_tensor of fp64 row
+    blocks, all_reduce SUM of P_c N doubles, the ranks' agreement (MIN), all_to_all_single -- and a whole row-form step whose
+    collectives go through the backend, against the same step without.  Library load, fp64 support, stream ordering between the
+    engine's kernels and the communicator, HSA_ENABLE_IPC_MODE_LEGACY=0: all exercised here instead of first on an 8-GPU node."""
+    import json
+    _release_device_memory()
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = str(tmp_path / "rccl1.json")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "_rccl_one_worker.py"), out]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    res = json.load(open(out))
+    print(res)
+    assert res["backend"] == "nccl" and res["world"] == 1 and res["ranks_reported_by_backend"] == 1
+    assert res["all_gather_into_tensor_equal"] and res["all_reduce_sum_equal"] and res["all_reduce_matrix_equal"]
+    assert res["all_to_all_single_equal"] and res["agree"] == [True, False]
+    assert res["collectives_timed_forced"] == ["xgmi_all_gather", "xgmi_all_reduce"]
+    assert res["row_form_step_bit_identical"], res["row_form_step_max_abs_diff"]
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_nccl_ranks_match_single_rank(world, tmp_path):
     if torch.cuda.device_count() < world:

@@ -29,6 +29,45 @@ __global__ void runk(const T* in, T* out, long CS, long C, int NY, long R) {   /
   if (MODE == 1) out[c0 + (long)blockIdx.y * CS] = acc;
 }
 
+// Round 5: the access pattern a per-mode MFMA y stage would need -- a workgroup owns MC consecutive modes
+// (MC * 8 bytes: 64- or 128-byte segments), all NY planes, a share of the rows; 16-byte lanes, MC / 2 lanes per segment, a 256-thread
+// workgroup covers 512 / MC (row, y) segments per pass.  MODE 0 copy, 1 read only, 4 read once + write twice (two property blocks).
+template <int MC, int MODE>
+__global__ void __launch_bounds__(256) segk(const v2d* in, v2d* out, v2d* out2, long CS2, int NY, long R) {   // CS2 = plane stride in v2d
+  constexpr int LPS = MC / 2, SPP = 256 / LPS;                 // lanes per segment, segments per pass
+  const int l = threadIdx.x % LPS, slot = threadIdx.x / LPS;
+  const long c = (long)blockIdx.x * LPS + l;
+  v2d acc = {0., 0.};
+  for (long r = blockIdx.y; r < R; r += gridDim.y)
+    for (int y0 = 0; y0 < NY; y0 += SPP) {
+      const int y = y0 + slot;
+      if (y >= NY) continue;
+      const long o = (r * NY + y) * CS2 + c;
+      const v2d v = in[o];
+      if (MODE == 0 || MODE == 4) out[o] = v * 1.0000001;
+      if (MODE == 4) out2[o] = v * 0.9999999;
+      if (MODE == 1) acc += v;
+    }
+  if (MODE == 1) out[(long)blockIdx.y * CS2 + c] = acc;
+}
+
+template <int MC, int MODE>
+static void runseg(const char* what, double* a, double* b, double* b2, long Cd, long padd, int NY, long R, int gy) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  float best = 1e30f;
+  for (int rep = 0; rep < 3; ++rep) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((segk<MC, MODE>), dim3((unsigned)(Cd / MC), gy), dim3(256), 0, 0, (const v2d*)a, (v2d*)b, (v2d*)b2, (Cd + padd) / 2, NY, R);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best) best = ms;
+  }
+  const double bytes = (MODE == 0 ? 2.0 : MODE == 4 ? 3.0 : 1.0) * (double)R * NY * Cd * 8;
+  printf("%-12s %3d-byte segments (%2d modes per workgroup)  plane stride %6ld+%-4ld doubles  gridy %3d : %7.3f ms  %5.2f TB/s\n", what, MC * 8, MC, Cd,
+         padd, gy, best, bytes / best / 1e9);
+  hipEventDestroy(e0); hipEventDestroy(e1);
+}
+
 template <class T>
 __global__ void lineark(const T* in, T* out, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = in[i] * 1.0000001;
@@ -73,6 +112,23 @@ int main(int argc, char** argv) {
       }
       printf("contiguous copy, lane %2d B: %7.3f ms  %5.2f TB/s (read + write)\n", w ? 16 : 8, best, 2.0 * nn * 8 / best / 1e9);
     }
+  }
+  {   // round 5: per-mode-group segments (the MFMA y stage's pattern); second output buffer for the two-block form
+    double* b2; hipMalloc(&b2, n * 8); hipMemset(b2, 0, n * 8);
+    printf("---- segments of MC modes per workgroup, 16-byte lanes ----\n");
+    for (int gy = 8; gy <= 32; gy *= 2) {
+      runseg<16, 0>("seg copy", a, b, b2, C, 0, NY, R, gy);
+      runseg<8, 0>("seg copy", a, b, b2, C, 0, NY, R, gy);
+    }
+    runseg<32, 0>("seg copy", a, b, b2, C, 0, NY, R, 16);
+    runseg<16, 0>("seg copy", a, b, b2, C, 256, NY, R, 16);
+    runseg<8, 0>("seg copy", a, b, b2, C, 256, NY, R, 16);
+    runseg<16, 1>("seg read", a, b, b2, C, 0, NY, R, 16);
+    runseg<8, 1>("seg read", a, b, b2, C, 0, NY, R, 16);
+    runseg<16, 4>("seg 1r + 2w", a, b, b2, C, 0, NY, R, 16);
+    runseg<8, 4>("seg 1r + 2w", a, b, b2, C, 0, NY, R, 16);
+    runseg<16, 4>("seg 1r + 2w", a, b, b2, C, 256, NY, R, 16);
+    hipFree(b2);
   }
   const long pads[3] = {0, 32, 256};
   for (int pi = 0; pi < 3; ++pi) {

@@ -13,6 +13,12 @@ GROUPS = [["GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_VALU_MFMA_BUSY_CYCLES"],
           ["SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAIT_INST_ANY"],
           ["FETCH_SIZE"], ["WRITE_SIZE"],     # FETCH_SIZE costs 3 of the 4 TCC slots: one pass each
           ["TCC_HIT_sum", "TCC_MISS_sum"]]
+# second argument "valu" (round 5): issue-side counters of the VALU-bound stream kernels -- where do the SIMD
+# cycles that are not FMA issue go?  (SQ_INST_CYCLES_VALU does not exist on gfx9; SQ_ACTIVE_INST_* count in quad-cycles per SIMD.)
+VALU_GROUPS = [["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU_FMA_F64", "SQ_THREAD_CYCLES_VALU"],
+               ["SQ_WAIT_INST_LDS", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_ANY"],
+               ["SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VMEM", "SQ_INSTS_SALU"],
+               ["SQ_WAVES", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_ACTIVE_INST_SCA"]]
 DRIVERS = {"posterior": ("run_posterior_once.py", "gemm_f64_kernel<4, 2, 2, 1", "pmc_posterior_reduce.json"),
            "fused": ("run_fused_once.py", "gemm_f64_kernel<4, 2, 3", "pmc_ak_fused_grid.json"),
            "xz2d_fwd": ("run_spectral_kernels_once.py xz2d_fwd", "xz2d_kernel<64, 64, 128, 128>", "pmc_xz2d_fwd.json"),
@@ -27,6 +33,7 @@ DRIVERS = {"posterior": ("run_posterior_once.py", "gemm_f64_kernel<4, 2, 2, 1", 
            "xz2d32_bwd": ("run_spectral_kernels_once.py xz2d32_bwd", "xz2d_kernel<128, 64, 64, 32>", "pmc_xz2d32_bwd.json"),
            "ymul": ("run_spectral_kernels_once.py ymul", "ymul_kernel", "pmc_ymul.json"),
            "ymul_gemm": ("run_spectral_kernels_once.py ymul_gemm", "gemm_f64_kernel<2, 2, 2, 0", "pmc_ymul_as_gemm_batched.json"),
+           "potrf_dag": ("run_potrf_once.py 8448 noctx", "potrf_dag_kernel", "pmc_potrf_dag.json"),
            "rank_update": ("run_rank_update_once.py", "gemm_f64_kernel<4, 2, 1, 0", "pmc_rank_update_k128.json"),
            "kblock_exp": ("run_k_block_once.py exp f64", "k_block_kernel", "pmc_k_block_exp_f64.json"),
            "kblock_matern": ("run_k_block_once.py matern32 f64", "k_block_kernel", "pmc_k_block_matern32_f64.json"),
@@ -45,7 +52,10 @@ def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "posterior"
     script, kmatch, outname = DRIVERS[which]
     counters, text = {}, ""
-    for grp in GROUPS:
+    valu = len(sys.argv) > 2 and sys.argv[2] == "valu"
+    if valu:
+        outname = outname.replace(".json", "_valu.json")
+    for grp in (GROUPS[:1] + VALU_GROUPS if valu else GROUPS):
         d = tempfile.mkdtemp(prefix="pmc_", dir="/tmp")
         sc = script.split()
         cmd = ["rocprofv3", "--pmc", *grp, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.join(HERE, sc[0]), *sc[1:]]
@@ -70,6 +80,19 @@ def main():
         d["clock_GHz_during_profiled_pass"] = counters["GRBM_GUI_ACTIVE"] / 8.0 / secs / 1e9
         if "SQ_VALU_MFMA_BUSY_CYCLES" in counters:
             d["mfma_busy_frac_of_simd_cycles"] = counters["SQ_VALU_MFMA_BUSY_CYCLES"] / (counters["GRBM_GUI_ACTIVE"] / 8.0 * 1024)
+    if valu and "GRBM_GUI_ACTIVE" in counters:
+        simd_cycles = counters["GRBM_GUI_ACTIVE"] / 8.0 * 1024          # 8 XCDs report GUI_ACTIVE; 256 CUs x 4 SIMDs
+        for k in ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_ANY"):
+            if k in counters:
+                d[k.lower() + "_x4_over_simd_cycles"] = 4.0 * counters[k] / simd_cycles
+        if counters.get("SQ_INSTS_VALU"):
+            d["fma_f64_share_of_valu_instructions"] = counters.get("SQ_INSTS_VALU_FMA_F64", 0.0) / counters["SQ_INSTS_VALU"]
+            d["valu_instructions_per_simd_cycle"] = counters["SQ_INSTS_VALU"] / simd_cycles
+            d["fma_f64_issue_cycles_over_simd_cycles"] = 4.0 * counters.get("SQ_INSTS_VALU_FMA_F64", 0.0) / simd_cycles   # a wave64 fp64 FMA occupies its SIMD for 4 cycles... x2 on a half-rate pipe
+        if counters.get("SQ_WAVES") and counters.get("SQ_WAIT_INST_LDS") is not None:
+            d["wait_inst_lds_cycles_per_wave_x4"] = 4.0 * counters["SQ_WAIT_INST_LDS"] / counters["SQ_WAVES"]
+        if counters.get("SQ_WAIT_ANY") is not None and counters.get("SQ_WAVES"):
+            d["wait_any_cycles_per_wave_x4"] = 4.0 * counters["SQ_WAIT_ANY"] / counters["SQ_WAVES"]
     if counters.get("SQ_LDS_IDX_ACTIVE"):
         d["lds_bank_conflict_frac"] = counters.get("SQ_LDS_BANK_CONFLICT", 0.0) / counters["SQ_LDS_IDX_ACTIVE"]
     if "FETCH_SIZE" in counters:

@@ -25,4 +25,7 @@ for mode in modes:
         e0.record(); hip.potrf_inv(L, Linv, ws, ctx=ctx); e1.record()
         t_host = time.perf_counter() - t0
         torch.cuda.synchronize()
-        print("potrf_inv m=%d %-5s: %.2f ms on the stream, %.2f ms of host enqueue time" % (m, mode, e0.elapsed_time(e1), 1e3 * t_host))
+        ms = e0.elapsed_time(e1)
+        print("potrf_inv m=%d %-5s: %.2f ms on the stream, %.2f ms of host enqueue time" % (m, mode, ms, 1e3 * t_host))
+    # (last line in the form tools/pmc_collect.py parses: seconds, rate, executed flop = m^3/3 for L + m^3/3 for L^-1)
+    print("potrf_inv m=%d %s: %.6f s, %.2f TF/s flop %d" % (m, mode, ms * 1e-3, 2.0 * m ** 3 / 3.0 / (ms * 1e-3) / 1e12, int(2.0 * m ** 3 / 3.0)))

@@ -167,6 +167,32 @@ def soak(seed=0, seconds=None, iters=60, verbose=True):
             e = (ow[j] - ref).abs().max().item() / ref.abs().max().item()
             if not e < 1e-13:
                 bad += 1; print("toeplitz windowed ny=%d R=%d C=%d blocks=%d slab [%d, %d) err %.3e" % (nyw, Rw, Cw, npw, ya, yb, e), flush=True)
+        # ---- round 5: the persistent tile-DAG factorisation (geobo_potrf_inv from m = 1024): inter-workgroup hand-offs through
+        #      agent-scope counters.  Random block counts, the result buffers poisoned with NaN (a tile or a zero that is read before
+        #      its producer's write-through stores have landed shows up as NaN), every other iteration under uneven load: a long
+        #      GEMM on a second stream takes CUs away while the tasks are drawn ------------------------------------------------------
+        nbd = int(rng.integers(8, 25))
+        md = 128 * nbd
+        Bd = rnd(md, 256)
+        Sd = Bd @ Bd.t() / 256 + 0.3 * torch.eye(md, dtype=torch.float64, device="cuda")
+        Lref = torch.linalg.cholesky(Sd)
+        Ld = Sd.clone()
+        Xd = torch.full((md, md), float("nan"), dtype=torch.float64, device="cuda")
+        if it % 2:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                big = rnd(4096, 4096)
+                for _ in range(3):
+                    big = (big @ big) * 1e-3
+        _, info = hip.potrf_inv(Ld, Xd)
+        if it % 2:
+            torch.cuda.current_stream().wait_stream(side)
+        eL = (torch.tril(Ld) - Lref).abs().max().item()
+        eX = (Xd @ Lref - torch.eye(md, dtype=torch.float64, device="cuda")).abs().max().item()
+        up = torch.triu(Xd, 1).abs().max().item()
+        if not (int(info.item()) == 0 and eL < 1e-12 and eX < 1e-10 and up == 0.0):
+            bad += 1; print("potrf_inv (tile DAG) nb=%d loaded=%d info=%d errs %.3e %.3e upper %.1e" % (nbd, it % 2, int(info.item()), eL, eX, up), flush=True)
     if verbose:
         print("soak: %d iterations, %d mismatches" % (it, bad))
     return it, bad
