@@ -353,6 +353,42 @@ def gemm_nn(X, Y, C_, alpha=1.0, beta=0.0, x_lower=False, y_lower=False):
     return C_
 
 
+def _check_extents(fn, ops, batch):
+    """Operand tiles may overhang the valid rows -- by contract into slack of the same allocation: checked before the launch."""
+    for T, lead, stride, rows, cols, what in ops:
+        last = (batch - 1) * int(stride) + (int(rows) - 1) * int(lead) + int(cols)
+        room = T.untyped_storage().nbytes() // T.element_size() - T.storage_offset()
+        if last > room:
+            raise ValueError("%s: operand %s (%d x %d, ld %d, batch %d x stride %d) reads %d elements past its allocation"
+                             % (fn, what, rows, cols, lead, batch, stride, last - room))
+
+
+def axis_pass(fold, y_is_kn, inverse, *args):
+    """One batched axis pass of the spectral route against the basis G (analysis) or G^T (synthesis): the radix-2 kernel when `fold`
+    (the matrix operand has the pair structure and the strides allow it), else the plain batched GEMM on the same operands."""
+    even = (4, 5, 7, 8) + ((10, 11) if not (y_is_kn or inverse) else ())     # operand strides; pair stores of the contiguous analysis
+    if fold and all(int(args[i]) % 2 == 0 for i in even):
+        return gemm_fold(y_is_kn, inverse, *args)
+    return gemm_batched(y_is_kn, *args)
+
+
+def gemm_fold(y_is_kn, inverse, m, n, k, X, ldx, strideX, Y, ldy, strideY, C_, ldc, strideC, m_valid, n_valid, batch):
+    """Radix-2 form of a gemm_batched axis pass against the pair-interleaved basis G / G^T (geobo_gemm_fold): same arguments as the
+    gemm_batched call it replaces (alpha = 1, beta = 0), half the multiply-adds."""
+    lib = require_gpu()
+    _check_extents("geobo_gemm_fold", ((X, ldx, strideX, m, k, "X"), (Y, ldy, strideY, k if y_is_kn else n, n if y_is_kn else k, "Y")), batch)
+    done = 0
+    while done < batch:
+        nb = min(batch - done, 65535)
+        _lib.check(lib.geobo_gemm_fold(1 if y_is_kn else 0, 1 if inverse else 0, int(m), int(n), int(k),
+                                       C.c_void_p(X.data_ptr() + done * strideX * 8), int(ldx), int(strideX),
+                                       C.c_void_p(Y.data_ptr() + done * strideY * 8), int(ldy), int(strideY),
+                                       C.c_void_p(C_.data_ptr() + done * strideC * 8), int(ldc), int(strideC), int(m_valid), int(n_valid),
+                                       int(nb), _stream()), "geobo_gemm_fold")
+        done += nb
+    return C_
+
+
 def gemm_batched(y_is_kn, m, n, k, X, ldx, strideX, Y, ldy, strideY, C_, ldc, strideC, m_valid, n_valid, batch, alpha=1.0,
                  beta=0.0):
     """Raw batched GEMM (see include/geobo_hip.h); X/Y/C are tensors whose data_ptr is the batch-0 origin.

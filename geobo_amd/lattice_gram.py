@@ -169,8 +169,8 @@ class LatticeGram:
                 Lc.copy_(src[:Rb, :ny * nx])
                 src = Lc
             t1 = sp.buf("LG_Lt", Rb * ny * Px + nyp * Px)                             # [row][jy][kx]
-            hip.gemm_batched(False, nyp, hip.pad_n(Px), nx, src, nx, src.stride(0), sp.G["x"], nx, 0, t1, Px, ny * Px, ny, Px, Rb)
-            hip.gemm_batched(True, hip.pad_n(Py), hip.pad_n(Px), ny, sp.G["y"], ny, 0, t1, Px, ny * Px, lh, Px, Py * Px, Py, Px, Rb)
+            hip.axis_pass(sp.fold, False, False, nyp, hip.pad_n(Px), nx, src, nx, src.stride(0), sp.G["x"], nx, 0, t1, Px, ny * Px, ny, Px, Rb)
+            hip.axis_pass(sp.fold, True, False, hip.pad_n(Py), hip.pad_n(Px), ny, sp.G["y"], ny, 0, t1, Px, ny * Px, lh, Px, Py * Px, Py, Px, Rb)
 
     def apply_transpose(self, Lrows, nrows, lamW, out):
         """out[r, :ny*nx*nz] = interior-slab part of  sum_c Lrows[r, c] A[c, :]  (boundary slabs zero), r < nrows.
@@ -190,7 +190,7 @@ class LatticeGram:
             W = sp.buf("LG_W", R * Px * nz * Py)
             hip.lattice_wbuild(Rb, Py, Px, nz, lamW, lh, W)
             U = sp.buf("LG_U", R * nx * nz * Py)
-            hip.gemm_batched(True, hip.pad_n(nx), nz * Py, Px, sp.GT["x"], Px, 0, W, nz * Py, Px * nz * Py, U, nz * Py, nx * nz * Py, nx, nz * Py, Rb)
+            hip.axis_pass(sp.fold, True, True, hip.pad_n(nx), nz * Py, Px, sp.GT["x"], Px, 0, W, nz * Py, Px * nz * Py, U, nz * Py, nx * nz * Py, nx, nz * Py, Rb)
             hip.gemm_batched(False, hip.pad_n(ny), nx * nz, Py, self._GyT0, Py, 0, U, Py, nx * nz * Py, out[r0:], nx * nz, out.stride(0), ny, nx * nz, Rb)
 
     def transpose_tables3(self, lam):
@@ -332,8 +332,9 @@ class LatticeGram:
             if (Py, Ly) in hip.YMUL_SHAPES and plane % 64 == 0:
                 hip.ymul(Py, Ly, plane, R, gy, X[r0:], X.stride(0), y1b, Py * plane)      # G_y in registers, rows streamed once
             else:
-                hip.gemm_batched(True, hip.pad_n(Py), hip.pad_n(plane), Ly, gy, ny, 0, X[r0:], plane, X.stride(0), y1b, plane,
-                                 Py * plane, Py, plane, R)
+                # (radix-2 when the slab starts on an even y: the parity of the local input index is the basis row pair's)
+                hip.axis_pass(sp.fold and y0 % 2 == 0, True, False, hip.pad_n(Py), hip.pad_n(plane), Ly, gy, ny, 0, X[r0:], plane, X.stride(0),
+                              y1b, plane, Py * plane, Py, plane, R)
             s = sp.buf("LG_S", R * Py * Px)
             if sp.fold and nx == nz and "x" in sp.F:
                 hip.xcorr_reduce_fold(nx, R, Py, y1b, Py * plane, plane, sp.F["x"], lam, s, Py * Px, Px)
@@ -342,7 +343,7 @@ class LatticeGram:
             else:
                 # any other extent: D[r, ky] = Gx X[r, ky] as a batch of small GEMMs, then the eigenvalue scaling and the channel sum
                 D = sp.buf("LG_D", R * Py * Px * nz)
-                hip.gemm_batched(True, hip.pad_n(Px), hip.pad_n(nz), nx, sp.G["x"], nx, 0, y1b, nz, plane, D, nz, Px * nz, Px, nz, R * Py)
+                hip.axis_pass(sp.fold, True, False, hip.pad_n(Px), hip.pad_n(nz), nx, sp.G["x"], nx, 0, y1b, nz, plane, D, nz, Px * nz, Px, nz, R * Py)
                 hip.lamdot_z(R * Py, Py, Px, nz, D, self.lam_oz(lam), s)
             # "x" of geobo_xz2d is this grid's y axis, its "z" this grid's x axis: S_r (Py x Px) -> Gy^T S_r Gx (ny x nx)
             if sp.fold and ny == nx and "y" in sp.F:
@@ -351,7 +352,7 @@ class LatticeGram:
                 hip.xz2d(True, ny, nx, R, 1, s, Py * Px, Py * Px, sp.GT["y"], sp.GT["x"], out[r0:], out.stride(0), ny * nx)
             else:
                 t1 = sp.buf("LG_Bt", R * ny * Px + hip.pad_n(ny) * Px)             # [row][iy][kx]
-                hip.gemm_batched(True, hip.pad_n(ny), hip.pad_n(Px), Py, sp.GT["y"], Py, 0, s, Px, Py * Px, t1, Px, ny * Px, ny, Px, R)
+                hip.axis_pass(sp.fold, True, True, hip.pad_n(ny), hip.pad_n(Px), Py, sp.GT["y"], Py, 0, s, Px, Py * Px, t1, Px, ny * Px, ny, Px, R)
                 hip.gemm_batched(True, hip.pad_n(ny), hip.pad_n(nx), Px, t1, Px, ny * Px, sp.G["x"], nx, 0, out[r0:], nx, out.stride(0), ny, nx, R)
 
     def lam_oz(self, lam):

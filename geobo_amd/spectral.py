@@ -225,10 +225,12 @@ class SpectralProduct:
             hip.xz2d(False, 2 * nx, nz, R, ny // 2, src, lds, 2 * nx * nz, self._paired(M["x"], Px, nx), M["z"], t2, ny * Px * Pz,
                      2 * Px * Pz)
             return t2
+        # any other extent: two batched passes, radix-2 (geobo_gemm_fold: half the multiply-adds) against the pair-interleaved basis
+        fold = self.fold and M is self.G
         t1 = self.buf("T1", rows * Pz)
-        hip.gemm_batched(False, hip.pad_n(ny * nx), hip.pad_n(Pz), nz, src, nz, lds, M["z"], nz, 0, t1, Pz, ny * nx * Pz, ny * nx, Pz, R)
+        hip.axis_pass(fold, False, False, hip.pad_n(ny * nx), hip.pad_n(Pz), nz, src, nz, lds, M["z"], nz, 0, t1, Pz, ny * nx * Pz, ny * nx, Pz, R)
         t2 = self.buf(out_name, R * ny * Px * Pz)
-        hip.gemm_batched(True, hip.pad_n(Px), hip.pad_n(Pz), nx, M["x"], nx, 0, t1, Pz, nx * Pz, t2, Pz, Px * Pz, Px, Pz, R * ny)
+        hip.axis_pass(fold, True, False, hip.pad_n(Px), hip.pad_n(Pz), nx, M["x"], nx, 0, t1, Pz, nx * Pz, t2, Pz, Px * Pz, Px, Pz, R * ny)
         return t2
 
     def forward(self, src, R, M, out_name="T3", src_row_stride=None):
@@ -275,12 +277,12 @@ class SpectralProduct:
                          self._paired(self.GT["x"], nx, Px), self.GT["z"], out, ldo, 2 * nx * nz)
             return
         u1 = self.buf("U1", R * Ly * nx * Pz)
-        hip.gemm_batched(True, hip.pad_n(nx), hip.pad_n(Pz), Px, self.GT["x"], Px, 0, u2, Pz, Px * Pz, u1, Pz, nx * Pz, nx, Pz,
-                         R * Ly)
+        hip.axis_pass(self.fold, True, True, hip.pad_n(nx), hip.pad_n(Pz), Px, self.GT["x"], Px, 0, u2, Pz, Px * Pz, u1, Pz, nx * Pz, nx, Pz,
+                      R * Ly)
         for ya, yb, out, ldo in targets:
             slab = yb - ya
-            hip.gemm_batched(False, hip.pad_n(slab * nx), hip.pad_n(nz), Pz, u1[(ya - ylo) * nx * Pz:], Pz, Ly * nx * Pz,
-                             self.GT["z"], Pz, 0, out, nz, ldo, slab * nx, nz, R)
+            hip.axis_pass(self.fold, False, True, hip.pad_n(slab * nx), hip.pad_n(nz), Pz, u1[(ya - ylo) * nx * Pz:], Pz, Ly * nx * Pz,
+                          self.GT["z"], Pz, 0, out, nz, ldo, slab * nx, nz, R)
 
     def flops(self, rows, nblocks, slab):
         """Executed flop of product(): forward passes once, the rest per property block (compute extents)."""
@@ -288,6 +290,8 @@ class SpectralProduct:
         pn = hip.pad_n
         fwd = 2.0 * (ny * nx * pn(Pz) * nz + ny * pn(Px) * pn(Pz) * nx)
         bwd = 2.0 * (slab * pn(nx) * pn(Pz) * Px + pn(slab * nx) * pn(nz) * Pz)
+        if self.fold and not (self.fused_xz or self.quad_xz or self.pair_xz):
+            fwd, bwd = 0.5 * fwd, 0.5 * bwd         # radix-2 batched passes (geobo_gemm_fold)
         if self.quad_xz:                            # four planes per 64-point radix-2 plane: folded, both axes over the zero blocks
             fwd = 0.25 * ny * (64.0 * 64 * 128 + 128.0 * 64 * 128)
             bwd = 0.25 * slab * (128.0 * 128 * 64 + 64.0 * 128 * 64)

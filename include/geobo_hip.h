@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GEOBO_VERSION 206 /* 201: flag word of geobo_gemm_nt, (64, 32) instance of geobo_xz2d, workspace layout of geobo_potrf_inv; 202: geobo_ymul, geobo_xz2d_fold_lattice; 203: geobo_sumsq_accum, geobo_lamdot_z, geobo_toeplitz_y2t, geobo_xz2d_fold_quad; 204: geobo_toeplitz_y3_add; 205: workspace layout of geobo_potrf_inv (one T buffer per tree node); 206: geobo_potrf_inv as one persistent tile-DAG launch from m = 1024 (workspace: + counters) */
+#define GEOBO_VERSION 207 /* 201: flag word of geobo_gemm_nt, (64, 32) instance of geobo_xz2d, workspace layout of geobo_potrf_inv; 202: geobo_ymul, geobo_xz2d_fold_lattice; 203: geobo_sumsq_accum, geobo_lamdot_z, geobo_toeplitz_y2t, geobo_xz2d_fold_quad; 204: geobo_toeplitz_y3_add; 205: workspace layout of geobo_potrf_inv (one T buffer per tree node); 206: geobo_potrf_inv as one persistent tile-DAG launch from m = 1024 (workspace: + counters); 207: geobo_gemm_fold */
 
 #define GEOBO_PAD_M 256 /* row padding of M-like dimensions (observation rows)            */
 #define GEOBO_PAD_N 128 /* padding of voxel-like dimensions (columns / contraction index) */
@@ -215,6 +215,21 @@ int geobo_gemm_nn(int64_t m, int64_t n, int64_t k, double alpha, const double* X
 int geobo_gemm_batched(int y_is_kn, int64_t m, int64_t n, int64_t k, double alpha, const double* X, int64_t ldx,
                        int64_t strideX, const double* Y, int64_t ldy, int64_t strideY, double beta, double* C, int64_t ldc,
                        int64_t strideC, int64_t m_valid, int64_t n_valid, int batch, void* stream);
+
+/* Radix-2 ("folded") form of a geobo_gemm_batched axis pass whose matrix operand is the pair-interleaved real eigenvector basis G
+ * (P x n, P = 2n; row 2b+1 = (-1)^i row 2b: geobo_amd/spectral.py forward_matrix) or its transpose -- the (x, z) transforms of the
+ * covariance products A_s K_sj and (L^-1 A) K (kernels.py:158-195, inversion.py:96,114-117) and of the lattice Gram / lattice
+ * convolution on every grid extent that has no fused two-axis kernel (geobo_xz2d_fold: 64 x 64 planes only).  SAME operands, strides
+ * and extents as the geobo_gemm_batched call it replaces (alpha = 1, beta = 0), half the multiply-adds:
+ *     inverse = 0 (analysis, k = n inputs -> P outputs):  out[2b], out[2b+1] = E_b +- O_b, E / O = even- / odd-input sums against row 2b
+ *     inverse = 1 (synthesis, k = P -> n outputs):        out[i] = sum_b G[2b][i] (s[2b] + (-1)^i s[2b+1])
+ *     y_is_kn = 0: the data is X (m x k, k-contiguous), the matrix is Y (n x k): G for the analysis, G^T for the synthesis;
+ *     y_is_kn = 1: the data is Y (k x n, n-contiguous), the matrix is X (m x k).
+ * m, n: compute extents (multiples of 128; operands readable over them, as for geobo_gemm_batched), k % 16 == 0, batch <= 65535.
+ * Agrees with the plain product up to summation order.  GEOBO_E_ALIGN for odd strides / an odd valid extent along the pair axis. */
+int geobo_gemm_fold(int y_is_kn, int inverse, int64_t m, int64_t n, int64_t k, const double* X, int64_t ldx, int64_t strideX,
+                    const double* Y, int64_t ldy, int64_t strideY, double* C, int64_t ldc, int64_t strideC, int64_t m_valid,
+                    int64_t n_valid, int64_t batch, void* stream);
 
 /* out[i] = a[i] * b[i % nb]   (spectrum x eigenvalue table, broadcast over the batch) */
 int geobo_scale_broadcast(const double* a, const double* b, int64_t n, int64_t nb, double* out, void* stream);

@@ -299,6 +299,62 @@ def test_xz2d_fold_matches_the_plain_transform(hip, rows, ppr):
     assert (out.reshape(2, 3, P, P) - ref).abs().max().item() <= 1e-13 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("n", [16, 32, 48, 80, 96, 128, 144])
+def test_gemm_fold_matches_the_plain_passes(hip, n):
+    """geobo_gemm_fold (radix-2 axis passes for every extent without a fused kernel) against geobo_gemm_batched on the SAME operands
+    -- the four forms spectral.py uses: analysis / synthesis along the contiguous axis (data on the X side) and along a strided axis
+    (data on the Y side, batched) -- and against torch; ragged row / column counts, padded compute extents, slack behind the buffers."""
+    from geobo_amd.spectral import _pad_rows, forward_matrix
+    P = 2 * n
+    Gh = forward_matrix(n)
+    G, GT = hip.to_dev(_pad_rows(Gh)), hip.to_dev(_pad_rows(Gh.T.copy()))
+    Gt, pn = torch.as_tensor(Gh, device="cuda"), hip.pad_n
+    slack = 128 * 2 * P + 4096
+    buf = lambda *shape: torch.full((int(np.prod(shape)) + slack,), float("nan"), dtype=torch.float64, device="cuda")
+    rows, cols, B = 200, 3 * n - 8, 5
+    # analysis along the contiguous axis: out[r][o] = sum_i x[r][i] G[o][i]
+    x = buf(rows, n); x[:rows * n] = _rand((rows * n,), 60 + n); x[rows * n:] = 0.0
+    for fold in (False, True):
+        out = buf(rows, P)
+        if fold:
+            hip.gemm_fold(False, False, pn(rows), pn(P), n, x, n, 0, G, n, 0, out, P, 0, rows, P, 1)
+        else:
+            hip.gemm_batched(False, pn(rows), pn(P), n, x, n, 0, G, n, 0, out, P, 0, rows, P, 1)
+        ref = x[:rows * n].view(rows, n) @ Gt.t()
+        got = out[:rows * P].view(rows, P)
+        assert (got - ref).abs().max().item() <= 1e-13 * ref.abs().max().item(), ("fwd z", fold)
+        assert torch.isnan(out[rows * P:]).all()
+    spec_z = ref.clone()
+    # synthesis along the contiguous axis: out[r][i] = sum_o s[r][o] G[o][i]
+    sz = buf(rows, P); sz[:rows * P] = spec_z.reshape(-1); sz[rows * P:] = 0.0
+    for fold in (False, True):
+        out = buf(rows, n)
+        (hip.gemm_fold(False, True, pn(rows), pn(n), P, sz, P, 0, GT, P, 0, out, n, 0, rows, n, 1) if fold else
+         hip.gemm_batched(False, pn(rows), pn(n), P, sz, P, 0, GT, P, 0, out, n, 0, rows, n, 1))
+        ref = spec_z @ Gt
+        assert (out[:rows * n].view(rows, n) - ref).abs().max().item() <= 1e-13 * ref.abs().max().item(), ("inv z", fold)
+        assert torch.isnan(out[rows * n:]).all()
+    # analysis along a strided axis, batched: out[b][o][c] = sum_i G[o][i] y[b][i][c]
+    y = buf(B, n, cols); y[:B * n * cols] = _rand((B * n * cols,), 70 + n); y[B * n * cols:] = 0.0
+    for fold in (False, True):
+        out = buf(B, P, cols)
+        (hip.gemm_fold(True, False, pn(P), pn(cols), n, G, n, 0, y, cols, n * cols, out, cols, P * cols, P, cols, B) if fold else
+         hip.gemm_batched(True, pn(P), pn(cols), n, G, n, 0, y, cols, n * cols, out, cols, P * cols, P, cols, B))
+        ref = torch.einsum("oi,bic->boc", Gt, y[:B * n * cols].view(B, n, cols))
+        assert (out[:B * P * cols].view(B, P, cols) - ref).abs().max().item() <= 1e-13 * ref.abs().max().item(), ("fwd x", fold)
+        assert torch.isnan(out[B * P * cols:]).all()
+    spec_x = ref.clone()
+    # synthesis along a strided axis: out[b][i][c] = sum_o G[o][i] s[b][o][c]
+    sx = buf(B, P, cols); sx[:B * P * cols] = spec_x.reshape(-1); sx[B * P * cols:] = 0.0
+    for fold in (False, True):
+        out = buf(B, n, cols)
+        (hip.gemm_fold(True, True, pn(n), pn(cols), P, GT, P, 0, sx, cols, P * cols, out, cols, n * cols, n, cols, B) if fold else
+         hip.gemm_batched(True, pn(n), pn(cols), P, GT, P, 0, sx, cols, P * cols, out, cols, n * cols, n, cols, B))
+        ref = torch.einsum("oi,boc->bic", Gt, spec_x)
+        assert (out[:B * n * cols].view(B, n, cols) - ref).abs().max().item() <= 1e-13 * ref.abs().max().item(), ("inv x", fold)
+        assert torch.isnan(out[B * n * cols:]).all()
+
+
 def test_soak_hand_synchronised_kernels():
     """Short form of tools/soak_kernels.py: randomised plane / row counts through geobo_xz2d (both directions), geobo_xcorr_reduce
     and geobo_toeplitz_y against torch einsum references -- the counted vmcnt waits of the LDS-DMA rings must never let a tile be
