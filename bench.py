@@ -93,7 +93,8 @@ def synthetic_inputs(inv, md):
 
 
 PMC_FILES = {"ak_fused_grid": "r01_pmc_ak_fused_grid_v2.json", "posterior_reduce": "r03_pmc_posterior_reduce.json",
-             "k_block_grid": "r03_pmc_k_block_grid_f64.json", "toeplitz_y": "r04_pmc_toeplitz_y.json", "toeplitz_y2t": "r04_pmc_toeplitz_y2t.json"}
+             "k_block_grid": "r03_pmc_k_block_grid_f64.json", "toeplitz_y": "r05_pmc_toeplitz_y.json", "toeplitz_y2t": "r05_pmc_toeplitz_y2t.json"}
+PMC_VALU_FILES = {"toeplitz_y": "r05_pmc_toeplitz_y_valu.json", "toeplitz_y2t": "r05_pmc_toeplitz_y2t_valu.json"}
 GPU_DENSE_ROUTE = "profiles/r01_bench64_dense.json"   # builder-run bench line of `--method dense` (same algorithm as the CPU sample)
 
 
@@ -468,7 +469,7 @@ def main():
             # FMA flop of the mean launch: ny per output element and term (one-term launches: two of the three streams are outputs)
             vflop = d["valu"] / calls if d["valu"] > 0 else 2.0 * eng.ny * (by / 8.0) * (2.0 / 3.0)
             traffic, tsrc = None, None
-            for pf in (PMC_FILES[dom.split(":")[1]], PMC_FILES[dom.split(":")[1]].replace("r04_", "r03_")):
+            for pf in (PMC_FILES[dom.split(":")[1]], PMC_FILES[dom.split(":")[1]].replace("r05_", "r04_")):
                 try:
                     p = json.load(open(os.path.join(ROOT, "profiles", pf)))
                     traffic = p["derived"]["hbm_bytes_per_launch_corrected"] * by / p["derived"]["algorithmic_bytes"]
@@ -485,17 +486,27 @@ def main():
                     ytab[k.split(":")[1]] = {"ms_per_step": round(1e3 * v["seconds"] / a.steps, 2), "launches_per_step": c_ / a.steps,
                                              "mean_launch_ms": round(1e3 * m_, 4), "frac_hbm_8TBps": round(b_ / m_ / 8e12, 3),
                                              "frac_fp64_pipe_78.6TF": round(vf / m_ / 1e12 / FP64_MATRIX_PEAK_TFLOPS, 3)}
-            # Both roofs as peers.  The binding one names `bound`: the fp64 FMA pipe counts as "mfma" -- on gfx950 vector fp64 FMAs and
-            # v_mfma_f64 issue on the same pipe with the same 78.6 TFLOP/s peak (profiles/r01_mfma_coissue.txt)
-            pipe = f_valu >= f_hbm
-            roof = {"bound": "mfma" if pipe else "hbm", "kernel": kernel_names[dom],
-                    "achieved": vflop / mean_s / 1e12 if pipe else by / mean_s / 1e9, "peak": FP64_MATRIX_PEAK_TFLOPS if pipe else 8000.0,
-                    "unit": "TFLOP/s" if pipe else "GB/s", "frac": f_valu if pipe else f_hbm, "frac_hbm": f_hbm, "frac_fp64_valu": f_valu,
+            # Both roofs as peers.  `bound` / `frac` are the contract's HBM roof (round-4 review: "mfma" for a kernel with no MFMA busy
+            # cycles misleads a consumer of `bound`); the fp64 FMA pipe -- which vector FMAs and v_mfma_f64 share on gfx950, same
+            # 78.6 TFLOP/s peak (profiles/r01_mfma_coissue.txt) -- is reported beside it as `co_bound`: the kernel sits on the ridge.
+            issue = None
+            try:
+                pv = json.load(open(os.path.join(ROOT, "profiles", PMC_VALU_FILES[dom.split(":")[1]])))["derived"]
+                issue = {"source": "profiles/" + PMC_VALU_FILES[dom.split(":")[1]] + " (committed rocprofv3 --pmc passes of a lone launch)",
+                         "valu_busy_of_simd_cycles": round(pv["sq_active_inst_valu_x4_over_simd_cycles"], 3),
+                         "fma_f64_share_of_valu_instructions": round(pv["fma_f64_share_of_valu_instructions"], 3),
+                         "clock_GHz_of_the_profiled_launch": round(pv["clock_GHz_during_profiled_pass"], 2)}
+            except Exception:
+                pass
+            roof = {"bound": "hbm", "kernel": kernel_names[dom], "achieved": by / mean_s / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": f_hbm,
+                    "co_bound": {"roof": "fp64_pipe (vector FMA; shared with v_mfma_f64)", "achieved": vflop / mean_s / 1e12,
+                                 "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": f_valu, "issue_counters": issue},
+                    "frac_hbm": f_hbm, "frac_fp64_valu": f_valu,
                     "bound_note": "the y stage runs on the fp64 VECTOR FMAs (one (x, z) mode per lane, ny^2 FMA per mode, block and term: no operand "
-                                  "is shared between modes, so no MFMA) and streams its spectra once: HBM and the fp64 pipe limit it together.  `frac` is "
-                                  "the binding one of the two; `bound` says \"mfma\" for the fp64 FMA pipe, which vector FMAs and v_mfma_f64 share on gfx950 "
-                                  "(same 78.6 TFLOP/s peak, nominal 2.4 GHz; a launch inside the pipeline clocks at ~2.0 GHz, where the pipe side is ~1.2x "
-                                  "the figure); `flop_per_launch` = algorithmic FMA flop, `bytes_per_launch` = algorithmic bytes",
+                                  "is shared between modes, so no MFMA) and streams its spectra once: arithmetic intensity 10.7 flop/B against a ridge of "
+                                  "9.8 -- HBM and the fp64 pipe limit it together (`co_bound`; nominal 2.4 GHz: a launch inside the pipeline clocks at "
+                                  "~2.0 GHz, where the pipe side is ~1.2x the figure).  Counters: the VALU issues 74-79 % of the SIMD cycles, 94-95 % of "
+                                  "it FMAs, LDS waits negligible; `flop_per_launch` = algorithmic FMA flop, `bytes_per_launch` = algorithmic bytes",
                     "traffic": traffic,
                     "traffic_source": None if tsrc is None else tsrc + " (committed rocprofv3 --pmc passes of the same kernel: FETCH_SIZE x2 + "
                     "WRITE_SIZE, scaled by the algorithmic bytes; not collected in this run)",
@@ -560,14 +571,30 @@ def main():
             F64 = 2.0 * 8192 * 262144.0 ** 2 * 2 + 2.0 * 8242 * 8192 * 262144 + 8242 ** 3 / 3.0 + 8242.0 ** 2 * 2 * 262144 + 4.0 * 8242 * 2 * 262144 + 8242 ** 2
             cb["forms"] = cpu_baseline_forms(sizes, dsizes, F64, cb["gflops"])
             out["cpu_baseline"] = cb
-            out["config"]["speedup_vs_cpu_baseline"] = value / cb["value"]
+            # GPU / CPU ratios, like for like first (round-4 review).  (i) the SAME matrix-free algorithm on both sides at the largest size
+            # the CPU form was measured at; (ii) the same DENSE algorithm on both sides at 64^3 (committed `--method dense` line against
+            # this run's dense-algorithm sample); (iii) last, and NOT like for like: this run's structured GPU step against that dense
+            # CPU sample -- the ratio the r01-r04 lines called speedup_vs_cpu_baseline.  None of them says anything about kernel quality.
+            ratios = {}
+            mf = sorted((int(k.split("_")[-1]), v) for k, v in cb["forms"].items() if k.startswith("matrix_free_") and v.get("measured"))
+            if mf:
+                nmf, fmf = mf[-1]
+                try:
+                    g = json.load(open(os.path.join(ROOT, "profiles", "r05_bench%d_config2.json" % nmf)))
+                    ratios["same_matrix_free_algorithm_at_%d_cubed" % nmf] = {
+                        "gpu_voxel_properties_per_s": g["value"], "gpu_source": "profiles/r05_bench%d_config2.json (committed line, exp kernel, no drill rows)" % nmf,
+                        "cpu_voxel_properties_per_s_measured_here": fmf["voxel_properties_per_s"], "ratio": g["value"] / fmf["voxel_properties_per_s"]}
+                except Exception:
+                    pass
             try:   # the same (dense) algorithm on the GPU: committed bench line of `--method dense`
                 dense = json.load(open(os.path.join(ROOT, GPU_DENSE_ROUTE)))
-                out["config"]["speedup_same_algorithm_dense_route"] = {
-                    "gpu_dense_route_voxel_properties_per_s": dense["value"], "source": GPU_DENSE_ROUTE,
-                    "ratio_vs_cpu_sample": dense["value"] / cb["value"]}
+                ratios["same_dense_algorithm_at_64_cubed"] = {
+                    "gpu_dense_route_voxel_properties_per_s": dense["value"], "gpu_source": GPU_DENSE_ROUTE,
+                    "cpu_sample_voxel_properties_per_s": cb["value"], "ratio": dense["value"] / cb["value"]}
             except Exception:
                 pass
+            ratios["structured_gpu_step_vs_dense_cpu_sample_NOT_like_for_like"] = value / cb["value"]
+            out["config"]["gpu_over_cpu"] = ratios
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -31,8 +31,9 @@ constexpr int YBUF = BK * YS_NN;              // >= TN * XS
 constexpr int STAGE = XBUF + YBUF;
 constexpr size_t LDS_BYTES = 2 * STAGE * sizeof(double);      // 66 560 B
 
-enum { FWD_Z = 0, FWD_X = 1, INV_Z = 2, INV_X = 3 };          // bit 0: the data is the Y operand ([k][n]: analysis / synthesis along a
-                                                              // strided axis), bit 1: synthesis
+// FWD / INV: analysis / synthesis; _Z: the data is X (m x k), the matrix Y (n x k); _X: the matrix is X (m x k), the data Y (k x n);
+// INV_XT: synthesis with the matrix as X and the data as Y in the n x k layout (C = G^T S^T: the last pass of the lattice convolution)
+enum { FWD_Z = 0, FWD_X = 1, INV_Z = 2, INV_X = 3, INV_XT = 4 };
 
 struct FoldArgs {
   const double* X; int64_t ldx, sX;
@@ -49,7 +50,7 @@ __device__ __forceinline__ int swz(int row) {
 
 template <int MODE>
 __global__ void __launch_bounds__(256, 2) gemm_fold_kernel(const FoldArgs a) {
-  constexpr bool NN = (MODE & 1) != 0, INV = (MODE & 2) != 0;
+  constexpr bool NN = MODE == FWD_X || MODE == INV_X, INV = MODE >= INV_Z, BX = MODE == INV_X || MODE == INV_XT;
   constexpr int XROWS = (MODE == FWD_X) ? 64 : 128;           // rows of the X tile in LDS (analysis, matrix on the X side: base rows only)
   constexpr int YROWS = (MODE == FWD_Z) ? 64 : 128;           // rows of an NT Y tile
   constexpr int MT = (MODE == FWD_X) ? 2 : 4, NTL = (MODE == FWD_Z) ? 2 : 4;   // 16-row / 16-column tiles per wave
@@ -72,7 +73,7 @@ __global__ void __launch_bounds__(256, 2) gemm_fold_kernel(const FoldArgs a) {
 #pragma unroll
   for (int i = 0; i < XROWS / 32; ++i) {
     const int r = i * 32 + srow;
-    const int64_t g = (MODE == FWD_X) ? 2 * ((int64_t)bi * 64 + r) : (MODE == INV_X) ? row0 + 2 * (r & 63) + (r >> 6) : row0 + r;
+    const int64_t g = (MODE == FWD_X) ? 2 * ((int64_t)bi * 64 + r) : BX ? row0 + 2 * (r & 63) + (r >> 6) : row0 + r;
     xsrc[i] = (g * a.ldx + 2 * ((tid & 7) ^ swz(r))) * 8;
   }
 #pragma unroll
@@ -81,7 +82,7 @@ __global__ void __launch_bounds__(256, 2) gemm_fold_kernel(const FoldArgs a) {
       ysrc[i] = ((int64_t)(i * 4 + wave) * a.ldy + col0 + 2 * lane) * 8;            // one 1-KiB k-row per wave instruction
     } else {
       const int r = i * 32 + srow;
-      const int64_t g = (MODE == FWD_Z) ? 2 * ((int64_t)bj * 64 + r) : col0 + 2 * (r & 63) + (r >> 6);
+      const int64_t g = (MODE == FWD_Z) ? 2 * ((int64_t)bj * 64 + r) : (MODE == INV_Z) ? col0 + 2 * (r & 63) + (r >> 6) : col0 + r;
       ysrc[i] = (g * a.ldy + 2 * ((tid & 7) ^ swz(r))) * 8;
     }
   }
@@ -118,7 +119,7 @@ __global__ void __launch_bounds__(256, 2) gemm_fold_kernel(const FoldArgs a) {
   const int xo0 = 2 * ((2 * lg + 0) ^ swz(lr)), xo1 = 2 * ((2 * lg + 1) ^ swz(lr));
   const int xbase = (MODE == FWD_X ? wm * 32 : wm * 64) + lr;
   const int ybase = NN ? (wn * 64 + lr) : ((MODE == FWD_Z ? wn * 32 : wn * 64) + lr) * XS;
-  const double sgnz = (MODE == INV_Z && wn) ? -1.0 : 1.0, sgnx = (MODE == INV_X && wm) ? -1.0 : 1.0;
+  const double sgnz = (MODE == INV_Z && wn) ? -1.0 : 1.0, sgnx = (BX && wm) ? -1.0 : 1.0;
 
   stage(0, 0);
   __syncthreads();
@@ -220,7 +221,7 @@ __global__ void __launch_bounds__(256, 2) gemm_fold_kernel(const FoldArgs a) {
       for (int n = 0; n < 4; ++n)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int64_t row = (MODE == INV_X) ? row0 + 2 * (m * 16 + lg + 4 * r) + wm : row0 + wm * 64 + m * 16 + lg + 4 * r;
+          const int64_t row = BX ? row0 + 2 * (m * 16 + lg + 4 * r) + wm : row0 + wm * 64 + m * 16 + lg + 4 * r;
           const int64_t col = (MODE == INV_Z) ? col0 + 2 * (n * 16 + lr) + wn : col0 + wn * 64 + n * 16 + lr;
           if (row < a.m_valid && col < a.n_valid) Cp[row * a.ldc + col] = accs[m][n][r];
         }
@@ -262,6 +263,7 @@ extern "C" int geobo_gemm_fold(int y_is_kn, int inverse, int64_t m, int64_t n, i
   a.k = k; a.m_valid = m_valid; a.n_valid = n_valid;
   a.nbi = (int)(m / 128); a.nbj = (int)(n / 128);
   hipStream_t st = (hipStream_t)stream;
+  if (inverse == 2) return y_is_kn ? GEOBO_E_UNSUPPORTED : launch_fold<INV_XT>(a, batch, st);
   switch ((y_is_kn ? 1 : 0) | (inverse ? 2 : 0)) {
     case FWD_Z: return launch_fold<FWD_Z>(a, batch, st);
     case FWD_X: return launch_fold<FWD_X>(a, batch, st);

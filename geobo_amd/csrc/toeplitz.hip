@@ -1,5 +1,5 @@
 // toeplitz.hip -- the y-axis stage of the structured covariance product  AK = A_s K_sj  (kernels.py:158-195 builds
-// K_sj densely; on the grid of kernels.py:27-42 it is symmetric three-level Toeplitz, DESIGN.md section 3).
+// K_sj densely; on the grid of kernels.py:27-42 it is symmetric three-level Toeplitz, DESIGN.md section 2).
 //
 // After the real-DFT passes over z and x (geobo_gemm_batched against fixed cosine/sine matrices) every mode
 // c = (ox, oz) of a sensor row is an independent ny-vector, and the covariance acts on it as a symmetric Toeplitz

@@ -1,4 +1,4 @@
-// xz2d.hip -- fused two-axis real-DFT passes of the structured covariance product (DESIGN.md section 3;
+// xz2d.hip -- fused two-axis real-DFT passes of the structured covariance product (DESIGN.md section 2;
 // replaces the dense K_sj blocks of kernels.py:158-195 on the grid of kernels.py:27-42).
 //
 // Every (sensor row, y) plane of the forward operator goes   X (nx x nz)  ->  Gx X Gz^T (2nx x 2nz)   into the (x, z)

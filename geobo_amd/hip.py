@@ -380,7 +380,7 @@ def gemm_fold(y_is_kn, inverse, m, n, k, X, ldx, strideX, Y, ldy, strideY, C_, l
     done = 0
     while done < batch:
         nb = min(batch - done, 65535)
-        _lib.check(lib.geobo_gemm_fold(1 if y_is_kn else 0, 1 if inverse else 0, int(m), int(n), int(k),
+        _lib.check(lib.geobo_gemm_fold(1 if y_is_kn else 0, int(inverse), int(m), int(n), int(k),
                                        C.c_void_p(X.data_ptr() + done * strideX * 8), int(ldx), int(strideX),
                                        C.c_void_p(Y.data_ptr() + done * strideY * 8), int(ldy), int(strideY),
                                        C.c_void_p(C_.data_ptr() + done * strideC * 8), int(ldc), int(strideC), int(m_valid), int(n_valid),

@@ -191,7 +191,7 @@ class LatticeGram:
             hip.lattice_wbuild(Rb, Py, Px, nz, lamW, lh, W)
             U = sp.buf("LG_U", R * nx * nz * Py)
             hip.axis_pass(sp.fold, True, True, hip.pad_n(nx), nz * Py, Px, sp.GT["x"], Px, 0, W, nz * Py, Px * nz * Py, U, nz * Py, nx * nz * Py, nx, nz * Py, Rb)
-            hip.gemm_batched(False, hip.pad_n(ny), nx * nz, Py, self._GyT0, Py, 0, U, Py, nx * nz * Py, out[r0:], nx * nz, out.stride(0), ny, nx * nz, Rb)
+            hip.axis_pass(sp.fold and 2, False, 2, hip.pad_n(ny), nx * nz, Py, self._GyT0, Py, 0, U, Py, nx * nz * Py, out[r0:], nx * nz, out.stride(0), ny, nx * nz, Rb)
 
     def transpose_tables3(self, lam):
         """Lambda3[iz][ky][kx] (spectral planes per z channel) from the Gram's eigen-data lam = Lambda^T[ky][z][kx] / (Py Px)."""

@@ -224,7 +224,8 @@ int geobo_gemm_batched(int y_is_kn, int64_t m, int64_t n, int64_t k, double alph
  *     inverse = 0 (analysis, k = n inputs -> P outputs):  out[2b], out[2b+1] = E_b +- O_b, E / O = even- / odd-input sums against row 2b
  *     inverse = 1 (synthesis, k = P -> n outputs):        out[i] = sum_b G[2b][i] (s[2b] + (-1)^i s[2b+1])
  *     y_is_kn = 0: the data is X (m x k, k-contiguous), the matrix is Y (n x k): G for the analysis, G^T for the synthesis;
- *     y_is_kn = 1: the data is Y (k x n, n-contiguous), the matrix is X (m x k).
+ *     y_is_kn = 1: the data is Y (k x n, n-contiguous), the matrix is X (m x k);
+ *     inverse = 2 (y_is_kn = 0 only): synthesis with the matrix G^T as X (m x k) and the data as Y in the n x k layout, C = G^T S^T.
  * m, n: compute extents (multiples of 128; operands readable over them, as for geobo_gemm_batched), k % 16 == 0, batch <= 65535.
  * Agrees with the plain product up to summation order.  GEOBO_E_ALIGN for odd strides / an odd valid extent along the pair axis. */
 int geobo_gemm_fold(int y_is_kn, int inverse, int64_t m, int64_t n, int64_t k, const double* X, int64_t ldx, int64_t strideX,
@@ -237,7 +238,7 @@ int geobo_scale_broadcast(const double* a, const double* b, int64_t n, int64_t n
 int geobo_scale_broadcast2(const double* a, const double* b0, const double* b1, int64_t n, int64_t nb, double* out0,
                            double* out1, void* stream);
 
-/* Fused (x, z) real-DFT passes of the structured product (DESIGN.md section 3): every plane (r, p), r < rows,
+/* Fused (x, z) real-DFT passes of the structured product (DESIGN.md section 2): every plane (r, p), r < rows,
  * p < planes_per_row, at in + r*in_row + p*in_plane goes  X -> Mx X Mz^T  to out + r*out_row + p*out_plane.
  * inverse = 0: X is nx x nz, Mx = G_x (2nx x nx), Mz = G_z (2nz x nz), result 2nx x 2nz (into the spectrum);
  * inverse = 1: X is 2nx x 2nz, Mx = G_x^T (nx x 2nx), Mz = G_z^T (nz x 2nz), result nx x nz (back, cropped).
@@ -323,7 +324,7 @@ int geobo_ymul(int m, int k, int64_t C, int64_t rows, const double* G, int64_t l
 int geobo_xcorr_reduce_fold(int n, int64_t rows, int planes, const double* in, int64_t in_row, int64_t in_plane,
                             const double* F, const double* lamT, double* out, int64_t out_row, int64_t out_plane, void* stream);
 
-/* y-axis stage of the structured product on a regular grid (DESIGN.md section 3): for every mode c < C (the (x, z)
+/* y-axis stage of the structured product on a regular grid (DESIGN.md section 2): for every mode c < C (the (x, z)
  * spectral index, contiguous) and row r < R,   out_j[r][y - y0][c] = sum_{y'} tab_j[|y - y'|][c] * in[r][y'][c]
  * for y in [y0, y1) -- the symmetric Toeplitz blocks of create_cov's K_sj (kernels.py:158-195) applied directly.
  * in: [R][ny][plane]; tab_j: [ny][C]; out_j: [R][y1-y0][plane]; plane >= C is the stride between the y-planes of in and out in
@@ -416,7 +417,7 @@ int geobo_trmv_stats(int64_t m, const double* Linv, int64_t ldi, const double* y
 int geobo_mfma_f64_peak(int blocks, int iters, double* out, void* stream);
 
 /* co-issue probe: `nv` VALU ops (mode 1 fp64 fma, 2 fp32 fma, 3 int mad; 0 none) after every fp64 MFMA of the same
- * wave; used to decide what the generator stage may cost (DESIGN.md "what shares the fp64 pipe"). */
+ * wave; used to decide what the generator stage may cost (DESIGN.md section 4 "what shares the fp64 pipe"). */
 int geobo_mfma_mix(int mode, int nv, int blocks, int iters, double* out, void* stream);
 
 #ifdef __cplusplus

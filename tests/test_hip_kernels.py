@@ -353,6 +353,14 @@ def test_gemm_fold_matches_the_plain_passes(hip, n):
         ref = torch.einsum("oi,boc->bic", Gt, spec_x)
         assert (out[:B * n * cols].view(B, n, cols) - ref).abs().max().item() <= 1e-13 * ref.abs().max().item(), ("inv x", fold)
         assert torch.isnan(out[B * n * cols:]).all()
+    # synthesis with the matrix on the X side and the data in the (cols x P) layout: out[b][i][c] = sum_o G[o][i] s[b][c][o]
+    st = buf(B, cols, P); st[:B * cols * P] = spec_x.permute(0, 2, 1).reshape(-1); st[B * cols * P:] = 0.0
+    for fold in (False, True):
+        out = buf(B, n, cols)
+        (hip.gemm_fold(False, 2, pn(n), pn(cols), P, GT, P, 0, st, P, cols * P, out, cols, n * cols, n, cols, B) if fold else
+         hip.gemm_batched(False, pn(n), pn(cols), P, GT, P, 0, st, P, cols * P, out, cols, n * cols, n, cols, B))
+        assert (out[:B * n * cols].view(B, n, cols) - ref).abs().max().item() <= 1e-13 * ref.abs().max().item(), ("inv x, transposed data", fold)
+        assert torch.isnan(out[B * n * cols:]).all()
 
 
 def test_soak_hand_synchronised_kernels():
