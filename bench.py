@@ -417,13 +417,15 @@ def main():
         # the multi-rank form of this step on the one rank there is -- row form forced, its all-gather / all-reduce / agreement issued
         # through the backend (sharding._live) -- against the cubes of the timed steps (a second engine beside the timed one: 2 x 50 GB)
         os.environ["GEOBO_ROWS"] = "1"
-        solo = Inversion(settings=s, props=(0, 1, 2)[:a.props], rank=0, world=1, device="cuda:%d" % local, method=a.method,
-                         assembly=a.assembly, operators=a.operators)
-        os.environ.pop("GEOBO_ROWS")
-        solo.engine.force_collectives = True
-        solo.engine.kernel_events = []
-        solo.gp_length = (gp_length.copy() if gp_length is not None else s.gp_lengthscale * np.asarray([s.xvoxsize] * 3))
-        ref = solo.cubing(grav, mag, drill0[drill0 != 0], loc, drill0)
+        try:
+            solo = Inversion(settings=s, props=(0, 1, 2)[:a.props], rank=0, world=1, device="cuda:%d" % local, method=a.method,
+                             assembly=a.assembly, operators=a.operators)
+            solo.engine.force_collectives = True
+            solo.engine.kernel_events = []
+            solo.gp_length = (gp_length.copy() if gp_length is not None else s.gp_lengthscale * np.asarray([s.xvoxsize] * 3))
+            ref = solo.cubing(grav, mag, drill0[drill0 != 0], loc, drill0)
+        finally:
+            os.environ.pop("GEOBO_ROWS", None)
         idx = (0, 1, 3, 4) if a.props == 2 else range(6)
         evs = [(e[0], e[4].elapsed_time(e[5])) for e in solo.engine.kernel_events if e[0] in coll_names]
         check = {"what": "row form forced on the one rank, collectives through backend '%s' with world size 1" % a.backend,
@@ -486,9 +488,8 @@ def main():
                     ytab[k.split(":")[1]] = {"ms_per_step": round(1e3 * v["seconds"] / a.steps, 2), "launches_per_step": c_ / a.steps,
                                              "mean_launch_ms": round(1e3 * m_, 4), "frac_hbm_8TBps": round(b_ / m_ / 8e12, 3),
                                              "frac_fp64_pipe_78.6TF": round(vf / m_ / 1e12 / FP64_MATRIX_PEAK_TFLOPS, 3)}
-            # Both roofs as peers.  `bound` / `frac` are the contract's HBM roof (round-4 review: "mfma" for a kernel with no MFMA busy
-            # cycles misleads a consumer of `bound`); the fp64 FMA pipe -- which vector FMAs and v_mfma_f64 share on gfx950, same
-            # 78.6 TFLOP/s peak (profiles/r01_mfma_coissue.txt) -- is reported beside it as `co_bound`: the kernel sits on the ridge.
+            # Both roofs as peers (round-4 review: "mfma" for a kernel with no MFMA busy cycles misleads a consumer of `bound`).  The fp64
+            # FMA pipe is the one vector FMAs and v_mfma_f64 share on gfx950, same 78.6 TFLOP/s peak (profiles/r01_mfma_coissue.txt).
             issue = None
             try:
                 pv = json.load(open(os.path.join(ROOT, "profiles", PMC_VALU_FILES[dom.split(":")[1]])))["derived"]
@@ -498,10 +499,16 @@ def main():
                          "clock_GHz_of_the_profiled_launch": round(pv["clock_GHz_during_profiled_pass"], 2)}
             except Exception:
                 pass
-            roof = {"bound": "hbm", "kernel": kernel_names[dom], "achieved": by / mean_s / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": f_hbm,
-                    "co_bound": {"roof": "fp64_pipe (vector FMA; shared with v_mfma_f64)", "achieved": vflop / mean_s / 1e12,
-                                 "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": f_valu, "issue_counters": issue},
-                    "frac_hbm": f_hbm, "frac_fp64_valu": f_valu,
+            # the binding roof of the two names `bound`: "hbm", or "fp64_pipe" -- NOT "mfma": the kernel has no MFMA busy cycles; the pipe
+            # is the one v_mfma_f64 shares -- and the other one is `co_bound` (the one-term launches sit on the ridge, HBM 0.53 / pipe 0.57;
+            # the two-term kernel is pipe-bound, 0.35 / 0.57)
+            r_hbm = {"roof": "hbm", "achieved": by / mean_s / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": f_hbm}
+            r_pipe = {"roof": "fp64_pipe (vector FMA; shared with v_mfma_f64)", "achieved": vflop / mean_s / 1e12,
+                      "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": f_valu, "issue_counters": issue}
+            bind, other = (r_pipe, r_hbm) if f_valu >= f_hbm else (r_hbm, r_pipe)
+            roof = {"bound": "fp64_pipe" if bind is r_pipe else "hbm", "kernel": kernel_names[dom], "achieved": bind["achieved"],
+                    "peak": bind["peak"], "unit": bind["unit"], "frac": bind["frac"], "co_bound": other,
+                    "issue_counters": issue, "frac_hbm": f_hbm, "frac_fp64_valu": f_valu,
                     "bound_note": "the y stage runs on the fp64 VECTOR FMAs (one (x, z) mode per lane, ny^2 FMA per mode, block and term: no operand "
                                   "is shared between modes, so no MFMA) and streams its spectra once: arithmetic intensity 10.7 flop/B against a ridge of "
                                   "9.8 -- HBM and the fp64 pipe limit it together (`co_bound`; nominal 2.4 GHz: a launch inside the pipeline clocks at "

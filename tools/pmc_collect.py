@@ -40,9 +40,9 @@ DRIVERS = {"posterior": ("run_posterior_once.py", "gemm_f64_kernel<4, 2, 2, 1", 
            "kblock_exp_f32": ("run_k_block_once.py exp f32", "k_block_kernel", "pmc_k_block_exp_f32.json"),
            "toeplitz128": ("run_spectral_kernels_once.py toeplitz128", "toeplitz_y_win_kernel", "pmc_toeplitz_y_win128.json"),
            "kblock_grid": ("run_k_block_once.py matern32_x f64 grid", "k_block_grid_kernel", "pmc_k_block_grid_f64.json"),
-           "fold_inv_ss": ("run_spectral_kernels_once.py fold_inv_ss", "xz_fold_inv_kernel<64, 1>", "pmc_xz2d_fold_inv_ss.json"),
-           "fold_inv_strided": ("run_spectral_kernels_once.py fold_inv_strided", "xz_fold_inv_kernel<64, 0>", "pmc_xz2d_fold_inv_strided.json"),
-           "fold_inv_mul": ("run_spectral_kernels_once.py fold_inv_mul", "xz_fold_inv_kernel<64, 2>", "pmc_xz2d_fold_inv_mul.json"),
+           "fold_inv_ss": ("run_spectral_kernels_once.py fold_inv_ss", "xz_fold_inv_kernel<64, 1,", "pmc_xz2d_fold_inv_ss.json"),
+           "fold_inv_strided": ("run_spectral_kernels_once.py fold_inv_strided", "xz_fold_inv_kernel<64, 0,", "pmc_xz2d_fold_inv_strided.json"),
+           "fold_inv_mul": ("run_spectral_kernels_once.py fold_inv_mul", "xz_fold_inv_kernel<64, 2,", "pmc_xz2d_fold_inv_mul.json"),
            "wplanes": ("run_spectral_kernels_once.py wplanes", "lattice_wplanes_kernel", "pmc_lattice_wplanes.json"),
            "colgemv": ("run_spectral_kernels_once.py colgemv", "colgemv_kernel", "pmc_colgemv.json"),
            "kblock_grid_f32": ("run_k_block_once.py matern32_x f32 grid", "k_block_grid_kernel", "pmc_k_block_grid_f32.json")}
