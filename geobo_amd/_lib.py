@@ -44,6 +44,7 @@ SIGNATURES = {
     "geobo_gemm_nt_splitk": (_int, [_i64, _i64, _i64, _int, _dp, _i64, _dp, _i64, _dp, _i64, _int, _i64, _dp, _sz, _dp]),
     "geobo_gemm_nn": (_int, [_i64, _i64, _i64, _f64, _dp, _i64, _dp, _i64, _f64, _dp, _i64, _int, _int, _dp]),
     "geobo_gemm_batched": (_int, [_int, _i64, _i64, _i64, _f64, _dp, _i64, _i64, _dp, _i64, _i64, _f64, _dp, _i64, _i64, _i64, _i64, _int, _dp]),
+    "geobo_gemm_fold_lamdot": (_int, [_i64, _i64, _i64, _dp, _i64, _dp, _i64, _i64, _dp, _int, _i64, _dp, _i64, _dp]),
     "geobo_gemm_fold": (_int, [_int, _int, _i64, _i64, _i64, _dp, _i64, _i64, _dp, _i64, _i64, _dp, _i64, _i64, _i64, _i64, _i64, _dp]),
     "geobo_scale_broadcast": (_int, [_dp, _dp, _i64, _i64, _dp, _dp]),
     "geobo_scale_broadcast2": (_int, [_dp, _dp, _dp, _i64, _i64, _dp, _dp, _dp]),

@@ -41,6 +41,8 @@ struct FoldArgs {
   double* C; int64_t ldc, sC;
   int64_t k, m_valid, n_valid;
   int nbi, nbj;
+  // FWD_X with the lattice Gram's x-step epilogue (LAM): C[batch][o] = sum_z (G X_batch)[o][z] * lam[(batch0 + batch) % planes][o][z]
+  const double* lam; int planes; int64_t batch0;
 };
 
 __device__ __forceinline__ int swz(int row) {
@@ -48,8 +50,9 @@ __device__ __forceinline__ int swz(int row) {
   return (p & 1) | (((p >> 2) & 1) * 6);
 }
 
-template <int MODE>
+template <int MODE, bool LAM = false>
 __global__ void __launch_bounds__(256, 2) gemm_fold_kernel(const FoldArgs a) {
+  static_assert(!LAM || MODE == FWD_X, "the eigenvalue / channel-sum epilogue belongs to the analysis along a strided axis");
   constexpr bool NN = MODE == FWD_X || MODE == INV_X, INV = MODE >= INV_Z, BX = MODE == INV_X || MODE == INV_XT;
   constexpr int XROWS = (MODE == FWD_X) ? 64 : 128;           // rows of the X tile in LDS (analysis, matrix on the X side: base rows only)
   constexpr int YROWS = (MODE == FWD_Z) ? 64 : 128;           // rows of an NT Y tile
@@ -199,6 +202,39 @@ __global__ void __launch_bounds__(256, 2) gemm_fold_kernel(const FoldArgs a) {
             *reinterpret_cast<v2d*>(Cp + row * a.ldc + col) = (v2d){e + o, e - o};
           }
         }
+  } else if constexpr (MODE == FWD_X && LAM) {
+    // x step of the lattice Gram (AkA = (A K) A^T on a lattice survey, inversion.py:96) without its intermediate: the tile holds
+    // D[o][z] = (G_x X)[o][z] for 128 spectral rows o and ALL channels z (one column tile); scale by the stencil's eigen-data, sum over
+    // z -- 4 column tiles per lane, 16 lanes by shuffles, the two column halves of the tile through LDS -- and store 128 sums.  The
+    // batched form wrote D (Px nz doubles per (row, ky) plane: 67 MB per row at 128^3) and read it back in geobo_lamdot_z.
+    const double* const lamp = a.lam + ((a.batch0 + blockIdx.y) % a.planes) * (a.m_valid * a.n_valid);
+    double* const red = smem;          // [2 column halves][128 rows]; the loop's last barrier has been passed by every wave
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rl = 2 * (wm * 32 + m * 16 + lg + 4 * r);            // local row of the pair's first output
+        const int64_t row = (int64_t)bi * 128 + rl;
+        double pe = 0.0, po = 0.0;
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          const int64_t col = wn * 64 + n * 16 + lr;
+          const bool ok = row < a.m_valid && col < a.n_valid;
+          const int64_t ri = ok ? row : 0, ci = ok ? col : 0;
+          const double le = lamp[ri * a.n_valid + ci], lo = lamp[(ri + 1) * a.n_valid + ci];
+          const double e = acc[0][n][m][r], o = acc[1][n][m][r];
+          pe = __builtin_fma(ok ? e + o : 0.0, le, pe);
+          po = __builtin_fma(ok ? e - o : 0.0, lo, po);
+        }
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) { pe += __shfl_xor(pe, off); po += __shfl_xor(po, off); }
+        if (lr == 0) { red[wn * 128 + rl] = pe; red[wn * 128 + rl + 1] = po; }
+      }
+    __syncthreads();
+    if (tid < 128) {
+      const int64_t row = (int64_t)bi * 128 + tid;
+      if (row < a.m_valid) Cp[row] = red[tid] + red[128 + tid];
+    }
   } else if constexpr (MODE == FWD_X) {
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -228,18 +264,18 @@ __global__ void __launch_bounds__(256, 2) gemm_fold_kernel(const FoldArgs a) {
   }
 }
 
-template <int MODE>
+template <int MODE, bool LAM = false>
 int launch_fold(const FoldArgs& a, int64_t batch, hipStream_t st) {
   static std::atomic<uint64_t> attr_done{0};     // opt-in to > 64 KiB dynamic LDS, once per DEVICE (as in gemm_f64.hip)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return GEOBO_E_LAUNCH;
   if (!((attr_done.load(std::memory_order_acquire) >> dev) & 1)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fold_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fold_kernel<MODE, LAM>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)LDS_BYTES) != hipSuccess)
       return GEOBO_E_LAUNCH;
     attr_done.fetch_or((uint64_t)1 << dev, std::memory_order_release);
   }
-  hipLaunchKernelGGL(gemm_fold_kernel<MODE>, dim3((unsigned)(a.nbi * a.nbj), (unsigned)batch), dim3(256), LDS_BYTES, st, a);
+  hipLaunchKernelGGL((gemm_fold_kernel<MODE, LAM>), dim3((unsigned)(a.nbi * a.nbj), (unsigned)batch), dim3(256), LDS_BYTES, st, a);
   return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
 }
 
@@ -262,6 +298,7 @@ extern "C" int geobo_gemm_fold(int y_is_kn, int inverse, int64_t m, int64_t n, i
   a.C = C; a.ldc = ldc; a.sC = strideC;
   a.k = k; a.m_valid = m_valid; a.n_valid = n_valid;
   a.nbi = (int)(m / 128); a.nbj = (int)(n / 128);
+  a.lam = nullptr; a.planes = 1; a.batch0 = 0;
   hipStream_t st = (hipStream_t)stream;
   if (inverse == 2) return y_is_kn ? GEOBO_E_UNSUPPORTED : launch_fold<INV_XT>(a, batch, st);
   switch ((y_is_kn ? 1 : 0) | (inverse ? 2 : 0)) {
@@ -270,4 +307,21 @@ extern "C" int geobo_gemm_fold(int y_is_kn, int inverse, int64_t m, int64_t n, i
     case INV_Z: return launch_fold<INV_Z>(a, batch, st);
     default: return launch_fold<INV_X>(a, batch, st);
   }
+}
+
+extern "C" int geobo_gemm_fold_lamdot(int64_t px, int64_t nz, int64_t k, const double* G, int64_t ldg, const double* Y, int64_t ldy,
+                                      int64_t strideY, const double* lam, int planes, int64_t batch0, double* out, int64_t batch,
+                                      void* stream) {
+  if (!G || !Y || !lam || !out) return GEOBO_E_ARG;
+  if (px <= 0 || nz <= 0 || k <= 0 || planes <= 0 || batch0 < 0 || batch <= 0 || batch > 65535) return GEOBO_E_ARG;
+  if (nz > 128) return GEOBO_E_UNSUPPORTED;                   // one column tile holds every channel
+  if ((px & 1) || k % 16 || (ldg & 1) || (ldy & 1) || (strideY & 1)) return GEOBO_E_ALIGN;
+  FoldArgs a;
+  a.X = G; a.ldx = ldg; a.sX = 0;
+  a.Y = Y; a.ldy = ldy; a.sY = strideY;
+  a.C = out; a.ldc = 0; a.sC = px;
+  a.k = k; a.m_valid = px; a.n_valid = nz;
+  a.nbi = (int)((px + 127) / 128); a.nbj = 1;
+  a.lam = lam; a.planes = planes; a.batch0 = batch0;
+  return launch_fold<FWD_X, true>(a, batch, (hipStream_t)stream);
 }

@@ -372,6 +372,20 @@ def axis_pass(fold, y_is_kn, inverse, *args):
     return gemm_batched(y_is_kn, *args)
 
 
+def gemm_fold_lamdot(px, nz, k, G, ldg, Y, ldy, strideY, lam, planes, out, batch):
+    """Gram x step in one launch (geobo_gemm_fold_lamdot): out[b][o] = sum_z (G Y_b)[o][z] * lam[b % planes][o][z]."""
+    lib = require_gpu()
+    _check_extents("geobo_gemm_fold_lamdot", ((G, ldg, 0, pad_n(px), k, "G"), (Y, ldy, strideY, k, pad_n(nz), "Y")), batch)
+    done = 0
+    while done < batch:
+        nb = min(batch - done, 65535)
+        _lib.check(lib.geobo_gemm_fold_lamdot(int(px), int(nz), int(k), _p(G), int(ldg), C.c_void_p(Y.data_ptr() + done * strideY * 8),
+                                              int(ldy), int(strideY), _p(_chk(lam, "lam")), int(planes), int(done),
+                                              C.c_void_p(out.data_ptr() + done * px * 8), int(nb), _stream()), "geobo_gemm_fold_lamdot")
+        done += nb
+    return out
+
+
 def gemm_fold(y_is_kn, inverse, m, n, k, X, ldx, strideX, Y, ldy, strideY, C_, ldc, strideC, m_valid, n_valid, batch):
     """Radix-2 form of a gemm_batched axis pass against the pair-interleaved basis G / G^T (geobo_gemm_fold): same arguments as the
     gemm_batched call it replaces (alpha = 1, beta = 0), half the multiply-adds."""

@@ -342,9 +342,13 @@ class LatticeGram:
                 hip.xcorr_reduce(nx, nz, R, Py, y1b, Py * plane, plane, sp.G["x"], lam, s, Py * Px, Px)
             else:
                 # any other extent: D[r, ky] = Gx X[r, ky] as a batch of small GEMMs, then the eigenvalue scaling and the channel sum
-                D = sp.buf("LG_D", R * Py * Px * nz)
-                hip.axis_pass(sp.fold, True, False, hip.pad_n(Px), hip.pad_n(nz), nx, sp.G["x"], nx, 0, y1b, nz, plane, D, nz, Px * nz, Px, nz, R * Py)
-                hip.lamdot_z(R * Py, Py, Px, nz, D, self.lam_oz(lam), s)
+                if sp.fold and nz <= 128:
+                    # one launch: radix-2 analysis with the scaling and the channel sum as its epilogue, D never written
+                    hip.gemm_fold_lamdot(Px, nz, nx, sp.G["x"], nx, y1b, nz, plane, self.lam_oz(lam), Py, s, R * Py)
+                else:
+                    D = sp.buf("LG_D", R * Py * Px * nz)
+                    hip.axis_pass(sp.fold, True, False, hip.pad_n(Px), hip.pad_n(nz), nx, sp.G["x"], nx, 0, y1b, nz, plane, D, nz, Px * nz, Px, nz, R * Py)
+                    hip.lamdot_z(R * Py, Py, Px, nz, D, self.lam_oz(lam), s)
             # "x" of geobo_xz2d is this grid's y axis, its "z" this grid's x axis: S_r (Py x Px) -> Gy^T S_r Gx (ny x nx)
             if sp.fold and ny == nx and "y" in sp.F:
                 hip.xz2d_fold(True, ny, R, 1, s, Py * Px, Py * Px, sp.F["y"], sp.F["x"], out[r0:], out.stride(0), ny * nx)

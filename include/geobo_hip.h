@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GEOBO_VERSION 207 /* 201: flag word of geobo_gemm_nt, (64, 32) instance of geobo_xz2d, workspace layout of geobo_potrf_inv; 202: geobo_ymul, geobo_xz2d_fold_lattice; 203: geobo_sumsq_accum, geobo_lamdot_z, geobo_toeplitz_y2t, geobo_xz2d_fold_quad; 204: geobo_toeplitz_y3_add; 205: workspace layout of geobo_potrf_inv (one T buffer per tree node); 206: geobo_potrf_inv as one persistent tile-DAG launch from m = 1024 (workspace: + counters); 207: geobo_gemm_fold */
+#define GEOBO_VERSION 208 /* 201: flag word of geobo_gemm_nt, (64, 32) instance of geobo_xz2d, workspace layout of geobo_potrf_inv; 202: geobo_ymul, geobo_xz2d_fold_lattice; 203: geobo_sumsq_accum, geobo_lamdot_z, geobo_toeplitz_y2t, geobo_xz2d_fold_quad; 204: geobo_toeplitz_y3_add; 205: workspace layout of geobo_potrf_inv (one T buffer per tree node); 206: geobo_potrf_inv as one persistent tile-DAG launch from m = 1024 (workspace: + counters); 207: geobo_gemm_fold; 208: geobo_gemm_fold_lamdot */
 
 #define GEOBO_PAD_M 256 /* row padding of M-like dimensions (observation rows)            */
 #define GEOBO_PAD_N 128 /* padding of voxel-like dimensions (columns / contraction index) */
@@ -231,6 +231,15 @@ int geobo_gemm_batched(int y_is_kn, int64_t m, int64_t n, int64_t k, double alph
 int geobo_gemm_fold(int y_is_kn, int inverse, int64_t m, int64_t n, int64_t k, const double* X, int64_t ldx, int64_t strideX,
                     const double* Y, int64_t ldy, int64_t strideY, double* C, int64_t ldc, int64_t strideC, int64_t m_valid,
                     int64_t n_valid, int64_t batch, void* stream);
+
+/* x step of the lattice Gram (AkA = (A K) A^T on a lattice survey, inversion.py:96) for extents without the fused kernel
+ * (geobo_xcorr_reduce(_fold): nx = nz = 64), in ONE launch: the radix-2 analysis D_b = G X_b of geobo_gemm_fold (y_is_kn = 1; G: px x k
+ * basis rows, X_b = Y + b * strideY: k x nz) with the eigenvalue scaling and the channel sum of geobo_lamdot_z as its epilogue,
+ *     out[b][o] = sum_(z < nz) D_b[o][z] * lam[(batch0 + b) % planes][o][z],      b < batch, o < px
+ * -- the intermediate D (px * nz doubles per batch element: 67 MB per sensor row at 128^3) is never written.  nz <= 128 (one column
+ * tile holds every channel; GEOBO_E_UNSUPPORTED otherwise: geobo_gemm_fold + geobo_lamdot_z), px even, k % 16 == 0, batch <= 65535. */
+int geobo_gemm_fold_lamdot(int64_t px, int64_t nz, int64_t k, const double* G, int64_t ldg, const double* Y, int64_t ldy, int64_t strideY,
+                           const double* lam, int planes, int64_t batch0, double* out, int64_t batch, void* stream);
 
 /* out[i] = a[i] * b[i % nb]   (spectrum x eigenvalue table, broadcast over the batch) */
 int geobo_scale_broadcast(const double* a, const double* b, int64_t n, int64_t nb, double* out, void* stream);

@@ -363,6 +363,29 @@ def test_gemm_fold_matches_the_plain_passes(hip, n):
         assert torch.isnan(out[B * n * cols:]).all()
 
 
+@pytest.mark.parametrize("nx,nz", [(16, 16), (48, 32), (80, 96), (96, 96), (128, 128), (32, 128)])
+def test_gemm_fold_lamdot_matches_the_two_kernel_form(hip, nx, nz):
+    """geobo_gemm_fold_lamdot (x step of the lattice Gram for extents without the fused n = 64 kernel, one launch) against the radix-2
+    pass + geobo_lamdot_z it replaces, and against torch: out[b][o] = sum_z (Gx X_b)[o][z] lam[b % planes][o][z]."""
+    from geobo_amd.spectral import _pad_rows, forward_matrix
+    Px, planes, batch = 2 * nx, 5, 23
+    Gh = forward_matrix(nx)
+    G, Gt = hip.to_dev(_pad_rows(Gh)), torch.as_tensor(Gh, device="cuda")
+    X = torch.zeros(batch * nx * nz + 4096, dtype=torch.float64, device="cuda")
+    X[:batch * nx * nz] = _rand((batch * nx * nz,), 80 + nx)
+    lam = _rand((planes * Px * nz,), 81 + nz)
+    ref = torch.einsum("oi,biz,boz->bo", Gt, X[:batch * nx * nz].view(batch, nx, nz), lam.view(planes, Px, nz)[torch.arange(batch) % planes])
+    got = torch.full((batch * Px + 64,), float("nan"), dtype=torch.float64, device="cuda")
+    hip.gemm_fold_lamdot(Px, nz, nx, G, nx, X, nz, nx * nz, lam, planes, got, batch)
+    assert (got[:batch * Px].view(batch, Px) - ref).abs().max().item() <= 1e-13 * ref.abs().max().item()
+    assert torch.isnan(got[batch * Px:]).all()
+    D = torch.zeros(batch * Px * nz + 128 * 128 * 2, dtype=torch.float64, device="cuda")
+    hip.gemm_fold(True, False, hip.pad_n(Px), hip.pad_n(nz), nx, G, nx, 0, X, nz, nx * nz, D, nz, Px * nz, Px, nz, batch)
+    two = torch.empty(batch * Px, dtype=torch.float64, device="cuda")
+    hip.lamdot_z(batch, planes, Px, nz, D, lam, two)
+    assert (got[:batch * Px] - two).abs().max().item() <= 1e-13 * ref.abs().max().item()
+
+
 def test_soak_hand_synchronised_kernels():
     """Short form of tools/soak_kernels.py: randomised plane / row counts through geobo_xz2d (both directions), geobo_xcorr_reduce
     and geobo_toeplitz_y against torch einsum references -- the counted vmcnt waits of the LDS-DMA rings must never let a tile be
