@@ -291,6 +291,7 @@ struct ToeplitzWinArgs {
   double* out[3];         // [R][y1-y0][S] per property block
   int64_t C, S, R;
   int nprop, y0, y1, cw;
+  int ngroups, nbx;       // grid decode (round 5): chunk groups per row, 64-mode blocks
 };
 
 template <int NH, int OC, int G>
@@ -325,9 +326,20 @@ __global__ void __launch_bounds__(512, 1) toeplitz_y_win_kernel(ToeplitzWinArgs 
   const int nw = 2 * g.nprop * g.cw;
   const int prop = (w >> 1) % g.nprop, ck = (w >> 1) / g.nprop, mg = w & 1, h = lane >> 5;
   const int mode = 32 * mg + (lane & 31);                                // this lane's mode inside the 64-mode block
-  const int64_t S = g.S, c0 = (int64_t)blockIdx.x * 64;
+  // Workgroup -> (mode block, chunk group, row group).  The chunk groups of one (mode block, row group) stage the SAME input rows:
+  // with a (mode block, chunk group, row group) grid they were 1024 workgroups apart in dispatch order -- never resident together, so
+  // every group fetched its rows from HBM again (two blocks at ny = 128: four times; the launch ran at 3.5 TB/s of real traffic for
+  // 1.8 of algorithmic).  1-D grid, block b on XCD b % 8 (observed dispatch rule): the groups of one (mode block, row group) are
+  // consecutive workgroups of ONE XCD, run together and share the staged rows through its L2.
+  // (mode-block counts that are not a multiple of 8 -- tests, tiny grids -- keep the groups adjacent without the XCD interleave)
+  const bool x8 = (g.nbx & 7) == 0;
+  const int bid = blockIdx.x, bs = x8 ? bid >> 3 : bid, nbxs = x8 ? g.nbx >> 3 : g.nbx;
+  const int by = bs % g.ngroups, bt = bs / g.ngroups;
+  const int bx = x8 ? (bt % nbxs) * 8 + (bid & 7) : bt % nbxs;
+  const int64_t bz = bt / nbxs, gzn = (int64_t)gridDim.x / ((int64_t)g.nbx * g.ngroups);
+  const int64_t S = g.S, c0 = (int64_t)bx * 64;
   const int S8 = (int)(S * 8), out_bytes = (g.y1 - g.y0) * S8;
-  const int ob = g.y0 + OC * ((int)blockIdx.y * g.cw + ck);              // first output of this wave's chunk (may lie behind y1:
+  const int ob = g.y0 + OC * (by * g.cw + ck);                           // first output of this wave's chunk (may lie behind y1:
                                                                          // such a wave only helps staging the rows)
   double t[WIN];
   {
@@ -341,9 +353,9 @@ __global__ void __launch_bounds__(512, 1) toeplitz_y_win_kernel(ToeplitzWinArgs 
       t[k] = tp[(int64_t)d * g.C];
     }
   }
-  int64_t r = blockIdx.z;
+  int64_t r = bz;
   if (r >= g.R) return;
-  const int64_t rstep = gridDim.z;
+  const int64_t rstep = gzn;
   const int64_t ostep = (int64_t)(g.y1 - g.y0) * S;
   double* po = g.out[prop] + c0 + r * ostep + (int64_t)(ob - g.y0) * S;
   const double* ps = g.in + r * NY * S + c0;
@@ -424,7 +436,9 @@ int launch_win(const ToeplitzWinArgs& g, hipStream_t st) {
   const int ngroups = (nchunks + a.cw - 1) / a.cw;
   int64_t gz = 1;                                   // one workgroup per CU: a few waves of workgroups, each sweeping R / gz rows
   while ((g.C / 64) * ngroups * gz < 1024 && gz < g.R) ++gz;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(g.C / 64), (unsigned)ngroups, (unsigned)gz), dim3(128 * g.nprop * a.cw), lds, st, a);
+  a.ngroups = ngroups;
+  a.nbx = (int)(g.C / 64);
+  hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)a.nbx * ngroups * gz)), dim3(128 * g.nprop * a.cw), lds, st, a);
   return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
 }
 
