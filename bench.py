@@ -392,7 +392,7 @@ def main():
         # so that no sum over stages can mix the two units
         d["bytes" if name.startswith("kernel:") else "alg"] += alg
         d["valu"] += valu
-    single = [k for k in stages if k in ("ak_fused_grid", "ak_fused", "posterior_reduce", "posterior_zgemm", "aka_gemm_nt", "kernel:toeplitz_y", "kernel:toeplitz_y2t")]
+    single = [k for k in stages if k in ("ak_fused_grid", "ak_fused", "posterior_reduce", "posterior_zgemm", "aka_gemm_nt", "kernel:toeplitz_y", "kernel:toeplitz_y2t", "kernel:toeplitz_y2s")]
     dom = max(single, key=lambda k: stages[k]["seconds"]) if single else None
     kernel_names = {"ak_fused_grid": "geobo_ak_fused_grid (gemm_f64_kernel<4,2,TAB>)", "ak_fused": "geobo_ak_fused (gemm_f64_kernel<4,2,GEN>)",
                     "posterior_reduce": "geobo_posterior_reduce (gemm_f64_kernel<4,2,NN,REDUCE>)",
@@ -401,6 +401,8 @@ def main():
                                          "spectrum): y stage of the covariance products (A K and V = (L^-1 A) K)",
                     "kernel:toeplitz_y2t": "geobo_toeplitz_y2t (toeplitz_y2_kernel<64>: the two-term rows of the transposed posterior, V = Z_g K_0j + "
                                            "Z_m K_1j for two property blocks in one pass over both input spectra)",
+                    "kernel:toeplitz_y2s": "geobo_toeplitz_y2s (toeplitz_y2s_kernel<64>: the two-term rows of the transposed posterior with the shared "
+                                           "cross block K_01 = K_10 -- three products per mode instead of four, both property blocks in one pass)",
                     "aka_gemm_nt": "geobo_gemm_nt (gemm_f64_kernel<4,2,NT>)"}
 
     coll_names = {"xgmi_all_gather": "all_gather", "xgmi_all_reduce": "all_reduce", "xgmi_all_to_all": "all_to_all"}
@@ -462,7 +464,7 @@ def main():
         F_valu = sum(d["valu"] for d in mfma.values()) / a.steps
         step_ms = sorted(1e3 * (b - a_) for a_, b in zip(marks[:-1], marks[1:]))
         roof = None
-        if dom in ("kernel:toeplitz_y", "kernel:toeplitz_y2t"):
+        if dom in ("kernel:toeplitz_y", "kernel:toeplitz_y2t", "kernel:toeplitz_y2s"):
             # HBM / fp64-VALU co-limited stream kernel: algorithmic bytes (spectrum read once + one output slab per property block)
             d = stages[dom]
             calls = d["calls"]
@@ -471,7 +473,8 @@ def main():
             # FMA flop of the mean launch: ny per output element and term (one-term launches: two of the three streams are outputs)
             vflop = d["valu"] / calls if d["valu"] > 0 else 2.0 * eng.ny * (by / 8.0) * (2.0 / 3.0)
             traffic, tsrc = None, None
-            for pf in (PMC_FILES[dom.split(":")[1]], PMC_FILES[dom.split(":")[1]].replace("r05_", "r04_")):
+            pmc_key = dom.split(":")[1].replace("y2s", "y2t")      # (no counter pass of the three-product kernel: same streams as y2t)
+            for pf in (PMC_FILES[pmc_key], PMC_FILES[pmc_key].replace("r05_", "r04_")):
                 try:
                     p = json.load(open(os.path.join(ROOT, "profiles", pf)))
                     traffic = p["derived"]["hbm_bytes_per_launch_corrected"] * by / p["derived"]["algorithmic_bytes"]
@@ -492,8 +495,8 @@ def main():
             # FMA pipe is the one vector FMAs and v_mfma_f64 share on gfx950, same 78.6 TFLOP/s peak (profiles/r01_mfma_coissue.txt).
             issue = None
             try:
-                pv = json.load(open(os.path.join(ROOT, "profiles", PMC_VALU_FILES[dom.split(":")[1]])))["derived"]
-                issue = {"source": "profiles/" + PMC_VALU_FILES[dom.split(":")[1]] + " (committed rocprofv3 --pmc passes of a lone launch)",
+                pv = json.load(open(os.path.join(ROOT, "profiles", PMC_VALU_FILES[pmc_key])))["derived"]
+                issue = {"source": "profiles/" + PMC_VALU_FILES[pmc_key] + " (committed rocprofv3 --pmc passes of a lone launch)",
                          "valu_busy_of_simd_cycles": round(pv["sq_active_inst_valu_x4_over_simd_cycles"], 3),
                          "fma_f64_share_of_valu_instructions": round(pv["fma_f64_share_of_valu_instructions"], 3),
                          "clock_GHz_of_the_profiled_launch": round(pv["clock_GHz_during_profiled_pass"], 2)}

@@ -62,6 +62,7 @@ SIGNATURES = {
     "geobo_xcorr_reduce": (_int, [_int, _int, _i64, _int, _dp, _i64, _i64, _dp, _i64, _dp, _dp, _i64, _i64, _dp]),
     "geobo_toeplitz_y": (_int, [_int, _i64, _i64, _i64, _int, _dp, _dp, _dp, _dp, _dp, _int, _int, _dp]),
     "geobo_toeplitz_y2t": (_int, [_int, _i64, _i64, _i64, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
+    "geobo_toeplitz_y2s": (_int, [_int, _i64, _i64, _i64, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     "geobo_toeplitz_y3": (_int, [_int, _i64, _i64, _i64, _int, _dp, C.POINTER(_dp), C.POINTER(_dp), _int, _int, _dp]),
     "geobo_toeplitz_y3_add": (_int, [_int, _i64, _i64, _i64, _int, _dp, C.POINTER(_dp), C.POINTER(_dp), _int, _int, _dp]),
     "geobo_potrf_ws_bytes": (_sz, [_i64]),

@@ -274,6 +274,169 @@ int launch2(const Toeplitz2Args& g, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
 }
 
+// ---- two-term rows with a SHARED cross block (round 5): three products instead of four --------------------------------------------------
+// create_cov's prior is symmetric, K_10 = K_01 (kernels.py:181-195: block (i, j) = W[i][j] k_cross(l_i, l_j), W symmetric, k_cross even in
+// the exchange of its lengths), so the two-term rows  V_0 = Z_g K_00 + Z_m K_10,  V_1 = Z_g K_01 + Z_m K_11  share one Toeplitz block X:
+//     V_0 = T(D0) x_g + T(X)(x_g + x_m),     V_1 = T(D1) x_m + T(X)(x_g + x_m),     D0 = t_00 - t_01,  D1 = t_11 - t_01
+// -- three NY x NY products per mode instead of four.  Eight waves again, but of two sizes: waves 0-3 = (D0 on x_g | D1 on x_m) x (half of
+// the outputs), NY x NY/2 multiply-adds each as before; waves 4-7 = the shared product on x_g + x_m, split into QUARTERS of the outputs
+// (half, part), NY x NY/4 multiply-adds each.  Wave w runs on SIMD w % 4, so every SIMD carries one wave of each size: 3/4 of the issue
+// slots of the four-product kernel.  The quarter waves hand their sums to both full waves of their half through a dedicated 32 KiB of
+// LDS (2 stages x 2 terms x NY x 512 B + 2 x NY/2 x 512 B = 160 KiB at NY = 64: the whole LDS of a CU, one workgroup per CU as before):
+// two barriers per row (sums written | sums read) instead of three.
+struct Toeplitz2sArgs {
+  const double* in[2];        // [R][NY][S] per term
+  const double* tab[3];       // D0, X, D1: [NY][C]
+  double* out[2];             // [R][NY][S] per property block
+  int64_t C, S, R;
+};
+
+// toeplitz_group for inputs that are the SUM of the two staged rows (x = xs[term 0] + xs[term 1]: two LDS reads and one addition per input)
+template <int NY, int OC, int G, int O0>
+__device__ __forceinline__ void toeplitz_group_sum(const double (&t)[NY], double (&acc)[OC], double (&xb)[2][2 * GX], unsigned xaddr, unsigned xaddr2,
+                                                   int xstep) {
+  constexpr int NGX = NY / GX;
+  if constexpr (G == 0) {
+#pragma unroll
+    for (int i = 0; i < GX; ++i) {
+      asm volatile("ds_read_b64 %0, %1" : "=v"(xb[0][i]) : "v"(xaddr + (unsigned)(i * xstep)));
+      asm volatile("ds_read_b64 %0, %1" : "=v"(xb[0][GX + i]) : "v"(xaddr2 + (unsigned)(i * xstep)));
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (G + 1 < NGX) {
+#pragma unroll
+    for (int i = 0; i < GX; ++i) {
+      asm volatile("ds_read_b64 %0, %1" : "=v"(xb[(G + 1) & 1][i]) : "v"(xaddr + (unsigned)(((G + 1) * GX + i) * xstep)));
+      asm volatile("ds_read_b64 %0, %1" : "=v"(xb[(G + 1) & 1][GX + i]) : "v"(xaddr2 + (unsigned)(((G + 1) * GX + i) * xstep)));
+    }
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(xb[G & 1][0]), "+v"(xb[G & 1][1]), "+v"(xb[G & 1][2]), "+v"(xb[G & 1][3]), "+v"(xb[G & 1][4]), "+v"(xb[G & 1][5]),
+                   "+v"(xb[G & 1][6]), "+v"(xb[G & 1][7])
+                 : "n"(2 * GX));
+  } else {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(xb[G & 1][0]), "+v"(xb[G & 1][1]), "+v"(xb[G & 1][2]), "+v"(xb[G & 1][3]), "+v"(xb[G & 1][4]), "+v"(xb[G & 1][5]),
+                   "+v"(xb[G & 1][6]), "+v"(xb[G & 1][7]));
+  }
+#pragma unroll
+  for (int i = 0; i < GX; ++i) {
+    const int yp = G * GX + i;
+    const double x = xb[G & 1][i] + xb[G & 1][GX + i];
+#pragma unroll
+    for (int o = 0; o < OC; ++o) {
+      const int d = O0 + o - yp;
+      acc[o] = (yp == 0) ? t[d < 0 ? -d : d] * x : __builtin_fma(t[d < 0 ? -d : d], x, acc[o]);
+    }
+  }
+  if constexpr (G + 1 < NGX) toeplitz_group_sum<NY, OC, G + 1, O0>(t, acc, xb, xaddr, xaddr2, xstep);
+}
+
+template <int NY>
+__global__ void __launch_bounds__(512, 1) toeplitz_y2s_kernel(Toeplitz2sArgs g) {
+  static_assert(GX == 4 && NY % 16 == 0, "shape");
+  constexpr int OCF = NY / 2, OCQ = NY / 4;
+  extern __shared__ __attribute__((aligned(16))) double xs2s_dyn[];         // [2 stages][2 terms][NY][64] | exchange [2 halves][NY/2][64]
+  double (*xs)[2][NY][64] = reinterpret_cast<double (*)[2][NY][64]>(xs2s_dyn);
+  double* const exch = xs2s_dyn + (size_t)2 * 2 * NY * 64;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool shared = w >= 4;
+  const int pos = w & 3, half = pos & 1, sel = pos >> 1;       // full waves: sel = block (0: D0 on x_g, 1: D1 on x_m); quarter waves: part
+  const unsigned lane8 = (unsigned)lane * 8u;
+  const int64_t C = g.S, c0 = (int64_t)blockIdx.x * 64;
+  const int C8 = (int)(C * 8);
+  double t[NY];
+  {
+    const int T8 = (int)(g.C * 8);
+    const rsrc_t tr = make_rsrc(g.tab[shared ? 1 : 2 * sel] + c0, NY * T8);
+#pragma unroll
+    for (int d = 0; d < NY; ++d) t[d] = ld_lane(tr, lane8, d * T8);
+  }
+  int64_t r = blockIdx.y;
+  if (r >= g.R) return;
+  const int64_t rstep = gridDim.y, rowlen = (int64_t)NY * C;
+  double* po = g.out[sel] + c0 + r * rowlen;                   // (full waves only)
+  const double* ps0 = g.in[0] + r * rowlen + c0;
+  const double* ps1 = g.in[1] + r * rowlen + c0;
+  const int64_t dma_lane = (int64_t)(lane >> 5) * C + (lane & 31) * 2;   // one DMA instruction moves two y-planes of 64 modes
+  auto stage = [&](const double* row0, const double* row1, int b) {
+    for (int i = w; i < NY / 2; i += 8) {
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(row0 + (int64_t)(2 * i) * C + dma_lane), (lds_ptr_t)&xs[b][0][2 * i][0], 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(row1 + (int64_t)(2 * i) * C + dma_lane), (lds_ptr_t)&xs[b][1][2 * i][0], 16, 0, 0);
+    }
+  };
+  stage(ps0, ps1, 0);
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  const int xstep = half ? -512 : 512;
+  const int ysgn = half ? -1 : 1, ybase = half ? NY - 1 : 0;
+  double* const ex = exch + (size_t)(half * OCF) * 64 + lane;   // [o of the half][lane]
+  int b = 0;
+  for (; r < g.R; r += rstep) {
+    const bool more = r + rstep < g.R;
+    if (more) {
+      ps0 += rstep * rowlen;
+      ps1 += rstep * rowlen;
+      stage(ps0, ps1, b ^ 1);
+    }
+    const int yrow = half ? NY - 1 : 0;
+    if (!shared) {
+      double acc[OCF], xb[2][GX];
+      const unsigned xaddr = (unsigned)(uintptr_t)(lds_ptr_t)&xs[b][sel][yrow][0] + lane8;
+      toeplitz_group<NY, OCF, 0>(t, acc, xb, xaddr, xstep);
+#pragma unroll
+      for (int o = 0; o < OCF; ++o) asm volatile("" : "+v"(acc[o]));
+      __builtin_amdgcn_s_waitcnt(vmcnt_only(0));    // this wave's share of the next rows has landed (and last row's stores are out)
+      __builtin_amdgcn_s_barrier();                 // (A) the shared product's sums are in the exchange area; stage b is free
+#pragma unroll
+      for (int o = 0; o < OCF; ++o) acc[o] += ex[o * 64];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                 // (B) the exchange area has been read: the next row's sums may overwrite it
+      const rsrc_t dst = make_rsrc(po, NY * C8);
+      int pitch = C8;
+      asm volatile("" : "+s"(pitch));
+#pragma unroll
+      for (int o = 0; o < OCF; ++o) st_lane(dst, lane8, (ybase + ysgn * o) * pitch, acc[o]);
+      po += rstep * rowlen;
+    } else {
+      double acc[OCQ], xb[2][2 * GX];
+      const unsigned xa0 = (unsigned)(uintptr_t)(lds_ptr_t)&xs[b][0][yrow][0] + lane8;
+      const unsigned xa1 = (unsigned)(uintptr_t)(lds_ptr_t)&xs[b][1][yrow][0] + lane8;
+      if (sel == 0) toeplitz_group_sum<NY, OCQ, 0, 0>(t, acc, xb, xa0, xa1, xstep);
+      else toeplitz_group_sum<NY, OCQ, 0, OCQ>(t, acc, xb, xa0, xa1, xstep);
+#pragma unroll
+      for (int o = 0; o < OCQ; ++o) asm volatile("" : "+v"(acc[o]));
+      __builtin_amdgcn_s_waitcnt(vmcnt_only(0));
+      double* const exq = ex + (size_t)(sel * OCQ) * 64;
+#pragma unroll
+      for (int o = 0; o < OCQ; ++o) exq[o * 64] = acc[o];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                 // (A)
+      __builtin_amdgcn_s_barrier();                 // (B)
+    }
+    b ^= 1;
+  }
+}
+
+template <int NY>
+int launch2s(const Toeplitz2sArgs& g, hipStream_t st) {
+  constexpr size_t lds = (size_t)(2 * 2 * NY + NY) * 64 * sizeof(double);
+  static_assert(lds <= 163840, "LDS");
+  auto kern = toeplitz_y2s_kernel<NY>;
+  static std::atomic<uint64_t> attr_done{0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return GEOBO_E_LAUNCH;
+  if (!((attr_done.load(std::memory_order_acquire) >> dev) & 1)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return GEOBO_E_LAUNCH;
+    attr_done.fetch_or((uint64_t)1 << dev, std::memory_order_release);
+  }
+  int64_t gy = g.R < 2 ? g.R : 2;      // one workgroup per CU: 256 column blocks x 2 at 64^3 = two rounds of the chip
+  while ((g.C / 64) * gy < 512 && gy < g.R) ++gy;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(g.C / 64), (unsigned)gy), dim3(512), lds, st, g);
+  return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
+}
+
 // ---- long y axes (NY = 128: the 128^3 configuration): the NY table values of a lane no longer fit its registers ---------------
 // A lane owns ONE mode and ONE HALF of the inputs (lanes 0-31: y' < NY/2, lanes 32-63 the same 32 modes with y' >= NY/2) and a chunk of
 // OC consecutive outputs o = ob .. ob+OC-1.  The distances d = o - y' it meets form a window of NY/2 + OC - 1 consecutive values, so
@@ -490,6 +653,22 @@ extern "C" int geobo_toeplitz_y2t(int ny, int64_t C, int64_t plane, int64_t R, c
     case 64: return launch2<64>(g, (hipStream_t)stream);
     case 48: return launch2<48>(g, (hipStream_t)stream);
     case 32: return launch2<32>(g, (hipStream_t)stream);
+    default: return GEOBO_E_UNSUPPORTED;
+  }
+}
+
+extern "C" int geobo_toeplitz_y2s(int ny, int64_t C, int64_t plane, int64_t R, const double* in_g, const double* in_m, const double* tab_d0,
+                                  const double* tab_x, const double* tab_d1, double* out0, double* out1, void* stream) {
+  if (!in_g || !in_m || !tab_d0 || !tab_x || !tab_d1 || !out0 || !out1) return GEOBO_E_ARG;
+  if (R <= 0 || plane < C) return GEOBO_E_ARG;
+  if (C <= 0 || C % 64 || (plane & 1) || (int64_t)ny * plane * 8 >= (1ll << 31)) return GEOBO_E_ALIGN;
+  Toeplitz2sArgs g;
+  g.in[0] = in_g; g.in[1] = in_m; g.tab[0] = tab_d0; g.tab[1] = tab_x; g.tab[2] = tab_d1;
+  g.out[0] = out0; g.out[1] = out1; g.C = C; g.S = plane; g.R = R;
+  switch (ny) {
+    case 64: return launch2s<64>(g, (hipStream_t)stream);
+    case 48: return launch2s<48>(g, (hipStream_t)stream);
+    case 32: return launch2s<32>(g, (hipStream_t)stream);
     default: return GEOBO_E_UNSUPPORTED;
   }
 }

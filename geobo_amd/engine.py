@@ -874,10 +874,18 @@ class PosteriorEngine(RowFormMixin, TransposedPosteriorMixin, ColumnExchangeMixi
             # ... and every read-back of the step is queued in front of that one wait (each further wait is a host wake-up: ~1 ms)
             h_info = self._to_host_async(info, "info")
             st = self._to_host_async(stats, "stats") if calclogl else None
+            resid = getattr(self._spectral, "sym_residual", None)
+            h_res = self._to_host_async(resid.reshape(1), "sym_residual") if resid is not None else None
             torch.cuda.current_stream(self.device).synchronize()
             info_h = int(h_info[0])
             if info_h != 0:
                 raise CholeskyError(info_h)
+            if h_res is not None:
+                self._spectral.sym_residual = None
+                if not float(h_res[0]) <= 1e-12:
+                    # the three-product y stage (geobo_toeplitz_y2s) took blocks (0, 1) and (1, 0) of the prior for one block
+                    raise RuntimeError("the covariance blocks (0, 1) and (1, 0) differ (relative %.3e): this prior is not symmetric; "
+                                       "set GEOBO_Y2S=0 for the four-product y stage" % float(h_res[0]))
             if calclogl:
                 out["uu"], out["logdet"] = float(st[0]), float(st[1])
                 out["logl"] = -0.5 * (st[0] + st[1] + self.N * math.log(2 * math.pi))  # inversion.py:107-110

@@ -575,6 +575,16 @@ def toeplitz_y2t(ny, C, R, src_g, src_m, tabs_g, tabs_m, outs, plane=None):
                                       _p(_chk(outs[0], "out")), _p(_chk(outs[1], "out")), _stream()), "geobo_toeplitz_y2t")
 
 
+def toeplitz_y2s(ny, C, R, src_g, src_m, tab_d0, tab_x, tab_d1, outs, plane=None):
+    """Two-term rows with a shared cross block (K_10 = K_01) as three products per mode instead of four:
+    outs[0] = T(tab_d0) src_g + T(tab_x)(src_g + src_m),  outs[1] = T(tab_d1) src_m + T(tab_x)(src_g + src_m)   (geobo_toeplitz_y2s)."""
+    lib = require_gpu()
+    assert len(outs) == 2
+    _lib.check(lib.geobo_toeplitz_y2s(int(ny), int(C), int(C if plane is None else plane), int(R), _p(_chk(src_g, "src_g")), _p(_chk(src_m, "src_m")),
+                                      _p(_chk(tab_d0, "tab")), _p(_chk(tab_x, "tab")), _p(_chk(tab_d1, "tab")),
+                                      _p(_chk(outs[0], "out")), _p(_chk(outs[1], "out")), _stream()), "geobo_toeplitz_y2s")
+
+
 class PotrfContext:
     """Fork streams / events of geobo_potrf_inv on the device that is current at construction (owned by the caller: one per
     engine; never shared between concurrent factorisations)."""

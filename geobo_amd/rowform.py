@@ -179,6 +179,8 @@ class RowFormMixin:
         gens_g, gens_m = [self._gens[(0, j)] for j in props], [self._gens[(1, j)] for j in props]
         swap = (lambda g: g.view(ny, sp.Px, sp.Pz).transpose(1, 2).contiguous().view(-1)) if zx else (lambda g: g)
         tg, tm = [swap(g) for g in gens_g], [swap(g) for g in gens_m]
+        # blocks (0, 1) and (1, 0) of a symmetric prior coincide: three y-stage products per two-term row instead of four
+        y2s = sp.y2s_tables(tg, tm) if tuple(props[:2]) == (0, 1) else None
         fl_z = gram.flops(1, ny) + 2 * 3 * 2.0 * 128 * 128 * 64
         for two in (False, True):
             for c0 in range(0, rows_r, zc):
@@ -191,8 +193,8 @@ class RowFormMixin:
                         self._lattice_Z(Linv[b0:b0 + n, Msp:2 * Msp], n, "magn", None, Zm, zx=zx, edge=Em)
                 self._timed("posterior_zlattice", (2 if two else 1) * n * fl_z, zlattice)
                 self._timed("posterior_spectral", sp.flops_ss(0 if two else n, n if two else 0, P_c),
-                            lambda: sp.reduce_ss(Zg, n, tg, Zm if two else None, 0, tm, ss),
-                            valu=(2 if two else 1) * n * P_c * 2.0 * ny * ny * sp.Px * sp.Pz)
+                            lambda: sp.reduce_ss(Zg, n, tg, Zm if two else None, 0, tm, ss, y2s=y2s),
+                            valu=((1.5 if y2s is not None and P_c == 2 else 2) if two else 1) * n * P_c * 2.0 * ny * ny * sp.Px * sp.Pz)
         for jj, t in enumerate(ss):
             if zx:
                 ssq[jj].copy_(t.sum(0).view(ny, nz, nx).transpose(1, 2).reshape(-1))

@@ -398,15 +398,33 @@ class SpectralProduct:
         """Partial cubes per property block that reduce_ss adds to (sum over them afterwards)."""
         return hip.xz2d_fold_inv_ss_slots(self.nx, self.R, self.ny) if self.fused_ss() else self.GENERIC_SS_SLOTS
 
-    def reduce_ss(self, Zg, Mg, gens_g, Zm, m_first, gens_m, ss):
+    def y2s_tables(self, gens_g, gens_m, pair=(0, 1)):
+        """Tables of the three-product form of the two-term rows for the block pair (a, b) = `pair` (b = a + 1, a even), or None where
+        the kernel does not apply.  The caller states that gens_g[b] and gens_m[a] are the SAME covariance block -- K_01 = K_10:
+        create_cov's prior is symmetric (kernels.py:181-195) -- and the statement is verified on the device: `sym_residual`
+        (max |gens_g[b] - gens_m[a]| over max |gens_g[b]|, a 0-d device tensor) is left for the caller to read at its next
+        synchronisation (engine.posterior raises above 1e-12).  Returns (a, D0 = gens_g[a] - X, X = gens_g[b], D1 = gens_m[b] - X)."""
+        self.sym_residual = None
+        a, b = pair
+        if not (self.fused_ss() and self.ny in hip.TOEPLITZ_Y2T_NY and b == a + 1 and a % 2 == 0 and b < len(gens_g)
+                and os.environ.get("GEOBO_Y2S", "1") != "0"):
+            return None
+        x = gens_g[b]
+        self.sym_residual = (x - gens_m[a]).abs().max() / x.abs().max()
+        return (a, gens_g[a] - x, x, gens_m[b] - x)
+
+    def reduce_ss(self, Zg, Mg, gens_g, Zm, m_first, gens_m, ss, y2s=None):
         """ss[j][slot][y][x*z] += sum_m V_j[m]^2  with  V_j[m] = Zg[m] * K_0j  (+ Zm[m - m_first] * K_1j for m >= m_first),  m < Mg:
         rows of L^-1 A_s carried through the covariance product and squared on the way out of the inverse transform -- V is never
         written.  Zg: (>= Mg x N) rows, Zm: (>= Mg - m_first x N) rows or None; gens_g[j] / gens_m[j]: Toeplitz generators of the
         blocks (0, j) / (1, j) (eigenvalues()); ss[j]: zeroed partial cubes (ss_slots() slots each).
         Batches never straddle m_first (a batch is entirely one-term or entirely two-term).  Grids without the fused reduction
-        (fused_ss): the storing product of every batch into a scratch of R rows, then geobo_sumsq_accum."""
+        (fused_ss): the storing product of every batch into a scratch of R rows, then geobo_sumsq_accum.
+        y2s: tables of y2s_tables() for a pair of blocks whose cross blocks coincide -- the two-term rows of that pair then cost three
+        y-stage products instead of four (geobo_toeplitz_y2s)."""
         nx, ny, nz, C, Cp, R = self.nx, self.ny, self.nz, self.Px * self.Pz, self.Cp, self.R
         P_c = len(gens_g)
+        y2s_tabs = y2s
         if Zm is None:
             m_first = Mg
         starts = list(range(0, min(m_first, Mg), R)) + list(range(m_first, Mg, R))
@@ -450,12 +468,18 @@ class SpectralProduct:
                 js = list(range(j, min(j + 2, P_c)))
                 sg = [self.buf(("S", "S1")[i], Rb * ny * Cp) for i in range(len(js))]
                 if two and len(js) == 2 and ny in hip.TOEPLITZ_Y2T_NY:
-                    # both terms in ONE y-stage pass (geobo_toeplitz_y2t): one output spectrum per block, one input of the inverse
-                    fn = lambda: hip.toeplitz_y2t(ny, C, Rb, t2g, t2m, [gens_g[jj] for jj in js], [gens_m[jj] for jj in js], sg, plane=Cp)
+                    # both terms in ONE y-stage pass: one output spectrum per block, one input of the inverse; with the shared cross
+                    # block three products per mode (geobo_toeplitz_y2s), otherwise four (geobo_toeplitz_y2t)
+                    if y2s_tabs is not None and y2s_tabs[0] == j:
+                        fn = lambda: hip.toeplitz_y2s(ny, C, Rb, t2g, t2m, y2s_tabs[1], y2s_tabs[2], y2s_tabs[3], sg, plane=Cp)
+                        kname, nprod = "kernel:toeplitz_y2s", 3
+                    else:
+                        fn = lambda: hip.toeplitz_y2t(ny, C, Rb, t2g, t2m, [gens_g[jj] for jj in js], [gens_m[jj] for jj in js], sg, plane=Cp)
+                        kname, nprod = "kernel:toeplitz_y2t", 4
                     if self.kernel_timer is None:
                         fn()
                     else:
-                        self.kernel_timer("kernel:toeplitz_y2t", 8.0 * Rb * C * (2 * ny + 2 * ny), fn, valu=2.0 * (2 * ny) * ny * C * Rb * 2)
+                        self.kernel_timer(kname, 8.0 * Rb * C * (2 * ny + 2 * ny), fn, valu=2.0 * nprod * ny * ny * C * Rb)
                     for i, jj in enumerate(js):
                         hip.xz2d_fold_inv_ss(nx, Rb, ny, sg[i], ny * Cp, Cp, self.F["x"], self.F["z"], ss[jj])
                     continue

@@ -159,8 +159,10 @@ class TransposedPosteriorMixin:
         zx = lat and zx
         swap = (lambda g: g.view(ny, sp.Px, sp.Pz).transpose(1, 2).contiguous().view(-1)) if zx else (lambda g: g)   # tables of transposed planes
         tg, tm = [swap(g) for g in gens_g], [swap(g) for g in gens_m]
-        self._timed("posterior_spectral", sp.flops_ss(Msp, Msp, P_c), lambda: sp.reduce_ss(Zg, 2 * Msp, tg, Zm, Msp, tm, ss),
-                    valu=3.0 * Msp * P_c * 2.0 * ny * ny * sp.Px * sp.Pz)
+        # blocks (0, 1) and (1, 0) of a symmetric prior coincide: three y-stage products per two-term row instead of four
+        y2s = sp.y2s_tables(tg, tm) if tuple(props[:2]) == (0, 1) else None
+        self._timed("posterior_spectral", sp.flops_ss(Msp, Msp, P_c), lambda: sp.reduce_ss(Zg, 2 * Msp, tg, Zm, Msp, tm, ss, y2s=y2s),
+                    valu=(2.5 if y2s is not None and P_c == 2 else 3.0) * Msp * P_c * 2.0 * ny * ny * sp.Px * sp.Pz)
         if zx:
             ssum = torch.stack([t.sum(0).view(ny, nz, nx).transpose(1, 2).reshape(-1) for t in ss])   # planes came out as [iz][ix]
         else:

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GEOBO_VERSION 208 /* 201: flag word of geobo_gemm_nt, (64, 32) instance of geobo_xz2d, workspace layout of geobo_potrf_inv; 202: geobo_ymul, geobo_xz2d_fold_lattice; 203: geobo_sumsq_accum, geobo_lamdot_z, geobo_toeplitz_y2t, geobo_xz2d_fold_quad; 204: geobo_toeplitz_y3_add; 205: workspace layout of geobo_potrf_inv (one T buffer per tree node); 206: geobo_potrf_inv as one persistent tile-DAG launch from m = 1024 (workspace: + counters); 207: geobo_gemm_fold; 208: geobo_gemm_fold_lamdot */
+#define GEOBO_VERSION 209 /* 201: flag word of geobo_gemm_nt, (64, 32) instance of geobo_xz2d, workspace layout of geobo_potrf_inv; 202: geobo_ymul, geobo_xz2d_fold_lattice; 203: geobo_sumsq_accum, geobo_lamdot_z, geobo_toeplitz_y2t, geobo_xz2d_fold_quad; 204: geobo_toeplitz_y3_add; 205: workspace layout of geobo_potrf_inv (one T buffer per tree node); 206: geobo_potrf_inv as one persistent tile-DAG launch from m = 1024 (workspace: + counters); 207: geobo_gemm_fold; 208: geobo_gemm_fold_lamdot; 209: geobo_toeplitz_y2s */
 
 #define GEOBO_PAD_M 256 /* row padding of M-like dimensions (observation rows)            */
 #define GEOBO_PAD_N 128 /* padding of voxel-like dimensions (columns / contraction index) */
@@ -352,6 +352,17 @@ int geobo_toeplitz_y(int ny, int64_t C, int64_t plane, int64_t R, int nprop, con
  * inverse transform that follows).  ny in {32, 48, 64} (GEOBO_E_UNSUPPORTED otherwise), C % 64 == 0, plane >= C even. */
 int geobo_toeplitz_y2t(int ny, int64_t C, int64_t plane, int64_t R, const double* in_g, const double* in_m, const double* tab_g0,
                        const double* tab_g1, const double* tab_m0, const double* tab_m1, double* out0, double* out1, void* stream);
+
+/* The same two-term rows where the cross blocks coincide, K_10 = K_01 -- create_cov's prior is symmetric (kernels.py:181-195: block
+ * (i, j) = W[i][j] k_cross(l_i, l_j) with W symmetric and every cross kernel even in the exchange of its lengths) -- as THREE products
+ * per mode instead of four:
+ *     out_0 = T(tab_d0) in_g + T(tab_x)(in_g + in_m),     out_1 = T(tab_d1) in_m + T(tab_x)(in_g + in_m)
+ * with tab_x = the shared generator t_01, tab_d0 = t_00 - t_01, tab_d1 = t_11 - t_01 (formed by the caller, once per step).  Eight waves
+ * of two sizes -- four own a half of the outputs of a difference product, four a quarter of the shared one -- so that every SIMD issues
+ * 3/4 of the multiply-adds of geobo_toeplitz_y2t; the shared sums reach their two consumers through a dedicated exchange area
+ * (the kernel takes all 160 KiB of a CU's LDS at ny = 64).  Same shapes and errors as geobo_toeplitz_y2t. */
+int geobo_toeplitz_y2s(int ny, int64_t C, int64_t plane, int64_t R, const double* in_g, const double* in_m, const double* tab_d0,
+                       const double* tab_x, const double* tab_d1, double* out0, double* out1, void* stream);
 
 /* The same stage for up to THREE property blocks per sweep of the input (tabs / outs: HOST arrays of nprop device pointers) and
  * for ny in {80, 96, 112, 128} (128: BASELINE config 5, 128^3 x 3 properties): there the ny table values of a mode no longer fit a

@@ -554,6 +554,42 @@ def test_toeplitz_y2t_matches_torch(hip, ny, C, R):
         assert torch.equal(outp[j][:, :, :C], outs[j]) and bool((outp[j][:, :, C:] == 7.0).all())
 
 
+@pytest.mark.parametrize("ny,C,R", [(64, 256, 5), (64, 16384, 37), (48, 128, 9), (32, 1024, 70), (64, 128, 1), (64, 512, 23)])
+def test_toeplitz_y2s_matches_torch(hip, ny, C, R):
+    # two-term rows with a shared cross block (K_10 = K_01) as three products: out_0 = T(d0) g + T(x)(g + m), out_1 = T(d1) m + T(x)(g + m);
+    # waves of two sizes, a dedicated exchange area (all 160 KiB of LDS at ny = 64), two barriers per row; NaN-poisoned outputs, many
+    # rows per workgroup, a padded plane stride -- and against the four-product kernel on the tables it stands for
+    src_g, src_m = _rand((R, ny, C), 41), _rand((R, ny, C), 42)
+    t00, t01, t11 = (_rand((ny, C), 43 + j) for j in range(3))
+    d0, d1 = t00 - t01, t11 - t01
+    flat = lambda t: t.reshape(-1)
+    outs = [torch.full((R, ny, C), float("nan"), dtype=torch.float64, device="cuda") for _ in range(2)]
+    hip.toeplitz_y2s(ny, C, R, flat(src_g), flat(src_m), flat(d0), flat(t01), flat(d1), [flat(o) for o in outs])
+    torch.cuda.synchronize()
+    idx = (torch.arange(ny)[:, None] - torch.arange(ny)[None, :]).abs().cuda()
+    ref = [torch.einsum("ypc,rpc->ryc", t00[idx], src_g) + torch.einsum("ypc,rpc->ryc", t01[idx], src_m),
+           torch.einsum("ypc,rpc->ryc", t01[idx], src_g) + torch.einsum("ypc,rpc->ryc", t11[idx], src_m)]
+    for j in range(2):
+        assert normwise(outs[j].cpu().numpy(), ref[j].cpu().numpy()) < 1e-14
+    four = [torch.empty((R, ny, C), dtype=torch.float64, device="cuda") for _ in range(2)]
+    hip.toeplitz_y2t(ny, C, R, flat(src_g), flat(src_m), [flat(t00), flat(t01)], [flat(t01), flat(t11)], [flat(o) for o in four])
+    for j in range(2):
+        assert normwise(outs[j].cpu().numpy(), four[j].cpu().numpy()) < 1e-14
+    again = [torch.full((R, ny, C), float("nan"), dtype=torch.float64, device="cuda") for _ in range(2)]
+    hip.toeplitz_y2s(ny, C, R, flat(src_g), flat(src_m), flat(d0), flat(t01), flat(d1), [flat(o) for o in again])
+    for j in range(2):
+        assert torch.equal(again[j], outs[j])            # the exchange is ordered by barriers, not by timing: bit-reproducible
+    S = C + 256
+    gp, mp = (torch.full((R, ny, S), float("nan"), dtype=torch.float64, device="cuda") for _ in range(2))
+    gp[:, :, :C], mp[:, :, :C] = src_g, src_m
+    outp = [torch.full((R, ny, S), 7.0, dtype=torch.float64, device="cuda") for _ in range(2)]
+    hip.toeplitz_y2s(ny, C, R, flat(gp), flat(mp), flat(d0), flat(t01), flat(d1), [flat(o) for o in outp], plane=S)
+    for j in range(2):
+        assert torch.equal(outp[j][:, :, :C], outs[j]) and bool((outp[j][:, :, C:] == 7.0).all())
+    with pytest.raises(RuntimeError):
+        hip.toeplitz_y2s(80, C, R, flat(src_g), flat(src_m), flat(d0), flat(t01), flat(d1), [flat(o) for o in outs])
+
+
 @pytest.mark.parametrize("nx,nz,rows,ppr", [(48, 64, 3, 37), (64, 64, 3, 37), (64, 64, 4, 800), (48, 64, 7, 500), (64, 32, 3, 37),
                                             (64, 32, 5, 900)])
 @pytest.mark.parametrize("inverse", [False, True])

@@ -136,6 +136,15 @@ def soak(seed=0, seconds=None, iters=60, verbose=True):
             e = (o2[j] - ref).abs().max().item() / ref.abs().max().item()
             if not e < 1e-13:
                 bad += 1; print("toeplitz_y2t ny=%d R=%d C=%d err %.3e" % (nyt, Rt, Ct, e), flush=True)
+        # ---- round 5: the same rows with the shared cross block (three products; waves of two sizes, dedicated exchange area) --------
+        o3 = [torch.full((Rt, nyt, Ct), float("nan"), dtype=torch.float64, device="cuda") for _ in range(2)]
+        hip.toeplitz_y2s(nyt, Ct, Rt, sg_.reshape(-1), sm_.reshape(-1), (tg_[0] - tg_[1]).reshape(-1), tg_[1].reshape(-1),
+                         (tm_[1] - tg_[1]).reshape(-1), [o.reshape(-1) for o in o3])
+        for j, (ta, tb) in enumerate(((tg_[0], tg_[1]), (tg_[1], tm_[1]))):
+            ref = torch.einsum("ypc,rpc->ryc", ta[idt], sg_) + torch.einsum("ypc,rpc->ryc", tb[idt], sm_)
+            e = (o3[j] - ref).abs().max().item() / ref.abs().max().item()
+            if not e < 1e-13:
+                bad += 1; print("toeplitz_y2s ny=%d R=%d C=%d err %.3e" % (nyt, Rt, Ct, e), flush=True)
         # ---- round 4: 32 x 32 planes four at a time on the n = 64 radix-2 kernels ---------------------------------------------------
         rq, gq = int(rng.integers(1, 30)), int(rng.integers(1, 12))
         for inverse in (False, True):

@@ -28,3 +28,4 @@ if n > 64:
     timed("toeplitz_y 1 block, 16-plane slab", R * C * 2.0 * n * 16, R * C * 8.0 * (n + 16), lambda: hip.toeplitz_y(n, C, R, src, tabs[:1], outs[:1], 16, 32))
     sys.exit(0)
 timed("toeplitz_y2t", R * C * 2.0 * n * n * 4, R * n * C * 8.0 * 4, lambda: hip.toeplitz_y2t(n, C, R, src, src2, tabs[:2], tabs[2:], outs[:2]))
+timed("toeplitz_y2s (3 products)", R * C * 2.0 * n * n * 3, R * n * C * 8.0 * 4, lambda: hip.toeplitz_y2s(n, C, R, src, src2, tabs[0], tabs[1], tabs[2], outs[:2]))
