@@ -280,6 +280,55 @@ __device__ __forceinline__ void inv_step1r(v2d (&a)[KW], const double (&gz)[KP],
   if constexpr (T + 1 < KP) inv_step1r<KW, T + 1, KP>(a, gz, sgn, d, xs, q, lr);
 }
 
+// ---- radix-4 synthesis along z (round 5; dense planes) ---------------------------------------------------------------------------
+// The basis of spectral.base_modes comes in groups of eight spectral positions 8 w .. 8 w + 7 = the base rows cos w, sin w,
+// cos(n/2 - w), sin(n/2 - w) with their mirrors (w = 1 .. 15; w = 0: cos 0, the middle pair, cos 16, sin 16).  On the outputs
+// z = 4 j + rho of ONE residue class the rows of frequency n/2 -+ w are +-(cos | sin) of frequency w, so
+//     x[4j + rho] = sum_w  g_cos(w)[4j + rho] C'_rho(w) + g_sin(w)[4j + rho] S'_rho(w)
+// with two signed sums C', S' of the eight values of a group (for w = 0: the constant row and the alternating one; tests/
+// test_spectral_cpu.py::test_radix4_synthesis_identity has the signs).  Wave rho of a workgroup owns class rho: per 16-row chunk it
+// reads the same 16 x 16 bytes per lane as the radix-2 form, forms (C', S') for the four frequencies w = t + 4 q of a k-step with
+// six multiply-adds, and issues EIGHT MFMAs against the cos / sin rows of its class where the radix-2 form issues sixteen.
+// The matrix operand is unchanged (the folded pairs (Fe, Fo) of the base rows: g_b[i] = F[b][i >> 1][i & 1]); only the ORDER of the
+// base rows is assumed.  The quad form (four 32 x 32 planes, block-diagonal matrices) keeps radix 2.
+struct R4Lane {
+  double s1, s2, s3;            // wave-uniform signs of class rho
+  double cB, cP, dB, dP, dQ;    // per lane, k-step 0: C' = A + cB B + cP P,  S' = dB B + dP P + dQ Q  (w = 0 in the lanes q == 0)
+  int eP, eQ;                   // 16-byte slots (of the group's four) that feed P and Q
+};
+
+__device__ __forceinline__ R4Lane r4_lane(int rho, int q) {
+  R4Lane c;
+  const double r2 = 1.4142135623730951;
+  c.s1 = (rho & 1) ? -1.0 : 1.0;
+  c.s2 = rho >= 2 ? -1.0 : 1.0;
+  c.s3 = (rho == 1 || rho == 2) ? 1.0 : -1.0;
+  c.eP = (rho & 1) ? 3 : 2;
+  c.eQ = (rho & 1) ? 2 : 3;
+  if (q == 0) {                 // the group of w = 0: C' = A + t1 B,  S' = kP P + kQ Q
+    c.cB = rho < 2 ? 1.0 : -1.0; c.cP = 0.0; c.dB = 0.0;
+    c.dP = rho == 0 ? r2 : rho == 2 ? 0.0 : 1.0;
+    c.dQ = rho == 0 ? 0.0 : rho == 1 ? 1.0 : rho == 2 ? r2 : -1.0;
+  } else {
+    c.cB = 0.0; c.cP = c.s2; c.dB = 1.0; c.dP = 0.0; c.dQ = c.s3;
+  }
+  return c;
+}
+
+// the two signed sums of one group (o[0..3] = the slots A, B, P, Q: pairs (s[2b], s[2b+1]) of the group's four base rows)
+template <bool FIRST>
+__device__ __forceinline__ void r4_sums(const v2d (&o)[4], const R4Lane& c, double& Cp, double& Sp) {
+  const double A_ = __builtin_fma(c.s1, o[0].y, o[0].x), B_ = __builtin_fma(c.s1, o[1].y, o[1].x);
+  const double P_ = __builtin_fma(c.s1, o[2].y, o[2].x), Q_ = __builtin_fma(c.s1, o[3].y, o[3].x);
+  if constexpr (FIRST) {
+    Cp = __builtin_fma(c.cP, P_, __builtin_fma(c.cB, B_, A_));
+    Sp = __builtin_fma(c.dQ, Q_, __builtin_fma(c.dP, P_, c.dB * B_));
+  } else {
+    Cp = __builtin_fma(c.s2, P_, A_);
+    Sp = __builtin_fma(c.s3, Q_, B_);
+  }
+}
+
 template <int N, int RING>
 struct InvCfg {
   static constexpr int NW = 4, P = 2 * N, RT = P / 16, KP = N / 4, ROWB = P * 8, CHB = 16 * ROWB, ND = CHB / 1024 / NW;
@@ -308,16 +357,33 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, q = lane >> 4;
-  const int par = w >> 1, jt = w & 1;                         // this wave: outputs z = 2 (16 jt + lane column) + par
+  constexpr bool R4 = !QUAD;                                  // radix-4 synthesis along z: wave w owns the outputs z = 4 (lane column) + w
+  const int par = w >> 1, jt = w & 1;                         // radix 2: outputs z = 2 (16 jt + lane column) + par
 
   for (int idx = tid; idx < N * H; idx += 64 * K::NW) {
     const int bx = idx / H, j = idx % H;
     *reinterpret_cast<v2d*>(mxf + ((j * N + (bx ^ (j & 15))) << 1)) = *reinterpret_cast<const v2d*>(g.Fx + ((int64_t)idx << 1));
   }
-  double gz[KP];                                              // B[k = q][j = lr]: F{e|o}_z[b = 4 t + q][j = 16 jt + lr]
+  double gz[R4 ? 1 : KP];                                     // B[k = q][j = lr]: F{e|o}_z[b = 4 t + q][j = 16 jt + lr]
+  double gzc[4], gzs[4];                                      // radix 4: B[k = q][j = lr] = (cos | sin) row of frequency t + 4 q at z = 4 lr + w
+  if constexpr (R4) {
+    const int i = 4 * lr + w;
 #pragma unroll
-  for (int t = 0; t < KP; ++t) gz[t] = g.Fz[(((int64_t)(4 * t + q) * H + 16 * jt + lr) << 1) + par];
+    for (int t = 0; t < 4; ++t) {
+      const int om = t + 4 * q;
+      const double c = g.Fz[(((int64_t)(4 * om) * H + (i >> 1)) << 1) + (i & 1)];
+      const double sn = g.Fz[(((int64_t)(4 * om + 1) * H + (i >> 1)) << 1) + (i & 1)];
+      gzc[t] = c;
+      gzs[t] = om ? sn : ((lr & 1) ? -c : c);                // frequency 0: the constant row and the alternating one
+    }
+    gz[0] = 0.0;
+  } else {
+#pragma unroll
+    for (int t = 0; t < KP; ++t) gz[t] = g.Fz[(((int64_t)(4 * t + q) * H + 16 * jt + lr) << 1) + par];
+  }
   const double sgn = par ? -1.0 : 1.0;
+  const R4Lane r4 = r4_lane(w, q);
+  const unsigned qlr = (unsigned)((q << 8) | (lr << 4));      // radix 4: slot (16 q + c) ^ lr of row lr = (chunk row base | qlr) ^ (c << 4)
   // step-2 fragments (Fe_x, Fo_x)[bx = 8 rt + 4 h + q][j = 16 m + lr]: row j of the image, slot bx ^ (j & 15) = 16 (rt >> 1) +
   // [(8 (rt & 1) + 4 h + q) ^ lr]  ->  faddr[rt & 1][h] + m * 16 * N * 16 + (rt >> 1) * 256  (one per-lane VGPR + an immediate)
   unsigned faddr[2][2];
@@ -437,7 +503,39 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
       }
       const unsigned xs = ring_lds + ((slot0 + c) % RING) * K::CHB + lr * K::ROWB;
       v4d tc;
-      if constexpr (MUL) {
+      if constexpr (R4) {
+        // (ring_lds is the start of the dynamic LDS segment and the only __shared__ object: bits 4..9 of xs are clear)
+        const unsigned xq = xs | qlr;
+        const unsigned pP = (unsigned)r4.eP << 4, pQ = (unsigned)r4.eQ << 4;
+        v4d d2[2];
+        d2[0] = d2[1] = (v4d){0., 0., 0., 0.};
+        constexpr int NF = MUL ? 2 : 4;                           // groups in flight (MUL: the staged loads need the registers)
+        v2d o[NF][4];
+        auto issue = [&](v2d (&oo)[4], int t) {
+          asm volatile("ds_read_b128 %0, %1" : "=v"(oo[0]) : "v"(xq ^ (unsigned)((4 * t) << 4)));
+          asm volatile("ds_read_b128 %0, %1" : "=v"(oo[1]) : "v"(xq ^ (unsigned)((4 * t + 1) << 4)));
+          asm volatile("ds_read_b128 %0, %1" : "=v"(oo[2]) : "v"(xq ^ ((unsigned)((4 * t) << 4) | pP)));
+          asm volatile("ds_read_b128 %0, %1" : "=v"(oo[3]) : "v"(xq ^ ((unsigned)((4 * t) << 4) | pQ)));
+        };
+#pragma unroll
+        for (int t = 0; t < NF; ++t) issue(o[t], t);
+        static_for<0, 4>([&](auto tt) {
+          constexpr int t = decltype(tt)::value;
+          constexpr int left = 4 * ((t + NF < 4 ? NF : 4 - t) - 1);   // reads still allowed in flight when group t is taken
+          v2d (&ot)[4] = o[t % NF];
+          asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(ot[0]), "+v"(ot[1]), "+v"(ot[2]), "+v"(ot[3]) : "n"(left));
+          double Cp, Sp;
+          r4_sums<t == 0>(ot, r4, Cp, Sp);
+          if constexpr (t + NF < 4) {
+            // (behind the sums: the registers of group t are free only now)
+            asm volatile("" : "+v"(Cp), "+v"(Sp));
+            issue(ot, t + NF);
+          }
+          d2[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(Cp, gzc[t], d2[0], 0, 0, 0);
+          d2[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(Sp, gzs[t], d2[1], 0, 0, 0);
+        });
+        tc = d2[0] + d2[1];
+      } else if constexpr (MUL) {
         constexpr int KH = KP / 2;
         v2d ah[KH];
         v4d d2[2];
@@ -496,7 +594,8 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
       // columns 2 (16 jt + lr) + par: wave pair jt = 1 writes the right half (another plane in the quad form); rows >= N / 2 the bottom half
       int64_t ors = g.out_rs;
       asm volatile("" : "+s"(ors));                           // (per plane: keeps the 16 store offsets from being hoisted into 32 live VGPRs)
-      double* const op = g.out + (p / g.ppr) * g.out_row + (p % g.ppr) * g.out_plane + 2 * lr + par + jt * (out_halfB >> 3) + 2 * q * ors;
+      double* const op = g.out + (p / g.ppr) * g.out_row + (p % g.ppr) * g.out_plane + 2 * q * ors +
+                         (R4 ? 4 * lr + w : 2 * lr + par + jt * (out_halfB >> 3));
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const v4d ev = xe[m][0] + xe[m][1], od = xo[m][0] + xo[m][1];
@@ -513,7 +612,7 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
   if constexpr (RED) {
     // this workgroup's planes all have y = first % ppr (the grid is a multiple of ppr): add its sums to its own partial plane
     __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
-    double* const sp = g.ss + ((int64_t)(blockIdx.x / g.ppr) * g.ppr + (first % g.ppr)) * (N * N) + 2 * (16 * jt + lr) + par;
+    double* const sp = g.ss + ((int64_t)(blockIdx.x / g.ppr) * g.ppr + (first % g.ppr)) * (N * N) + (R4 ? 4 * lr + w : 2 * (16 * jt + lr) + par);
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll

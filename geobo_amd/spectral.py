@@ -30,15 +30,27 @@ SLACK = 4096  # doubles of slack behind every buffer: compute tiles may overhang
 
 
 def base_modes(n):
-    """Base rows b = 0 .. n-1 of the real eigenvector basis of symmetric circulants of size P = 2n, as (kind, omega):
-    cosines omega = 0 .. n/2-1, the middle pair (omega = n/2), sines omega = 1 .. n/2-1.  Every base row g_b comes with its
-    MIRROR row (-1)^z g_b, which is the eigenvector of frequency n - omega (cos) / minus that eigenvector (sin); for the middle
-    frequency the pair is (c + s, c - s) instead of (c, s) -- any rotation inside an eigenspace is as good a basis.
-    Spectral position 2b holds base row b, position 2b+1 its mirror: the two rows differ only in the sign of the odd inputs,
-    which is what the radix-2 (folded) transform kernels exploit -- per pair ONE even-input and ONE odd-input partial sum,
-    outputs E + O and E - O (half the multiply-adds of the plain matrix product)."""
-    h = n // 2
-    return [("cos", b) for b in range(h)] + [("mid", h)] + [("sin", b - h) for b in range(h + 1, n)]
+    """Base rows b = 0 .. n-1 of the real eigenvector basis of symmetric circulants of size P = 2n, as (kind, omega).  Every base row
+    g_b comes with its MIRROR row (-1)^i g_b, which is the eigenvector of frequency n - omega (cos) / minus that eigenvector (sin); for
+    the middle frequency n/2 the pair is (c + s, c - s) instead of (c, s) -- any rotation inside an eigenspace is as good a basis.
+    Spectral position 2b holds base row b, position 2b+1 its mirror: the two rows differ only in the sign of the odd inputs, which is
+    what the radix-2 (folded) transform kernels exploit -- per pair ONE even-input and ONE odd-input partial sum, outputs E + O and
+    E - O (half the multiply-adds of the plain matrix product).
+
+    ORDER (round 5): base rows come in groups of four, one per frequency omega = 0 .. n/4 - 1,
+        b = 4 omega + (0: cos omega, 1: sin omega, 2: cos(n/2 - omega), 3: sin(n/2 - omega)),     omega >= 1
+        b = 0 .. 3: cos 0, the middle pair (n/2), cos(n/4), sin(n/4)
+    so that the eight spectral positions 8 omega .. 8 omega + 7 hold the frequencies omega, n - omega, n/2 - omega, n/2 + omega: the
+    orbit of omega under a shift by a QUARTER period.  On the inputs i = 4j + rho of one residue class the rows of frequency
+    n/2 -+ omega are +-(cos | sin) of frequency omega, so a transform needs only the cos / sin rows of omega < n/4 per class
+    (RADIX 4: a quarter of the multiply-adds of the plain product; xz2d_fold.hip uses it for the synthesis along z).  The radix-2
+    kernels see a pair-interleaved basis as before."""
+    assert n % 4 == 0
+    q = n // 4
+    modes = [("cos", 0), ("mid", n // 2), ("cos", q), ("sin", q)]
+    for om in range(1, q):
+        modes += [("cos", om), ("sin", om), ("cos", n // 2 - om), ("sin", n // 2 - om)]
+    return modes
 
 
 def _base_row(kind, om, n):

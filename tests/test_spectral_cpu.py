@@ -25,14 +25,49 @@ def test_pair_interleaved_layout(n):
     alt = 1.0 - 2.0 * (np.arange(n) % 2)
     assert np.array_equal(G[1::2], G[0::2] * alt)                       # row 2b+1 = (-1)^i row 2b, exactly
     modes = base_modes(n)
-    assert len(modes) == n and modes[0] == ("cos", 0) and modes[n // 2] == ("mid", n // 2) and modes[-1] == ("sin", n // 2 - 1)
+    assert len(modes) == n and modes[:4] == [("cos", 0), ("mid", n // 2), ("cos", n // 4), ("sin", n // 4)]
+    assert sorted(modes) == sorted([("cos", w) for w in range(n // 2)] + [("mid", n // 2)] + [("sin", w) for w in range(1, n // 2)])
+    for w in range(1, n // 4):                  # groups of four base rows: the orbit of omega under a quarter-period shift
+        assert modes[4 * w:4 * w + 4] == [("cos", w), ("sin", w), ("cos", n // 2 - w), ("sin", n // 2 - w)]
     # the mirror row carries the eigenvalue of the mirrored frequency n - omega; both rows of the middle pair the same one
     d = np.arange(n)
     for b, (kind, om) in enumerate(modes):
         for pos, w in ((2 * b, om), (2 * b + 1, n - om)):
             want = np.cos(2 * np.pi * ((w * d) % (2 * n)) / (2 * n)) * np.where(d == 0, 1.0, 2.0)
             assert np.abs(Em[pos] - want).max() < 1e-14
-    assert np.array_equal(Em[n], Em[n + 1])
+    assert np.array_equal(Em[2], Em[3])                                 # (the middle pair sits at positions 2, 3)
+
+
+@pytest.mark.parametrize("n", [16, 64])
+def test_radix4_synthesis_identity(n):
+    """What the synthesis along z of xz_fold_inv_kernel computes (radix 4): the outputs i = 4j + rho of residue class rho need, per
+    frequency omega < n/4, ONE cosine and ONE sine row of the basis -- the eight spectral values of the group enter through two
+    signed sums C', S' -- and for omega = 0 the constant row and the alternating one.  Also with a column scaling of the basis (the
+    kernels take the folded matrices as they are handed in)."""
+    rng = np.random.default_rng(4)
+    f = 1.0 + 0.01 * np.arange(n)
+    for scale in (np.ones(n), f):
+        G = forward_matrix(n) * scale[None, :]
+        s = rng.standard_normal(2 * n)
+        ref = G.T @ s
+        got = np.zeros(n)
+        for rho in range(4):
+            i = 4 * np.arange(n // 4) + rho
+            s1 = -1.0 if rho & 1 else 1.0
+            pair = lambda w, k: s[8 * w + 2 * k] + s1 * s[8 * w + 2 * k + 1]          # s[2b] +- s[2b+1] of base row b = 4w + k
+            P, Q = (2, 3) if rho % 2 == 0 else (3, 2)
+            s2, s3 = ((1, -1), (1, 1), (-1, 1), (-1, -1))[rho]
+            for w in range(1, n // 4):
+                C = pair(w, 0) + s2 * pair(w, P)
+                S = pair(w, 1) + s3 * pair(w, Q)
+                got[i] += G[8 * w, i] * C + G[8 * w + 2, i] * S                       # rows cos omega, sin omega on the class
+            t1 = 1.0 if rho < 2 else -1.0
+            kP, kQ = ((np.sqrt(2), 0), (1, 1), (0, np.sqrt(2)), (1, -1))[rho]
+            C0 = pair(0, 0) + t1 * pair(0, 1)
+            S0 = kP * pair(0, P) + kQ * pair(0, Q)
+            alt = 1.0 - 2.0 * (np.arange(n // 4) % 2)
+            got[i] += G[0, i] * C0 + alt * G[0, i] * S0
+        assert np.abs(got - ref).max() < 1e-12
 
 
 @pytest.mark.parametrize("n", [16, 64])
