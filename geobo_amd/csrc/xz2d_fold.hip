@@ -75,6 +75,10 @@ int ensure_lds_attr(std::atomic<uint64_t>& done, const void* kern, size_t lds) {
 // row i of a chunk in LDS <- row rowperm(i) of the chunk in memory: D register reg = i >> 2 of lane group q = i & 3
 __device__ __forceinline__ int rowperm(int i) { return 8 * (i >> 3) + 2 * (i & 3) + ((i >> 2) & 1); }
 
+// radix-4 analysis along the row axis (round 5): D register reg of lane group q holds row 4 q + reg of the chunk -- register = residue
+// class of the input row mod 4, so that an MFMA k-step (k = q) contracts four rows of ONE class
+__device__ __forceinline__ int rowperm4(int i) { return 4 * (i & 3) + (i >> 2); }
+
 // ---- forward: X (N x N) -> O (2N x 2N) -------------------------------------------------------------------------------------
 // Register budget (two workgroups per CU = 256 VGPRs per wave): the 16 output accumulator tiles of step 2 (128 VGPRs) stay live for
 // the whole plane and every chunk is carried through BOTH steps before the next one is touched -- T never exists beyond one
@@ -115,10 +119,28 @@ __global__ void __launch_bounds__(256, 2) xz_fold_fwd_kernel(FoldArgs g) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, q = lane >> 4;
 
+  // Radix-4 analysis along x (dense planes; the quad form's block-diagonal matrices keep radix 2).  The inputs x = 4 j + rho of one
+  // residue class need, per frequency w < 16, ONE cosine and ONE sine row of the basis (w = 0: the constant row and the alternating
+  // one): image [rho][w][j] of pairs (cos, sin) taken from the folded matrix as handed in, g_b[i] = Fx[b][i >> 1][i & 1] with the base
+  // rows b = 4 w, 4 w + 1 of spectral.base_modes -- 16 KiB, 16-byte slots XOR-swizzled by w.  Per chunk and class one fragment read
+  // feeds FOUR MFMAs (cos | sin tile x the two columns of the pair): 16 per chunk where the radix-2 form issues 32; the partial sums
+  // of the four classes meet in the plane's epilogue (eight outputs per frequency from eight sums, all in one lane).
+  constexpr bool R4 = !QUAD;
+  if constexpr (R4) {
+    for (int idx = tid; idx < 4 * 16 * 16; idx += 64 * K::NW) {
+      const int rho = idx >> 8, om = (idx >> 4) & 15, j = idx & 15, i = 4 * j + rho;
+      const double c = g.Fx[(((int64_t)(4 * om) * H + (i >> 1)) << 1) + (i & 1)];
+      const double sn = g.Fx[(((int64_t)(4 * om + 1) * H + (i >> 1)) << 1) + (i & 1)];
+      *reinterpret_cast<v2d*>(mxf + ((((rho * 16 + om) * 16) + (j ^ om)) << 1)) = (v2d){c, om ? sn : ((j & 1) ? -c : c)};
+    }
+  } else {
   for (int idx = tid; idx < N * H; idx += 64 * K::NW) {
     const int bx = idx / H, j = idx % H;
     *reinterpret_cast<v2d*>(mxf + ((bx * H + (j ^ (bx & 15))) << 1)) = *reinterpret_cast<const v2d*>(g.Fx + ((int64_t)idx << 1));
   }
+  }
+  // radix 4: fragment of class rho for chunk c (k = q <-> j = 4 c + q) at fx4 ^ (c << 6) + rho * 4096
+  const unsigned fx4 = mxf_lds + lr * 256 + (((lr & 12) | (q ^ (lr & 3))) << 4);
   double gE[KP], gO[KP];                                      // B[k = q][j = lr]: F?_z[b = 16 w + lr][j = 4 t + q]
 #pragma unroll
   for (int t = 0; t < KP; ++t) {
@@ -146,7 +168,7 @@ __global__ void __launch_bounds__(256, 2) xz_fold_fwd_kernel(FoldArgs g) {
   for (int j = 0; j < K::ND; ++j) {
     const int row = (w + K::NW * j) * K::RPI + drow;          // LDS row of the chunk <- memory row rowperm(row)
     const int sl = dpos ^ (row & 15);                         // 16-byte slot of the kernel row (LPR slots; the right half may be another plane)
-    doff[j] = rowperm(row) * in_rowB + ((sl & (K::LPR / 2 - 1)) << 4) + (sl / (K::LPR / 2)) * in_halfB;
+    doff[j] = (R4 ? rowperm4(row) : rowperm(row)) * in_rowB + ((sl & (K::LPR / 2 - 1)) << 4) + (sl / (K::LPR / 2)) * in_halfB;
   }
   const int in_chunkB = 16 * in_rowB;
   auto plane_ptr = [&](int64_t p) {
@@ -176,6 +198,7 @@ __global__ void __launch_bounds__(256, 2) xz_fold_fwd_kernel(FoldArgs g) {
     const int64_t pn = p + pstep < g.nplanes ? p + pstep : p;
     const char* nxt = plane_ptr(pn);
     v4d e2[MT][2], o2[MT][2];                                 // [base row tile][column 2b | 2b+1]: even-row / odd-row partial sums
+    // (radix 4: e2[rho][v] = cosine tile, o2[rho][v] = sine tile of class rho, column variant v)
 #pragma unroll
     for (int m = 0; m < MT; ++m) e2[m][0] = e2[m][1] = o2[m][0] = o2[m][1] = (v4d){0., 0., 0., 0.};
     static_for<0, RT>([&](auto cc) {
@@ -188,8 +211,11 @@ __global__ void __launch_bounds__(256, 2) xz_fold_fwd_kernel(FoldArgs g) {
         else stage(nxt, cn - RT, cn % RING);
       }
       // ---- step 1 on chunk c: E over even inputs, O over odd inputs, two chains each ----------------------------------------
-      v4d e[2], o[2];
-      e[0] = e[1] = o[0] = o[1] = (v4d){0., 0., 0., 0.};
+      // (E and O alternate, so one accumulator each is two chains: a dependent fp64 MFMA issues back to back; radix 4 needs the
+      // registers a second pair would take)
+      v4d e[R4 ? 1 : 2], o[R4 ? 1 : 2];
+#pragma unroll
+      for (int i = 0; i < (R4 ? 1 : 2); ++i) e[i] = o[i] = (v4d){0., 0., 0., 0.};
       static_for<0, 2>([&](auto hb) {                         // two batches of four fragment reads (16 VGPRs in flight)
         constexpr int t0 = 4 * decltype(hb)::value;
         v2d a[4];
@@ -198,12 +224,29 @@ __global__ void __launch_bounds__(256, 2) xz_fold_fwd_kernel(FoldArgs g) {
         static_for<0, 4>([&](auto tt) {
           constexpr int t = decltype(tt)::value;
           asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a[t]) : "n"(3 - t));
-          e[t & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t].x, gE[t0 + t], e[t & 1], 0, 0, 0);
-          o[t & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t].y, gO[t0 + t], o[t & 1], 0, 0, 0);
+          constexpr int ch = R4 ? 0 : (t & 1);
+          e[ch] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t].x, gE[t0 + t], e[ch], 0, 0, 0);
+          o[ch] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t].y, gO[t0 + t], o[ch], 0, 0, 0);
         });
       });
-      const v4d es = e[0] + e[1], os = o[0] + o[1];
+      v4d es = e[0], os = o[0];
+      if constexpr (!R4) { es += e[1]; os += o[1]; }
       const v4d tp = es + os, tm = es - os;                   // T[rows of the chunk][column 2b], [column 2b+1]
+      if constexpr (R4) {
+        // ---- step 2, radix 4: register rho of T = the chunk's rows of class rho; k = q <-> input 4 c + q of the class ---------------
+        v2d f[4];
+        const unsigned fa = fx4 ^ (unsigned)(c << 6);
+#pragma unroll
+        for (int rho = 0; rho < 4; ++rho) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[rho]) : "v"(fa), "n"(rho * 4096));
+        static_for<0, 4>([&](auto rr) {
+          constexpr int rho = decltype(rr)::value;
+          asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f[rho]) : "n"(3 - rho));
+          e2[rho][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[rho].x, tp[rho], e2[rho][0], 0, 0, 0);
+          e2[rho][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[rho].x, tm[rho], e2[rho][1], 0, 0, 0);
+          o2[rho][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[rho].y, tp[rho], o2[rho][0], 0, 0, 0);
+          o2[rho][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[rho].y, tm[rho], o2[rho][1], 0, 0, 0);
+        });
+      } else
       // ---- step 2, k-steps (c, h): register 2h = even rows -> E2, register 2h+1 = odd rows -> O2 ------------------------------
       static_for<0, 2>([&](auto hh) {
         constexpr int h = decltype(hh)::value;
@@ -225,6 +268,48 @@ __global__ void __launch_bounds__(256, 2) xz_fold_fwd_kernel(FoldArgs g) {
     // wait has this plane's stores between itself and the chunk it waits for
     __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
     char* const op = reinterpret_cast<char*>(g.out + (p / g.ppr) * g.out_row + (p % g.ppr) * g.out_plane) + soff;
+    if constexpr (R4) {
+      // register r of a lane = frequency w = q + 4 r: its eight sums (C_rho, S_rho) give the eight spectral rows 8 w .. 8 w + 7
+      // (cos w, its mirror, sin w, mirror, cos(n/2 - w), mirror, sin(n/2 - w), mirror); w = 0 (lanes q == 0, r = 0): the rows of
+      // frequency 0, n, the middle pair and n/4 from the constant-row sums C and the alternating sums S
+      char* const op4 = op + (size_t)(8 * q) * out_rowB - (size_t)(q * 2) * out_rowB;      // (soff carries rows 2 q of the radix-2 layout)
+      const bool w0 = q == 0;
+      const double r2 = 1.4142135623730951;
+      static_for<0, 4>([&](auto rr_) {
+        constexpr int r = decltype(rr_)::value;
+        // one frequency at a time, stores issued as the rows are formed (left to itself the scheduler interleaves the four
+        // frequencies and spills: the 16 accumulator tiles are still live here)
+        __builtin_amdgcn_sched_barrier(0);
+        v2d u0, u1, v0, v1, ws, wd, z0, z1;                    // [column 2b | 2b+1]
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+          u0[v] = e2[0][v][r] + e2[2][v][r]; u1[v] = e2[0][v][r] - e2[2][v][r];
+          v0[v] = e2[1][v][r] + e2[3][v][r]; v1[v] = e2[1][v][r] - e2[3][v][r];
+          ws[v] = o2[0][v][r] + o2[2][v][r]; wd[v] = o2[0][v][r] - o2[2][v][r];
+          z0[v] = o2[1][v][r] + o2[3][v][r]; z1[v] = o2[1][v][r] - o2[3][v][r];
+        }
+        char* const rowp = op4 + (size_t)(32 * r) * out_rowB;
+        auto put = [&](int k, v2d val) { *reinterpret_cast<v2d*>(rowp + (size_t)k * out_rowB) = val; };
+        put(0, u0 + v0);
+        put(1, u0 - v0);
+        if constexpr (r == 0) {
+          const v2d a0 = (v2d){r2 * o2[0][0][r], r2 * o2[0][1][r]}, a2 = (v2d){r2 * o2[2][0][r], r2 * o2[2][1][r]};
+          put(2, w0 ? u1 + v1 : ws + z0);
+          put(3, w0 ? u1 - v1 : ws - z0);
+          put(4, w0 ? a0 + z1 : u1 + z1);
+          put(5, w0 ? a0 - z1 : u1 - z1);
+          put(6, w0 ? a2 + z0 : v1 - wd);
+          put(7, w0 ? a2 - z0 : -wd - v1);
+        } else {
+          put(2, ws + z0);
+          put(3, ws - z0);
+          put(4, u1 + z1);
+          put(5, u1 - z1);
+          put(6, v1 - wd);
+          put(7, -wd - v1);
+        }
+      });
+    } else
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -315,6 +400,15 @@ __device__ __forceinline__ R4Lane r4_lane(int rho, int q) {
   return c;
 }
 
+// the four 16-byte reads of group T of a row (slots A, B and the class's P, Q); SB: byte offset of the ring slot (an immediate)
+template <int T, int SB>
+__device__ __forceinline__ void r4_issue(v2d (&oo)[4], unsigned xq, unsigned pP, unsigned pQ) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(oo[0]) : "v"(xq ^ (unsigned)((4 * T) << 4)), "n"(SB));
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(oo[1]) : "v"(xq ^ (unsigned)((4 * T + 1) << 4)), "n"(SB));
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(oo[2]) : "v"(xq ^ ((unsigned)((4 * T) << 4) | pP)), "n"(SB));
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(oo[3]) : "v"(xq ^ ((unsigned)((4 * T) << 4) | pQ)), "n"(SB));
+}
+
 // the two signed sums of one group (o[0..3] = the slots A, B, P, Q: pairs (s[2b], s[2b+1]) of the group's four base rows)
 template <bool FIRST>
 __device__ __forceinline__ void r4_sums(const v2d (&o)[4], const R4Lane& c, double& Cp, double& Sp) {
@@ -347,9 +441,18 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
   constexpr bool RED = MODE == 1, MUL = MODE == 2;
   const int in_rowB = QUAD ? g.in_rowB : 2 * N * 8, in_halfB = QUAD ? g.in_halfB : N * 8, in_botB = QUAD ? g.in_botB : 0;
   const int out_halfB = QUAD ? g.out_halfB : N * 4, out_botB = QUAD ? g.out_botB : 0;
-  constexpr int RING = 3;
+  // Radix 4 (dense planes) along BOTH axes: along z wave w owns the outputs z = 4 (lane column) + w; along x (the spectral rows of a
+  // plane) the chunks come in pairs -- the 32 rows of a pair are four groups of eight spectral positions, and lane group q holds one
+  // whole group in the four D registers of the pair's two chunks (the DMA gathers the rows accordingly: chunk 2 c' + h takes rows
+  // 32 c' + 8 q + 4 h + r into LDS row q + 4 r).  The signed sums (C', S') of the four output classes x = 4 j + rho are formed in the
+  // lane and contracted against the class's cos / sin rows: 8 MFMAs per pair where the radix-2 form issues 16.  The class image of
+  // the x matrix is 16 KiB (the radix-2 image 32): the ring takes a FOURTH slot in the same 80 KiB -- three chunks in flight per
+  // workgroup instead of two (the kernel is bound by the loads it can keep outstanding).
+  constexpr bool R4 = !QUAD;
+  constexpr int RING = R4 ? 4 : 3;
   using K = InvCfg<N, RING>;
   constexpr int RT = K::RT, KP = K::KP, MT = K::MT, H = N / 2;
+  static_assert((size_t)RING * K::CHB + (R4 ? 16384 : N * N * 8) <= InvCfg<N, 3>::LDS, "LDS");
   extern __shared__ __attribute__((aligned(16))) double smem[];
   char* const ring = reinterpret_cast<char*>(smem);
   double* const mxf = smem + RING * K::CHB / 8;               // [N/2 output pairs j][N slots bx of (Fe, Fo)[bx][j]], slots XOR row & 15
@@ -357,13 +460,24 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, q = lane >> 4;
-  constexpr bool R4 = !QUAD;                                  // radix-4 synthesis along z: wave w owns the outputs z = 4 (lane column) + w
   const int par = w >> 1, jt = w & 1;                         // radix 2: outputs z = 2 (16 jt + lane column) + par
 
+  if constexpr (R4) {
+    // image [rho][j][w] of pairs (cos, sin): rows of frequency w at the outputs x = 4 j + rho (w = 0: constant and alternating row)
+    for (int idx = tid; idx < 4 * 16 * 16; idx += 64 * K::NW) {
+      const int rho = idx >> 8, j = (idx >> 4) & 15, om = idx & 15, i = 4 * j + rho;
+      const double c = g.Fx[(((int64_t)(4 * om) * H + (i >> 1)) << 1) + (i & 1)];
+      const double sn = g.Fx[(((int64_t)(4 * om + 1) * H + (i >> 1)) << 1) + (i & 1)];
+      *reinterpret_cast<v2d*>(mxf + ((((rho * 16 + j) * 16) + (om ^ j)) << 1)) = (v2d){c, om ? sn : ((j & 1) ? -c : c)};
+    }
+  } else {
   for (int idx = tid; idx < N * H; idx += 64 * K::NW) {
     const int bx = idx / H, j = idx % H;
     *reinterpret_cast<v2d*>(mxf + ((j * N + (bx ^ (j & 15))) << 1)) = *reinterpret_cast<const v2d*>(g.Fx + ((int64_t)idx << 1));
   }
+  }
+  // radix 4: fragment of class rho for the chunk pair c' (k = q <-> frequency 4 c' + q) at fx4 ^ (c' << 6) + rho * 4096
+  const unsigned fx4 = (unsigned)(uintptr_t)(lds_ptr_t)mxf + lr * 256 + (((lr & 12) | (q ^ (lr & 3))) << 4);
   double gz[R4 ? 1 : KP];                                     // B[k = q][j = lr]: F{e|o}_z[b = 4 t + q][j = 16 jt + lr]
   double gzc[4], gzs[4];                                      // radix 4: B[k = q][j = lr] = (cos | sin) row of frequency t + 4 q at z = 4 lr + w
   if constexpr (R4) {
@@ -383,7 +497,8 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
   }
   const double sgn = par ? -1.0 : 1.0;
   const R4Lane r4 = r4_lane(w, q);
-  const unsigned qlr = (unsigned)((q << 8) | (lr << 4));      // radix 4: slot (16 q + c) ^ lr of row lr = (chunk row base | qlr) ^ (c << 4)
+  // radix 4: slot (16 q + c) ^ lr of row lr of ring slot s = (xq0 ^ (c << 4)) + s * CHB
+  const unsigned xq0 = ring_lds + lr * K::ROWB + (unsigned)((q << 8) | (lr << 4));
   // step-2 fragments (Fe_x, Fo_x)[bx = 8 rt + 4 h + q][j = 16 m + lr]: row j of the image, slot bx ^ (j & 15) = 16 (rt >> 1) +
   // [(8 (rt & 1) + 4 h + q) ^ lr]  ->  faddr[rt & 1][h] + m * 16 * N * 16 + (rt >> 1) * 256  (one per-lane VGPR + an immediate)
   unsigned faddr[2][2];
@@ -407,7 +522,8 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
     for (int j = 0; j < K::ND; ++j) {
       const int row = w + K::NW * j;                          // one 1-KiB row per DMA instruction
       const int sl = lane ^ (row & 15);
-      const char* src = reinterpret_cast<const char*>(plane) + (int64_t)(16 * c + rowperm(row)) * in_rowB + (c >= RT / 2 ? in_botB : 0) +
+      const int mrow = R4 ? 32 * (c >> 1) + 8 * (row & 3) + 4 * (c & 1) + (row >> 2) : 16 * c + rowperm(row);
+      const char* src = reinterpret_cast<const char*>(plane) + (int64_t)mrow * in_rowB + (c >= RT / 2 ? in_botB : 0) +
                         ((sl & 31) << 4) + (sl >> 5) * in_halfB;
       __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(ring + slot * K::CHB + row * 1024), 16, 0, 0);
     }
@@ -431,13 +547,14 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
 #pragma unroll
   for (int j = 0; j < K::ND; ++j) {
     const int row = w + K::NW * j;
-    fo[j] = (unsigned)(rowperm(row) * K::ROWB + ((lane ^ (row & 15)) << 4));
+    fo[j] = (unsigned)((R4 ? 8 * (row & 3) + (row >> 2) : rowperm(row)) * K::ROWB + ((lane ^ (row & 15)) << 4));
   }
   auto fetch = [&](rsrc_t ra, rsrc_t rb, int c) {
+    const int cb = R4 ? (32 * (c >> 1) + 4 * (c & 1)) * K::ROWB : c * K::CHB;     // first row of the chunk's gather
 #pragma unroll
     for (int j = 0; j < K::ND; ++j) {
-      fa[c & 1][j] = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(ra, fo[j], c * K::CHB, 0));
-      fb[c & 1][j] = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(rb, fo[j], c * K::CHB, 0));
+      fa[c & 1][j] = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(ra, fo[j], cb, 0));
+      fb[c & 1][j] = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(rb, fo[j], cb, 0));
     }
   };
   auto commit = [&](int c, int slot) {
@@ -474,9 +591,10 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
     // through BOTH contractions before the next one is touched (round 4; like the forward kernel).  With step 2 as one burst of 64
     // MFMAs at the end of the plane the chunk stream ran dry behind every plane (only RING - 1 chunks of the next plane are requested
     // during the burst): 55-64 % MFMA busy.  Terms of a two-term row simply accumulate (both contractions are linear).
-    v4d xe[MT][2], xo[MT][2];
+    v4d xe[MT][2], xo[MT][2];                                 // (radix 4: xe[rho >> 1][rho & 1] = the outputs x = 4 j + rho)
 #pragma unroll
     for (int m = 0; m < MT; ++m) xe[m][0] = xe[m][1] = xo[m][0] = xo[m][1] = (v4d){0., 0., 0., 0.};
+    v4d tcA = (v4d){0., 0., 0., 0.};                          // radix 4: step-1 result of the pair's first chunk
     for (int term = 0; term < nt; ++term) {
     const bool last_term = term + 1 == nt;
     const int64_t pn = last_term ? (p + pstep < g.nplanes ? p + pstep : p) : p;
@@ -504,21 +622,24 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
       const unsigned xs = ring_lds + ((slot0 + c) % RING) * K::CHB + lr * K::ROWB;
       v4d tc;
       if constexpr (R4) {
-        // (ring_lds is the start of the dynamic LDS segment and the only __shared__ object: bits 4..9 of xs are clear)
-        const unsigned xq = xs | qlr;
+        // (ring_lds is the start of the dynamic LDS segment and the only __shared__ object: bits 4..9 of a row's address are clear.
+        // RT % RING == 0: the ring slot of chunk c is c % RING for every plane -- an immediate; the per-lane part is made opaque per
+        // chunk, or the 128 read addresses of a plane are hoisted out of the plane loop as loop invariants and spill)
+        static_assert(RT % RING == 0, "ring slot = chunk index");
+        unsigned xq = xq0;
+        asm volatile("" : "+v"(xq));
+        constexpr int SB = (c % RING) * K::CHB;
         const unsigned pP = (unsigned)r4.eP << 4, pQ = (unsigned)r4.eQ << 4;
         v4d d2[2];
         d2[0] = d2[1] = (v4d){0., 0., 0., 0.};
         constexpr int NF = MUL ? 2 : 4;                           // groups in flight (MUL: the staged loads need the registers)
         v2d o[NF][4];
-        auto issue = [&](v2d (&oo)[4], int t) {
-          asm volatile("ds_read_b128 %0, %1" : "=v"(oo[0]) : "v"(xq ^ (unsigned)((4 * t) << 4)));
-          asm volatile("ds_read_b128 %0, %1" : "=v"(oo[1]) : "v"(xq ^ (unsigned)((4 * t + 1) << 4)));
-          asm volatile("ds_read_b128 %0, %1" : "=v"(oo[2]) : "v"(xq ^ ((unsigned)((4 * t) << 4) | pP)));
-          asm volatile("ds_read_b128 %0, %1" : "=v"(oo[3]) : "v"(xq ^ ((unsigned)((4 * t) << 4) | pQ)));
-        };
-#pragma unroll
-        for (int t = 0; t < NF; ++t) issue(o[t], t);
+        r4_issue<0, SB>(o[0], xq, pP, pQ);
+        r4_issue<1, SB>(o[1], xq, pP, pQ);
+        if constexpr (NF == 4) {
+          r4_issue<2, SB>(o[2], xq, pP, pQ);
+          r4_issue<3, SB>(o[3], xq, pP, pQ);
+        }
         static_for<0, 4>([&](auto tt) {
           constexpr int t = decltype(tt)::value;
           constexpr int left = 4 * ((t + NF < 4 ? NF : 4 - t) - 1);   // reads still allowed in flight when group t is taken
@@ -529,7 +650,7 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
           if constexpr (t + NF < 4) {
             // (behind the sums: the registers of group t are free only now)
             asm volatile("" : "+v"(Cp), "+v"(Sp));
-            issue(ot, t + NF);
+            r4_issue<t + NF, SB>(ot, xq, pP, pQ);
           }
           d2[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(Cp, gzc[t], d2[0], 0, 0, 0);
           d2[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(Sp, gzs[t], d2[1], 0, 0, 0);
@@ -556,6 +677,38 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
       inv_step1<KP, 0>(a, gz, sgn, d);
       tc = (d[0] + d[1]) + (d[2] + d[3]);
       }
+      if constexpr (R4) {
+        // ---- step 2, radix 4, on the second chunk of a pair: the lane's group of eight = registers 0..3 of both chunks -------------
+        if constexpr ((c & 1) == 0) {
+          tcA = tc;
+        } else {
+          constexpr int cp = c >> 1;
+          v2d f[4];
+          const unsigned fa4 = fx4 ^ (unsigned)(cp << 6);
+#pragma unroll
+          for (int rho = 0; rho < 4; ++rho) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[rho]) : "v"(fa4), "n"(rho * 4096));
+          const double Ap = tcA[0] + tcA[1], Am = tcA[0] - tcA[1], Bp = tcA[2] + tcA[3], Bm = tcA[2] - tcA[3];
+          const double Pp = tc[0] + tc[1], Pm = tc[0] - tc[1], Qp = tc[2] + tc[3], Qm = tc[2] - tc[3];
+          double Cs[4] = {Ap + Pp, Am + Qm, Ap - Pp, Am - Qm};
+          double Ss[4] = {Bp - Qp, Bm + Pm, Bp + Qp, Bm - Pm};
+          if constexpr (cp == 0) {
+            // frequency 0 (lanes q == 0): C' = A +- B,  S' = sqrt(2) P+ | P- + Q- | sqrt(2) Q+ | Q- - P-
+            const bool w0 = q == 0;
+            const double r2 = 1.4142135623730951;
+            Cs[0] = w0 ? Ap + Bp : Cs[0]; Cs[1] = w0 ? Am + Bm : Cs[1]; Cs[2] = w0 ? Ap - Bp : Cs[2]; Cs[3] = w0 ? Am - Bm : Cs[3];
+            Ss[0] = w0 ? r2 * Pp : Ss[0]; Ss[1] = w0 ? Pm + Qm : Ss[1]; Ss[2] = w0 ? r2 * Qp : Ss[2]; Ss[3] = w0 ? Qm - Pm : Ss[3];
+          }
+          static_for<0, 4>([&](auto rr) {
+            constexpr int rho = decltype(rr)::value;
+            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f[rho]) : "n"(3 - rho));
+            xe[rho >> 1][rho & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[rho].x, Cs[rho], xe[rho >> 1][rho & 1], 0, 0, 0);
+          });
+          static_for<0, 4>([&](auto rr) {
+            constexpr int rho = decltype(rr)::value;
+            xe[rho >> 1][rho & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[rho].y, Ss[rho], xe[rho >> 1][rho & 1], 0, 0, 0);
+          });
+        }
+      } else
       // ---- step 2 on the chunk's rows: row pairs (2 bx, 2 bx + 1) sit in registers (2h, 2h+1): U = sum, V = difference; even output
       //      rows from U with Fe_x, odd ones from V with Fo_x.  The fragment reads are issued behind step 1's (their latency runs under
       //      the tail of its MFMAs) and are inline asm: for LDS reads it can see the compiler drains every outstanding LDS-DMA first.
@@ -581,7 +734,13 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
     curA = nxtA;
     curB = nxtB;
     }   // terms
-    if constexpr (RED) {
+    if constexpr (RED && R4) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        sse[m] += xe[m][0] * xe[m][0];                          // (sse[m] <-> class 2 m, sso[m] <-> class 2 m + 1)
+        sso[m] += xe[m][1] * xe[m][1];
+      }
+    } else if constexpr (RED) {
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const v4d ev = xe[m][0] + xe[m][1], od = xo[m][0] + xo[m][1];
@@ -596,6 +755,14 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
       asm volatile("" : "+s"(ors));                           // (per plane: keeps the 16 store offsets from being hoisted into 32 live VGPRs)
       double* const op = g.out + (p / g.ppr) * g.out_row + (p % g.ppr) * g.out_plane + 2 * q * ors +
                          (R4 ? 4 * lr + w : 2 * lr + par + jt * (out_halfB >> 3));
+      if constexpr (R4) {
+        // output row x = 4 (q + 4 r) + rho: the lane part 4 q sits in op4
+        double* const op4 = op + (int64_t)(2 * q) * ors;        // (op carries rows 2 q of the radix-2 layout)
+#pragma unroll
+        for (int rho = 0; rho < 4; ++rho)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) op4[(int64_t)(16 * r + rho) * ors] = xe[rho >> 1][rho & 1][r];
+      } else
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const v4d ev = xe[m][0] + xe[m][1], od = xo[m][0] + xo[m][1];
@@ -617,9 +784,15 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
     for (int m = 0; m < MT; ++m)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
+        if constexpr (R4) {
+          const int x0 = 4 * (q + 4 * r) + 2 * m;             // classes 2 m (sse) and 2 m + 1 (sso)
+          sp[(int64_t)x0 * N] += sse[m][r];
+          sp[(int64_t)(x0 + 1) * N] += sso[m][r];
+        } else {
         const int j = 16 * m + q + 4 * r;
         sp[(int64_t)(2 * j) * N] += sse[m][r];
         sp[(int64_t)(2 * j + 1) * N] += sso[m][r];
+        }
       }
   }
 }
