@@ -93,8 +93,9 @@ def synthetic_inputs(inv, md):
 
 
 PMC_FILES = {"ak_fused_grid": "r01_pmc_ak_fused_grid_v2.json", "posterior_reduce": "r03_pmc_posterior_reduce.json",
-             "k_block_grid": "r03_pmc_k_block_grid_f64.json", "toeplitz_y": "r05_pmc_toeplitz_y.json", "toeplitz_y2t": "r05_pmc_toeplitz_y2t.json"}
-PMC_VALU_FILES = {"toeplitz_y": "r05_pmc_toeplitz_y_valu.json", "toeplitz_y2t": "r05_pmc_toeplitz_y2t_valu.json"}
+             "k_block_grid": "r03_pmc_k_block_grid_f64.json", "toeplitz_y": "r05_pmc_toeplitz_y.json", "toeplitz_y2t": "r05_pmc_toeplitz_y2t.json", "toeplitz_y2s": "r05_pmc_toeplitz_y2s.json"}
+PMC_VALU_FILES = {"toeplitz_y": "r05_pmc_toeplitz_y_valu.json", "toeplitz_y2t": "r05_pmc_toeplitz_y2t_valu.json",
+                  "toeplitz_y2s": "r05_pmc_toeplitz_y2s_valu.json"}
 GPU_DENSE_ROUTE = "profiles/r01_bench64_dense.json"   # builder-run bench line of `--method dense` (same algorithm as the CPU sample)
 
 
@@ -473,7 +474,7 @@ def main():
             # FMA flop of the mean launch: ny per output element and term (one-term launches: two of the three streams are outputs)
             vflop = d["valu"] / calls if d["valu"] > 0 else 2.0 * eng.ny * (by / 8.0) * (2.0 / 3.0)
             traffic, tsrc = None, None
-            pmc_key = dom.split(":")[1].replace("y2s", "y2t")      # (no counter pass of the three-product kernel: same streams as y2t)
+            pmc_key = dom.split(":")[1]
             for pf in (PMC_FILES[pmc_key], PMC_FILES[pmc_key].replace("r05_", "r04_")):
                 try:
                     p = json.load(open(os.path.join(ROOT, "profiles", pf)))

@@ -310,9 +310,11 @@ class LatticeGram:
     def flops(self, rows, Ly=None):
         nx, ny, nz, Px, Py = self.nx, self.ny, self.nz, self.Px, self.Py
         Ly = ny if Ly is None else Ly
-        h = 0.5 if (self.sp.fold and nx == nz == 64) else 1.0     # radix-2 x step and back-transform: half the MFMAs of the plain products
+        f = self.sp.fold and nx == nz == 64
+        h = 0.5 if f else 1.0             # radix-2 x step: half the MFMAs of the plain product
+        hb = 0.25 if f else 1.0           # back-transform on the radix-4 inverse kernel: a quarter
         zsum = 0.0 if self.fast(nx, ny, nz) else 2.0 * Py * Px * nz  # (the stand-alone scaling + channel sum of the batched-GEMM form, fp64 VALU)
-        return rows * (2.0 * (hip.pad_n(Py) * nx * nz * Ly + h * Py * Px * nx * nz + h * (ny * Py * Px + ny * nx * Px)) + zsum)
+        return rows * (2.0 * (hip.pad_n(Py) * nx * nz * Ly + h * Py * Px * nx * nz + hb * (ny * Py * Px + ny * nx * Px)) + zsum)
 
     def gram_rows(self, X, nrows, lam, out, y0=0, y1=None):
         """out[r, :ny*nx] = interior-slab part of (A K)[r] . A^T for r < nrows.  X: (>= nrows x >= (y1-y0)*nx*nz) rows of A K for

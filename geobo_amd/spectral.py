@@ -311,7 +311,10 @@ class SpectralProduct:
             fwd += 2.0 * ny * Px * Pz * nx
             bwd += 2.0 * slab * nx * Pz * Px
         if self.fused_xz and self.fold and "x" in self.F and nx == nz:
-            fwd, bwd = 0.5 * fwd, 0.5 * bwd         # radix-2 kernels: one even-input and one odd-input sum per spectral pair
+            # radix-2 / radix-4 kernels (xz2d_fold.hip): forward z step one even- and one odd-input sum per spectral pair (half the plain
+            # multiply-adds), forward x step and both inverse steps one cos / sin row per frequency group and residue class (a quarter)
+            fwd = 2.0 * ny * (0.5 * nx * pn(Pz) * nz + 0.25 * pn(Px) * pn(Pz) * nx)
+            bwd = 0.25 * bwd
         if self.dense_y:
             # ny <= 64: the kernel computes every output y and stores the slab; ny = 128: chunks of 16 outputs covering the slab
             bwd += 2.0 * ny * (ny if ny <= 64 else (slab + 15) // 16 * 16) * Px * Pz
@@ -510,8 +513,8 @@ class SpectralProduct:
         """Executed flop of reduce_ss: rows_one one-term rows, rows_two two-term rows (forward + y stage per term, one second
         inverse step per row; the first inverse step per term)."""
         nx, ny, nz, Px, Pz = self.nx, self.ny, self.nz, self.Px, self.Pz
-        fwd = 1.0 * ny * (nx * nz * Pz + Px * nx * Pz)                 # folded: half the plain products
+        fwd = 1.0 * ny * (nx * nz * Pz + 0.5 * Px * nx * Pz)           # radix 2 along z (half the plain products), radix 4 along x (a quarter)
         toe = 2.0 * ny * ny * Px * Pz
-        inv1, inv2 = 1.0 * ny * Px * Pz * nz, 1.0 * ny * nx * Px * nz
+        inv1, inv2 = 0.5 * ny * Px * Pz * nz, 0.5 * ny * nx * Px * nz  # radix 4 both ways
         terms = rows_one + 2 * rows_two
         return terms * (fwd + nblocks * (toe + inv1)) + (rows_one + rows_two) * nblocks * inv2

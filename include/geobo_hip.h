@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GEOBO_VERSION 209 /* 201: flag word of geobo_gemm_nt, (64, 32) instance of geobo_xz2d, workspace layout of geobo_potrf_inv; 202: geobo_ymul, geobo_xz2d_fold_lattice; 203: geobo_sumsq_accum, geobo_lamdot_z, geobo_toeplitz_y2t, geobo_xz2d_fold_quad; 204: geobo_toeplitz_y3_add; 205: workspace layout of geobo_potrf_inv (one T buffer per tree node); 206: geobo_potrf_inv as one persistent tile-DAG launch from m = 1024 (workspace: + counters); 207: geobo_gemm_fold; 208: geobo_gemm_fold_lamdot; 209: geobo_toeplitz_y2s */
+#define GEOBO_VERSION 210 /* 201: flag word of geobo_gemm_nt, (64, 32) instance of geobo_xz2d, workspace layout of geobo_potrf_inv; 202: geobo_ymul, geobo_xz2d_fold_lattice; 203: geobo_sumsq_accum, geobo_lamdot_z, geobo_toeplitz_y2t, geobo_xz2d_fold_quad; 204: geobo_toeplitz_y3_add; 205: workspace layout of geobo_potrf_inv (one T buffer per tree node); 206: geobo_potrf_inv as one persistent tile-DAG launch from m = 1024 (workspace: + counters); 207: geobo_gemm_fold; 208: geobo_gemm_fold_lamdot; 209: geobo_toeplitz_y2s; 210: geobo_xz2d_fold* dense planes take the quarter-period group order of the basis (radix 4) */
 
 #define GEOBO_PAD_M 256 /* row padding of M-like dimensions (observation rows)            */
 #define GEOBO_PAD_N 128 /* padding of voxel-like dimensions (columns / contraction index) */
@@ -258,11 +258,19 @@ int geobo_xz2d(int inverse, int nx, int nz, int64_t rows, int planes_per_row, co
                int64_t in_plane, const double* Mx, int64_t ldmx, const double* Mz, int64_t ldmz, double* out,
                int64_t out_row, int64_t out_plane, void* stream);
 
-/* Radix-2 ("folded") form of geobo_xz2d for the pair-interleaved spectral basis (geobo_amd/spectral.py: position 2b = base
+/* Radix-2 / radix-4 ("folded") form of geobo_xz2d for the pair-interleaved spectral basis (geobo_amd/spectral.py: position 2b = base
  * row g_b, position 2b+1 = (-1)^i g_b): per pair one even-input and one odd-input partial sum, outputs E + O and E - O -- half
- * the MFMAs of the plain matrix product on both axes.  Fx, Fz: [n][n/2][2] = (Fe[b][j], Fo[b][j]) = (g_b[2j], g_b[2j+1]) of the
+ * the MFMAs of the plain matrix product.  Fx, Fz: [n][n/2][2] = (Fe[b][j], Fo[b][j]) = (g_b[2j], g_b[2j+1]) of the
  * row axis and of the contiguous axis.  inverse = 0: planes n x n -> 2n x 2n; inverse = 1: 2n x 2n -> n x n (cropped).
- * n = 64 (GEOBO_E_UNSUPPORTED otherwise: use geobo_xz2d); strides even, 16-byte aligned bases. */
+ * n = 64 (GEOBO_E_UNSUPPORTED otherwise: use geobo_xz2d); strides even, 16-byte aligned bases.
+ * BASIS ORDER (version 210).  The dense-plane entry points (this one, _lattice, _inv_ss, _inv_strided, _inv_mul) additionally take
+ * the base rows in the order of spectral.base_modes -- groups of four per frequency w < n/4: b = 4w + (cos w, sin w, cos(n/2 - w),
+ * sin(n/2 - w)); b = 0..3: cos 0, the middle pair, cos(n/4), sin(n/4) -- so that the eight spectral positions 8w .. 8w+7 are the orbit
+ * of w under a quarter-period shift.  On the inputs / outputs i = 4j + rho of one residue class the rows of frequency n/2 -+ w are
+ * +-(cos | sin) of frequency w: the forward x step and both inverse steps contract ONE cosine and ONE sine row per group and class
+ * (RADIX 4, a quarter of the plain multiply-adds; the forward z step stays radix 2) and meet the eight values of a group through
+ * signed sums in one lane.  Only rows b = 4w and 4w + 1 of F are read on those steps (w = 0: row 0 and its alternating-sign copy);
+ * a column scaling of the basis (F = folded(G diag(f))) is honoured.  geobo_xz2d_fold_quad (block-diagonal matrices) is radix 2. */
 int geobo_xz2d_fold(int inverse, int n, int64_t rows, int planes_per_row, const double* in, int64_t in_row, int64_t in_plane,
                     const double* Fx, const double* Fz, double* out, int64_t out_row, int64_t out_plane, void* stream);
 

@@ -25,6 +25,7 @@ DRIVERS = {"posterior": ("run_posterior_once.py", "gemm_f64_kernel<4, 2, 2, 1", 
            "xz2d_bwd": ("run_spectral_kernels_once.py xz2d_bwd", "xz2d_kernel<128, 128, 64, 64>", "pmc_xz2d_bwd.json"),
            "toeplitz": ("run_spectral_kernels_once.py toeplitz", "toeplitz_y_kernel", "pmc_toeplitz_y.json"),
            "toeplitz2t": ("run_spectral_kernels_once.py toeplitz2t", "toeplitz_y2_kernel", "pmc_toeplitz_y2t.json"),
+           "toeplitz2s": ("run_spectral_kernels_once.py toeplitz2s", "toeplitz_y2s_kernel", "pmc_toeplitz_y2s.json"),
            "xcorr": ("run_spectral_kernels_once.py xcorr", "xcorr_kernel", "pmc_xcorr.json"),
            "fold_fwd": ("run_spectral_kernels_once.py fold_fwd", "xz_fold_fwd_kernel", "pmc_xz2d_fold_fwd.json"),
            "fold_bwd": ("run_spectral_kernels_once.py fold_bwd", "xz_fold_inv_kernel", "pmc_xz2d_fold_bwd.json"),

@@ -40,25 +40,33 @@ if which in ("all", "toeplitz2t"):
     outs = [torch.empty(R * n * C, dtype=torch.float64, device=dev) for _ in range(2)]
     timed("toeplitz_y2t", R * C * 2.0 * n * n * 4, R * n * C * 8.0 * 4, lambda: hip.toeplitz_y2t(n, C, R, src_g, src_m, tg, tm, outs))
     del src_g, src_m, tg, tm, outs
+if which in ("all", "toeplitz2s"):
+    C = P * P
+    src_g, src_m = rnd(R * n * C), rnd(R * n * C)
+    t3 = [rnd(n * C) for _ in range(3)]
+    outs = [torch.empty(R * n * C, dtype=torch.float64, device=dev) for _ in range(2)]
+    timed("toeplitz_y2s", R * C * 2.0 * n * n * 3, R * n * C * 8.0 * 4, lambda: hip.toeplitz_y2s(n, C, R, src_g, src_m, t3[0], t3[1], t3[2], outs))
+    del src_g, src_m, t3, outs
 if which in ("all", "xcorr"):
     src = rnd(R, P * n * n)
     lam = rnd(P * n * P)
     out = torch.empty((R, P * P), dtype=torch.float64, device=dev)
     timed("xcorr", R * P * 2.0 * P * n * n, R * P * (n * n + P) * 8.0,
           lambda: hip.xcorr_reduce(n, n, R, P, src, src.stride(0), n * n, Gx, lam, out, out.stride(0), P))
-# ---- radix-2 kernels (round 2): flop = what the folded kernels execute on the matrix pipe (half of the plain products) -------
+# ---- radix-2 / radix-4 kernels: flop = what the folded kernels execute on the matrix pipe (forward: half of the plain product along z,
+# a quarter along x; inverse: a quarter both ways; xcorr_fold: half) -----------------------------------------------------------------
 if which in ("all", "fold_fwd", "fold_bwd", "xcorr_fold", "fold_inv_ss", "fold_inv_strided", "fold_inv_mul"):
     import numpy as np
     from geobo_amd.spectral import folded_matrices
     F = hip.to_dev(np.stack(folded_matrices(n), axis=2))
 if which in ("all", "fold_fwd"):
     src, out = rnd(R, n * n * n), torch.empty((R, n * P * P), dtype=torch.float64, device=dev)
-    timed("xz2d_fold_fwd", R * n * 1.0 * (n * n * P + P * n * P), R * n * (n * n + P * P) * 8.0,
+    timed("xz2d_fold_fwd", R * n * (1.0 * n * n * P + 0.5 * P * n * P), R * n * (n * n + P * P) * 8.0,
           lambda: hip.xz2d_fold(False, n, R, n, src, src.stride(0), n * n, F, F, out, out.stride(0), P * P))
     del src, out
 if which in ("all", "fold_bwd"):
     src, out = rnd(R, n * P * P), torch.empty((R, n * n * n), dtype=torch.float64, device=dev)
-    timed("xz2d_fold_bwd", R * n * 1.0 * (P * P * n + n * P * n), R * n * (n * n + P * P) * 8.0,
+    timed("xz2d_fold_bwd", R * n * 0.5 * (P * P * n + n * P * n), R * n * (n * n + P * P) * 8.0,
           lambda: hip.xz2d_fold(True, n, R, n, src, src.stride(0), P * P, F, F, out, out.stride(0), n * n))
     del src, out
 if which in ("all", "xcorr_fold"):
@@ -116,13 +124,13 @@ if which in ("all", "fold_inv_ss"):
     s1, s2 = rnd(R, n * P * P), rnd(R, n * P * P)
     slots = hip.xz2d_fold_inv_ss_slots(n, R, n)
     ss = torch.zeros((slots, n, n * n), dtype=torch.float64, device=dev)
-    timed("xz2d_fold_inv_ss", R * n * 1.0 * (2 * P * P * n + n * P * n), 2.0 * R * n * P * P * 8.0,
+    timed("xz2d_fold_inv_ss", R * n * 0.5 * (2 * P * P * n + n * P * n), 2.0 * R * n * P * P * 8.0,
           lambda: hip.xz2d_fold_inv_ss(n, R, n, s1, n * P * P, P * P, F, F, ss, src2=s2, in2_row=n * P * P, r2_first=0))
     del s1, s2, ss
 if which in ("all", "fold_inv_strided"):
     # rows of L^-1 A on a lattice survey: one inverse two-axis transform per (row, z) plane of W = Lambda[iz] * lhat_r, written as [iy][iz][ix]
     W, out = rnd(R, n * P * P), torch.empty((R, n * n * n), dtype=torch.float64, device=dev)
-    timed("xz2d_fold_inv_strided", R * n * 1.0 * (P * P * n + n * P * n), R * n * (n * n + P * P) * 8.0,
+    timed("xz2d_fold_inv_strided", R * n * 0.5 * (P * P * n + n * P * n), R * n * (n * n + P * P) * 8.0,
           lambda: hip.xz2d_fold_inv_strided(n, R, n, W, n * P * P, P * P, F, F, out, out.stride(0), n, n * n))
     del W, out
 if which in ("all", "wplanes"):
@@ -140,6 +148,6 @@ if which in ("all", "fold_inv_mul"):
     # (once each, algorithmically), writes the rows
     lam3, lh = rnd(n * P * P), rnd(R * P * P)
     out = torch.empty((R, n * n * n), dtype=torch.float64, device=dev)
-    timed("xz2d_fold_inv_mul", R * n * 1.0 * (P * P * n + n * P * n), (n * P * P + R * P * P + R * n * n * n) * 8.0,
+    timed("xz2d_fold_inv_mul", R * n * 0.5 * (P * P * n + n * P * n), (n * P * P + R * P * P + R * n * n * n) * 8.0,
           lambda: hip.xz2d_fold_inv_mul(n, R, n, lam3, P * P, lh, P * P, F, F, out, out.stride(0), n, n * n))
     del lam3, lh, out
