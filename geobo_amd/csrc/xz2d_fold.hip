@@ -797,12 +797,9 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
   }
 }
 
-// ---- lattice Gram, x step + eigenvalue scaling + channel sum (radix-2 form of xcorr_kernel in xz2d.hip) -----------------------
+// ---- lattice Gram, x step + eigenvalue scaling + channel sum (folded form of xcorr_kernel in xz2d.hip) -------------------------
 // For every (row r, y-mode p) plane X (N x N, x rows, z contiguous):   out[r][p][o] = sum_z lamT[p][z][o] * sum_x G_x[o][x] X[x][z].
-// The product is formed transposed (D[z][o]: the z sum then runs over accumulator registers and the four 16-lane groups), and
-// folded over the parity of x:  E[z][b] = sum_(x even) X[x][z] Fe[b][x/2],  O[z][b] = sum_(x odd) X[x][z] Fo[b][(x-1)/2],
-// D[z][2b] = E + O, D[z][2b+1] = E - O  -- half the MFMAs.  A k-step takes rows of ONE parity (rows 8s + 2q + parity of a chunk);
-// the pair (Fe, Fo)[b][j] is one 16-byte LDS read, and so is the eigenvalue pair lamT[p][z][2b .. 2b+1].
+// The product is formed transposed (D[z][o]: the z sum then runs over accumulator registers and the four 16-lane groups).
 struct XCFArgs {
   const double* in; int64_t in_row, in_plane;   // plane (r, p) at in + r*in_row + p*in_plane
   const double* F;                              // [N][N/2][2] folded x matrices
@@ -811,38 +808,43 @@ struct XCFArgs {
   int64_t rows, nplanes;
 };
 
-// slot swizzle of the input chunks: a ds_read_b64 serves lanes 0-31 together = rows 8s + parity and 8s + 2 + parity, 16 z columns
-// each; bit 1 of the row goes to bit 3 of the slot XOR, so the two rows land in different 128-byte halves of the 256-byte bank row
-__device__ __forceinline__ int xfswz(int row) { return (((row >> 1) & 1) << 3) | ((row & 1) << 2) | ((row >> 2) & 3); }
-
+// RADIX 4 (round 5; the radix-2 kernel of round 2 -- E / O sums over the parity of x, 64 MFMAs per chunk on eight waves -- is retired).
+// The inputs x = 4 j + rho of one residue class need ONE cosine and ONE sine row of the basis per frequency w < 16 (spectral.base_modes:
+// the eight spectral positions 8 w .. 8 w + 7 are the orbit of w under a quarter-period shift), so D[z][.] costs 32 MFMAs per 16-row
+// chunk instead of 64.  Four waves = the four z tiles; a wave contracts the cosine and the sine rows for the four classes (8 MFMAs per
+// chunk; register rho of a lane group = class rho, one 16-byte image read per class feeds both), holds the eight sums of a frequency
+// in ONE lane and forms its eight outputs there, scales them by the eight eigenvalues of (z, w) and sums over z (registers, lane
+// groups, waves) as before.  256 threads, 56 KiB of LDS: two workgroups per CU with the registers of two waves per SIMD.
 template <int N>
-__global__ void __launch_bounds__(512, 2) xcorr_fold_kernel(XCFArgs g) {
-  constexpr int RING = 4, NW = 8, PX = 2 * N, H = N / 2, NCH = N / 16, ROWB = N * 8, CHB = 16 * ROWB, LPR = ROWB / 16, RPI = 64 / LPR;
-  constexpr int ND = CHB / 1024 / NW, BT = N / 16 / 2, NL = BT * 4;   // base tiles per wave, eigenvalue loads per plane
-  static_assert(N == 64 && ND >= 1 && NCH >= RING - 1, "shape");
+__global__ void __launch_bounds__(256, 2) xcorr_fold4_kernel(XCFArgs g) {
+  constexpr int RING = 4, NW = 4, PX = 2 * N, H = N / 2, NCH = N / 16, ROWB = N * 8, CHB = 16 * ROWB, LPR = ROWB / 16, RPI = 64 / LPR;
+  constexpr int ND = CHB / 1024 / NW, NL = 16;         // eigenvalue loads per plane (16 bytes each)
+  static_assert(N == 64 && ND == 2 && NCH >= RING - 1, "shape");
   extern __shared__ __attribute__((aligned(16))) double smem[];
   char* const ring = reinterpret_cast<char*>(smem);
-  double* const fx = smem + RING * CHB / 8;            // [N/2 rows j][N slots b of (Fe, Fo)[b][j]]
-  double* const red = fx + H * N * 2;                  // [2][4][PX]
+  double* const img = smem + RING * CHB / 8;           // [rho][j][w] pairs (cosine, sine) of frequency w at the input x = 4 j + rho
+  double* const red = img + 4 * 16 * 16 * 2;           // [2][4 waves][PX]
   const unsigned ring_lds = (unsigned)(uintptr_t)(lds_ptr_t)ring;
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int w = wv & 3, bt0 = (wv >> 2) * BT;          // z tile, first base column tile of this wave
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);     // z tile
   const int lr = lane & 15, q = lane >> 4;
-  for (int idx = tid; idx < N * H; idx += 64 * NW) {
-    const int b = idx / H, j = idx % H;
-    *reinterpret_cast<v2d*>(fx + ((j * N + b) << 1)) = *reinterpret_cast<const v2d*>(g.F + ((int64_t)idx << 1));
+  for (int idx = tid; idx < 4 * 16 * 16; idx += 64 * NW) {
+    const int rho = idx >> 8, j = (idx >> 4) & 15, om = idx & 15, i = 4 * j + rho;
+    const double c = g.F[(((int64_t)(4 * om) * H + (i >> 1)) << 1) + (i & 1)];
+    const double sn = g.F[(((int64_t)(4 * om + 1) * H + (i >> 1)) << 1) + (i & 1)];
+    *reinterpret_cast<v2d*>(img + 2 * idx) = (v2d){c, om ? sn : ((j & 1) ? -c : c)};     // (w = 0: constant and alternating row)
   }
   const int64_t first = blockIdx.x, pstep = gridDim.x;
   if (first >= g.nplanes) return;
   const int drow = lane / LPR, dpos = lane % LPR;
+  auto swz = [](int row) { return ((row >> 2) & 1) << 3; };   // rows 4 q + rho of lane groups q, q + 1: different 128-byte halves of a bank row
   auto plane_ptr = [&](int64_t p) { return g.in + (p % g.rows) * g.in_row + (p / g.rows) * g.in_plane; };
   auto stage = [&](const double* plane, int c, int slot) {
 #pragma unroll
     for (int j = 0; j < ND; ++j) {
-      const int ii = wv + NW * j;
+      const int ii = w + NW * j;
       const int row = ii * RPI + drow;
-      const char* src = reinterpret_cast<const char*>(plane) + (int64_t)(16 * c + row) * ROWB + ((dpos ^ xfswz(row)) << 4);
+      const char* src = reinterpret_cast<const char*>(plane) + (int64_t)(16 * c + row) * ROWB + ((dpos ^ swz(row)) << 4);
       __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(ring + slot * CHB + ii * 1024), 16, 0, 0);
     }
   };
@@ -852,20 +854,30 @@ __global__ void __launch_bounds__(512, 2) xcorr_fold_kernel(XCFArgs g) {
   for (int c = 0; c < RING - 1; ++c) stage(cur, c, c);
   int slot0 = 0, it = 0;
   const int col = 16 * w + lr;                         // this lane's z (row i of the transposed product)
+  const bool w0 = lr == 0;                             // the lane column of frequency 0
+  const double r2 = 1.4142135623730951;
+  // A fragments: X[x = 16 c + 4 q + rho][z = col] (the swizzle of row 4 q + rho depends on q alone: the classes are immediates);
+  // B fragments: img[rho][j = 4 c + q][w = lr]
+  const unsigned aoff = ring_lds + 4 * q * ROWB + ((((col >> 1) ^ swz(4 * q)) << 4) | ((col & 1) << 3));
+  const unsigned boff = (unsigned)(uintptr_t)(lds_ptr_t)img + q * 256 + lr * 16;
+  using lrsrc_t = __amdgpu_buffer_rsrc_t;
+  const unsigned lofs = (unsigned)(((16 * w + q) * PX + 8 * lr) * 8);
   for (int64_t p = first; p < g.nplanes; p += pstep, ++it) {
     const int64_t pn = p + pstep < g.nplanes ? p + pstep : p;
     const double* nxt = plane_ptr(pn);
-    v4d e[BT], o[BT];
+    v4d ac[4], as[4];                                  // [class]: cosine-row sums C_rho, sine-row sums S_rho; registers r <-> z = 16 w + q + 4 r
 #pragma unroll
-    for (int b = 0; b < BT; ++b) e[b] = o[b] = (v4d){0., 0., 0., 0.};
-    // this plane's eigenvalue pairs: issued now, consumed after the MFMAs (their L2 latency hides under the chunk loop)
+    for (int rho = 0; rho < 4; ++rho) ac[rho] = as[rho] = (v4d){0., 0., 0., 0.};
+    // this plane's eigenvalues lamT[pl][z][8 w .. 8 w + 7]: issued now, consumed behind the MFMAs (their L2 latency hides under the
+    // chunk loop); buffer loads: plane base in SGPRs, one 32-bit lane offset, the row as a scalar offset
     const int64_t pl = p / g.rows;
-    const double* lp = g.lamT + pl * (int64_t)(N * PX) + (int64_t)(16 * w + q) * PX + 2 * (16 * bt0 + lr);
-    v2d lam[BT][4];
+    const lrsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(g.lamT + pl * (int64_t)(N * PX)), 0, N * PX * 8, 0x00020000);
+    v2d lam[4][4];
 #pragma unroll
-    for (int b = 0; b < BT; ++b)
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) lam[b][r] = *reinterpret_cast<const v2d*>(lp + 4 * r * PX + 32 * b);
+      for (int k = 0; k < 4; ++k)
+        lam[r][k] = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(lrs, lofs, 4 * r * PX * 8 + 16 * k, 0));
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       // chunk c has landed when at most the newer operations are in flight: RING-2 chunks, plus -- for the chunks that were
@@ -878,44 +890,57 @@ __global__ void __launch_bounds__(512, 2) xcorr_fold_kernel(XCFArgs g) {
         if (cn < NCH) stage(cur, cn, (slot0 + cn) % RING);
         else stage(nxt, cn - NCH, (slot0 + cn) % RING);
       }
-      const unsigned xs = ring_lds + ((slot0 + c) % RING) * CHB;
-      double a[4];                                     // [2 s + parity]: X[x = 16 c + 8 s + 2 q + parity][z = col]
+      const unsigned so = ((slot0 + c) % RING) * CHB;
+      double a[4];
+      v2d f[4];
 #pragma unroll
-      for (int sp = 0; sp < 4; ++sp) {
-        const int row = 8 * (sp >> 1) + 2 * q + (sp & 1);
-        const unsigned addr = xs + row * ROWB + ((((col >> 1) ^ xfswz(row)) << 4) | ((col & 1) << 3));
-        asm volatile("ds_read_b64 %0, %1" : "=v"(a[sp]) : "v"(addr));
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
+      for (int rho = 0; rho < 4; ++rho) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a[rho]) : "v"(aoff + so), "n"(rho * ROWB));
+      const unsigned bo = boff + c * 1024;
 #pragma unroll
-      for (int s_ = 0; s_ < 2; ++s_) {
-        const double* bp = fx + (((8 * c + 4 * s_ + q) * N + 16 * bt0 + lr) << 1);   // B[k = q][j = lr]: (Fe, Fo)[b][j = 8c + 4s + q]
-#pragma unroll
-        for (int b = 0; b < BT; ++b) {
-          const v2d f = *reinterpret_cast<const v2d*>(bp + 32 * b);
-          e[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2 * s_], f.x, e[b], 0, 0, 0);
-          o[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2 * s_ + 1], f.y, o[b], 0, 0, 0);
-        }
-      }
+      for (int rho = 0; rho < 4; ++rho) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[rho]) : "v"(bo), "n"(rho * 4096));
+      // (LDS reads return in order: class rho may start once its image pair is there)
+      asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(f[0]));
+      ac[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], f[0].x, ac[0], 0, 0, 0);
+      as[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0], f[0].y, as[0], 0, 0, 0);
+      asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(f[1]));
+      ac[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], f[1].x, ac[1], 0, 0, 0);
+      as[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1], f[1].y, as[1], 0, 0, 0);
+      asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(f[2]));
+      ac[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], f[2].x, ac[2], 0, 0, 0);
+      as[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2], f[2].y, as[2], 0, 0, 0);
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[3]));
+      ac[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], f[3].x, ac[3], 0, 0, 0);
+      as[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[3], f[3].y, as[3], 0, 0, 0);
     }
-    // ---- butterfly, scale by the eigenvalues and sum over z: registers (4 z per lane), the four 16-lane groups, the waves -----
-    double* const rp = red + (it & 1) * (4 * PX) + w * PX + 2 * (16 * bt0 + lr);
+    // ---- the eight outputs of frequency w = lr per z, scaled by the eigenvalues and summed over z: registers, lane groups, waves ------
+    v2d o[4];
 #pragma unroll
-    for (int b = 0; b < BT; ++b) {
-      double vp = 0., vm = 0.;
+    for (int k = 0; k < 4; ++k) o[k] = (v2d){0., 0.};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        vp = __builtin_fma(e[b][r] + o[b][r], lam[b][r].x, vp);
-        vm = __builtin_fma(e[b][r] - o[b][r], lam[b][r].y, vm);
-      }
-      vp += __shfl_xor(vp, 16); vp += __shfl_xor(vp, 32);
-      vm += __shfl_xor(vm, 16); vm += __shfl_xor(vm, 32);
-      if (q == 0) *reinterpret_cast<v2d*>(rp + 32 * b) = (v2d){vp, vm};
+    for (int r = 0; r < 4; ++r) {
+      const double u0 = ac[0][r] + ac[2][r], u1 = ac[0][r] - ac[2][r], v0 = ac[1][r] + ac[3][r], v1 = ac[1][r] - ac[3][r];
+      const double ws = as[0][r] + as[2][r], wd = as[0][r] - as[2][r], z0 = as[1][r] + as[3][r], z1 = as[1][r] - as[3][r];
+      // positions (cos w, mirror | sin w, mirror | cos(n/2 - w), mirror | sin(n/2 - w), mirror); frequency 0: (0, n | middle pair |
+      // cos n/4, mirror | sin n/4, mirror) from the constant-row sums C and the alternating-row sums S
+      const double a0 = r2 * as[0][r], a2 = r2 * as[2][r];
+      o[0] += (v2d){u0 + v0, u0 - v0} * lam[r][0];
+      o[1] += (w0 ? (v2d){u1 + v1, u1 - v1} : (v2d){ws + z0, ws - z0}) * lam[r][1];
+      o[2] += (w0 ? (v2d){a0 + z1, a0 - z1} : (v2d){u1 + z1, u1 - z1}) * lam[r][2];
+      o[3] += (w0 ? (v2d){a2 + z0, a2 - z0} : (v2d){v1 - wd, -wd - v1}) * lam[r][3];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) { o[k][e] += __shfl_xor(o[k][e], 16); o[k][e] += __shfl_xor(o[k][e], 32); }
+    if (q == 0) {
+      v2d* const rp = reinterpret_cast<v2d*>(red + (it & 1) * (NW * PX) + w * PX + 8 * lr);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) rp[k] = o[k];
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (tid < PX) {
-      const double* r4 = red + (it & 1) * (4 * PX) + tid;
+      const double* r4 = red + (it & 1) * (NW * PX) + tid;
       g.out[(p % g.rows) * g.out_row + pl * g.out_plane + tid] = (r4[0] + r4[PX]) + (r4[2 * PX] + r4[3 * PX]);
     }
     slot0 = (slot0 + NCH) % RING;
@@ -965,12 +990,12 @@ extern "C" int geobo_xcorr_reduce_fold(int n, int64_t rows, int planes, const do
   g.in = in; g.in_row = in_row; g.in_plane = in_plane; g.F = F; g.lamT = lamT;
   g.out = out; g.out_row = out_row; g.out_plane = out_plane; g.rows = rows; g.nplanes = rows * planes;
   constexpr int N = 64;
-  constexpr size_t lds = (size_t)4 * 16 * N * 8 + (size_t)N * N * 8 + 2 * 4 * (2 * N) * 8;
-  auto kern = xcorr_fold_kernel<N>;
+  constexpr size_t lds = (size_t)4 * 16 * N * 8 + (size_t)4 * 16 * 16 * 16 + 2 * 4 * (2 * N) * 8;
+  auto kern = xcorr_fold4_kernel<N>;
   static std::atomic<uint64_t> attr_done{0};
   if (int rc = ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), lds)) return rc;
   const int64_t nwg = g.nplanes < 2048 ? g.nplanes : 2048;
-  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(512), lds, (hipStream_t)stream, g);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, (hipStream_t)stream, g);
   return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
 }
 

@@ -311,7 +311,7 @@ class LatticeGram:
         nx, ny, nz, Px, Py = self.nx, self.ny, self.nz, self.Px, self.Py
         Ly = ny if Ly is None else Ly
         f = self.sp.fold and nx == nz == 64
-        h = 0.5 if f else 1.0             # radix-2 x step: half the MFMAs of the plain product
+        h = 0.25 if f else 1.0            # radix-4 x step: a quarter of the MFMAs of the plain product
         hb = 0.25 if f else 1.0           # back-transform on the radix-4 inverse kernel: a quarter
         zsum = 0.0 if self.fast(nx, ny, nz) else 2.0 * Py * Px * nz  # (the stand-alone scaling + channel sum of the batched-GEMM form, fp64 VALU)
         return rows * (2.0 * (hip.pad_n(Py) * nx * nz * Ly + h * Py * Px * nx * nz + hb * (ny * Py * Px + ny * nx * Px)) + zsum)

@@ -54,7 +54,7 @@ if which in ("all", "xcorr"):
     timed("xcorr", R * P * 2.0 * P * n * n, R * P * (n * n + P) * 8.0,
           lambda: hip.xcorr_reduce(n, n, R, P, src, src.stride(0), n * n, Gx, lam, out, out.stride(0), P))
 # ---- radix-2 / radix-4 kernels: flop = what the folded kernels execute on the matrix pipe (forward: half of the plain product along z,
-# a quarter along x; inverse: a quarter both ways; xcorr_fold: half) -----------------------------------------------------------------
+# a quarter along x; inverse and xcorr_fold: a quarter) -----------------------------------------------------------------
 if which in ("all", "fold_fwd", "fold_bwd", "xcorr_fold", "fold_inv_ss", "fold_inv_strided", "fold_inv_mul"):
     import numpy as np
     from geobo_amd.spectral import folded_matrices
@@ -73,7 +73,7 @@ if which in ("all", "xcorr_fold"):
     src = rnd(R, P * n * n)
     lam = rnd(P * n * P)
     out = torch.empty((R, P * P), dtype=torch.float64, device=dev)
-    timed("xcorr_fold", R * P * 1.0 * P * n * n, R * P * (n * n + P) * 8.0,
+    timed("xcorr_fold", R * P * 0.5 * P * n * n, R * P * (n * n + P) * 8.0,
           lambda: hip.xcorr_reduce_fold(n, R, P, src, src.stride(0), n * n, F, lam, out, out.stride(0), P))
 if which in ("all", "ymul"):
     # y step of the lattice Gram: the (128 x 64) matrix from the left of every (64 x 4096) row; flop = MFMA, bytes = in + out
