@@ -124,6 +124,23 @@ __global__ void __launch_bounds__(256, 2) gemm_fold_kernel(const FoldArgs a) {
   const int ybase = NN ? (wn * 64 + lr) : ((MODE == FWD_Z ? wn * 32 : wn * 64) + lr) * XS;
   const double sgnz = (MODE == INV_Z && wn) ? -1.0 : 1.0, sgnx = (BX && wm) ? -1.0 : 1.0;
 
+  // 16-row / 16-column tiles of this wave that hold no valid output are skipped (wave-uniform masks: extents that are not multiples of
+  // the 128 x 128 tile -- P = 192 at n = 96 -- otherwise spend a quarter of their MFMAs on padding)
+  unsigned mmask = 0, nmask = 0;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int64_t r = (MODE == FWD_X) ? 2 * ((int64_t)bi * 64 + wm * 32 + m * 16) : BX ? row0 + 32 * m : row0 + wm * 64 + m * 16;
+    mmask |= (unsigned)(r < a.m_valid && (MODE != FWD_X || m < 2)) << m;
+  }
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    const int64_t c = (MODE == FWD_Z) ? 2 * ((int64_t)bj * 64 + wn * 32 + n * 16) : (MODE == INV_Z) ? col0 + 32 * n : col0 + wn * 64 + n * 16;
+    nmask |= (unsigned)(c < a.n_valid && (MODE != FWD_Z || n < 2)) << n;
+  }
+  mmask = __builtin_amdgcn_readfirstlane(mmask);
+  nmask = __builtin_amdgcn_readfirstlane(nmask);
+  const bool full = (mmask == (MODE == FWD_X ? 3u : 15u)) && (nmask == (MODE == FWD_Z ? 3u : 15u));
+
   stage(0, 0);
   __syncthreads();
   int cur = 0;
@@ -156,6 +173,7 @@ __global__ void __launch_bounds__(256, 2) gemm_fold_kernel(const FoldArgs a) {
           for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int n = 0; n < NTL; ++n) {
+              if (!full && !(((mmask >> m) & 1) && ((nmask >> n) & 1))) continue;
               v4d& c = (MODE == FWD_Z) ? acc[p][m][n] : acc[p][n][m];
               c = __builtin_amdgcn_mfma_f64_16x16x4f64(av[h][m][p], bv[h][n][p], c, 0, 0, 0);
             }
@@ -168,7 +186,10 @@ __global__ void __launch_bounds__(256, 2) gemm_fold_kernel(const FoldArgs a) {
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
-          for (int n = 0; n < 4; ++n) accs[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(uv[m], bv[h][n][0], accs[m][n], 0, 0, 0);
+          for (int n = 0; n < 4; ++n) {
+            if (!full && !(((mmask >> m) & 1) && ((nmask >> n) & 1))) continue;
+            accs[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(uv[m], bv[h][n][0], accs[m][n], 0, 0, 0);
+          }
       }
     } else {
 #pragma unroll
@@ -179,7 +200,10 @@ __global__ void __launch_bounds__(256, 2) gemm_fold_kernel(const FoldArgs a) {
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
-          for (int n = 0; n < 4; ++n) accs[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[h][m][0], uv[n], accs[m][n], 0, 0, 0);
+          for (int n = 0; n < 4; ++n) {
+            if (!full && !(((mmask >> m) & 1) && ((nmask >> n) & 1))) continue;
+            accs[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[h][m][0], uv[n], accs[m][n], 0, 0, 0);
+          }
       }
     }
     __syncthreads();
