@@ -6,9 +6,10 @@
 R=${1:-r05}
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 ROOT=$(pwd)
-python tools/pmc_collect.py toeplitz2t > /dev/null 2>&1; cp gpurun_out/pmc_toeplitz_y2t.json gpurun_out/${R}_pmc_toeplitz_y2t.json; python tools/pmc_collect.py toeplitz > /dev/null 2>&1; cp gpurun_out/pmc_toeplitz_y.json gpurun_out/${R}_pmc_toeplitz_y.json
-for k in toeplitz toeplitz2t fold_inv_mul fold_inv_ss; do python tools/pmc_collect.py $k valu > /dev/null 2>&1; done
-cp gpurun_out/pmc_toeplitz_y_valu.json gpurun_out/${R}_pmc_toeplitz_y_valu.json; cp gpurun_out/pmc_toeplitz_y2t_valu.json gpurun_out/${R}_pmc_toeplitz_y2t_valu.json
+python tools/pmc_collect.py toeplitz2s > /dev/null 2>&1; cp gpurun_out/pmc_toeplitz_y2s.json gpurun_out/${R}_pmc_toeplitz_y2s.json; python tools/pmc_collect.py toeplitz > /dev/null 2>&1; cp gpurun_out/pmc_toeplitz_y.json gpurun_out/${R}_pmc_toeplitz_y.json
+for k in toeplitz toeplitz2s fold_inv_mul fold_inv_ss; do python tools/pmc_collect.py $k valu > /dev/null 2>&1; done
+cp gpurun_out/pmc_toeplitz_y_valu.json gpurun_out/${R}_pmc_toeplitz_y_valu.json; cp gpurun_out/pmc_toeplitz_y2s_valu.json gpurun_out/${R}_pmc_toeplitz_y2s_valu.json
+for k in fold_fwd fold_bwd fold_inv_ss fold_inv_mul xcorr_fold ymul toeplitz toeplitz2t toeplitz2s; do python tools/run_spectral_kernels_once.py $k 2>&1 | grep -v amdgpu.ids | tail -1; done > gpurun_out/${R}_spectral_kernels_once.txt
 cp gpurun_out/pmc_xz2d_fold_inv_mul_valu.json gpurun_out/${R}_pmc_xz2d_fold_inv_mul_valu.json; cp gpurun_out/pmc_xz2d_fold_inv_ss_valu.json gpurun_out/${R}_pmc_xz2d_fold_inv_ss_valu.json
 python bench.py --steps 20 --warmup 5 2> gpurun_out/${R}_bench64.err | grep '^{' > gpurun_out/${R}_bench64_spectral.json
 (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_b && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu 2>/dev/null | grep '^{' > $ROOT/gpurun_out/${R}_bench64_spectral_under_rocprof.json; cp $(find /tmp/prof_b -name "*kernel_stats.csv" | head -1) $ROOT/gpurun_out/${R}_bench64_spectral_kernel_stats.csv)
