@@ -50,28 +50,37 @@ constexpr int vmcnt_only(int v) { return (v & 15) | (7 << 4) | (15 << 8) | ((v >
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
-// NY x (NY/2) multiply-adds of one wave-row, all table indices compile-time constants.  The wave computes outputs
-// o = 0..OC-1 of the row as stored in LDS; the second half of the outputs uses the SAME code on the reversed row
-// (T is persymmetric: out[NY-1-o] = sum_y'' t(|o - y''|) in[NY-1-y'']), selected by the sign of `xstep`.
+// NY x OC multiply-adds of one wave-row, all table indices compile-time constants: outputs O0 .. O0 + OC - 1 of the row.
+// (Rounds 2-4 shared ONE body between the two halves of the outputs -- T is persymmetric, the second half ran the same code on
+// the row read backwards, `xstep` < 0; the kernels of this file now take the IMM form below.)
 // The LDS reads of the row are inline asm: for LDS reads it can see, the compiler first waits for EVERY outstanding LDS-DMA
 // (vmcnt(0): it cannot tell the two ring halves apart), i.e. for the NEXT row that was requested a moment ago -- no prefetch
 // at all.  Groups of GX inputs, double buffered: group g+1 is requested before the FMAs of group g.
 constexpr int GX = 4;
 
-template <int NY, int OC, int G, int O0 = 0>
+// IMM (round 5): the inputs are read in their stored order -- row y' at xaddr + 512 y', an instruction immediate -- and the chunk of
+// outputs is named by O0 alone (one body per chunk, selected by a wave-uniform branch).  The runtime-stride form shares ONE body between the
+// two halves of the outputs (the second half reads the row backwards: T is persymmetric) at the price of a 32-bit address add per read
+// -- a VALU instruction like any other on this machine: 3 % of the issue slots of a half wave, 10 % of a quarter wave.
+template <int NY, int OC, int G, int O0 = 0, bool IMM = false>
 __device__ __forceinline__ void toeplitz_group(const double (&t)[NY], double (&acc)[OC], double (&xb)[2][GX], unsigned xaddr, int xstep) {
   constexpr int NGX = NY / GX;
   if constexpr (G == 0) {
     // the first group is requested HERE, inside the (possibly branched-to) body that consumes it: registers an inline-asm read is
     // still filling must not cross a branch -- the compiler may copy them at the join before the data has landed
 #pragma unroll
-    for (int i = 0; i < GX; ++i) asm volatile("ds_read_b64 %0, %1" : "=v"(xb[0][i]) : "v"(xaddr + (unsigned)(i * xstep)));
+    for (int i = 0; i < GX; ++i) {
+      if constexpr (IMM) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xb[0][i]) : "v"(xaddr), "n"(i * 512));
+      else asm volatile("ds_read_b64 %0, %1" : "=v"(xb[0][i]) : "v"(xaddr + (unsigned)(i * xstep)));
+    }
   }
   __builtin_amdgcn_sched_barrier(0);   // keep the groups apart: interleaving them costs registers the table needs
   if constexpr (G + 1 < NGX) {
 #pragma unroll
-    for (int i = 0; i < GX; ++i)
-      asm volatile("ds_read_b64 %0, %1" : "=v"(xb[(G + 1) & 1][i]) : "v"(xaddr + (unsigned)(((G + 1) * GX + i) * xstep)));
+    for (int i = 0; i < GX; ++i) {
+      if constexpr (IMM) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xb[(G + 1) & 1][i]) : "v"(xaddr), "n"(((G + 1) * GX + i) * 512));
+      else asm volatile("ds_read_b64 %0, %1" : "=v"(xb[(G + 1) & 1][i]) : "v"(xaddr + (unsigned)(((G + 1) * GX + i) * xstep)));
+    }
     // group G (requested one group earlier) is complete once only the GX reads just issued are outstanding
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(xb[G & 1][0]), "+v"(xb[G & 1][1]), "+v"(xb[G & 1][2]), "+v"(xb[G & 1][3]) : "n"(GX));
   } else {
@@ -87,7 +96,7 @@ __device__ __forceinline__ void toeplitz_group(const double (&t)[NY], double (&a
       acc[o] = (yp == 0) ? t[d < 0 ? -d : d] * x : __builtin_fma(t[d < 0 ? -d : d], x, acc[o]);
     }
   }
-  if constexpr (G + 1 < NGX) toeplitz_group<NY, OC, G + 1, O0>(t, acc, xb, xaddr, xstep);
+  if constexpr (G + 1 < NGX) toeplitz_group<NY, OC, G + 1, O0, IMM>(t, acc, xb, xaddr, xstep);
 }
 
 // Workgroup = 2 * nprop * Q waves sharing ONE row at a time: wave (prop, part q of a half, half).  The next row streams into the
@@ -127,8 +136,7 @@ __global__ void __launch_bounds__(256, 2) toeplitz_y_kernel(ToeplitzArgs g) {
   stage(ps, 0);
   __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): this wave's planes have landed
   __syncthreads();
-  const int xstep = half ? -512 : 512;
-  const int ysgn = half ? -1 : 1, ybase = half ? NY - 1 : 0;
+  const int ch = half * Q + qq;          // this wave's chunk of OC outputs: y = ch * OC + o (one body per chunk: immediate-offset reads)
   int b = 0;
   for (; r < g.R; r += rstep) {
     const bool more = r + rstep < g.R;
@@ -137,12 +145,15 @@ __global__ void __launch_bounds__(256, 2) toeplitz_y_kernel(ToeplitzArgs g) {
       stage(ps, b ^ 1);
     }
     double acc[OC], xb[2][GX];
-    const unsigned xaddr = (unsigned)(uintptr_t)(lds_ptr_t)&xs[b][half ? NY - 1 : 0][0] + lane8;
+    const unsigned xaddr = (unsigned)(uintptr_t)(lds_ptr_t)&xs[b][0][0] + lane8;
     if constexpr (Q == 1) {
-      toeplitz_group<NY, OC, 0>(t, acc, xb, xaddr, xstep);
+      if (ch == 0) toeplitz_group<NY, OC, 0, 0, true>(t, acc, xb, xaddr, 0);
+      else toeplitz_group<NY, OC, 0, OC, true>(t, acc, xb, xaddr, 0);
     } else {
-      if (qq == 0) toeplitz_group<NY, OC, 0, 0>(t, acc, xb, xaddr, xstep);      // (the distances o - y' index the register table: static)
-      else toeplitz_group<NY, OC, 0, OC>(t, acc, xb, xaddr, xstep);
+      if (ch == 0) toeplitz_group<NY, OC, 0, 0, true>(t, acc, xb, xaddr, 0);     // (the distances o - y' index the register table: static)
+      else if (ch == 1) toeplitz_group<NY, OC, 0, OC, true>(t, acc, xb, xaddr, 0);
+      else if (ch == 2) toeplitz_group<NY, OC, 0, 2 * OC, true>(t, acc, xb, xaddr, 0);
+      else toeplitz_group<NY, OC, 0, 3 * OC, true>(t, acc, xb, xaddr, 0);
     }
     // pin the sums here: otherwise the tail of every sum is sunk into its (predicated) store block, which keeps the last
     // inputs and half the table live across all of them (spills; scratch reloads are VMEM and drain the prefetch)
@@ -157,7 +168,7 @@ __global__ void __launch_bounds__(256, 2) toeplitz_y_kernel(ToeplitzArgs g) {
     asm volatile("" : "+s"(y0), "+s"(y1), "+s"(pitch));
 #pragma unroll
     for (int o = 0; o < OC; ++o) {
-      const int y = ybase + ysgn * (qq * OC + o);
+      const int y = ch * OC + o;
       if (y >= y0 && y < y1) st_lane(dst, lane8, (y - y0) * pitch, acc[o]);
     }
     po += rstep * ostep;
@@ -215,8 +226,6 @@ __global__ void __launch_bounds__(512, 1) toeplitz_y2_kernel(Toeplitz2Args g) {
   stage(ps0, ps1, 0);
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
-  const int xstep = half ? -512 : 512;
-  const int ysgn = half ? -1 : 1, ybase = half ? NY - 1 : 0;
   int b = 0;
   for (; r < g.R; r += rstep) {
     const bool more = r + rstep < g.R;
@@ -226,8 +235,9 @@ __global__ void __launch_bounds__(512, 1) toeplitz_y2_kernel(Toeplitz2Args g) {
       stage(ps0, ps1, b ^ 1);
     }
     double acc[OC], xb[2][GX];
-    const unsigned xaddr = (unsigned)(uintptr_t)(lds_ptr_t)&xs[b][term][half ? NY - 1 : 0][0] + lane8;
-    toeplitz_group<NY, OC, 0>(t, acc, xb, xaddr, xstep);
+    const unsigned xaddr = (unsigned)(uintptr_t)(lds_ptr_t)&xs[b][term][0][0] + lane8;
+    if (half == 0) toeplitz_group<NY, OC, 0, 0, true>(t, acc, xb, xaddr, 0);         // outputs y = half * NY/2 + o, immediate-offset reads
+    else toeplitz_group<NY, OC, 0, OC, true>(t, acc, xb, xaddr, 0);
 #pragma unroll
     for (int o = 0; o < OC; ++o) asm volatile("" : "+v"(acc[o]));
     __builtin_amdgcn_s_waitcnt(vmcnt_only(0));      // this wave's share of the next rows has landed (and last row's stores are out)
@@ -247,7 +257,7 @@ __global__ void __launch_bounds__(512, 1) toeplitz_y2_kernel(Toeplitz2Args g) {
       int pitch = C8;
       asm volatile("" : "+s"(pitch));
 #pragma unroll
-      for (int o = 0; o < OC; ++o) st_lane(dst, lane8, (ybase + ysgn * o) * pitch, acc[o]);
+      for (int o = 0; o < OC; ++o) st_lane(dst, lane8, (half * OC + o) * pitch, acc[o]);
     }
     po += rstep * rowlen;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -292,23 +302,23 @@ struct Toeplitz2sArgs {
 };
 
 // toeplitz_group for inputs that are the SUM of the two staged rows (x = xs[term 0] + xs[term 1]: two LDS reads and one addition per input)
+// (immediate-offset reads: row y' of the first term at xaddr + 512 y', of the second term NY rows behind it)
 template <int NY, int OC, int G, int O0>
-__device__ __forceinline__ void toeplitz_group_sum(const double (&t)[NY], double (&acc)[OC], double (&xb)[2][2 * GX], unsigned xaddr, unsigned xaddr2,
-                                                   int xstep) {
+__device__ __forceinline__ void toeplitz_group_sum(const double (&t)[NY], double (&acc)[OC], double (&xb)[2][2 * GX], unsigned xaddr) {
   constexpr int NGX = NY / GX;
   if constexpr (G == 0) {
 #pragma unroll
     for (int i = 0; i < GX; ++i) {
-      asm volatile("ds_read_b64 %0, %1" : "=v"(xb[0][i]) : "v"(xaddr + (unsigned)(i * xstep)));
-      asm volatile("ds_read_b64 %0, %1" : "=v"(xb[0][GX + i]) : "v"(xaddr2 + (unsigned)(i * xstep)));
+      asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xb[0][i]) : "v"(xaddr), "n"(i * 512));
+      asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xb[0][GX + i]) : "v"(xaddr), "n"((NY + i) * 512));
     }
   }
   __builtin_amdgcn_sched_barrier(0);
   if constexpr (G + 1 < NGX) {
 #pragma unroll
     for (int i = 0; i < GX; ++i) {
-      asm volatile("ds_read_b64 %0, %1" : "=v"(xb[(G + 1) & 1][i]) : "v"(xaddr + (unsigned)(((G + 1) * GX + i) * xstep)));
-      asm volatile("ds_read_b64 %0, %1" : "=v"(xb[(G + 1) & 1][GX + i]) : "v"(xaddr2 + (unsigned)(((G + 1) * GX + i) * xstep)));
+      asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xb[(G + 1) & 1][i]) : "v"(xaddr), "n"(((G + 1) * GX + i) * 512));
+      asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(xb[(G + 1) & 1][GX + i]) : "v"(xaddr), "n"((NY + (G + 1) * GX + i) * 512));
     }
     asm volatile("s_waitcnt lgkmcnt(%8)"
                  : "+v"(xb[G & 1][0]), "+v"(xb[G & 1][1]), "+v"(xb[G & 1][2]), "+v"(xb[G & 1][3]), "+v"(xb[G & 1][4]), "+v"(xb[G & 1][5]),
@@ -329,7 +339,7 @@ __device__ __forceinline__ void toeplitz_group_sum(const double (&t)[NY], double
       acc[o] = (yp == 0) ? t[d < 0 ? -d : d] * x : __builtin_fma(t[d < 0 ? -d : d], x, acc[o]);
     }
   }
-  if constexpr (G + 1 < NGX) toeplitz_group_sum<NY, OC, G + 1, O0>(t, acc, xb, xaddr, xaddr2, xstep);
+  if constexpr (G + 1 < NGX) toeplitz_group_sum<NY, OC, G + 1, O0>(t, acc, xb, xaddr);
 }
 
 template <int NY>
@@ -368,9 +378,7 @@ __global__ void __launch_bounds__(512, 1) toeplitz_y2s_kernel(Toeplitz2sArgs g) 
   stage(ps0, ps1, 0);
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
-  const int xstep = half ? -512 : 512;
-  const int ysgn = half ? -1 : 1, ybase = half ? NY - 1 : 0;
-  double* const ex = exch + (size_t)(half * OCF) * 64 + lane;   // [o of the half][lane]
+  double* const ex = exch + (size_t)(half * OCF) * 64 + lane;   // [o of the half][lane]: output y = half * NY/2 + o
   int b = 0;
   for (; r < g.R; r += rstep) {
     const bool more = r + rstep < g.R;
@@ -379,11 +387,12 @@ __global__ void __launch_bounds__(512, 1) toeplitz_y2s_kernel(Toeplitz2sArgs g) 
       ps1 += rstep * rowlen;
       stage(ps0, ps1, b ^ 1);
     }
-    const int yrow = half ? NY - 1 : 0;
+    // (immediate-offset reads, one body per chunk of outputs: no address arithmetic on the vector pipe)
     if (!shared) {
       double acc[OCF], xb[2][GX];
-      const unsigned xaddr = (unsigned)(uintptr_t)(lds_ptr_t)&xs[b][sel][yrow][0] + lane8;
-      toeplitz_group<NY, OCF, 0>(t, acc, xb, xaddr, xstep);
+      const unsigned xaddr = (unsigned)(uintptr_t)(lds_ptr_t)&xs[b][sel][0][0] + lane8;
+      if (half == 0) toeplitz_group<NY, OCF, 0, 0, true>(t, acc, xb, xaddr, 0);
+      else toeplitz_group<NY, OCF, 0, OCF, true>(t, acc, xb, xaddr, 0);
 #pragma unroll
       for (int o = 0; o < OCF; ++o) asm volatile("" : "+v"(acc[o]));
       __builtin_amdgcn_s_waitcnt(vmcnt_only(0));    // this wave's share of the next rows has landed (and last row's stores are out)
@@ -396,14 +405,15 @@ __global__ void __launch_bounds__(512, 1) toeplitz_y2s_kernel(Toeplitz2sArgs g) 
       int pitch = C8;
       asm volatile("" : "+s"(pitch));
 #pragma unroll
-      for (int o = 0; o < OCF; ++o) st_lane(dst, lane8, (ybase + ysgn * o) * pitch, acc[o]);
+      for (int o = 0; o < OCF; ++o) st_lane(dst, lane8, (half * OCF + o) * pitch, acc[o]);
       po += rstep * rowlen;
     } else {
       double acc[OCQ], xb[2][2 * GX];
-      const unsigned xa0 = (unsigned)(uintptr_t)(lds_ptr_t)&xs[b][0][yrow][0] + lane8;
-      const unsigned xa1 = (unsigned)(uintptr_t)(lds_ptr_t)&xs[b][1][yrow][0] + lane8;
-      if (sel == 0) toeplitz_group_sum<NY, OCQ, 0, 0>(t, acc, xb, xa0, xa1, xstep);
-      else toeplitz_group_sum<NY, OCQ, 0, OCQ>(t, acc, xb, xa0, xa1, xstep);
+      const unsigned xa0 = (unsigned)(uintptr_t)(lds_ptr_t)&xs[b][0][0][0] + lane8;
+      if (pos == 0) toeplitz_group_sum<NY, OCQ, 0, 0>(t, acc, xb, xa0);                   // pos = half + 2 part: outputs y = half * NY/2 + part * NY/4 + o
+      else if (pos == 2) toeplitz_group_sum<NY, OCQ, 0, OCQ>(t, acc, xb, xa0);
+      else if (pos == 1) toeplitz_group_sum<NY, OCQ, 0, 2 * OCQ>(t, acc, xb, xa0);
+      else toeplitz_group_sum<NY, OCQ, 0, 3 * OCQ>(t, acc, xb, xa0);
 #pragma unroll
       for (int o = 0; o < OCQ; ++o) asm volatile("" : "+v"(acc[o]));
       __builtin_amdgcn_s_waitcnt(vmcnt_only(0));
