@@ -818,7 +818,7 @@ struct XCFArgs {
 template <int N>
 __global__ void __launch_bounds__(256, 2) xcorr_fold4_kernel(XCFArgs g) {
   constexpr int RING = 4, NW = 4, PX = 2 * N, H = N / 2, NCH = N / 16, ROWB = N * 8, CHB = 16 * ROWB, LPR = ROWB / 16, RPI = 64 / LPR;
-  constexpr int ND = CHB / 1024 / NW, NL = 16;         // eigenvalue loads per plane (16 bytes each)
+  constexpr int ND = CHB / 1024 / NW;
   static_assert(N == 64 && ND == 2 && NCH >= RING - 1, "shape");
   extern __shared__ __attribute__((aligned(16))) double smem[];
   char* const ring = reinterpret_cast<char*>(smem);
@@ -834,21 +834,37 @@ __global__ void __launch_bounds__(256, 2) xcorr_fold4_kernel(XCFArgs g) {
     const double sn = g.F[(((int64_t)(4 * om + 1) * H + (i >> 1)) << 1) + (i & 1)];
     *reinterpret_cast<v2d*>(img + 2 * idx) = (v2d){c, om ? sn : ((j & 1) ? -c : c)};     // (w = 0: constant and alternating row)
   }
-  const int64_t first = blockIdx.x, pstep = gridDim.x;
-  if (first >= g.nplanes) return;
-  const int drow = lane / LPR, dpos = lane % LPR;
-  auto swz = [](int row) { return ((row >> 2) & 1) << 3; };   // rows 4 q + rho of lane groups q, q + 1: different 128-byte halves of a bank row
-  auto plane_ptr = [&](int64_t p) { return g.in + (p % g.rows) * g.in_row + (p / g.rows) * g.in_plane; };
+  // Workgroup b keeps ONE y-mode pl = b % planes and walks the rows b / planes, + gridDim.x / planes, ... (the grid is a multiple of the
+  // y-mode count): the eigenvalues of its (z, w) stay in registers for the whole launch -- reloaded per plane they were 64 KiB of L2
+  // traffic per 32 KiB of input and a fifth of the launch (0.38 -> 0.31 ms with the loads taken out)
+  const int64_t nky = g.nplanes / g.rows, pl = blockIdx.x % nky, rstep = gridDim.x / nky;
+  const int64_t rfirst = blockIdx.x / nky;
+  if (rfirst >= g.rows) return;
+  // WAVE-PRIVATE staging: a wave needs only ITS 16 columns of a chunk (the z tiles are independent until the final sum), so it fetches
+  // them itself -- 16 rows x 128 bytes = two DMA instructions per chunk into its own quarter of the ring -- and waits on its own vmcnt:
+  // no workgroup barrier per chunk (the shared-chunk form had five barriers per plane on four waves: MFMA busy 36 %).  Ring position
+  // p = 4 rho + q of a chunk holds its row 4 q + rho: the rows of lane groups q, q + 1 sit in different 128-byte halves of a bank row.
+  auto plane_ptr = [&](int64_t row) { return g.in + row * g.in_row + pl * g.in_plane; };
   auto stage = [&](const double* plane, int c, int slot) {
 #pragma unroll
     for (int j = 0; j < ND; ++j) {
-      const int ii = w + NW * j;
-      const int row = ii * RPI + drow;
-      const char* src = reinterpret_cast<const char*>(plane) + (int64_t)(16 * c + row) * ROWB + ((dpos ^ swz(row)) << 4);
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(ring + slot * CHB + ii * 1024), 16, 0, 0);
+      const int pos = 8 * j + (lane >> 3), row = 4 * (pos & 3) + (pos >> 2);
+      const char* src = reinterpret_cast<const char*>(plane) + (int64_t)(16 * c + row) * ROWB + w * 128 + ((lane & 7) << 4);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(ring + (w * RING + slot) * (CHB / NW) + j * 1024), 16, 0, 0);
     }
   };
-  const double* cur = plane_ptr(first);
+  const double* cur = plane_ptr(rfirst);
+  using lrsrc_t = __amdgpu_buffer_rsrc_t;
+  const unsigned lofs = (unsigned)(((16 * w + q) * PX + 8 * lr) * 8);
+  // eigenvalues lamT[pl][z = 16 w + q + 4 r][8 w' .. 8 w' + 7] of this lane (buffer loads: plane base in SGPRs, one 32-bit lane offset, the
+  // row as a scalar offset); requested BEFORE the first DMA, so that every counted vmcnt wait below has them behind it
+  const lrsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(g.lamT + pl * (int64_t)(N * PX)), 0, N * PX * 8, 0x00020000);
+  v2d lam[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      lam[r][k] = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(lrs, lofs, 4 * r * PX * 8 + 16 * k, 0));
   __syncthreads();
 #pragma unroll
   for (int c = 0; c < RING - 1; ++c) stage(cur, c, c);
@@ -858,43 +874,30 @@ __global__ void __launch_bounds__(256, 2) xcorr_fold4_kernel(XCFArgs g) {
   const double r2 = 1.4142135623730951;
   // A fragments: X[x = 16 c + 4 q + rho][z = col] (the swizzle of row 4 q + rho depends on q alone: the classes are immediates);
   // B fragments: img[rho][j = 4 c + q][w = lr]
-  const unsigned aoff = ring_lds + 4 * q * ROWB + ((((col >> 1) ^ swz(4 * q)) << 4) | ((col & 1) << 3));
+  const unsigned aoff = ring_lds + w * RING * (CHB / NW) + q * 128 + lr * 8;
   const unsigned boff = (unsigned)(uintptr_t)(lds_ptr_t)img + q * 256 + lr * 16;
-  using lrsrc_t = __amdgpu_buffer_rsrc_t;
-  const unsigned lofs = (unsigned)(((16 * w + q) * PX + 8 * lr) * 8);
-  for (int64_t p = first; p < g.nplanes; p += pstep, ++it) {
-    const int64_t pn = p + pstep < g.nplanes ? p + pstep : p;
-    const double* nxt = plane_ptr(pn);
+  for (int64_t row = rfirst; row < g.rows; row += rstep, ++it) {
+    const int64_t rn = row + rstep < g.rows ? row + rstep : row;
+    const double* nxt = plane_ptr(rn);
     v4d ac[4], as[4];                                  // [class]: cosine-row sums C_rho, sine-row sums S_rho; registers r <-> z = 16 w + q + 4 r
 #pragma unroll
     for (int rho = 0; rho < 4; ++rho) ac[rho] = as[rho] = (v4d){0., 0., 0., 0.};
-    // this plane's eigenvalues lamT[pl][z][8 w .. 8 w + 7]: issued now, consumed behind the MFMAs (their L2 latency hides under the
-    // chunk loop); buffer loads: plane base in SGPRs, one 32-bit lane offset, the row as a scalar offset
-    const int64_t pl = p / g.rows;
-    const lrsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(g.lamT + pl * (int64_t)(N * PX)), 0, N * PX * 8, 0x00020000);
-    v2d lam[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        lam[r][k] = __builtin_bit_cast(v2d, __builtin_amdgcn_raw_buffer_load_b128(lrs, lofs, 4 * r * PX * 8 + 16 * k, 0));
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       // chunk c has landed when at most the newer operations are in flight: RING-2 chunks, plus -- for the chunks that were
       // requested during the previous plane -- the NL eigenvalue loads above (conservative for the <= 1 result store)
-      if (c <= RING - 2) __builtin_amdgcn_s_waitcnt(vmcnt_imm((RING - 2) * ND + NL));
-      else __builtin_amdgcn_s_waitcnt(vmcnt_imm((RING - 2) * ND));
-      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_waitcnt(vmcnt_imm((RING - 2) * ND));       // (conservative for the <= 1 result store of the previous plane)
       {
+        // (slot of chunk c - 1: this wave's own reads of it completed before its MFMAs were issued)
         const int cn = c + RING - 1;
         if (cn < NCH) stage(cur, cn, (slot0 + cn) % RING);
         else stage(nxt, cn - NCH, (slot0 + cn) % RING);
       }
-      const unsigned so = ((slot0 + c) % RING) * CHB;
+      const unsigned so = ((slot0 + c) % RING) * (CHB / NW);
       double a[4];
       v2d f[4];
 #pragma unroll
-      for (int rho = 0; rho < 4; ++rho) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a[rho]) : "v"(aoff + so), "n"(rho * ROWB));
+      for (int rho = 0; rho < 4; ++rho) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a[rho]) : "v"(aoff + so), "n"(rho * 512));
       const unsigned bo = boff + c * 1024;
 #pragma unroll
       for (int rho = 0; rho < 4; ++rho) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f[rho]) : "v"(bo), "n"(rho * 4096));
@@ -941,7 +944,7 @@ __global__ void __launch_bounds__(256, 2) xcorr_fold4_kernel(XCFArgs g) {
     __builtin_amdgcn_s_barrier();
     if (tid < PX) {
       const double* r4 = red + (it & 1) * (NW * PX) + tid;
-      g.out[(p % g.rows) * g.out_row + pl * g.out_plane + tid] = (r4[0] + r4[PX]) + (r4[2 * PX] + r4[3 * PX]);
+      g.out[row * g.out_row + pl * g.out_plane + tid] = (r4[0] + r4[PX]) + (r4[2 * PX] + r4[3 * PX]);
     }
     slot0 = (slot0 + NCH) % RING;
     cur = nxt;
@@ -994,7 +997,9 @@ extern "C" int geobo_xcorr_reduce_fold(int n, int64_t rows, int planes, const do
   auto kern = xcorr_fold4_kernel<N>;
   static std::atomic<uint64_t> attr_done{0};
   if (int rc = ensure_lds_attr(attr_done, reinterpret_cast<const void*>(kern), lds)) return rc;
-  const int64_t nwg = g.nplanes < 2048 ? g.nplanes : 2048;
+  if (planes > 2048) return GEOBO_E_UNSUPPORTED;
+  const int64_t rper = 2048 / planes;                       // persistent: every workgroup keeps one y-mode (its eigenvalues in registers)
+  const int64_t nwg = (int64_t)planes * (rows < rper ? rows : rper);
   hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, (hipStream_t)stream, g);
   return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
 }

@@ -29,7 +29,7 @@ DRIVERS = {"posterior": ("run_posterior_once.py", "gemm_f64_kernel<4, 2, 2, 1", 
            "xcorr": ("run_spectral_kernels_once.py xcorr", "xcorr_kernel", "pmc_xcorr.json"),
            "fold_fwd": ("run_spectral_kernels_once.py fold_fwd", "xz_fold_fwd_kernel", "pmc_xz2d_fold_fwd.json"),
            "fold_bwd": ("run_spectral_kernels_once.py fold_bwd", "xz_fold_inv_kernel", "pmc_xz2d_fold_bwd.json"),
-           "xcorr_fold": ("run_spectral_kernels_once.py xcorr_fold", "xcorr_fold_kernel", "pmc_xcorr_fold.json"),
+           "xcorr_fold": ("run_spectral_kernels_once.py xcorr_fold", "xcorr_fold4_kernel", "pmc_xcorr_fold.json"),
            "xz2d32_fwd": ("run_spectral_kernels_once.py xz2d32_fwd", "xz2d_kernel<64, 32, 128, 64>", "pmc_xz2d32_fwd.json"),
            "xz2d32_bwd": ("run_spectral_kernels_once.py xz2d32_bwd", "xz2d_kernel<128, 64, 64, 32>", "pmc_xz2d32_bwd.json"),
            "ymul": ("run_spectral_kernels_once.py ymul", "ymul_kernel", "pmc_ymul.json"),
