@@ -350,6 +350,8 @@ __global__ void __launch_bounds__(512, 1) toeplitz_y2s_kernel(Toeplitz2sArgs g) 
   double (*xs)[2][NY][64] = reinterpret_cast<double (*)[2][NY][64]>(xs2s_dyn);
   double* const exch = xs2s_dyn + (size_t)2 * 2 * NY * 64;
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // (the pairing matters: with equal roles on the two waves of a SIMD -- full + full, quarter + quarter -- the launch takes 2.89 ms
+  // instead of 2.59)
   const bool shared = w >= 4;
   const int pos = w & 3, half = pos & 1, sel = pos >> 1;       // full waves: sel = block (0: D0 on x_g, 1: D1 on x_m); quarter waves: part
   const unsigned lane8 = (unsigned)lane * 8u;
