@@ -336,8 +336,10 @@ int geobo_xz2d_fold_inv_ss(int n, int64_t rows, int planes_per_row, const double
 int geobo_ymul(int m, int k, int64_t C, int64_t rows, const double* G, int64_t ldg, const double* in, int64_t in_row,
                double* out, int64_t out_row, void* stream);
 
-/* Radix-2 form of geobo_xcorr_reduce for the pair-interleaved basis: the x product folded over the parity of x (half the
- * MFMAs), F = [n][n/2][2] folded matrices of the x axis; lamT and out in spectral position order as before.  n = 64. */
+/* Folded form of geobo_xcorr_reduce for the pair-interleaved basis in the quarter-period group order of geobo_xz2d_fold (version 210):
+ * the x product in RADIX 4 -- one cosine and one sine row per frequency group and residue class of x mod 4, a quarter of the MFMAs of
+ * the plain product (rounds 2-4: radix 2, half); F = [n][n/2][2] folded matrices of the x axis (rows 4w, 4w + 1 are read); lamT and out
+ * in spectral position order as before.  A workgroup keeps one of the `planes` y-modes for the whole launch (planes <= 2048).  n = 64. */
 int geobo_xcorr_reduce_fold(int n, int64_t rows, int planes, const double* in, int64_t in_row, int64_t in_plane,
                             const double* F, const double* lamT, double* out, int64_t out_row, int64_t out_plane, void* stream);
 
