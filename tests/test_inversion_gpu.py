@@ -641,6 +641,43 @@ def test_cube64x48_against_whole_cube_oracle(family, monkeypatch):
         assert normwise(torch.diagonal(L)[:M].cpu().numpy(), f["L_diag"]) <= 1e-10
 
 
+def test_three_product_y_stage_against_the_four_product_one_and_its_symmetry_check(monkeypatch):
+    """The two-term rows of the transposed posterior take K_10 = K_01 for granted (three y-stage products per mode instead of four,
+    geobo_toeplitz_y2s): (i) the cubes agree with the four-product path (GEOBO_Y2S=0) far inside the parity tolerance, (ii) the route
+    really runs the three-product kernel, (iii) the symmetry is VERIFIED on the device -- a prior whose blocks (0, 1) and (1, 0)
+    differ makes the step raise instead of returning cubes of a different model."""
+    f = load_golden("oracle64x48_matern32.npz")
+    nx, ny, nz = (int(v) for v in f["dims"])
+    s = settings_for(nx, ny, nz, kernelfunc="matern32")
+    d0 = np.zeros(nx * ny * nz)
+    d0[f["sel"]] = f["drillvalues"]
+    d0 = d0.reshape(ny, nx, nz)
+
+    def run(inv):
+        inv.gp_length = f["gp_length_in"].copy()
+        return inv.cubing(f["gravfield"], f["magfield"], d0[d0 != 0], f["sensor_locations"], d0)
+
+    inv = _inv(s)
+    inv.engine.kernel_events = []
+    three = run(inv)
+    names = {e[0] for e in inv.engine.kernel_events}
+    inv.engine.kernel_events = None
+    assert "kernel:toeplitz_y2s" in names and "kernel:toeplitz_y2t" not in names, names
+    monkeypatch.setenv("GEOBO_Y2S", "0")
+    four = run(_inv(s))
+    monkeypatch.delenv("GEOBO_Y2S")
+    for a, b in zip(three, four):
+        assert np.abs(a - b).max() <= 1e-11 * np.abs(b).max()
+    # an asymmetric "prior": the generator of block (1, 0) scaled by (1 + 1e-6) behind the planner's back
+    inv2 = _inv(s)
+    run(inv2)                                       # builds the spectral product
+    sp = inv2.engine._spectral
+    orig = sp.y2s_tables
+    sp.y2s_tables = lambda tg, tm, pair=(0, 1): orig(tg, [tm[0] * (1.0 + 1e-6)] + list(tm[1:]), pair)
+    with pytest.raises(RuntimeError, match="not symmetric"):
+        run(inv2)
+
+
 def _engine_posterior(eng, f, kern, props=(0, 1, 2)):
     from geobo_amd.engine import create_cov_lengths
     A_g = eng.operator("grav", f["sensor_locations"])
