@@ -607,6 +607,7 @@ int launch_win(const ToeplitzWinArgs& g, hipStream_t st) {
   }
   ToeplitzWinArgs a = g;
   a.cw = g.nprop == 1 ? 4 : g.nprop == 2 ? 2 : 1;  // eight waves (256 VGPRs each: the table window alone is 158)
+  if (g.nprop == 1 && nchunks % 4 != 0 && nchunks % 3 == 0) a.cw = 3;   // ny = 96: 6 chunks as 3 + 3 (six waves), not 4 + 2 with two waves idle
   if (a.cw > nchunks) a.cw = nchunks;
   const int ngroups = (nchunks + a.cw - 1) / a.cw;
   int64_t gz = 1;                                   // one workgroup per CU: a few waves of workgroups, each sweeping R / gz rows
