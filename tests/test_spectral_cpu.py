@@ -71,6 +71,35 @@ def test_radix4_synthesis_identity(n):
 
 
 @pytest.mark.parametrize("n", [16, 64])
+def test_radix4_analysis_identity(n):
+    """What the analysis along x of xz_fold_fwd_kernel / xcorr_fold4_kernel computes (radix 4): per residue class rho of the input
+    index and frequency w < n/4 ONE cosine-row sum C_rho and ONE sine-row sum S_rho (w = 0: the constant-row and the alternating-row
+    sum); the eight spectral positions 8 w .. 8 w + 7 are signed sums of those eight numbers -- formed in one lane on the device."""
+    rng = np.random.default_rng(5)
+    G = forward_matrix(n)
+    x = rng.standard_normal(n)
+    ref = G @ x
+    got = np.empty(2 * n)
+    q = n // 4
+    j = np.arange(q)
+    alt = 1.0 - 2.0 * (j % 2)
+    for w in range(q):
+        C, S = np.empty(4), np.empty(4)
+        for rho in range(4):
+            i = 4 * j + rho
+            C[rho] = G[8 * w, i] @ x[i]                                    # base row 4 w (cos w; w = 0: the constant row)
+            S[rho] = (G[8 * w + 2, i] if w else alt * G[0, i]) @ x[i]      # base row 4 w + 1 (sin w; w = 0: the alternating row)
+        u0, u1, v0, v1 = C[0] + C[2], C[0] - C[2], C[1] + C[3], C[1] - C[3]
+        ws, wd, z0, z1 = S[0] + S[2], S[0] - S[2], S[1] + S[3], S[1] - S[3]
+        if w:
+            got[8 * w:8 * w + 8] = [u0 + v0, u0 - v0, ws + z0, ws - z0, u1 + z1, u1 - z1, v1 - wd, -wd - v1]
+        else:       # frequencies 0, n | the middle pair | cos n/4, mirror | sin n/4, mirror
+            r2 = np.sqrt(2.0)
+            got[0:8] = [u0 + v0, u0 - v0, u1 + v1, u1 - v1, r2 * S[0] + z1, r2 * S[0] - z1, r2 * S[2] + z0, r2 * S[2] - z0]
+    assert np.abs(got - ref).max() < 1e-12
+
+
+@pytest.mark.parametrize("n", [16, 64])
 def test_folded_forward_and_inverse_equal_the_plain_products(n):
     """out[2b] = E + O, out[2b+1] = E - O and x[2j] = Fe^T (s_even + s_odd), x[2j+1] = Fo^T (s_even - s_odd): what
     geobo_xz2d_fold / geobo_xcorr_reduce_fold compute per axis with half the multiply-adds."""
