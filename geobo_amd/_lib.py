@@ -59,6 +59,7 @@ SIGNATURES = {
     "geobo_xz2d_fold_inv_ss_slots": (_int, [_int, _i64, _int]),
     "geobo_xz2d_fold_inv_ss": (_int, [_int, _i64, _int, _dp, _i64, _i64, _dp, _i64, _i64, _dp, _dp, _dp, _dp]),
     "geobo_ymul": (_int, [_int, _int, _i64, _i64, _dp, _i64, _dp, _i64, _dp, _i64, _dp]),
+    "geobo_ymul_fold": (_int, [_int, _int, _i64, _i64, _dp, _i64, _dp, _i64, _dp, _i64, _dp]),
     "geobo_xcorr_reduce": (_int, [_int, _int, _i64, _int, _dp, _i64, _i64, _dp, _i64, _dp, _dp, _i64, _i64, _dp]),
     "geobo_toeplitz_y": (_int, [_int, _i64, _i64, _i64, _int, _dp, _dp, _dp, _dp, _dp, _int, _int, _dp]),
     "geobo_toeplitz_y2t": (_int, [_int, _i64, _i64, _i64, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),

@@ -376,6 +376,10 @@ struct YMulArgs {
   int64_t C, R, ntiles;                 // ntiles = R * (C / 64)
 };
 
+// FOLD (round 5, geobo_ymul_fold): G is the pair-interleaved basis (row 2b+1 = (-1)^j row 2b, e.g. spectral.forward_matrix with columns
+// zeroed): per pair ONE even-input and ONE odd-input sum, out[2b] = E + O, out[2b+1] = E - O -- 64 MFMAs per tile instead of 128 (the
+// kernel was on both roofs: 4.2 TB/s of HBM and 65 % MFMA busy); wave w owns the base rows 16 w .. 16 w + 15 = output rows 32 w .. 32 w + 31.
+template <bool FOLD>
 __global__ void __launch_bounds__(256, 2) ymul_kernel(YMulArgs g) {
   constexpr int NY = 64, CB = 64, TILE = NY * CB;          // doubles per staged tile (32 KiB)
   __shared__ __attribute__((aligned(16))) double xs[2][TILE];
@@ -383,11 +387,15 @@ __global__ void __launch_bounds__(256, 2) ymul_kernel(YMulArgs g) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, q = lane >> 4;
   // A fragments: A[i = lane & 15][k = lane >> 4] of M tile mt, k-step t  ->  G[32 w + 16 mt + lr][4 t + q]
+  // FOLD: a[0][t] = Fe[b = 16 w + lr][j = 4 t + q] = G[2 b][2 j], a[1][t] = Fo[b][j] = G[2 b][2 j + 1], t < 8
   double a[2][16];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int t = 0; t < 16; ++t) a[mt][t] = g.G[(int64_t)(32 * w + 16 * mt + lr) * g.ldg + 4 * t + q];
+    for (int t = 0; t < 16; ++t) {
+      if constexpr (FOLD) a[mt][t] = t < 8 ? g.G[(int64_t)(2 * (16 * w + lr)) * g.ldg + 2 * (4 * t + q) + mt] : 0.0;
+      else a[mt][t] = g.G[(int64_t)(32 * w + 16 * mt + lr) * g.ldg + 4 * t + q];
+    }
   const int64_t cbs = g.C / CB;
   int64_t tile = blockIdx.x;
   if (tile >= g.ntiles) return;
@@ -419,7 +427,12 @@ __global__ void __launch_bounds__(256, 2) ymul_kernel(YMulArgs g) {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) op[(int64_t)(32 * w + 16 * mt + q + 4 * r) * g.C + 16 * nt] = acc[mt][nt][r];
+        for (int r = 0; r < 4; ++r) {
+          if constexpr (FOLD)     // acc[0] = E, acc[1] = O of base row 16 w + q + 4 r: rows 2 b (mt = 0) and 2 b + 1 (mt = 1)
+            op[(int64_t)(2 * (16 * w + q + 4 * r) + mt) * g.C + 16 * nt] = mt ? acc[0][nt][r] - acc[1][nt][r] : acc[0][nt][r] + acc[1][nt][r];
+          else
+            op[(int64_t)(32 * w + 16 * mt + q + 4 * r) * g.C + 16 * nt] = acc[mt][nt][r];
+        }
   };
   for (; tile < g.ntiles; tile += gridDim.x) {
     __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));              // this tile has landed
@@ -434,6 +447,41 @@ __global__ void __launch_bounds__(256, 2) ymul_kernel(YMulArgs g) {
       for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = (v4d){0., 0., 0., 0.};
     // B[k = q][n = lr] of k-step t, column tile nt: xs[b][(4 t + q) * CB + 16 (nt ^ q) + lr].  Inline reads: for LDS reads it can see,
     // the compiler first waits for EVERY outstanding LDS-DMA (vmcnt(0)), i.e. for the tile that was requested a moment ago.
+    if constexpr (FOLD) {
+      // k-step t: the even rows y = 8 t + 2 q feed E, the odd rows y + 1 feed O (row y is stored with its column groups at nt ^ (y & 3))
+      unsigned xe[4], xo[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        xe[nt] = (unsigned)(uintptr_t)(lds_ptr_t)&xs[b][(2 * q) * CB + 16 * (nt ^ ((2 * q) & 3)) + lr];
+        xo[nt] = (unsigned)(uintptr_t)(lds_ptr_t)&xs[b][(2 * q + 1) * CB + 16 * (nt ^ ((2 * q + 1) & 3)) + lr];
+      }
+      double be[2][4], bo[2][4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        asm volatile("ds_read_b64 %0, %1" : "=v"(be[0][nt]) : "v"(xe[nt]));
+        asm volatile("ds_read_b64 %0, %1" : "=v"(bo[0][nt]) : "v"(xo[nt]));
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        if (t + 1 < 8) {
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(be[(t + 1) & 1][nt]) : "v"(xe[nt]), "n"(8 * (t + 1) * CB * 8));
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(bo[(t + 1) & 1][nt]) : "v"(xo[nt]), "n"(8 * (t + 1) * CB * 8));
+          }
+          asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(be[t & 1][0]), "+v"(be[t & 1][1]), "+v"(be[t & 1][2]), "+v"(be[t & 1][3]),
+                       "+v"(bo[t & 1][0]), "+v"(bo[t & 1][1]), "+v"(bo[t & 1][2]), "+v"(bo[t & 1][3]));
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(be[t & 1][0]), "+v"(be[t & 1][1]), "+v"(be[t & 1][2]), "+v"(be[t & 1][3]),
+                       "+v"(bo[t & 1][0]), "+v"(bo[t & 1][1]), "+v"(bo[t & 1][2]), "+v"(bo[t & 1][3]));
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          acc[0][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][t], be[t & 1][nt], acc[0][nt], 0, 0, 0);
+          acc[1][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1][t], bo[t & 1][nt], acc[1][nt], 0, 0, 0);
+        }
+      }
+    } else {
     unsigned xaddr[4];                                     // row q of a k-step, column group nt (stored at group nt ^ q)
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) xaddr[nt] = (unsigned)(uintptr_t)(lds_ptr_t)&xs[b][q * CB + 16 * (nt ^ q) + lr];
@@ -455,6 +503,7 @@ __global__ void __launch_bounds__(256, 2) ymul_kernel(YMulArgs g) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
           acc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt][t], bv[t & 1][nt], acc[mt][nt], 0, 0, 0);
+    }
     }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -524,6 +573,20 @@ extern "C" int geobo_ymul(int m, int k, int64_t C, int64_t rows, const double* G
   g.in = in; g.in_row = in_row; g.G = G; g.ldg = ldg; g.out = out; g.out_row = out_row; g.C = C; g.R = rows;
   g.ntiles = rows * (C / 64);
   const int64_t nwg = g.ntiles < 512 ? g.ntiles : 512;   // persistent: two workgroups per CU, 32 tiles each at 64^3
-  hipLaunchKernelGGL(ymul_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, g);
+  hipLaunchKernelGGL(ymul_kernel<false>, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, g);
+  return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
+}
+
+extern "C" int geobo_ymul_fold(int m, int k, int64_t C, int64_t rows, const double* G, int64_t ldg, const double* in, int64_t in_row,
+                               double* out, int64_t out_row, void* stream) {
+  if (!G || !in || !out) return GEOBO_E_ARG;
+  if (rows <= 0 || C <= 0) return GEOBO_OK;
+  if (m != 128 || k != 64) return GEOBO_E_UNSUPPORTED;
+  if (C % 64 || (in_row & 1) || ((uintptr_t)in & 15) || (C & 1)) return GEOBO_E_ALIGN;
+  YMulArgs g;
+  g.in = in; g.in_row = in_row; g.G = G; g.ldg = ldg; g.out = out; g.out_row = out_row; g.C = C; g.R = rows;
+  g.ntiles = rows * (C / 64);
+  const int64_t nwg = g.ntiles < 512 ? g.ntiles : 512;
+  hipLaunchKernelGGL(ymul_kernel<true>, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, g);
   return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
 }

@@ -512,11 +512,13 @@ def xz2d_fold_lattice(n, rows, ppr, Q, row_off, q_plane, edge, edge_row, Fx, Fz,
 YMUL_SHAPES = ((128, 64),)      # (m, k) geobo_ymul is instantiated for
 
 
-def ymul(m, k, C, rows, G, src, in_row, out, out_row):
-    """out[r] (m x C) = G (m x k) . src[r] (k x C) for every row (geobo_ymul)."""
+def ymul(m, k, C, rows, G, src, in_row, out, out_row, fold=False):
+    """out[r] (m x C) = G (m x k) . src[r] (k x C) for every row (geobo_ymul); fold: G is pair-interleaved (row 2b+1 = (-1)^j row 2b) and
+    the product runs in radix 2 (geobo_ymul_fold)."""
     lib = require_gpu()
-    _lib.check(lib.geobo_ymul(int(m), int(k), int(C), int(rows), _p(_chk(G, "G")), int(G.stride(0)), _p(_chk(src, "src")), int(in_row),
-                              _p(_chk(out, "out")), int(out_row), _stream()), "geobo_ymul")
+    fn, name = (lib.geobo_ymul_fold, "geobo_ymul_fold") if fold else (lib.geobo_ymul, "geobo_ymul")
+    _lib.check(fn(int(m), int(k), int(C), int(rows), _p(_chk(G, "G")), int(G.stride(0)), _p(_chk(src, "src")), int(in_row),
+                  _p(_chk(out, "out")), int(out_row), _stream()), name)
 
 
 def xcorr_reduce(nx, nz, rows, planes, src, in_row, in_plane, Mx, lam, out, out_row, out_plane):

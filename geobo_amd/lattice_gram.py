@@ -332,7 +332,9 @@ class LatticeGram:
             R = min(self.R, nrows - r0)
             y1b = sp.buf("LG_Y1", R * Py * plane)
             if (Py, Ly) in hip.YMUL_SHAPES and plane % 64 == 0:
-                hip.ymul(Py, Ly, plane, R, gy, X[r0:], X.stride(0), y1b, Py * plane)      # G_y in registers, rows streamed once
+                # G_y in registers, rows streamed once; radix 2 where the slab starts on an even y (Gy0 keeps the pair structure: its
+                # zeroed columns are zero in both rows of a pair)
+                hip.ymul(Py, Ly, plane, R, gy, X[r0:], X.stride(0), y1b, Py * plane, fold=sp.fold and y0 % 2 == 0)
             else:
                 # (radix-2 when the slab starts on an even y: the parity of the local input index is the basis row pair's)
                 hip.axis_pass(sp.fold and y0 % 2 == 0, True, False, hip.pad_n(Py), hip.pad_n(plane), Ly, gy, ny, 0, X[r0:], plane, X.stride(0),

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GEOBO_VERSION 210 /* 201: flag word of geobo_gemm_nt, (64, 32) instance of geobo_xz2d, workspace layout of geobo_potrf_inv; 202: geobo_ymul, geobo_xz2d_fold_lattice; 203: geobo_sumsq_accum, geobo_lamdot_z, geobo_toeplitz_y2t, geobo_xz2d_fold_quad; 204: geobo_toeplitz_y3_add; 205: workspace layout of geobo_potrf_inv (one T buffer per tree node); 206: geobo_potrf_inv as one persistent tile-DAG launch from m = 1024 (workspace: + counters); 207: geobo_gemm_fold; 208: geobo_gemm_fold_lamdot; 209: geobo_toeplitz_y2s; 210: geobo_xz2d_fold* dense planes take the quarter-period group order of the basis (radix 4) */
+#define GEOBO_VERSION 211 /* 201: flag word of geobo_gemm_nt, (64, 32) instance of geobo_xz2d, workspace layout of geobo_potrf_inv; 202: geobo_ymul, geobo_xz2d_fold_lattice; 203: geobo_sumsq_accum, geobo_lamdot_z, geobo_toeplitz_y2t, geobo_xz2d_fold_quad; 204: geobo_toeplitz_y3_add; 205: workspace layout of geobo_potrf_inv (one T buffer per tree node); 206: geobo_potrf_inv as one persistent tile-DAG launch from m = 1024 (workspace: + counters); 207: geobo_gemm_fold; 208: geobo_gemm_fold_lamdot; 209: geobo_toeplitz_y2s; 210: geobo_xz2d_fold* dense planes take the quarter-period group order of the basis (radix 4); 211: geobo_ymul_fold */
 
 #define GEOBO_PAD_M 256 /* row padding of M-like dimensions (observation rows)            */
 #define GEOBO_PAD_N 128 /* padding of voxel-like dimensions (columns / contraction index) */
@@ -335,6 +335,11 @@ int geobo_xz2d_fold_inv_ss(int n, int64_t rows, int planes_per_row, const double
  * m = 128, k = 64 (GEOBO_E_UNSUPPORTED otherwise: geobo_gemm_batched does the same), C % 64 == 0, in 16-byte aligned. */
 int geobo_ymul(int m, int k, int64_t C, int64_t rows, const double* G, int64_t ldg, const double* in, int64_t in_row,
                double* out, int64_t out_row, void* stream);
+/* The same product for a PAIR-INTERLEAVED matrix (row 2b+1 = (-1)^j row 2b: the basis of geobo_amd/spectral.py, also with columns zeroed
+ * or scaled) in radix 2: per pair one even-input and one odd-input sum, out[2b] = E + O, out[2b+1] = E - O -- half the MFMAs of
+ * geobo_ymul, which sat on the matrix pipe and on HBM at once.  Only the rows 2b of G are read.  Same shapes and errors. */
+int geobo_ymul_fold(int m, int k, int64_t C, int64_t rows, const double* G, int64_t ldg, const double* in, int64_t in_row,
+                    double* out, int64_t out_row, void* stream);
 
 /* Folded form of geobo_xcorr_reduce for the pair-interleaved basis in the quarter-period group order of geobo_xz2d_fold (version 210):
  * the x product in RADIX 4 -- one cosine and one sine row per frequency group and residue class of x mod 4, a quarter of the MFMAs of

@@ -913,6 +913,25 @@ def test_ymul_matches_torch(hip, rows, C):
     assert torch.isnan(out[:, 128 * C:]).all()
 
 
+@pytest.mark.parametrize("rows,C", [(1, 64), (3, 4096), (37, 192), (300, 4096)])
+def test_ymul_fold_matches_torch(hip, rows, C):
+    # the radix-2 form for a pair-interleaved matrix: the basis with two columns zeroed (what the lattice Gram hands in) and scaled
+    from geobo_amd.spectral import forward_matrix
+    Gh = forward_matrix(64) * (1.0 + 0.01 * np.arange(64))[None, :]
+    Gh[:, 0] = 0.0
+    Gh[:, 63] = 0.0
+    G = hip.to_dev(Gh)
+    in_row = 64 * C + 16
+    src = _rand((rows, in_row), 73)
+    out_row = 128 * C + 6
+    out = torch.full((rows, out_row), float("nan"), dtype=torch.float64, device="cuda")
+    hip.ymul(128, 64, C, rows, G, src, in_row, out, out_row, fold=True)
+    torch.cuda.synchronize()
+    ref = torch.einsum("ij,rjc->ric", G, src[:, :64 * C].reshape(rows, 64, C))
+    assert normwise(out[:, :128 * C].reshape(rows, 128, C).cpu().numpy(), ref.cpu().numpy()) < 1e-14
+    assert torch.isnan(out[:, 128 * C:]).all()
+
+
 @pytest.mark.parametrize("alpha,beta", [(1.0, 1.0), (-1.0, 1.0), (2.0, -2.0), (1.0, -1.0), (0.5, 1.0)])
 @pytest.mark.parametrize("m,small", [(512, False), (512, True), (384, False)])
 def test_gemm_nt_accumulating_forms(hip, alpha, beta, m, small):

@@ -80,6 +80,7 @@ if which in ("all", "ymul"):
     G = rnd(128, 64)
     src, out = rnd(R, 64 * n * n), torch.empty((R, 128 * n * n), dtype=torch.float64, device=dev)
     timed("ymul", R * 2.0 * 128 * 64 * n * n, R * (64 + 128) * n * n * 8.0, lambda: hip.ymul(128, 64, n * n, R, G, src, src.stride(0), out, out.stride(0)))
+    timed("ymul_fold", R * 1.0 * 128 * 64 * n * n, R * (64 + 128) * n * n * 8.0, lambda: hip.ymul(128, 64, n * n, R, G, src, src.stride(0), out, out.stride(0), fold=True))
 if which in ("all", "ymul_gemm"):   # the same product as a batched GEMM (what geobo_ymul replaced)
     G = rnd(128, 64)
     src, out = rnd(R, 64 * n * n), torch.empty((R, 128 * n * n), dtype=torch.float64, device=dev)
