@@ -314,7 +314,8 @@ class LatticeGram:
         h = 0.25 if f else 1.0            # radix-4 x step: a quarter of the MFMAs of the plain product
         hb = 0.25 if f else 1.0           # back-transform on the radix-4 inverse kernel: a quarter
         zsum = 0.0 if self.fast(nx, ny, nz) else 2.0 * Py * Px * nz  # (the stand-alone scaling + channel sum of the batched-GEMM form, fp64 VALU)
-        return rows * (2.0 * (hip.pad_n(Py) * nx * nz * Ly + h * Py * Px * nx * nz + hb * (ny * Py * Px + ny * nx * Px)) + zsum)
+        hy = 0.5 if (f and (Py, Ly) in hip.YMUL_SHAPES) else 1.0     # y step on geobo_ymul_fold: radix 2
+        return rows * (2.0 * (hy * hip.pad_n(Py) * nx * nz * Ly + h * Py * Px * nx * nz + hb * (ny * Py * Px + ny * nx * Px)) + zsum)
 
     def gram_rows(self, X, nrows, lam, out, y0=0, y1=None):
         """out[r, :ny*nx] = interior-slab part of (A K)[r] . A^T for r < nrows.  X: (>= nrows x >= (y1-y0)*nx*nz) rows of A K for
