@@ -419,6 +419,7 @@ def main():
     if a.check and world == 1:
         # the multi-rank form of this step on the one rank there is -- row form forced, its all-gather / all-reduce / agreement issued
         # through the backend (sharding._live) -- against the cubes of the timed steps (a second engine beside the timed one: 2 x 50 GB)
+        rows_before = os.environ.get("GEOBO_ROWS")
         os.environ["GEOBO_ROWS"] = "1"
         try:
             solo = Inversion(settings=s, props=(0, 1, 2)[:a.props], rank=0, world=1, device="cuda:%d" % local, method=a.method,
@@ -428,7 +429,10 @@ def main():
             solo.gp_length = (gp_length.copy() if gp_length is not None else s.gp_lengthscale * np.asarray([s.xvoxsize] * 3))
             ref = solo.cubing(grav, mag, drill0[drill0 != 0], loc, drill0)
         finally:
-            os.environ.pop("GEOBO_ROWS", None)
+            if rows_before is None:
+                os.environ.pop("GEOBO_ROWS", None)
+            else:
+                os.environ["GEOBO_ROWS"] = rows_before
         idx = (0, 1, 3, 4) if a.props == 2 else range(6)
         evs = [(e[0], e[4].elapsed_time(e[5])) for e in solo.engine.kernel_events if e[0] in coll_names]
         check = {"what": "row form forced on the one rank, collectives through backend '%s' with world size 1" % a.backend,

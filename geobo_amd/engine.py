@@ -38,7 +38,7 @@ import numpy as np
 import torch
 
 from . import geometry, hip
-from .plan import plan_route
+from .plan import COLUMN_FORM_MAX_BYTES, plan_route
 from .columnform import ColumnExchangeMixin
 from .rowform import RowFormMixin
 from .operators import StreamedOperator
@@ -245,12 +245,11 @@ class PosteriorEngine(RowFormMixin, TransposedPosteriorMixin, ColumnExchangeMixi
         assert loc.shape == (self.Ms, 3), "A_sens handles exactly xNcube*yNcube sensors (sensormodel.py:54,58)"
         xe, ye, ze = self.node_axes() if axes is None else axes
         # survey on the cube's own x-y lattice (the reference's workflow): translation-invariant stencil, ~2000x fewer potentials
-        plan = None
-        if True:      # (the lattice analysis is always attempted; a survey off the lattice gets plan = None)
-            pkey = (loc.tobytes(), xe.tobytes(), ye.tobytes(), ze.tobytes())
-            if self._lattice_plan is None or self._lattice_plan[0] != pkey:
-                self._lattice_plan = (pkey, hip.lattice_plan(loc, xe, ye, ze, self.nx, self.ny, self.nz, self.device))
-            plan = self._lattice_plan[1]
+        # (the lattice analysis is always attempted; a survey off the lattice gets plan = None)
+        pkey = (loc.tobytes(), xe.tobytes(), ye.tobytes(), ze.tobytes())
+        if self._lattice_plan is None or self._lattice_plan[0] != pkey:
+            self._lattice_plan = (pkey, hip.lattice_plan(loc, xe, ye, ze, self.nx, self.ny, self.nz, self.device))
+        plan = self._lattice_plan[1]
         # row form (rowform.py): this rank's sensor rows + the two boundary slabs of every sensor, nothing sharded by voxel columns.
         # Needs a row-major lattice survey and even stencils; a denial holds for exactly the survey / field it was found for.
         Bkey = None if B is None else tuple(np.asarray(B, dtype=float))
@@ -566,9 +565,11 @@ class PosteriorEngine(RowFormMixin, TransposedPosteriorMixin, ColumnExchangeMixi
                 self._rowpath = True
                 self._fullrows = {}
                 return None, M_pad
-        if self.route.rows_mandatory and self.use_spectral:
+        # what THIS step would materialise (its own property count and element size; the planner's figure is for two blocks)
+        ak_bytes = M_pad * len(props) * nc * (4 if self.f32 else 8)
+        if ak_bytes > COLUMN_FORM_MAX_BYTES and self.use_spectral:
             raise RuntimeError("A K of this grid would take %.0f GB on this rank and only the row form avoids it (%s)"
-                               % (self.route.ak_bytes / 1e9, self.route.note or "GEOBO_ROWS=0 / GEOBO_POSTERIOR=dense switch it off"))
+                               % (ak_bytes / 1e9, self.route.note or "GEOBO_ROWS=0 / GEOBO_POSTERIOR=dense switch it off"))
         AK = self._workspace2d("AK", M_pad, len(props) * nc, dtype=hip.F32 if self.f32 else F64)
         # every sensor/drill row is overwritten below; only the padding must be defined: rows behind each row block
         # (zero, so that AkA / V get zero rows) and voxel columns >= N of the last shard (finite: they meet zero A columns)
@@ -876,12 +877,13 @@ class PosteriorEngine(RowFormMixin, TransposedPosteriorMixin, ColumnExchangeMixi
             st = self._to_host_async(stats, "stats") if calclogl else None
             resid = getattr(self._spectral, "sym_residual", None)
             h_res = self._to_host_async(resid.reshape(1), "sym_residual") if resid is not None else None
+            if resid is not None:
+                self._spectral.sym_residual = None      # read (queued above) exactly once, whatever this step raises
             torch.cuda.current_stream(self.device).synchronize()
             info_h = int(h_info[0])
             if info_h != 0:
                 raise CholeskyError(info_h)
             if h_res is not None:
-                self._spectral.sym_residual = None
                 if not float(h_res[0]) <= 1e-12:
                     # the three-product y stage (geobo_toeplitz_y2s) took blocks (0, 1) and (1, 0) of the prior for one block
                     raise RuntimeError("the covariance blocks (0, 1) and (1, 0) differ (relative %.3e): this prior is not symmetric; "

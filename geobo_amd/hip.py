@@ -413,13 +413,7 @@ def gemm_batched(y_is_kn, m, n, k, X, ldx, strideX, Y, ldy, strideY, C_, ldc, st
     lib = require_gpu()
     done = 0
     esz = 8
-    for T, lead, stride, rows, cols, what in ((X, ldx, strideX, m, k, "X"),
-                                              (Y, ldy, strideY, k if y_is_kn else n, n if y_is_kn else k, "Y")):
-        last = (batch - 1) * int(stride) + (int(rows) - 1) * int(lead) + int(cols)
-        room = T.untyped_storage().nbytes() // T.element_size() - T.storage_offset()
-        if last > room:
-            raise ValueError("geobo_gemm_batched: operand %s (%d x %d, ld %d, batch %d x stride %d) reads %d elements past its allocation"
-                             % (what, rows, cols, lead, batch, stride, last - room))
+    _check_extents("geobo_gemm_batched", ((X, ldx, strideX, m, k, "X"), (Y, ldy, strideY, k if y_is_kn else n, n if y_is_kn else k, "Y")), batch)
     while done < batch:                      # gridDim.y limit
         nb = min(batch - done, 65535)
         _lib.check(lib.geobo_gemm_batched(1 if y_is_kn else 0, int(m), int(n), int(k), float(alpha),

@@ -79,7 +79,7 @@ def lattice_gram_supported(nx, ny, nz):
     return nx % 16 == 0 and ny % 16 == 0 and nz % 16 == 0 and ny >= 16
 
 
-def plan_route(nx, ny, nz, world=1, rank=0, assembly="f64", operators="resident", method="auto", env=None):
+def plan_route(nx, ny, nz, world=1, rank=0, assembly="f64", operators="resident", method="auto", env=None, nprops=2):
     env = {} if env is None else env
     on = lambda key, default="1": env.get(key, default) != "0"
     nx, ny, nz, world = int(nx), int(ny), int(nz), int(world)
@@ -105,7 +105,9 @@ def plan_route(nx, ny, nz, world=1, rank=0, assembly="f64", operators="resident"
     single = world == 1 and not f32 and spectral and unpadded and transposed and fused_ss
     quad_xz = pair_xz and ny % 4 == 0 and on("GEOBO_XZ_FOLD") and 64 in XZ2D_FOLD_N and on("GEOBO_XZ_QUAD")
     rows_mode = env.get("GEOBO_ROWS", "auto")           # "0": never; "1": wherever it is possible; "auto": where it pays
-    column_ak_bytes = (2 * Ms_pad + PAD_M) * 2 * N_pad * 8 // max(world, 1)
+    # a materialised A K of this rank: nprops property blocks in the element size of the assembly (fp32 assembly stores A K as fp32); the
+    # engine repeats the check with the step's own property count where it allocates (engine._assemble_AK)
+    column_ak_bytes = (2 * Ms_pad + PAD_M) * int(nprops) * N_pad * (4 if f32 else 8) // max(world, 1)
     pays = ((gram_fast and fused_ss) or ((fused_xz or quad_xz) and dense_y and N >= ROWS_MIN_VOXELS_FUSED)
             or (N >= ROWS_MIN_VOXELS and plane >= ROWS_MIN_PLANE) or (N >= ROWS_MIN_VOXELS_MID and plane >= ROWS_MIN_PLANE_MID)
             or column_ak_bytes > COLUMN_FORM_MAX_BYTES)

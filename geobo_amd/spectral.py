@@ -425,7 +425,10 @@ class SpectralProduct:
                 and os.environ.get("GEOBO_Y2S", "1") != "0"):
             return None
         x = gens_g[b]
-        self.sym_residual = (x - gens_m[a]).abs().max() / x.abs().max()
+        # (cross weight 0 -- gp_coeff = [.., .., 0], a legal prior -- makes both cross blocks exactly zero: 0 / 0 must not read as
+        # "asymmetric", so the residual is the difference against a denominator that is never zero)
+        den = torch.maximum(x.abs().max(), gens_m[a].abs().max())
+        self.sym_residual = (x - gens_m[a]).abs().max() / den.clamp_min(torch.finfo(x.dtype).tiny)
         return (a, gens_g[a] - x, x, gens_m[b] - x)
 
     def reduce_ss(self, Zg, Mg, gens_g, Zm, m_first, gens_m, ss, y2s=None):

@@ -289,3 +289,7 @@ def test_mandatory_row_form_is_flagged():
     off = plan_route(80, 128, 80, env={"GEOBO_ROWS": "0"})
     assert off.family != "rows" and off.rows_mandatory and "only the row form fits" in off.note
     assert not plan_route(64, 64, 64).rows_mandatory and not plan_route(128, 128, 128, world=8, assembly="f32").rows_mandatory
+    # round-5 advisory: the figure follows the element size of the assembly and the number of property blocks
+    assert plan_route(96, 96, 96).rows_mandatory and not plan_route(96, 96, 96, assembly="f32").rows_mandatory
+    assert plan_route(96, 96, 96, assembly="f32").ak_bytes * 2 == plan_route(96, 96, 96).ak_bytes
+    assert not plan_route(80, 96, 80).rows_mandatory and plan_route(80, 96, 80, nprops=3).rows_mandatory
