@@ -15,7 +15,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgeobo_hip.so")
-SOURCES = ["gemm_f64.hip", "gemm_fold.hip", "potrf.hip", "assembly.hip", "toeplitz.hip", "xz2d.hip", "xz2d_fold.hip", "reduce.hip"]
+SOURCES = ["gemm_f64.hip", "gemm_fold.hip", "potrf.hip", "assembly.hip", "toeplitz.hip", "spectral_y.hip", "xz2d.hip", "xz2d_fold.hip", "reduce.hip"]
 HEADERS = [os.path.join(CSRC, "covfun.h"), os.path.join(ROOT, "include", "geobo_hip.h")]
 
 

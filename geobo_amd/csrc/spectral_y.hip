@@ -1,0 +1,372 @@
+// spectral_y.hip -- the y-axis stage of the structured covariance product as an IN-KERNEL spectral product on the fp64 matrix pipe
+// (round 6).  Same operation as toeplitz.hip (kernels.py:158-195 builds K_sj densely; inversion.py:96,114 contract it):
+//
+//     out_j[r][y][c] = sum_{y'} t_{j,c}(|y - y'|) in[r][y'][c]        per mode c of the (x, z)-spectrum, j = property block
+//
+// toeplitz.hip applies T_c directly on the vector pipe (ny^2 multiply-adds per mode, block and term: the matrix differs per mode, so
+// no operand is shared along a tile edge).  Here the y axis goes through its OWN spectrum without leaving the registers:
+//
+//   * T_c (ny x ny, symmetric Toeplitz) is the leading block of a SKEW-circulant of size P = 2 ny (first column t_0 .. t_{ny-1}, *,
+//     -t_{ny-1} .. -t_1), which the real functions cos / sin(2 pi kappa y / P) of the HALF-INTEGER frequencies kappa = 1/2 .. ny - 1/2
+//     diagonalise with the real eigenvalues  lambda_c(kappa) = (1/ny) sum_d w_d t_c(d) cos(2 pi kappa d / P)  (w_0 = 1, else 2).
+//     Half-integer frequencies have no self-paired members (no constant / alternating / middle rows): all ny frequencies fall into
+//     ny / 4 ORBITS {kappa, ny - kappa, ny/2 + kappa, ny/2 - kappa}, kappa = omega + 1/2, omega < ny/4, of the shift by a quarter
+//     period.  On the inputs y = 4 j + rho of one residue class the cos / sin rows of the whole orbit are +-(cos | sin) of kappa:
+//     RADIX 4 -- the analysis is, per class, a (2 ny/4) x (ny/4) matrix product against G_rho (the SAME matrix for every mode:
+//     the 16 columns of an MFMA are 16 modes, 128-byte segments of the spectrum), then 16 additions per orbit; the synthesis
+//     is the transpose.  ny^2 / 2 multiply-adds per transform and mode.
+//   * one term, two blocks: 1 analysis + 2 syntheses = 1.5 ny^2 (direct: 2 ny^2); two-term rows with the shared cross block:
+//     2 + 2 = 2 ny^2 (three direct products: 3 ny^2) -- the terms meet in the spectrum, lambda_00 x^_g + lambda_01 x^_m.
+//   * a wave owns 16 modes and sweeps the rows: its 16 eigenvalues per lane and table stay in registers (computed in the prologue
+//     from the SAME Toeplitz generator tables toeplitz.hip takes: a drop-in), the transform fragments sit in LDS (shared by the
+//     workgroup), the inputs come straight from global memory into the B operand layout (lane = (y' mod 16 / 4, mode): four
+//     128-byte segments per instruction, one row ahead), the D tiles of the synthesis go straight back (the same segments).
+//     No per-lane table, no workgroup barrier in the row loop.
+//
+// Fragment / register layout (v_mfma_f64_16x16x4: A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15],
+// D[row = (lane >> 4) + 4 reg][col = lane & 15]); g = lane >> 4, c = lane & 15:
+//   analysis tile T of class rho: rows m < 8 = cos of omega = 8 T + m, rows m >= 8 = sin of omega = 8 T + m - 8, so that a lane
+//     holds C_rho (reg h) and S_rho (reg 2 + h) of ITS orbits omega = 8 T + 4 h + g, h = 0, 1: the butterflies are lane local;
+//   k-step s of the analysis contracts j = 4 s + g, i.e. input planes y' = 16 s + 4 g + rho;
+//   synthesis of class rho: k-step (T, r) takes register r of tile T as its B operand (k <-> g): (trig = r >> 1, omega = 8 T + 4 (r & 1) + g);
+//     D register r' holds output j = 16 mj + g + 4 r', y = 4 j + rho;
+//   eigenvalues: tile tau = 2 T + h, register f = member of the orbit: one MFMA sweep over the table per block in the prologue.
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <stdint.h>
+#include "geobo_hip.h"
+
+namespace {
+
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+using u32x2 = decltype(__builtin_amdgcn_raw_buffer_load_b64(*static_cast<rsrc_t*>(nullptr), 0, 0, 0));
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) double lds_double;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const double* base, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ double ld_lane(rsrc_t rs, unsigned voff, int soff) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0));
+}
+__device__ __forceinline__ void st_lane(rsrc_t rs, unsigned voff, int soff, double v) {
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rs, voff, soff, 0);
+}
+
+template <int NY>
+struct Shape {
+  static constexpr int P = 2 * NY, NW = NY / 4, NJ = NY / 4, NT = (NW + 7) / 8, MJ = (NJ + 15) / 16, KS = NJ / 4, KE = NY / 4;
+  static constexpr int NF_FWD = 4 * KS * NT, NF_INV = 4 * NT * 4 * MJ, NF_EIG = 2 * NT * KE;
+  static constexpr int NF = NF_FWD + NF_INV + NF_EIG;                 // fragments of 64 doubles
+  static_assert(NY % 16 == 0, "ny");
+  // fragment indices
+  static constexpr int fwd(int rho, int s, int T) { return (rho * KS + s) * NT + T; }
+  static constexpr int inv(int rho, int T, int r, int mj) { return NF_FWD + ((rho * NT + T) * 4 + r) * MJ + mj; }
+  static constexpr int eig(int tau, int s) { return NF_FWD + NF_INV + tau * KE + s; }
+};
+
+// ---- the basis blob: every fragment of the three transforms in lane order (filled once per ny by geobo_spectral_y_basis) ---------------
+template <int NY>
+__global__ void basis_kernel(double* out) {
+  using S = Shape<NY>;
+  const int f = blockIdx.x, lane = threadIdx.x, m = lane & 15, g = lane >> 4;
+  auto trig = [](int t, int om, int y) {      // cos / sin(2 pi (om + 1/2) y / P) with the phase reduced in integers
+    const int idx = ((2 * om + 1) * y) % (2 * S::P);
+    double s, c;
+    sincospi((double)idx / (double)S::P, &s, &c);
+    return t == 0 ? c : s;
+  };
+  double v = 0.0;
+  if (f < S::NF_FWD) {
+    const int T = f % S::NT, s = (f / S::NT) % S::KS, rho = f / (S::NT * S::KS);
+    const int y = 4 * (4 * s + g) + rho, om = 8 * T + (m & 7);
+    if (om < S::NW) v = trig(m >> 3, om, y);
+  } else if (f < S::NF_FWD + S::NF_INV) {
+    const int q = f - S::NF_FWD, mj = q % S::MJ, r = (q / S::MJ) % 4, T = (q / (4 * S::MJ)) % S::NT, rho = q / (4 * S::MJ * S::NT);
+    const int j = 16 * mj + m, om = 8 * T + 4 * (r & 1) + g;
+    if (om < S::NW && j < S::NJ) v = trig(r >> 1, om, 4 * j + rho);
+  } else {
+    const int q = f - S::NF_FWD - S::NF_INV, s = q % S::KE, tau = q / S::KE;
+    const int T = tau >> 1, h = tau & 1, fm = m >> 2, gg = m & 3;        // row m of tile tau = 4 f + g': member f of the orbit of lane group g'
+    const int om = 8 * T + 4 * h + gg, d = 4 * s + g;
+    if (om < S::NW) {
+      const int f2 = fm == 0 ? 2 * om + 1 : fm == 1 ? 2 * NY - (2 * om + 1) : fm == 2 ? NY + 2 * om + 1 : NY - (2 * om + 1);   // twice the frequency
+      const int idx = (int)(((int64_t)f2 * d) % (2 * S::P));
+      double sn, cs;
+      sincospi((double)idx / (double)S::P, &sn, &cs);
+      v = (d == 0 ? 1.0 : 2.0) * cs / (double)NY;
+    }
+  }
+  out[(size_t)f * 64 + lane] = v;
+}
+
+struct SYArgs {
+  const double* in[2];      // [R][NY][S] per term
+  const double* tab[3];     // Toeplitz generators [NY][C]: NIN = 1: one per output block; NIN = 2: D0, X, D1 (geobo_toeplitz_y2s)
+  double* out[2];           // [R][y1 - y0][S] per property block
+  const double* basis;      // Shape<NY>::NF fragments
+  int64_t C, S, R;
+  int y0, y1;
+};
+
+// one orbit's analysis butterfly: class sums C[rho], S[rho] -> (a_f, b_f), f = kappa, ny - kappa, ny/2 + kappa, ny/2 - kappa
+__device__ __forceinline__ void bfly_fwd(const double (&C)[4], const double (&S)[4], double (&a)[4], double (&b)[4]) {
+  const double p0 = C[0] + C[2], p1 = C[0] - C[2], p2 = C[1] + C[3], p3 = C[1] - C[3];
+  const double q0 = S[0] + S[2], q1 = S[0] - S[2], q2 = S[1] + S[3], q3 = S[1] - S[3];
+  a[0] = p0 + p2; a[1] = p0 - p2; b[0] = q0 + q2; b[1] = q2 - q0;
+  a[2] = p1 - q3; a[3] = p1 + q3; b[2] = q1 + p3; b[3] = p3 - q1;
+}
+
+template <int NY, int NIN, int NOUT, bool FULL>
+__global__ void __launch_bounds__(256, 1) spectral_y_kernel(SYArgs g) {
+  using S = Shape<NY>;
+  constexpr int NT = S::NT, MJ = S::MJ, KS = S::KS, NTAB = NIN == 2 ? 3 : NOUT;
+  static_assert((NIN == 1 && NOUT >= 1 && NOUT <= 2) || (NIN == 2 && NOUT == 2), "forms");
+  extern __shared__ __attribute__((aligned(16))) double frag[];           // [NF][64]
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 15, gq = lane >> 4;
+  for (int i = threadIdx.x; i < S::NF * 64; i += 256) frag[i] = g.basis[i];
+  __syncthreads();
+  lds_double* const fl0 = (lds_double*)frag + lane;
+  const int64_t Sd = g.S, m0 = ((int64_t)blockIdx.x * 4 + w) * 16;
+  if (m0 >= g.C) return;
+  const int S8 = (int)(Sd * 8);
+  const unsigned voff = (unsigned)((4 * gq) * S8 + c * 8);                // plane 4 g of a group of 16, mode c of the tile
+
+  // ---- eigenvalues of this lane's orbits: lam[tab][tau = 2 T + h][f] = (E t)(orbit member f of omega = 8 T + 4 h + g) ------------
+  d4 lam[NTAB][2 * NT];
+  {
+    const int T8 = (int)(g.C * 8);
+    const unsigned tvoff = (unsigned)(gq * T8 + c * 8);
+#pragma unroll
+    for (int t = 0; t < NTAB; ++t) {
+      const rsrc_t tr = make_rsrc(g.tab[t] + m0, NY * T8);
+#pragma unroll
+      for (int tau = 0; tau < 2 * NT; ++tau) lam[t][tau] = d4{0., 0., 0., 0.};
+#pragma unroll
+      for (int s = 0; s < S::KE; ++s) {
+        const double tv = ld_lane(tr, tvoff, 4 * s * T8);
+#pragma unroll
+        for (int tau = 0; tau < 2 * NT; ++tau)
+          lam[t][tau] = __builtin_amdgcn_mfma_f64_16x16x4f64(fl0[S::eig(tau, s) * 64], tv, lam[t][tau], 0, 0, 0);
+      }
+    }
+  }
+
+  int64_t r = blockIdx.y;
+  if (r >= g.R) return;
+  const int64_t rstep = gridDim.y, rowlen = (int64_t)NY * Sd;
+  const int ny_out = g.y1 - g.y0;
+  const int64_t ostep = (int64_t)ny_out * Sd;
+  const int in_bytes = NY * S8;
+
+  auto load_row = [&](double (&x)[NIN][4 * KS], int64_t row) {
+#pragma unroll
+    for (int t = 0; t < NIN; ++t) {
+      const rsrc_t rs = make_rsrc(g.in[t] + row * rowlen + m0, in_bytes);
+#pragma unroll
+      for (int rho = 0; rho < 4; ++rho)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) x[t][rho * KS + s] = ld_lane(rs, voff, (16 * s + rho) * S8);
+    }
+  };
+
+  auto body = [&](double (&x)[NIN][4 * KS], double (&xn)[NIN][4 * KS], int64_t row) {
+    if (row + rstep < g.R) load_row(xn, row + rstep);
+    // the fragment base is made opaque per row: the fragments are READ from LDS next to every MFMA (one ds_read_b64 each), not hoisted
+    // out of the row loop into 128-200 registers (accumulation registers at that: every use would then cost two v_accvgpr_read)
+    lds_double* fl = fl0;
+    asm volatile("" : "+v"(fl));
+    // ---- analysis: class sums per tile, then the orbit butterflies ----------------------------------------------------------
+    double a[NIN][NT][2][4], b[NIN][NT][2][4];
+#pragma unroll
+    for (int t = 0; t < NIN; ++t) {
+      d4 acc[4][NT];
+#pragma unroll
+      for (int rho = 0; rho < 4; ++rho)
+#pragma unroll
+        for (int T = 0; T < NT; ++T) acc[rho][T] = d4{0., 0., 0., 0.};
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int rho = 0; rho < 4; ++rho)
+#pragma unroll
+          for (int T = 0; T < NT; ++T)
+            acc[rho][T] = __builtin_amdgcn_mfma_f64_16x16x4f64(fl[S::fwd(rho, s, T) * 64], x[t][rho * KS + s], acc[rho][T], 0, 0, 0);
+#pragma unroll
+      for (int T = 0; T < NT; ++T)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const double Cc[4] = {acc[0][T][h], acc[1][T][h], acc[2][T][h], acc[3][T][h]};
+          const double Ss[4] = {acc[0][T][2 + h], acc[1][T][2 + h], acc[2][T][2 + h], acc[3][T][2 + h]};
+          bfly_fwd(Cc, Ss, a[t][T][h], b[t][T][h]);
+        }
+    }
+    // ---- per output block: eigenvalue scaling folded into the first level of the synthesis butterfly, synthesis, store --------
+#pragma unroll
+    for (int jb = 0; jb < NOUT; ++jb) {
+      asm volatile("" : "+v"(fl));      // (per block as well: the synthesis fragments of block 0 must not stay live through block 1)
+      double Y[4][NT][4];
+#pragma unroll
+      for (int T = 0; T < NT; ++T)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          double sa, da, sb, db, tb0, tb1, tb2, tb3;
+          if constexpr (NIN == 1) {
+            const d4 l = lam[jb][2 * T + h];
+            const double (&aa)[4] = a[0][T][h];
+            const double (&bb)[4] = b[0][T][h];
+            const double t0 = l[0] * aa[0], t1 = l[2] * aa[2], u0 = l[0] * bb[0], u1 = l[2] * bb[2];
+            sa = __builtin_fma(l[1], aa[1], t0); da = __builtin_fma(-l[1], aa[1], t0);
+            sb = __builtin_fma(l[3], aa[3], t1); db = __builtin_fma(-l[3], aa[3], t1);
+            tb1 = __builtin_fma(l[1], bb[1], u0); tb0 = __builtin_fma(-l[1], bb[1], u0);
+            tb3 = __builtin_fma(l[3], bb[3], u1); tb2 = __builtin_fma(-l[3], bb[3], u1);
+          } else {
+            // V_0 = T(D0) x_g + T(X)(x_g + x_m), V_1 = T(D1) x_m + T(X)(x_g + x_m): in the spectrum, per member of the orbit
+            const d4 ld = lam[jb == 0 ? 0 : 2][2 * T + h], lx = lam[1][2 * T + h];
+            double ya[4], yb[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+              const double pa = lx[f] * (a[0][T][h][f] + a[1][T][h][f]), pb = lx[f] * (b[0][T][h][f] + b[1][T][h][f]);
+              ya[f] = __builtin_fma(ld[f], a[jb][T][h][f], pa);
+              yb[f] = __builtin_fma(ld[f], b[jb][T][h][f], pb);
+            }
+            sa = ya[0] + ya[1]; da = ya[0] - ya[1]; sb = ya[2] + ya[3]; db = ya[2] - ya[3];
+            tb0 = yb[0] - yb[1]; tb1 = yb[0] + yb[1]; tb2 = yb[2] - yb[3]; tb3 = yb[2] + yb[3];
+          }
+          Y[0][T][h] = sa + sb; Y[2][T][h] = sa - sb; Y[1][T][h] = da + tb3; Y[3][T][h] = da - tb3;
+          Y[0][T][2 + h] = tb0 + tb2; Y[2][T][2 + h] = tb0 - tb2; Y[1][T][2 + h] = tb1 - db; Y[3][T][2 + h] = tb1 + db;
+        }
+      d4 o[4][MJ];
+#pragma unroll
+      for (int rho = 0; rho < 4; ++rho)
+#pragma unroll
+        for (int mj = 0; mj < MJ; ++mj) o[rho][mj] = d4{0., 0., 0., 0.};
+#pragma unroll
+      for (int T = 0; T < NT; ++T)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+          for (int rho = 0; rho < 4; ++rho)
+#pragma unroll
+            for (int mj = 0; mj < MJ; ++mj)
+              o[rho][mj] = __builtin_amdgcn_mfma_f64_16x16x4f64(fl[S::inv(rho, T, rr, mj) * 64], Y[rho][T][rr], o[rho][mj], 0, 0, 0);
+      // (slab [y0, y1): the descriptor's base is moved y0 planes in front of the row, so that plane y sits at offset y S8 whatever the
+      // slab -- scalar offsets are unsigned; only the lanes with y0 <= y < y1 store, all of them inside the row)
+      const rsrc_t dst = make_rsrc(g.out[jb] + row * ostep + m0 - (int64_t)g.y0 * Sd, g.y1 * S8);
+#pragma unroll
+      for (int rho = 0; rho < 4; ++rho)
+#pragma unroll
+        for (int mj = 0; mj < MJ; ++mj)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            // y = 4 (16 mj + g + 4 rr) + rho = (64 mj + 16 rr + rho) + 4 g: the lane part is the input's voff
+            const int yb = 64 * mj + 16 * rr + rho;
+            if (16 * mj + 4 * rr >= S::NJ) continue;                        // (padded outputs j >= ny/4 of an extent that is not a multiple of 64)
+            if constexpr (FULL) st_lane(dst, voff, yb * S8, o[rho][mj][rr]);
+            else {
+              const int y = yb + 4 * gq;
+              if (y >= g.y0 && y < g.y1) st_lane(dst, voff, yb * S8, o[rho][mj][rr]);
+            }
+          }
+    }
+  };
+
+  double xa[NIN][4 * KS], xb[NIN][4 * KS];
+  load_row(xa, r);
+  while (true) {
+    body(xa, xb, r);
+    r += rstep;
+    if (r >= g.R) break;
+    body(xb, xa, r);
+    r += rstep;
+    if (r >= g.R) break;
+  }
+}
+
+template <int NY, int NIN, int NOUT, bool FULL>
+int launch_full(const SYArgs& g, hipStream_t st) {
+  using S = Shape<NY>;
+  constexpr size_t lds = (size_t)S::NF * 64 * sizeof(double);
+  static_assert(lds <= 163840, "LDS");
+  auto kern = spectral_y_kernel<NY, NIN, NOUT, FULL>;
+  static std::atomic<uint64_t> attr_done{0};       // per-device "large-LDS attribute set" bits (include/geobo_hip.h, conventions)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return GEOBO_E_LAUNCH;
+  if (!((attr_done.load(std::memory_order_acquire) >> dev) & 1)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return GEOBO_E_LAUNCH;
+    attr_done.fetch_or((uint64_t)1 << dev, std::memory_order_release);
+  }
+  const int64_t nbx = (g.C + 63) / 64;
+  int64_t gy = 1;                                   // one 4-wave workgroup per CU and round: a wave keeps its 16 modes for R / gy rows
+  while (nbx * gy < 256 && gy < g.R) ++gy;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nbx, (unsigned)gy), dim3(256), lds, st, g);
+  return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
+}
+
+template <int NY, int NIN, int NOUT>
+int launch(const SYArgs& g, hipStream_t st) {
+  return (g.y0 == 0 && g.y1 == NY) ? launch_full<NY, NIN, NOUT, true>(g, st) : launch_full<NY, NIN, NOUT, false>(g, st);
+}
+
+template <int NY>
+int fill_basis(double* basis, hipStream_t st) {
+  hipLaunchKernelGGL(basis_kernel<NY>, dim3(Shape<NY>::NF), dim3(64), 0, st, basis);
+  return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" int64_t geobo_spectral_y_basis_doubles(int ny) {
+  switch (ny) {
+    case 64: return (int64_t)Shape<64>::NF * 64;
+    case 48: return (int64_t)Shape<48>::NF * 64;
+    case 32: return (int64_t)Shape<32>::NF * 64;
+    default: return 0;
+  }
+}
+
+extern "C" int geobo_spectral_y_basis(int ny, double* basis, void* stream) {
+  if (!basis) return GEOBO_E_ARG;
+  switch (ny) {
+    case 64: return fill_basis<64>(basis, (hipStream_t)stream);
+    case 48: return fill_basis<48>(basis, (hipStream_t)stream);
+    case 32: return fill_basis<32>(basis, (hipStream_t)stream);
+    default: return GEOBO_E_UNSUPPORTED;
+  }
+}
+
+extern "C" int geobo_spectral_y(int ny, int64_t C, int64_t plane, int64_t R, int nprop, const double* in, const double* tab0,
+                                const double* tab1, double* out0, double* out1, int y0, int y1, const double* basis, void* stream) {
+  if (!in || !tab0 || !out0 || !basis || (nprop == 2 && (!tab1 || !out1))) return GEOBO_E_ARG;
+  if (nprop < 1 || nprop > 2 || R <= 0 || y0 < 0 || y1 > ny || y1 <= y0 || plane < C) return GEOBO_E_ARG;
+  if (C <= 0 || C % 16 || (int64_t)ny * plane * 8 >= (1ll << 31)) return GEOBO_E_ALIGN;
+  SYArgs g;
+  g.in[0] = in; g.in[1] = in; g.tab[0] = tab0; g.tab[1] = nprop == 2 ? tab1 : tab0; g.tab[2] = tab0;
+  g.out[0] = out0; g.out[1] = nprop == 2 ? out1 : out0; g.basis = basis; g.C = C; g.S = plane; g.R = R; g.y0 = y0; g.y1 = y1;
+  hipStream_t st = (hipStream_t)stream;
+  switch (ny) {
+    case 64: return nprop == 2 ? launch<64, 1, 2>(g, st) : launch<64, 1, 1>(g, st);
+    case 48: return nprop == 2 ? launch<48, 1, 2>(g, st) : launch<48, 1, 1>(g, st);
+    case 32: return nprop == 2 ? launch<32, 1, 2>(g, st) : launch<32, 1, 1>(g, st);
+    default: return GEOBO_E_UNSUPPORTED;
+  }
+}
+
+extern "C" int geobo_spectral_y2s(int ny, int64_t C, int64_t plane, int64_t R, const double* in_g, const double* in_m, const double* tab_d0,
+                                  const double* tab_x, const double* tab_d1, double* out0, double* out1, const double* basis, void* stream) {
+  if (!in_g || !in_m || !tab_d0 || !tab_x || !tab_d1 || !out0 || !out1 || !basis) return GEOBO_E_ARG;
+  if (R <= 0 || plane < C) return GEOBO_E_ARG;
+  if (C <= 0 || C % 16 || (int64_t)ny * plane * 8 >= (1ll << 31)) return GEOBO_E_ALIGN;
+  SYArgs g;
+  g.in[0] = in_g; g.in[1] = in_m; g.tab[0] = tab_d0; g.tab[1] = tab_x; g.tab[2] = tab_d1;
+  g.out[0] = out0; g.out[1] = out1; g.basis = basis; g.C = C; g.S = plane; g.R = R; g.y0 = 0; g.y1 = ny;
+  hipStream_t st = (hipStream_t)stream;
+  switch (ny) {
+    case 64: return launch<64, 2, 2>(g, st);
+    case 48: return launch<48, 2, 2>(g, st);
+    case 32: return launch<32, 2, 2>(g, st);
+    default: return GEOBO_E_UNSUPPORTED;
+  }
+}

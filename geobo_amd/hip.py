@@ -581,6 +581,46 @@ def toeplitz_y2s(ny, C, R, src_g, src_m, tab_d0, tab_x, tab_d1, outs, plane=None
                                       _p(_chk(outs[0], "out")), _p(_chk(outs[1], "out")), _stream()), "geobo_toeplitz_y2s")
 
 
+SPECTRAL_Y_NY = (32, 48, 64)        # y extents of the in-kernel spectral y stage (geobo_spectral_y / _y2s)
+_spectral_y_basis = {}              # (ny, device index) -> fragment blob (constant of ny: filled once per device)
+
+
+def spectral_y_basis(ny, device=None):
+    """Transform fragments of geobo_spectral_y for one y extent (a constant of ny: built once per device, kept for the process)."""
+    lib = require_gpu()
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    b = _spectral_y_basis.get((ny, dev))
+    if b is None:
+        n = int(lib.geobo_spectral_y_basis_doubles(int(ny)))
+        if n <= 0:
+            raise RuntimeError("geobo_spectral_y: ny = %d is not instantiated" % ny)
+        b = torch.empty(n, dtype=F64, device="cuda:%d" % dev)
+        _lib.check(lib.geobo_spectral_y_basis(int(ny), _p(b), _stream()), "geobo_spectral_y_basis")
+        _spectral_y_basis[(ny, dev)] = b
+    return b
+
+
+def spectral_y(ny, C, R, src, tabs, outs, y0=0, y1=None, plane=None):
+    """The sums of toeplitz_y (one or two property blocks) through the y axis's own spectrum on the matrix pipe (geobo_spectral_y)."""
+    lib = require_gpu()
+    y1 = ny if y1 is None else y1
+    n = len(tabs)
+    assert 1 <= n <= 2 and len(outs) == n
+    _lib.check(lib.geobo_spectral_y(int(ny), int(C), int(C if plane is None else plane), int(R), n, _p(_chk(src, "src")),
+                                    _p(_chk(tabs[0], "tab")), _p(_chk(tabs[-1], "tab")), _p(_chk(outs[0], "out")), _p(_chk(outs[-1], "out")),
+                                    int(y0), int(y1), _p(spectral_y_basis(ny, src.device)), _stream()), "geobo_spectral_y")
+
+
+def spectral_y2s(ny, C, R, src_g, src_m, tab_d0, tab_x, tab_d1, outs, plane=None):
+    """The sums of toeplitz_y2s (two-term rows, shared cross block) with the terms meeting in the y spectrum (geobo_spectral_y2s)."""
+    lib = require_gpu()
+    assert len(outs) == 2
+    _lib.check(lib.geobo_spectral_y2s(int(ny), int(C), int(C if plane is None else plane), int(R), _p(_chk(src_g, "src_g")), _p(_chk(src_m, "src_m")),
+                                      _p(_chk(tab_d0, "tab")), _p(_chk(tab_x, "tab")), _p(_chk(tab_d1, "tab")),
+                                      _p(_chk(outs[0], "out")), _p(_chk(outs[1], "out")), _p(spectral_y_basis(ny, src_g.device)), _stream()),
+               "geobo_spectral_y2s")
+
+
 class PotrfContext:
     """Fork streams / events of geobo_potrf_inv on the device that is current at construction (owned by the caller: one per
     engine; never shared between concurrent factorisations)."""

@@ -141,6 +141,9 @@ class SpectralProduct:
         # y axis: applied as Toeplitz blocks per (x, z) mode (geobo_toeplitz_y) when the kernel has the extent, else carried
         # through the spectrum like x and z
         self.dense_y = ny in hip.TOEPLITZ_NY and os.environ.get("GEOBO_SPECTRAL_DENSE_Y", "1") != "0"
+        # ... and, where instantiated, through the y axis's own spectrum INSIDE the kernel, on the matrix pipe (round 6: geobo_spectral_y,
+        # same arguments, same sums to rounding; GEOBO_Y_MFMA=0 keeps the direct vector-pipe kernels: the A/B of profiles/r06_*)
+        self.y_mfma = self.dense_y and ny in hip.SPECTRAL_Y_NY and os.environ.get("GEOBO_Y_MFMA", "1") != "0"
         # x and z: one fused kernel per direction (geobo_xz2d) where it is instantiated, else two batched GEMM passes
         self.fused_xz = (nx, nz) in hip.XZ2D_SHAPES and os.environ.get("GEOBO_SPECTRAL_FUSED_XZ", "1") != "0"
         # 32 x 32 planes: two consecutive y-planes stacked along x go through the (64, 32) instance with diag(Mx, Mx) -- the z step
@@ -185,7 +188,12 @@ class SpectralProduct:
     def _ystage(self, ny, C, R, src, tabs, outs, y0, y1, plane, accumulate=False):
         """geobo_toeplitz_y launch, bracketed for the bench's per-kernel roofline when a timer is set: algorithmic bytes = the rows'
         (x, z)-spectrum read once + one output slab per property block (read as well when the launch accumulates)."""
-        fn = lambda: hip.toeplitz_y(ny, C, R, src, tabs, outs, y0, y1, plane=plane, accumulate=accumulate)
+        if self.y_mfma and not accumulate:
+            def fn():
+                for j in range(0, len(tabs), 2):        # two property blocks per read of the spectrum
+                    hip.spectral_y(ny, C, R, src, tabs[j:j + 2], outs[j:j + 2], y0, y1, plane=plane)
+        else:
+            fn = lambda: hip.toeplitz_y(ny, C, R, src, tabs, outs, y0, y1, plane=plane, accumulate=accumulate)
         if self.kernel_timer is None:
             return fn()
         # (one name per kernel symbol: single-block launches run toeplitz_y_kernel<ny, 2>, the others <ny, 1>)
@@ -489,7 +497,8 @@ class SpectralProduct:
                     # both terms in ONE y-stage pass: one output spectrum per block, one input of the inverse; with the shared cross
                     # block three products per mode (geobo_toeplitz_y2s), otherwise four (geobo_toeplitz_y2t)
                     if y2s_tabs is not None and y2s_tabs[0] == j:
-                        fn = lambda: hip.toeplitz_y2s(ny, C, Rb, t2g, t2m, y2s_tabs[1], y2s_tabs[2], y2s_tabs[3], sg, plane=Cp)
+                        y2s_fn = hip.spectral_y2s if self.y_mfma else hip.toeplitz_y2s
+                        fn = lambda: y2s_fn(ny, C, Rb, t2g, t2m, y2s_tabs[1], y2s_tabs[2], y2s_tabs[3], sg, plane=Cp)
                         kname, nprod = "kernel:toeplitz_y2s", 3
                     else:
                         fn = lambda: hip.toeplitz_y2t(ny, C, Rb, t2g, t2m, [gens_g[jj] for jj in js], [gens_m[jj] for jj in js], sg, plane=Cp)

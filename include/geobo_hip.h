@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GEOBO_VERSION 211 /* 201: flag word of geobo_gemm_nt, (64, 32) instance of geobo_xz2d, workspace layout of geobo_potrf_inv; 202: geobo_ymul, geobo_xz2d_fold_lattice; 203: geobo_sumsq_accum, geobo_lamdot_z, geobo_toeplitz_y2t, geobo_xz2d_fold_quad; 204: geobo_toeplitz_y3_add; 205: workspace layout of geobo_potrf_inv (one T buffer per tree node); 206: geobo_potrf_inv as one persistent tile-DAG launch from m = 1024 (workspace: + counters); 207: geobo_gemm_fold; 208: geobo_gemm_fold_lamdot; 209: geobo_toeplitz_y2s; 210: geobo_xz2d_fold* dense planes take the quarter-period group order of the basis (radix 4); 211: geobo_ymul_fold */
+#define GEOBO_VERSION 212 /* 201: flag word of geobo_gemm_nt, (64, 32) instance of geobo_xz2d, workspace layout of geobo_potrf_inv; 202: geobo_ymul, geobo_xz2d_fold_lattice; 203: geobo_sumsq_accum, geobo_lamdot_z, geobo_toeplitz_y2t, geobo_xz2d_fold_quad; 204: geobo_toeplitz_y3_add; 205: workspace layout of geobo_potrf_inv (one T buffer per tree node); 206: geobo_potrf_inv as one persistent tile-DAG launch from m = 1024 (workspace: + counters); 207: geobo_gemm_fold; 208: geobo_gemm_fold_lamdot; 209: geobo_toeplitz_y2s; 210: geobo_xz2d_fold* dense planes take the quarter-period group order of the basis (radix 4); 211: geobo_ymul_fold; 212: geobo_spectral_y, geobo_spectral_y2s, geobo_spectral_y_basis */
 
 #define GEOBO_PAD_M 256 /* row padding of M-like dimensions (observation rows)            */
 #define GEOBO_PAD_N 128 /* padding of voxel-like dimensions (columns / contraction index) */
@@ -392,6 +392,24 @@ int geobo_toeplitz_y3(int ny, int64_t C, int64_t plane, int64_t R, int nprop, co
  * ny <= 64).  ny in {80, 96, 112, 128}; GEOBO_E_UNSUPPORTED otherwise. */
 int geobo_toeplitz_y3_add(int ny, int64_t C, int64_t plane, int64_t R, int nprop, const double* in, const double* const* tabs,
                           double* const* outs, int y0, int y1, void* stream);
+
+/* The y stage as an IN-KERNEL SPECTRAL PRODUCT on the fp64 matrix pipe (round 6; csrc/spectral_y.hip): the same sums as
+ * geobo_toeplitz_y / geobo_toeplitz_y2s from the same arguments (tab_j are the Toeplitz generators, [ny][C]), computed through the
+ * y axis's own spectrum without leaving the registers.  T_c is the leading block of a skew-circulant of size 2 ny, diagonalised by
+ * cos / sin of the half-integer frequencies 1/2 .. ny - 1/2; radix 4 over the orbits {k, ny - k, ny/2 + k, ny/2 - k} of a
+ * quarter-period shift: per mode ny^2 / 2 multiply-adds per transform on MFMA (the transform matrix is the same for every mode: the
+ * 16 MFMA columns are 16 modes, 128-byte segments) plus 16 additions per orbit.  One term and two blocks cost 1.5 ny^2 (direct:
+ * 2 ny^2), two-term rows with the shared cross block 2 ny^2 (direct, three products: 3 ny^2).  Results agree with the direct kernels
+ * to rounding (a few 1e-16 of sum |t| |x|), not bit for bit.
+ * basis: geobo_spectral_y_basis_doubles(ny) doubles filled ONCE per ny by geobo_spectral_y_basis (transform fragments in lane order:
+ * the library keeps no state of its own).  ny in {32, 48, 64} (GEOBO_E_UNSUPPORTED otherwise; 0 doubles), C % 16 == 0, plane >= C,
+ * ny*plane*8 < 2^31.  Replaces the same reference lines as geobo_toeplitz_y: kernels.py:158-195, inversion.py:96,114-117. */
+int64_t geobo_spectral_y_basis_doubles(int ny);
+int geobo_spectral_y_basis(int ny, double* basis, void* stream);
+int geobo_spectral_y(int ny, int64_t C, int64_t plane, int64_t R, int nprop, const double* in, const double* tab0, const double* tab1,
+                     double* out0, double* out1, int y0, int y1, const double* basis, void* stream);
+int geobo_spectral_y2s(int ny, int64_t C, int64_t plane, int64_t R, const double* in_g, const double* in_m, const double* tab_d0,
+                       const double* tab_x, const double* tab_d1, double* out0, double* out1, const double* basis, void* stream);
 
 /* In-place lower Cholesky of the (m x m, ld) matrix A, m % 256 == 0 (padding rows/cols = identity);
  * scipy.linalg.cholesky(AkA, lower=True), inversion.py:100.  Also writes Linv = L^-1 (m x m, ldi; lower,

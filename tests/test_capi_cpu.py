@@ -43,7 +43,7 @@ def test_host_side_helpers(lib):
     lib.geobo_pad_n.argtypes = [ctypes.c_int64]
     lib.geobo_potrf_ws_bytes.restype = ctypes.c_size_t
     lib.geobo_potrf_ws_bytes.argtypes = [ctypes.c_int64]
-    assert lib.geobo_version() == 211
+    assert lib.geobo_version() == 212
     assert lib.geobo_pad_m(8242) == 8448 and lib.geobo_pad_m(256) == 256 and lib.geobo_pad_m(1) == 256
     assert lib.geobo_pad_n(480) == 512 and lib.geobo_pad_n(262144) == 262144
     # one T buffer per node [lo, mid, hi) of the L^-1 tree, (hi - mid) x (mid - lo) blocks of 128 x 128; split on even block counts

@@ -590,6 +590,76 @@ def test_toeplitz_y2s_matches_torch(hip, ny, C, R):
         hip.toeplitz_y2s(80, C, R, flat(src_g), flat(src_m), flat(d0), flat(t01), flat(d1), [flat(o) for o in outs])
 
 
+@pytest.mark.parametrize("ny,C,R,nprop,y0,y1", [(64, 64, 5, 2, 0, 64), (64, 16384, 7, 2, 0, 64), (64, 256, 3, 1, 0, 64), (64, 128, 4, 2, 8, 40),
+                                                 (48, 64, 5, 2, 0, 48), (48, 128, 3, 1, 5, 48), (32, 1024, 9, 2, 0, 32), (32, 64, 2, 1, 0, 17),
+                                                 (64, 48, 6, 2, 0, 64), (64, 16, 1, 2, 0, 64), (64, 1040, 4, 2, 0, 64)])
+def test_spectral_y_matches_torch(hip, ny, C, R, nprop, y0, y1):
+    # the y stage through its own spectrum on the matrix pipe (geobo_spectral_y): the sums of geobo_toeplitz_y from the same arguments;
+    # NaN-poisoned outputs, slabs, several rows per wave (the two-deep row prefetch), mode counts that do not fill a workgroup, a
+    # padded plane stride whose padding is neither read into a result nor written
+    src = _rand((R, ny, C), 11)
+    tabs = [_rand((ny, C), 12 + j) for j in range(nprop)]
+    outs = [torch.full((R, y1 - y0, C), float("nan"), dtype=torch.float64, device="cuda") for _ in range(nprop)]
+    hip.spectral_y(ny, C, R, src.reshape(-1), [t.reshape(-1) for t in tabs], [o.reshape(-1) for o in outs], y0, y1)
+    torch.cuda.synchronize()
+    idx = (torch.arange(ny)[:, None] - torch.arange(ny)[None, :]).abs().cuda()      # |y - y'|
+    for j in range(nprop):
+        ref = torch.einsum("ypc,rpc->ryc", tabs[j][idx], src)[:, y0:y1]
+        assert normwise(outs[j].cpu().numpy(), ref.cpu().numpy()) < 2e-14
+    if C % 64 == 0 and ny in hip.TOEPLITZ_NY:
+        direct = [torch.empty((R, y1 - y0, C), dtype=torch.float64, device="cuda") for _ in range(nprop)]
+        hip.toeplitz_y(ny, C, R, src.reshape(-1), [t.reshape(-1) for t in tabs], [o.reshape(-1) for o in direct], y0, y1)
+        for j in range(nprop):
+            assert normwise(outs[j].cpu().numpy(), direct[j].cpu().numpy()) < 2e-14
+    again = [torch.full((R, y1 - y0, C), float("nan"), dtype=torch.float64, device="cuda") for _ in range(nprop)]
+    hip.spectral_y(ny, C, R, src.reshape(-1), [t.reshape(-1) for t in tabs], [o.reshape(-1) for o in again], y0, y1)
+    for j in range(nprop):
+        assert torch.equal(again[j], outs[j])
+    S = C + 48
+    srcp = torch.full((R, ny, S), float("nan"), dtype=torch.float64, device="cuda")
+    srcp[:, :, :C] = src
+    outp = [torch.full((R, y1 - y0, S), 7.0, dtype=torch.float64, device="cuda") for _ in range(nprop)]
+    hip.spectral_y(ny, C, R, srcp.reshape(-1), [t.reshape(-1) for t in tabs], [o.reshape(-1) for o in outp], y0, y1, plane=S)
+    for j in range(nprop):
+        assert torch.equal(outp[j][:, :, :C], outs[j]) and bool((outp[j][:, :, C:] == 7.0).all())
+    with pytest.raises(RuntimeError):
+        hip.spectral_y(80, C, R, src.reshape(-1), [t.reshape(-1) for t in tabs], [o.reshape(-1) for o in outs], 0, 80)
+
+
+@pytest.mark.parametrize("ny,C,R", [(64, 256, 5), (64, 16384, 11), (48, 128, 9), (32, 1024, 30), (64, 128, 1), (64, 528, 8)])
+def test_spectral_y2s_matches_torch(hip, ny, C, R):
+    # two-term rows with a shared cross block, the terms meeting in the y spectrum (geobo_spectral_y2s): against torch, against the
+    # direct three-product kernel on the same tables, twice (bit-reproducible), with a padded plane stride
+    src_g, src_m = _rand((R, ny, C), 41), _rand((R, ny, C), 42)
+    t00, t01, t11 = (_rand((ny, C), 43 + j) for j in range(3))
+    d0, d1 = t00 - t01, t11 - t01
+    flat = lambda t: t.reshape(-1)
+    outs = [torch.full((R, ny, C), float("nan"), dtype=torch.float64, device="cuda") for _ in range(2)]
+    hip.spectral_y2s(ny, C, R, flat(src_g), flat(src_m), flat(d0), flat(t01), flat(d1), [flat(o) for o in outs])
+    torch.cuda.synchronize()
+    idx = (torch.arange(ny)[:, None] - torch.arange(ny)[None, :]).abs().cuda()
+    ref = [torch.einsum("ypc,rpc->ryc", t00[idx], src_g) + torch.einsum("ypc,rpc->ryc", t01[idx], src_m),
+           torch.einsum("ypc,rpc->ryc", t01[idx], src_g) + torch.einsum("ypc,rpc->ryc", t11[idx], src_m)]
+    for j in range(2):
+        assert normwise(outs[j].cpu().numpy(), ref[j].cpu().numpy()) < 2e-14
+    if C % 64 == 0:
+        direct = [torch.empty((R, ny, C), dtype=torch.float64, device="cuda") for _ in range(2)]
+        hip.toeplitz_y2s(ny, C, R, flat(src_g), flat(src_m), flat(d0), flat(t01), flat(d1), [flat(o) for o in direct])
+        for j in range(2):
+            assert normwise(outs[j].cpu().numpy(), direct[j].cpu().numpy()) < 2e-14
+    again = [torch.full((R, ny, C), float("nan"), dtype=torch.float64, device="cuda") for _ in range(2)]
+    hip.spectral_y2s(ny, C, R, flat(src_g), flat(src_m), flat(d0), flat(t01), flat(d1), [flat(o) for o in again])
+    for j in range(2):
+        assert torch.equal(again[j], outs[j])
+    S = C + 48
+    gp, mp = (torch.full((R, ny, S), float("nan"), dtype=torch.float64, device="cuda") for _ in range(2))
+    gp[:, :, :C], mp[:, :, :C] = src_g, src_m
+    outp = [torch.full((R, ny, S), 7.0, dtype=torch.float64, device="cuda") for _ in range(2)]
+    hip.spectral_y2s(ny, C, R, flat(gp), flat(mp), flat(d0), flat(t01), flat(d1), [flat(o) for o in outp], plane=S)
+    for j in range(2):
+        assert torch.equal(outp[j][:, :, :C], outs[j]) and bool((outp[j][:, :, C:] == 7.0).all())
+
+
 @pytest.mark.parametrize("nx,nz,rows,ppr", [(48, 64, 3, 37), (64, 64, 3, 37), (64, 64, 4, 800), (48, 64, 7, 500), (64, 32, 3, 37),
                                             (64, 32, 5, 900)])
 @pytest.mark.parametrize("inverse", [False, True])

@@ -27,5 +27,10 @@ if n > 64:
     timed("toeplitz_y 3 blocks", R * C * 2.0 * n * n * 3, R * n * C * 8.0 * 4, lambda: hip.toeplitz_y(n, C, R, src, tabs[:3], outs))
     timed("toeplitz_y 1 block, 16-plane slab", R * C * 2.0 * n * 16, R * C * 8.0 * (n + 16), lambda: hip.toeplitz_y(n, C, R, src, tabs[:1], outs[:1], 16, 32))
     sys.exit(0)
+if n in hip.SPECTRAL_Y_NY:
+    # executed multiply-adds per mode: ny^2 / 2 per transform on the matrix pipe (radix 4) + the orbit butterflies on the vector pipe
+    timed("spectral_y 2 blocks", R * C * 2.0 * (1.5 * n * n + 14 * n), R * n * C * 8.0 * 3, lambda: hip.spectral_y(n, C, R, src, tabs[:2], outs[:2]))
+    timed("spectral_y 1 block", R * C * 2.0 * (1.0 * n * n + 9 * n), R * n * C * 8.0 * 2, lambda: hip.spectral_y(n, C, R, src, tabs[:1], outs[:1]))
+    timed("spectral_y2s", R * C * 2.0 * (2.0 * n * n + 24 * n), R * n * C * 8.0 * 4, lambda: hip.spectral_y2s(n, C, R, src, src2, tabs[0], tabs[1], tabs[2], outs[:2]))
 timed("toeplitz_y2t", R * C * 2.0 * n * n * 4, R * n * C * 8.0 * 4, lambda: hip.toeplitz_y2t(n, C, R, src, src2, tabs[:2], tabs[2:], outs[:2]))
 timed("toeplitz_y2s (3 products)", R * C * 2.0 * n * n * 3, R * n * C * 8.0 * 4, lambda: hip.toeplitz_y2s(n, C, R, src, src2, tabs[0], tabs[1], tabs[2], outs[:2]))
