@@ -22,9 +22,9 @@ table; `--check` re-runs the problem on rank 0 alone inside the same job and com
 dense method keep the round-2 forms: voxel-column shards, all-reduce of the partial AkA or all-to-all of A K block-columns.)
 
 Prints ONE JSON line on rank 0 (see the driver contract); extra objects:
-  roofline      dominant kernel = geobo_toeplitz_y on the default route (the y stage of every covariance product, 30 % of the step;
-                HBM / fp64-VALU co-limited): ALGORITHMIC bytes per launch (spectrum read once + one output slab per property block)
-                / mean launch duration measured with HIP events on the launch stream, against 8 TB/s.  (GEOBO_POSTERIOR=dense:
+  roofline      dominant kernel = geobo_spectral_y on the default route (the y stage of every covariance product, as an in-kernel spectral
+                product on the matrix pipe since round 6; HBM-bound, fp64 pipe co-bound): ALGORITHMIC bytes per launch (spectrum read once +
+                one output slab per property block) / mean launch duration measured with HIP events on the launch stream, against 8 TB/s.  (GEOBO_POSTERIOR=dense:
                 geobo_posterior_reduce, --method dense: geobo_ak_fused_grid -- fp64 MFMA, algorithmic flop against 78.6 TFLOP/s.)
   roofline_assembly  the HBM-bound regime of SURVEY 8(d): one materialised covariance block (geobo_k_block), bytes written per
                 launch / HIP-event duration against 8 TB/s (outside the timed steps)
@@ -93,9 +93,11 @@ def synthetic_inputs(inv, md):
 
 
 PMC_FILES = {"ak_fused_grid": "r01_pmc_ak_fused_grid_v2.json", "posterior_reduce": "r03_pmc_posterior_reduce.json",
-             "k_block_grid": "r03_pmc_k_block_grid_f64.json", "toeplitz_y": "r05_pmc_toeplitz_y.json", "toeplitz_y2t": "r05_pmc_toeplitz_y2t.json", "toeplitz_y2s": "r05_pmc_toeplitz_y2s.json"}
+             "k_block_grid": "r03_pmc_k_block_grid_f64.json", "toeplitz_y": "r05_pmc_toeplitz_y.json", "toeplitz_y2t": "r05_pmc_toeplitz_y2t.json", "toeplitz_y2s": "r05_pmc_toeplitz_y2s.json",
+             "spectral_y": "r06_pmc_spectral_y.json", "spectral_y2s": "r06_pmc_spectral_y2s.json"}
 PMC_VALU_FILES = {"toeplitz_y": "r05_pmc_toeplitz_y_valu.json", "toeplitz_y2t": "r05_pmc_toeplitz_y2t_valu.json",
-                  "toeplitz_y2s": "r05_pmc_toeplitz_y2s_valu.json"}
+                  "toeplitz_y2s": "r05_pmc_toeplitz_y2s_valu.json", "spectral_y": "r06_pmc_spectral_y_valu.json",
+                  "spectral_y2s": "r06_pmc_spectral_y2s_valu.json"}
 GPU_DENSE_ROUTE = "profiles/r01_bench64_dense.json"   # builder-run bench line of `--method dense` (same algorithm as the CPU sample)
 
 
@@ -192,12 +194,19 @@ def cpu_baseline(inv, lengths, target_seconds=20.0):
     name = s.kernelfunc
     M = L.shape[0]
 
-    def sample(b, c0):
+    def columns(b):
+        """b voxel columns SPREAD over the cube (round-5 review: the sample was one contiguous block at the cube's centre): evenly strided
+        flat indices from the first to the last voxel -- every y-slab incl. the two padded ones iy = 0 and ny - 1, x / z faces, the corners
+        p = 0 and N - 1 -- plus up to eight drilled voxels."""
+        cols = np.unique(np.r_[np.linspace(0, N - 1, b).astype(np.int64), sel[:8]])
+        return cols
+
+    def sample(cols):
         t0 = time.perf_counter()
-        D2 = O.sqdist(P3, P3[c0:c0 + b])
+        D2 = O.sqdist(P3, P3[cols])
         out = []
         for j in (0, 1):
-            AK = np.empty((M, b))
+            AK = np.empty((M, cols.size))
             AK[:Ms] = A_g @ O.k_block(name, D2, lengths, W, 0, j)
             AK[Ms:2 * Ms] = A_m @ O.k_block(name, D2, lengths, W, 1, j)
             if sel.size:
@@ -206,17 +215,19 @@ def cpu_baseline(inv, lengths, target_seconds=20.0):
             out.append((V.T @ u, 1.0 - np.einsum("mq,mq->q", V, V)))
         return time.perf_counter() - t0, out
 
-    c0 = N // 2
-    t_small, _ = sample(16, c0)
+    t_small, _ = sample(columns(16))
     b = int(max(16, min(2048, 16 * target_seconds / max(t_small, 1e-3))))
-    t, out = sample(b, c0)
+    cols = columns(b)
+    b = cols.size
+    t, out = sample(cols)
     flop = 2.0 * b * (2.0 * (2 * Ms) * N + 1.0 * M * M + 4.0 * M)       # section 8(d) terms for b columns x 2 properties
     return dict(value=2.0 * b / t, unit="voxel-properties/s", cores=host_threads(), kind="port",
                 algorithm="dense (covariance evaluated from squared distances, N-deep contraction): SURVEY 8(d) flop model",
                 gflops=flop / t / 1e9,
-                sample="%d of %d voxel columns x 2 properties of the same workload: fused A.K + triangular solve + "
+                sample="%d of %d voxel columns x 2 properties of the same workload, spread over the cube (strided from the first to the last "
+                       "voxel: every y-slab incl. the padded ones, faces, corners; %d drilled voxels): fused A.K + triangular solve + "
                        "mean/variance reductions in NumPy/OpenBLAS (oracle/geobo_oracle.py); operators and Cholesky factor "
-                       "given, so this is an upper bound on the CPU rate; %.1f s" % (b, N, t)), (c0, b, out)
+                       "given, so this is an upper bound on the CPU rate; %.1f s" % (b, N, min(8, sel.size), t)), (cols, out)
 
 
 def cpu_baseline_forms(sizes, dense_sizes, F64, gflops_sample):
@@ -296,7 +307,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-forms", default="16,32", help="comma list of cube edges for the full matrix-free CPU oracle step "
                     "(SURVEY 8(d) form (b)); the 64^3 figure is extrapolated from the LARGEST one (32^3: ~1 min on the box's 128 threads)")
-    ap.add_argument("--cpu-dense-forms", default="", help="cube edges for the reference-shaped CPU form (a), e.g. '16' (~30 s) or '16,20'")
+    ap.add_argument("--cpu-dense-forms", default="16", help="cube edges for the reference-shaped CPU form (a) of SURVEY 8(d): full K and full "
+                    "posterior covariance like inversion.py:77-122; '16' (~30 s, the default) or '16,20' ('' = none)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU dry runs)")
     ap.add_argument("--oversubscribe", action="store_true", help="dry runs: allow several ranks per device (gloo backend)")
     ap.add_argument("--check", action="store_true", help="N > 1: after the timed steps rank 0 runs the same problem alone (a 1-rank engine on its "
@@ -464,40 +476,44 @@ def main():
         M = 2 * eng.Ms + int((drill0 != 0).sum())
         Msd = 2 * eng.Ms
         F = 2.0 * Msd * N * N * p_out + 2.0 * M * Msd * N + M ** 3 / 3.0 + 1.0 * M * M * p_out * N + 4.0 * M * p_out * N + M * M
-        mfma = {k: v for k, v in stages.items() if v["flop"] > 0}
+        mfma = {k: v for k, v in stages.items() if v["flop"] > 0 and not k.startswith("kernel:")}   # (per-kernel brackets sit INSIDE stage brackets)
         F_mfma = sum(d["flop"] - d["valu"] for d in mfma.values()) / a.steps   # `flop` = everything executed, `valu` = its fp64-VALU part
         F_valu = sum(d["valu"] for d in mfma.values()) / a.steps
         step_ms = sorted(1e3 * (b - a_) for a_, b in zip(marks[:-1], marks[1:]))
         roof = None
         if dom in ("kernel:toeplitz_y", "kernel:toeplitz_y2t", "kernel:toeplitz_y2s"):
-            # HBM / fp64-VALU co-limited stream kernel: algorithmic bytes (spectrum read once + one output slab per property block)
+            # The y stage of every covariance product.  Round 6: geobo_spectral_y* (the y axis through its own spectrum inside the kernel, on
+            # the matrix pipe) wherever instantiated; the direct vector-pipe kernels geobo_toeplitz_y* otherwise (GEOBO_Y_MFMA=0: the A/B).
+            # Both roofs as peers: algorithmic bytes per launch against 8 TB/s, executed flop per launch against the fp64 pipe that
+            # v_mfma_f64 and the vector FMAs share (78.6 TFLOP/s, profiles/r01_mfma_coissue.txt); `bound` names the larger fraction.
+            y_mfma = bool(getattr(eng._spectral, "y_mfma", False))
             d = stages[dom]
             calls = d["calls"]
             mean_s = d["seconds"] / calls
             by = d["bytes"] / calls
-            # FMA flop of the mean launch: ny per output element and term (one-term launches: two of the three streams are outputs)
-            vflop = d["valu"] / calls if d["valu"] > 0 else 2.0 * eng.ny * (by / 8.0) * (2.0 / 3.0)
-            traffic, tsrc = None, None
+            pflop = d["flop"] / calls if d["flop"] > 0 else (d["valu"] / calls if d["valu"] > 0 else 2.0 * eng.ny * (by / 8.0) * (2.0 / 3.0))
+            vflop = d["valu"] / calls
             pmc_key = dom.split(":")[1]
-            for pf in (PMC_FILES[pmc_key], PMC_FILES[pmc_key].replace("r05_", "r04_")):
+            if y_mfma:
+                pmc_key = {"toeplitz_y": "spectral_y", "toeplitz_y2s": "spectral_y2s"}.get(pmc_key, pmc_key)
+            traffic, tsrc = None, None
+            for pf in (PMC_FILES.get(pmc_key, ""), PMC_FILES.get(pmc_key, "").replace("r05_", "r04_")):
                 try:
-                    p = json.load(open(os.path.join(ROOT, "profiles", pf)))
-                    traffic = p["derived"]["hbm_bytes_per_launch_corrected"] * by / p["derived"]["algorithmic_bytes"]
+                    pj = json.load(open(os.path.join(ROOT, "profiles", pf)))
+                    traffic = pj["derived"]["hbm_bytes_per_launch_corrected"] * by / pj["derived"]["algorithmic_bytes"]
                     tsrc = "profiles/" + pf
                     break
                 except Exception:
                     pass
-            f_hbm, f_valu = by / mean_s / 8e12, vflop / mean_s / 1e12 / FP64_MATRIX_PEAK_TFLOPS
+            f_hbm, f_pipe = by / mean_s / 8e12, pflop / mean_s / 1e12 / FP64_MATRIX_PEAK_TFLOPS
             ytab = {}
             for k, v in stages.items():
                 if k.startswith("kernel:toeplitz"):
                     c_, m_, b_ = v["calls"], v["seconds"] / v["calls"], v["bytes"] / v["calls"]
-                    vf = v["valu"] / c_ if v["valu"] > 0 else 2.0 * eng.ny * (b_ / 8.0) * (2.0 / 3.0 if k == "kernel:toeplitz_y" else 0.5)
+                    pf_ = v["flop"] / c_ if v["flop"] > 0 else (v["valu"] / c_ if v["valu"] > 0 else 2.0 * eng.ny * (b_ / 8.0) * (2.0 / 3.0 if k == "kernel:toeplitz_y" else 0.5))
                     ytab[k.split(":")[1]] = {"ms_per_step": round(1e3 * v["seconds"] / a.steps, 2), "launches_per_step": c_ / a.steps,
                                              "mean_launch_ms": round(1e3 * m_, 4), "frac_hbm_8TBps": round(b_ / m_ / 8e12, 3),
-                                             "frac_fp64_pipe_78.6TF": round(vf / m_ / 1e12 / FP64_MATRIX_PEAK_TFLOPS, 3)}
-            # Both roofs as peers (round-4 review: "mfma" for a kernel with no MFMA busy cycles misleads a consumer of `bound`).  The fp64
-            # FMA pipe is the one vector FMAs and v_mfma_f64 share on gfx950, same 78.6 TFLOP/s peak (profiles/r01_mfma_coissue.txt).
+                                             "frac_fp64_pipe_78.6TF": round(pf_ / m_ / 1e12 / FP64_MATRIX_PEAK_TFLOPS, 3)}
             issue = None
             try:
                 pv = json.load(open(os.path.join(ROOT, "profiles", PMC_VALU_FILES[pmc_key])))["derived"]
@@ -505,27 +521,41 @@ def main():
                          "valu_busy_of_simd_cycles": round(pv["sq_active_inst_valu_x4_over_simd_cycles"], 3),
                          "fma_f64_share_of_valu_instructions": round(pv["fma_f64_share_of_valu_instructions"], 3),
                          "clock_GHz_of_the_profiled_launch": round(pv["clock_GHz_during_profiled_pass"], 2)}
+                if "mfma_busy_frac_of_simd_cycles" in pv:
+                    issue["mfma_busy_of_simd_cycles"] = round(pv["mfma_busy_frac_of_simd_cycles"], 3)
             except Exception:
                 pass
-            # the binding roof of the two names `bound`: "hbm", or "fp64_pipe" -- NOT "mfma": the kernel has no MFMA busy cycles; the pipe
-            # is the one v_mfma_f64 shares -- and the other one is `co_bound` (the one-term launches sit on the ridge, HBM 0.53 / pipe 0.57;
-            # the two-term kernel is pipe-bound, 0.35 / 0.57)
             r_hbm = {"roof": "hbm", "achieved": by / mean_s / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": f_hbm}
-            r_pipe = {"roof": "fp64_pipe (vector FMA; shared with v_mfma_f64)", "achieved": vflop / mean_s / 1e12,
-                      "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": f_valu, "issue_counters": issue}
-            bind, other = (r_pipe, r_hbm) if f_valu >= f_hbm else (r_hbm, r_pipe)
-            roof = {"bound": "fp64_pipe" if bind is r_pipe else "hbm", "kernel": kernel_names[dom], "achieved": bind["achieved"],
+            r_pipe = {"roof": "fp64_pipe (v_mfma_f64 and the vector FMAs share it)", "achieved": pflop / mean_s / 1e12,
+                      "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": f_pipe, "issue_counters": issue,
+                      "vector_part_TFLOPs": vflop / mean_s / 1e12}
+            bind, other = (r_pipe, r_hbm) if f_pipe >= f_hbm else (r_hbm, r_pipe)
+            if y_mfma:
+                kname = {"kernel:toeplitz_y": "geobo_spectral_y (spectral_y_kernel<64, 1, 2>: the launches with two property blocks per read of the "
+                                              "spectrum): y stage of the covariance products (A K and V = (L^-1 A) K), the y axis through its own "
+                                              "spectrum inside the kernel",
+                         "kernel:toeplitz_y2s": "geobo_spectral_y2s (spectral_y_kernel<64, 2, 2>: the two-term rows of the transposed posterior with "
+                                                "the shared cross block, the terms meeting in the y spectrum)"}.get(dom, kernel_names[dom])
+                note = ("the y stage is an in-kernel spectral product (csrc/spectral_y.hip): skew-circulant embedding of the per-mode Toeplitz "
+                        "block, radix 4 over quarter-period orbits -- ny^2 / 2 multiply-adds per transform and mode on v_mfma_f64_16x16x4 (the 16 "
+                        "MFMA columns are 16 modes: 128-byte segments), orbit butterflies and eigenvalue scaling on the vector pipe; one analysis per "
+                        "term + one synthesis per block.  It streams its spectra once (PMC: 1.003 x algorithmic) at the rate a bare 1-read-2-writes "
+                        "stream of the same segments reaches on this device (5.16 TB/s, profiles/r05_hbm_copy_runs.txt): HBM binds, the fp64 pipe "
+                        "is `co_bound`.  `flop_per_launch` = executed flop (MFMA + vector; additions count 1), `bytes_per_launch` = algorithmic bytes")
+            else:
+                kname = kernel_names[dom]
+                note = ("the y stage runs on the fp64 VECTOR FMAs (one (x, z) mode per lane, ny^2 FMA per mode, block and term: no operand "
+                        "is shared between modes, so no MFMA) and streams its spectra once: arithmetic intensity 10.7 flop/B against a ridge of "
+                        "9.8 -- HBM and the fp64 pipe limit it together (`co_bound`).  `flop_per_launch` = algorithmic FMA flop, "
+                        "`bytes_per_launch` = algorithmic bytes")
+            roof = {"bound": "fp64_pipe" if bind is r_pipe else "hbm", "kernel": kname, "achieved": bind["achieved"],
                     "peak": bind["peak"], "unit": bind["unit"], "frac": bind["frac"], "co_bound": other,
-                    "issue_counters": issue, "frac_hbm": f_hbm, "frac_fp64_valu": f_valu,
-                    "bound_note": "the y stage runs on the fp64 VECTOR FMAs (one (x, z) mode per lane, ny^2 FMA per mode, block and term: no operand "
-                                  "is shared between modes, so no MFMA) and streams its spectra once: arithmetic intensity 10.7 flop/B against a ridge of "
-                                  "9.8 -- HBM and the fp64 pipe limit it together (`co_bound`; nominal 2.4 GHz: a launch inside the pipeline clocks at "
-                                  "~2.0 GHz, where the pipe side is ~1.2x the figure).  Counters: the VALU issues 74-79 % of the SIMD cycles, 94-95 % of "
-                                  "it FMAs, LDS waits negligible; `flop_per_launch` = algorithmic FMA flop, `bytes_per_launch` = algorithmic bytes",
+                    "issue_counters": issue, "frac_hbm": f_hbm, "frac_fp64_pipe": f_pipe,
+                    "bound_note": note,
                     "traffic": traffic,
                     "traffic_source": None if tsrc is None else tsrc + " (committed rocprofv3 --pmc passes of the same kernel: FETCH_SIZE x2 + "
                     "WRITE_SIZE, scaled by the algorithmic bytes; not collected in this run)",
-                    "launches_timed": calls, "flop_per_launch": vflop, "bytes_per_launch": by,
+                    "launches_timed": calls, "flop_per_launch": pflop, "bytes_per_launch": by,
                     "bytes_per_launch_is": "algorithmic: the batch's (x, z)-spectrum read once (8 B x rows x ny x 4 nx nz; both terms' spectra for the "
                                            "two-term kernel) + one output slab per property block",
                     "y_stage_kernels": ytab,
@@ -578,9 +608,9 @@ def main():
             out["roofline_assembly"] = assembly_roofline(inv, [float(v) for v in inv.gp_length])
         if not a.no_cpu and world == 1:   # CPU baseline: rank 0 at N = 1 only
             lengths = inv.gp_length
-            cb, (c0, b, smp) = cpu_baseline(inv, [float(v) for v in lengths])
-            got_mu = inv.mu_rec[c0:c0 + b]
-            cb["sample_max_abs_diff_vs_gpu_mu"] = float(np.abs(smp[0][0] - got_mu).max())
+            cb, (cols, smp) = cpu_baseline(inv, [float(v) for v in lengths])
+            cb["sample_max_abs_diff_vs_gpu_mu"] = float(np.abs(smp[0][0] - inv.mu_rec[cols]).max())
+            cb["sample_max_abs_diff_vs_gpu_var"] = float(np.abs(smp[0][1] - inv.cov_rec.diagonal()[cols]).max())
             sizes = [int(v) for v in a.cpu_forms.split(",") if v]
             dsizes = [int(v) for v in a.cpu_dense_forms.split(",") if v]
             F64 = 2.0 * 8192 * 262144.0 ** 2 * 2 + 2.0 * 8242 * 8192 * 262144 + 8242 ** 3 / 3.0 + 8242.0 ** 2 * 2 * 262144 + 4.0 * 8242 * 2 * 262144 + 8242 ** 2

@@ -30,6 +30,7 @@ SIGNATURES = {
     "geobo_lamdot_z": (_int, [_i64, _int, _int, _int, _dp, _dp, _dp, _dp]),
     "geobo_colgemv_ws_bytes": (_sz, [_i64, _i64]),
     "geobo_colgemv": (_int, [_i64, _i64, _dp, _i64, _dp, _dp, _dp, _sz, _dp]),
+    "geobo_rowgemv": (_int, [_i64, _i64, _dp, _i64, _dp, _dp, _dp]),
     "geobo_convert": (_int, [_int, _dp, _i64, _dp, _i64, _i64, _i64, _dp]),
     "geobo_round_f32": (_int, [_dp, _i64, _dp]),
     "geobo_k_eval": (_int, [_int, _dp, _i64, _f64, _f64, _f64, _f64, _dp, _dp]),

@@ -9,6 +9,9 @@
 //                       x step of the lattice Gram (AkA on a lattice survey, inversion.py:96) behind a batched GEMM D = Gx X: the
 //                       eigenvalue scaling and the channel (z) sum.  Eight lanes share one (plane, o) row of nz doubles: 16-byte loads,
 //                       128 contiguous bytes per lane group, three shuffle steps.
+//   geobo_rowgemv       out[r] = sum_c X[r][c] * v[c]
+//                       a forward operator applied to a model, data = A rho (simcube.py:147-150; the synthetic surveys of bench.py and of
+//                       the tests): one workgroup per row, 16-byte loads, a fixed reduction tree (deterministic).  HBM read bound.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "geobo_hip.h"
@@ -62,7 +65,36 @@ __global__ void __launch_bounds__(256) lamdot_z_kernel(int64_t nrows, int planes
   }
 }
 
+__global__ void __launch_bounds__(256) rowgemv_kernel(int64_t m, int64_t n2, const double* __restrict__ X, int64_t ld,
+                                                      const double* __restrict__ v, double* __restrict__ out) {
+  __shared__ double part[4];
+  for (int64_t r = blockIdx.x; r < m; r += gridDim.x) {
+    const v2d* x = reinterpret_cast<const v2d*>(X + r * ld);
+    const v2d* w = reinterpret_cast<const v2d*>(v);
+    double acc = 0.0;
+    for (int64_t c = threadIdx.x; c < n2; c += 256) {
+      const v2d a = x[c], b = w[c];
+      acc = __builtin_fma(a.x, b.x, acc);
+      acc = __builtin_fma(a.y, b.y, acc);
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[r] = (part[0] + part[1]) + (part[2] + part[3]);
+    __syncthreads();
+  }
+}
+
 }  // namespace
+
+extern "C" int geobo_rowgemv(int64_t m, int64_t n, const double* X, int64_t ld, const double* v, double* out, void* stream) {
+  if (!X || !v || !out) return GEOBO_E_ARG;
+  if (m <= 0 || n <= 0) return GEOBO_OK;
+  if ((n & 1) || (ld & 1) || ld < n || ((uintptr_t)X & 15) || ((uintptr_t)v & 15)) return GEOBO_E_ALIGN;
+  const int64_t nb = m < 256 * 16 ? m : 256 * 16;
+  hipLaunchKernelGGL(rowgemv_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, m, n / 2, X, ld, v, out);
+  return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
+}
 
 extern "C" int geobo_sumsq_accum(int64_t rows, int64_t n, const double* a, int64_t lda, const double* b, int64_t ldb, int slots,
                                  double* ss, int64_t ld_ss, void* stream) {

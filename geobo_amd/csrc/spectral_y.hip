@@ -46,11 +46,23 @@ typedef __attribute__((address_space(3))) double lds_double;
 __device__ __forceinline__ rsrc_t make_rsrc(const double* base, int bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(base), 0, bytes, 0x00020000);
 }
+// Cache policy of the row streams (aux bit 1 = nt): every spectrum is read once and written once per launch, GBs of it -- nothing to
+// keep in L2.  Measured on the 64^3 batch shape (profiles/r06_spectral_y_ab.txt): two blocks 1.282 -> 1.250 ms, two-term rows
+// 1.875 -> 1.851 ms with non-temporal loads and stores.  The eigenvalue tables and the fragment blob are read with the default policy.
+#ifndef SY_LD_AUX
+#define SY_LD_AUX 2
+#endif
+#ifndef SY_ST_AUX
+#define SY_ST_AUX 2
+#endif
 __device__ __forceinline__ double ld_lane(rsrc_t rs, unsigned voff, int soff) {
   return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0));
 }
+__device__ __forceinline__ double ld_stream(rsrc_t rs, unsigned voff, int soff) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, SY_LD_AUX));
+}
 __device__ __forceinline__ void st_lane(rsrc_t rs, unsigned voff, int soff, double v) {
-  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rs, voff, soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rs, voff, soff, SY_ST_AUX);
 }
 
 template <int NY>
@@ -167,12 +179,15 @@ __global__ void __launch_bounds__(256, 1) spectral_y_kernel(SYArgs g) {
 #pragma unroll
       for (int rho = 0; rho < 4; ++rho)
 #pragma unroll
-        for (int s = 0; s < KS; ++s) x[t][rho * KS + s] = ld_lane(rs, voff, (16 * s + rho) * S8);
+        for (int s = 0; s < KS; ++s) x[t][rho * KS + s] = ld_stream(rs, voff, (16 * s + rho) * S8);
     }
   };
 
   auto body = [&](double (&x)[NIN][4 * KS], double (&xn)[NIN][4 * KS], int64_t row) {
     if (row + rstep < g.R) load_row(xn, row + rstep);
+#ifdef SY_ROW_BARRIER
+    __builtin_amdgcn_s_barrier();
+#endif
     // the fragment base is made opaque per row: the fragments are READ from LDS next to every MFMA (one ds_read_b64 each), not hoisted
     // out of the row loop into 128-200 registers (accumulation registers at that: every use would then cost two v_accvgpr_read)
     lds_double* fl = fl0;
@@ -299,8 +314,11 @@ int launch_full(const SYArgs& g, hipStream_t st) {
     attr_done.fetch_or((uint64_t)1 << dev, std::memory_order_release);
   }
   const int64_t nbx = (g.C + 63) / 64;
-  int64_t gy = 1;                                   // one 4-wave workgroup per CU and round: a wave keeps its 16 modes for R / gy rows
-  while (nbx * gy < 256 && gy < g.R) ++gy;
+  // a wave keeps its 16 modes for R / gy rows.  Two property blocks / two terms take more than 256 registers: one 4-wave workgroup per
+  // CU, one round; a single block fits 256 -- two workgroups per CU, 0.850 -> 0.808 ms (profiles/r06_spectral_y_ab.txt)
+  const int64_t target = (NIN == 1 && NOUT == 1) ? 512 : 256;
+  int64_t gy = 1;
+  while (nbx * gy < target && gy < g.R) ++gy;
   hipLaunchKernelGGL(kern, dim3((unsigned)nbx, (unsigned)gy), dim3(256), lds, st, g);
   return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
 }

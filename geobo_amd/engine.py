@@ -325,7 +325,7 @@ class PosteriorEngine(RowFormMixin, TransposedPosteriorMixin, ColumnExchangeMixi
                     return self.operator(func, sensor_locations, B=B, axes=axes, full=full)
                 from .spectral import SpectralProduct
                 if self._spectral is None and self.use_spectral:
-                    self._spectral = SpectralProduct(self.nx, self.ny, self.nz, self.device)
+                    self._spectral = SpectralProduct(self.nx, self.ny, self.nz, self.device, opts=self.route.opts())
                 if self.use_spectral and self._spectral.lattice_feed and not self.f32:
                     self._timed("a_sens_" + func, 0.0, lambda: A.keep_stencil(func))
             self._lam[func] = None if lam is None else (A, lam)
@@ -412,23 +412,23 @@ class PosteriorEngine(RowFormMixin, TransposedPosteriorMixin, ColumnExchangeMixi
         """operators="auto": True when neither the transforms nor AkA need a materialised operator."""
         if plan is None or self.world != 1 or self.f32 or not self.use_spectral or not plan["rowmajor"]:
             return False
-        if os.environ.get("GEOBO_AKA_LATTICE", "1") == "0":
+        if not self.route.opt("aka_lattice"):
             return False
         from .lattice_gram import LatticeGram
         from .spectral import SpectralProduct
         if not LatticeGram.supported(self.nx, self.ny, self.nz) or self.Ms_pad != self.Ms:
             return False
         if self._spectral is None:
-            self._spectral = SpectralProduct(self.nx, self.ny, self.nz, self.device)
+            self._spectral = SpectralProduct(self.nx, self.ny, self.nz, self.device, opts=self.route.opts())
         return self._spectral.lattice_feed
 
     def _spectral_product(self):
         """The grid's SpectralProduct, its per-kernel timer following the engine's kernel_events switch."""
         from .spectral import SpectralProduct
         if self._spectral is None:
-            self._spectral = SpectralProduct(self.nx, self.ny, self.nz, self.device)
+            self._spectral = SpectralProduct(self.nx, self.ny, self.nz, self.device, opts=self.route.opts())
         self._spectral.kernel_timer = None if self.kernel_events is None else (
-            lambda name, by, fn, valu=0.0: self._timed(name, 0.0, fn, alg=by, valu=valu))
+            lambda name, by, fn, valu=0.0, flop=0.0: self._timed(name, flop, fn, alg=by, valu=valu))
         return self._spectral
 
     def _timed(self, name, flops, fn, alg=0.0, valu=0.0):
@@ -495,7 +495,7 @@ class PosteriorEngine(RowFormMixin, TransposedPosteriorMixin, ColumnExchangeMixi
         """Row-batch buffer of the streamed operators: one size for every user (no reallocation between stages)."""
         if self._spectral is None:
             from .spectral import SpectralProduct
-            self._spectral = SpectralProduct(self.nx, self.ny, self.nz, self.device)
+            self._spectral = SpectralProduct(self.nx, self.ny, self.nz, self.device, opts=self.route.opts())
         return self._workspace2d("op_rows", max(256, self._spectral.R), self.N_pad)
 
     def _cov_table(self, kid, lj, ls, w, amp):
@@ -509,13 +509,16 @@ class PosteriorEngine(RowFormMixin, TransposedPosteriorMixin, ColumnExchangeMixi
         """A @ v for a resident or streamed forward operator (the synthetic surveys of bench.py: data = A rho); v: (N,) host or
         device vector, returns the (Ms,) device vector.  Streamed operators are generated 256 rows at a time."""
         vd = v if isinstance(v, torch.Tensor) else hip.to_dev(np.asarray(v, dtype=np.float64).reshape(-1), self.device)
+        if vd.numel() % 2 or vd.data_ptr() % 16:      # (geobo_rowgemv reads 16-byte pairs)
+            vd = torch.cat([vd.reshape(-1), vd.new_zeros(2 - vd.numel() % 2)])
+        n2 = self.N + self.N % 2                       # (an odd voxel count meets the zero column of the padding)
         if not isinstance(A, StreamedOperator):
-            return A[:self.Ms, :self.N] @ vd
+            return hip.rowgemv(A[:self.Ms, :n2], vd)
         buf = self._op_rows_buffer()
         out = torch.empty(self.Ms, dtype=F64, device=self.device)
         for r0 in range(0, self.Ms, 256):
             R = min(256, self.Ms - r0)
-            out[r0:r0 + R] = A.rows_into(buf, r0, R)[:, :self.N] @ vd
+            hip.rowgemv(A.rows_into(buf, r0, R)[:, :n2], vd, out=out[r0:r0 + R])
         return out
 
     def clear_operators(self):
@@ -683,7 +686,7 @@ class PosteriorEngine(RowFormMixin, TransposedPosteriorMixin, ColumnExchangeMixi
         # of AkA); the x step and the back-transform are not divided, so from ~5 ranks the N-deep GEMM over N/G columns is cheaper
         # (with the row exchange -- 4 ranks and more -- the GEMM over N/G columns is within a few ms of it: not used there)
         if (not self.use_spectral or not plan["rowmajor"] or self.Ms_pad != self.Ms
-                or not LatticeGram.supported(self.nx, self.ny, self.nz) or os.environ.get("GEOBO_AKA_LATTICE", "1") == "0"):
+                or not LatticeGram.supported(self.nx, self.ny, self.nz) or not self.route.opt("aka_lattice")):
             return None
         if not rows:
             # the column forms of the Gram run on the fused n = 64 kernels' grids only (their batched-GEMM stand-ins pay in the row form)
@@ -694,7 +697,7 @@ class PosteriorEngine(RowFormMixin, TransposedPosteriorMixin, ColumnExchangeMixi
                 return None
         if self._spectral is None:
             from .spectral import SpectralProduct
-            self._spectral = SpectralProduct(self.nx, self.ny, self.nz, self.device)
+            self._spectral = SpectralProduct(self.nx, self.ny, self.nz, self.device, opts=self.route.opts())
         if self._gram is None:
             self._gram = LatticeGram(self._spectral, self.device)
         return self._timed("aka_lattice_eigen", 0.0, lambda: self._gram.eigen(hip.a_sens_lattice_stencil(lws, self.nx, self.ny, self.nz)))

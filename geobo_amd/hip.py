@@ -16,7 +16,7 @@ F64 = torch.float64
 KERNEL_IDS = {"d2": 0, "exp": 1, "exp_x": 2, "matern32": 3, "matern32_x": 4, "sparse": 5, "sparse_x": 6}
 FUNC_IDS = {"grav": 0, "magn": 1}
 # kernel-instance tables and padding units: ONE definition (plan.py, which decides routes from them on the CPU); re-exported here
-from .plan import PAD_M, PAD_N, TOEPLITZ_NY, XZ2D_FOLD_N, XZ2D_SHAPES  # noqa: E402,F401
+from .plan import PAD_M, PAD_N, SPECTRAL_Y_NY, TOEPLITZ_NY, XZ2D_FOLD_N, XZ2D_SHAPES  # noqa: E402,F401
 
 
 def kernel_id(name, cross):
@@ -153,6 +153,18 @@ def colgemv(X, v, out=None, ws=None):
     if ws is None or ws.numel() * 8 < nbytes:
         ws = torch.empty(max(nbytes // 8, 1), dtype=F64, device=X.device)
     _lib.check(lib.geobo_colgemv(m, n, _p(X), ld, _p(v), _p(_chk(out, "out")), _p(ws), ws.numel() * 8, _stream()), "geobo_colgemv")
+    return out
+
+
+def rowgemv(X, v, out=None):
+    """out[r] = sum_c X[r, c] * v[c] (geobo_rowgemv): a forward operator applied to a model, data = A rho."""
+    lib = require_gpu()
+    ld = _rowmajor(X, "X")
+    m, n = X.shape
+    assert v.numel() >= n and v.dtype == F64 and v.is_cuda
+    if out is None:
+        out = torch.empty(m, dtype=F64, device=X.device)
+    _lib.check(lib.geobo_rowgemv(int(m), int(n), _p(X), int(ld), _p(v), _p(out), _stream()), "geobo_rowgemv")
     return out
 
 
@@ -318,7 +330,7 @@ def ak_fused_grid(A, nx, ny, nz, table, col0, ncols, out):
 
 def gemm_nt(X, Y, C_, alpha=1.0, beta=0.0, lower_only=False, m_valid=0, small_tiles=False):
     """C = alpha X Y^T + beta C.  m_valid > 0: rows >= m_valid of X are zero padding (not contracted, not stored).
-    small_tiles: 128-row workgroup tiles even when 256-row tiles would fit (GEOBO_GEMM_SMALL_TILES)."""
+    small_tiles: 128-row workgroup tiles even when 256-row tiles would fit."""
     lib = require_gpu()
     ldx, ldy, ldc = _rowmajor(X, "X"), _rowmajor(Y, "Y"), _rowmajor(C_, "C")
     m, k = X.shape
@@ -581,7 +593,7 @@ def toeplitz_y2s(ny, C, R, src_g, src_m, tab_d0, tab_x, tab_d1, outs, plane=None
                                       _p(_chk(outs[0], "out")), _p(_chk(outs[1], "out")), _stream()), "geobo_toeplitz_y2s")
 
 
-SPECTRAL_Y_NY = (32, 48, 64)        # y extents of the in-kernel spectral y stage (geobo_spectral_y / _y2s)
+# SPECTRAL_Y_NY (plan.py): y extents of the in-kernel spectral y stage (geobo_spectral_y / _y2s)
 _spectral_y_basis = {}              # (ny, device index) -> fragment blob (constant of ny: filled once per device)
 
 

@@ -28,7 +28,6 @@ transforms G as the covariance (spectral.py), channel by channel:
 
 2 x 1.9e8 flop per row instead of 2.1e9, and no N-deep pass over A."""
 import numpy as np
-import os
 
 import torch
 
@@ -198,7 +197,7 @@ class LatticeGram:
         return lam.view(self.Py, self.nz, self.Px).permute(1, 0, 2).contiguous().view(-1)
 
     def zx_supported(self):
-        return self.nx == self.ny == self.nz == 64 and self.sp.fold and "y" in self.sp.F and os.environ.get("GEOBO_Z_FUSED", "1") != "0"
+        return self.nx == self.ny == self.nz == 64 and self.sp.fold and "y" in self.sp.F and self.sp.opts["z_fused"]
 
     def apply_transpose_zx(self, Lrows, nrows, lam3, out):
         """The same product as apply_transpose with steps 2-4 as ONE fused inverse two-axis transform per (row, z channel) plane
@@ -214,7 +213,7 @@ class LatticeGram:
             Rb = min(R, nrows - r0)
             lh = sp.buf("LG_Lh", R * Py * Px)
             hip.xz2d_fold(False, ny, Rb, 1, Lrows[r0:], Lrows.stride(0), ny * nx, sp.F["y"], sp.F["x"], lh, Py * Px, Py * Px)
-            if os.environ.get("GEOBO_Z_MUL", "1") != "0":
+            if self.sp.opts["z_mul"]:
                 # W[r][iz] = Lambda3[iz] * lhat_r is formed inside the inverse kernel, chunk by chunk, from the two cache-resident factors
                 hip.xz2d_fold_inv_mul(ny, Rb, nz, lam3, Py * Px, lh, Py * Px, sp.F["y"], sp.F["x"], out[r0:], out.stride(0), nx, nz * nx)
                 continue

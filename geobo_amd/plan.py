@@ -23,6 +23,7 @@ PAD_M, PAD_N = 256, 128
 XZ2D_SHAPES = ((48, 64), (64, 64), (64, 32))      # fused (x, z) transform instances (hip.XZ2D_SHAPES)
 XZ2D_FOLD_N = (64,)                               # radix-2 instances (hip.XZ2D_FOLD_N)
 TOEPLITZ_NY = (16, 32, 48, 64, 80, 96, 112, 128)               # Toeplitz y-stage instances (hip.TOEPLITZ_NY)
+SPECTRAL_Y_NY = (32, 48, 64)                      # in-kernel spectral y stage on the matrix pipe (hip.SPECTRAL_Y_NY)
 ROWS_MIN_VOXELS = 1 << 18                         # batched-GEMM forms of the row algorithm pay from 64^3 voxels ...
 ROWS_MIN_PLANE = 96 * 96                          # ... and (x, z) planes that fill the 128 x 128 GEMM tiles
 ROWS_MIN_VOXELS_MID, ROWS_MIN_PLANE_MID = 3 << 17, 64 * 64   # ... or from 393 216 voxels with planes of 4096 modes: 80^3 3345 / 4733 ms (52 / 183 GB),
@@ -34,6 +35,28 @@ ROWS_MIN_VOXELS_FUSED = 1 << 17                   # with fused / four-plane (x, 
                                                   # (row form / column form, ms per step, one MI355X): 64x32x64 107 / 138, 32x128x32 379 / 482,
                                                   # 64x64x32 369 / 484, 48x64x64 341 / 424, 64x80x64 877 / 1736, 64x128x64 2365 / 6670 (50 / 235 GB);
                                                   # below: 64x32x32 101 / 80, 48x32x64 89 / 69, 32x64x32 87 / 77, 64x16x64 35 / 33
+
+
+# Every behaviour switch of a step, in ONE table: option -> the environment override that turns it off ("0").  plan_route is the only
+# reader of the environment; the engine hands the resolved options on (Route.opts()) to the spectral product, the lattice Gram and the
+# transposed posterior, which used to read os.environ themselves (round-5 review, item 8).  All of them are A/B and fallback-coverage
+# switches: the default of every option is "on", and every "off" path is a complete, tested form of the same arithmetic.
+SWITCHES = {"fused_xz": "GEOBO_SPECTRAL_FUSED_XZ",   # fused (x, z) transform kernels (else two batched passes)
+            "fold": "GEOBO_XZ_FOLD",                 # radix-2 / radix-4 transform kernels (else the plain products)
+            "quad": "GEOBO_XZ_QUAD",                 # 32 x 32 planes four at a time through the n = 64 radix-2 kernels (else stacked pairs)
+            "dense_y": "GEOBO_SPECTRAL_DENSE_Y",     # y axis applied per mode inside one kernel (else carried through the spectrum by passes)
+            "y_mfma": "GEOBO_Y_MFMA",                # ... as an in-kernel spectral product on the matrix pipe (else the direct vector-pipe kernels)
+            "y2s": "GEOBO_Y2S",                      # two-term rows with the shared cross block K_01 = K_10 (else four products)
+            "z_fused": "GEOBO_Z_FUSED",              # rows of L^-1 A: one fused inverse transform per (row, z) plane (else two GEMM passes)
+            "z_mul": "GEOBO_Z_MUL",                  # ... its input product formed inside the kernel (else written and read back)
+            "z_lattice": "GEOBO_Z_LATTICE",          # rows of L^-1 A as lattice convolutions (else triangular GEMMs against the operator)
+            "aka_lattice": "GEOBO_AKA_LATTICE"}      # AkA by the lattice Gram (else the N-deep GEMM)
+
+
+def switches(env=None):
+    """{option: bool} from an environment-like mapping (None: every option on)."""
+    env = {} if env is None else env
+    return {k: env.get(v, "1") != "0" for k, v in SWITCHES.items()}
 
 
 def _pad(v, m):
@@ -58,6 +81,13 @@ class Route:
     note: str               # why a faster family stepped aside for this shape ("" when nothing did)
     ak_bytes: int = 0       # what a materialised A K (column form / one-rank fused form) of this rank would take
     rows_mandatory: bool = False   # ak_bytes > COLUMN_FORM_MAX_BYTES: only the row form fits; a denied row form is an error, not a fallback
+    switches: tuple = ()    # ((option, bool), ...) of SWITCHES as resolved from the environment handed to plan_route
+
+    def opt(self, name):
+        return dict(self.switches).get(name, True)
+
+    def opts(self):
+        return dict(switches(None), **dict(self.switches))
 
     def describe(self):
         k = dict(self.kernels)
@@ -67,6 +97,7 @@ class Route:
     def as_dict(self):
         d = asdict(self)
         d["kernels"] = dict(self.kernels)
+        d["switches"] = dict(self.switches)
         return d
 
 
@@ -81,7 +112,7 @@ def lattice_gram_supported(nx, ny, nz):
 
 def plan_route(nx, ny, nz, world=1, rank=0, assembly="f64", operators="resident", method="auto", env=None, nprops=2):
     env = {} if env is None else env
-    on = lambda key, default="1": env.get(key, default) != "0"
+    sw = switches(env)
     nx, ny, nz, world = int(nx), int(ny), int(nz), int(world)
     N, Ms = nx * ny * nz, nx * ny
     N_pad, Ms_pad = _pad(N, PAD_N), _pad(Ms, PAD_M)
@@ -93,17 +124,18 @@ def plan_route(nx, ny, nz, world=1, rank=0, assembly="f64", operators="resident"
     shards = [shard_columns(N_pad, world, r) for r in range(world)]
     aligned = all(c0 % plane == 0 and c1 % plane == 0 and c1 > c0 for c0, c1 in shards)
     spectral = (method in ("auto", "spectral") and nx % 16 == 0 and ny % 16 == 0 and nz % 16 == 0 and N == N_pad and aligned)
-    fused_xz = (nx, nz) in XZ2D_SHAPES and on("GEOBO_SPECTRAL_FUSED_XZ")
-    pair_xz = (nx, nz) == (32, 32) and (64, 32) in XZ2D_SHAPES and ny % 2 == 0 and on("GEOBO_SPECTRAL_FUSED_XZ")
-    fold = on("GEOBO_XZ_FOLD") and nx == nz and nx in XZ2D_FOLD_N
-    dense_y = ny in TOEPLITZ_NY and on("GEOBO_SPECTRAL_DENSE_Y")
+    fused_xz = (nx, nz) in XZ2D_SHAPES and sw["fused_xz"]
+    pair_xz = (nx, nz) == (32, 32) and (64, 32) in XZ2D_SHAPES and ny % 2 == 0 and sw["fused_xz"]
+    fold = sw["fold"] and nx == nz and nx in XZ2D_FOLD_N
+    dense_y = ny in TOEPLITZ_NY and sw["dense_y"]
+    y_mfma = dense_y and ny in SPECTRAL_Y_NY and sw["y_mfma"]
     fused_ss = fused_xz and fold and dense_y          # (any Toeplitz ny: the reduction in the inverse transform takes any plane count)
     transposed = env.get("GEOBO_POSTERIOR", "zpath") == "zpath"
     unpadded = Ms == Ms_pad and N == N_pad
-    gram_ok = lattice_gram_supported(nx, ny, nz) and on("GEOBO_AKA_LATTICE")
+    gram_ok = lattice_gram_supported(nx, ny, nz) and sw["aka_lattice"]
     gram_fast = lattice_gram_fast(nx, ny, nz)
     single = world == 1 and not f32 and spectral and unpadded and transposed and fused_ss
-    quad_xz = pair_xz and ny % 4 == 0 and on("GEOBO_XZ_FOLD") and 64 in XZ2D_FOLD_N and on("GEOBO_XZ_QUAD")
+    quad_xz = pair_xz and ny % 4 == 0 and sw["fold"] and 64 in XZ2D_FOLD_N and sw["quad"]
     rows_mode = env.get("GEOBO_ROWS", "auto")           # "0": never; "1": wherever it is possible; "auto": where it pays
     # a materialised A K of this rank: nprops property blocks in the element size of the assembly (fp32 assembly stores A K as fp32); the
     # engine repeats the check with the step's own property count where it allocates (engine._assemble_AK)
@@ -112,7 +144,7 @@ def plan_route(nx, ny, nz, world=1, rank=0, assembly="f64", operators="resident"
             or (N >= ROWS_MIN_VOXELS and plane >= ROWS_MIN_PLANE) or (N >= ROWS_MIN_VOXELS_MID and plane >= ROWS_MIN_PLANE_MID)
             or column_ak_bytes > COLUMN_FORM_MAX_BYTES)
     xmode = env.get("GEOBO_SPECTRAL_EXCHANGE", "auto")    # "0": replicated forward transforms, column shards (also switches the row form off for N > 1)
-    rows = (spectral and unpadded and Ms % world == 0 and gram_ok and transposed and on("GEOBO_Z_LATTICE") and rows_mode != "0"
+    rows = (spectral and unpadded and Ms % world == 0 and gram_ok and transposed and sw["z_lattice"] and rows_mode != "0"
             and (pays or rows_mode == "1") and not (single and gram_fast and rows_mode != "1") and (world == 1 or xmode != "0" or rows_mode == "1"))
     ncs = {shard_columns(N_pad, world, r)[1] - shard_columns(N_pad, world, r)[0] for r in range(world)}
     xbase = spectral and world > 1 and Ms % world == 0 and len(ncs) == 1 and xmode != "0"
@@ -139,7 +171,7 @@ def plan_route(nx, ny, nz, world=1, rank=0, assembly="f64", operators="resident"
         ops = "streamed"
         notes.append("operator rows of a rank (%.0f GB) are generated per batch instead of being resident" % (rows_r * N_pad * 8 / 1e9))
     kernels = (("xz", "fold" if (fused_xz and fold) else "fused" if fused_xz else "quad" if quad_xz else "pair" if pair_xz else "gemm"),
-               ("y", "toeplitz" if dense_y else "spectrum"),
+               ("y", ("mfma" if y_mfma else "toeplitz") if dense_y else "spectrum"),
                ("gram", ("fused" if gram_fast else "gemm") if (family in ("rows", "single") and gram_ok) else "per-step"),
                ("ss", ("fused" if fused_ss else "stored") if family in ("rows", "single") else "reduction"))
     if column_ak_bytes > COLUMN_FORM_MAX_BYTES and family != "rows":
@@ -147,4 +179,4 @@ def plan_route(nx, ny, nz, world=1, rank=0, assembly="f64", operators="resident"
                      % (column_ak_bytes / 1e9, COLUMN_FORM_MAX_BYTES / 1e9, "switched off (GEOBO_ROWS=0)" if rows_mode == "0" else "not available here"))
     return Route(spectral=spectral, family=family, rows=rows, single=single, exchange=exchange, exchange_without_rows=exchange_without_rows,
                  operators=ops, kernels=kernels, note="; ".join(notes), ak_bytes=int(column_ak_bytes),
-                 rows_mandatory=bool(column_ak_bytes > COLUMN_FORM_MAX_BYTES))
+                 rows_mandatory=bool(column_ak_bytes > COLUMN_FORM_MAX_BYTES), switches=tuple(sorted(sw.items())))

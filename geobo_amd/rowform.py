@@ -192,9 +192,10 @@ class RowFormMixin:
                     if two:
                         self._lattice_Z(Linv[b0:b0 + n, Msp:2 * Msp], n, "magn", None, Zm, zx=zx, edge=Em)
                 self._timed("posterior_zlattice", (2 if two else 1) * n * fl_z, zlattice)
-                self._timed("posterior_spectral", sp.flops_ss(0 if two else n, n if two else 0, P_c),
+                shared = y2s is not None and P_c == 2
+                self._timed("posterior_spectral", sp.flops_ss(0 if two else n, n if two else 0, P_c, shared),
                             lambda: sp.reduce_ss(Zg, n, tg, Zm if two else None, 0, tm, ss, y2s=y2s),
-                            valu=((1.5 if y2s is not None and P_c == 2 else 2) if two else 1) * n * P_c * 2.0 * ny * ny * sp.Px * sp.Pz)
+                            valu=sp.valu_ss(0 if two else n, n if two else 0, P_c, shared))
         for jj, t in enumerate(ss):
             if zx:
                 ssq[jj].copy_(t.sum(0).view(ny, nz, nx).transpose(1, 2).reshape(-1))

@@ -123,10 +123,14 @@ class LatticeRows:
 class SpectralProduct:
     """AK rows by the real-DFT route for one grid; holds the transform matrices and the work buffers."""
 
-    def __init__(self, nx, ny, nz, device, rows_per_batch=None, plane_pad=0):
+    def __init__(self, nx, ny, nz, device, rows_per_batch=None, plane_pad=0, opts=None):
         if nx % 16 or ny % 16 or nz % 16:
             raise ValueError("spectral path needs grid extents that are multiples of 16")
         self.nx, self.ny, self.nz = nx, ny, nz
+        # behaviour switches: resolved ONCE by the planner (plan.switches; the engine hands its route's options in); a product built on
+        # its own (tests, tools) asks the planner with the process environment
+        from . import plan
+        self.opts = dict(plan.switches(os.environ)) if opts is None else dict(opts)
         self.Px, self.Py, self.Pz = 2 * nx, 2 * ny, 2 * nz
         self.N = nx * ny * nz
         self.P3 = self.Px * self.Py * self.Pz
@@ -137,23 +141,22 @@ class SpectralProduct:
         self.E = {a: dev(_pad_rows(eigen_matrix(n))) for a, n in (("x", nx), ("y", ny), ("z", nz))}
         # folded (radix-2) matrices [n][n/2][(Fe, Fo)] for the axes the radix-2 kernels are instantiated for
         self.F = {a: dev(np.stack(folded_matrices(n), axis=2)) for a, n in (("x", nx), ("y", ny), ("z", nz)) if n in hip.XZ2D_FOLD_N}
-        self.fold = os.environ.get("GEOBO_XZ_FOLD", "1") != "0"
+        self.fold = self.opts["fold"]
         # y axis: applied as Toeplitz blocks per (x, z) mode (geobo_toeplitz_y) when the kernel has the extent, else carried
         # through the spectrum like x and z
-        self.dense_y = ny in hip.TOEPLITZ_NY and os.environ.get("GEOBO_SPECTRAL_DENSE_Y", "1") != "0"
+        self.dense_y = ny in hip.TOEPLITZ_NY and self.opts["dense_y"]
         # ... and, where instantiated, through the y axis's own spectrum INSIDE the kernel, on the matrix pipe (round 6: geobo_spectral_y,
         # same arguments, same sums to rounding; GEOBO_Y_MFMA=0 keeps the direct vector-pipe kernels: the A/B of profiles/r06_*)
-        self.y_mfma = self.dense_y and ny in hip.SPECTRAL_Y_NY and os.environ.get("GEOBO_Y_MFMA", "1") != "0"
+        self.y_mfma = self.dense_y and ny in hip.SPECTRAL_Y_NY and self.opts["y_mfma"]
         # x and z: one fused kernel per direction (geobo_xz2d) where it is instantiated, else two batched GEMM passes
-        self.fused_xz = (nx, nz) in hip.XZ2D_SHAPES and os.environ.get("GEOBO_SPECTRAL_FUSED_XZ", "1") != "0"
+        self.fused_xz = (nx, nz) in hip.XZ2D_SHAPES and self.opts["fused_xz"]
         # 32 x 32 planes: two consecutive y-planes stacked along x go through the (64, 32) instance with diag(Mx, Mx) -- the z step
         # is row-wise anyway, the x step spends half its MFMAs on the zero blocks (cheap next to two GEMM passes through HBM)
-        self.pair_xz = ((nx, nz) == (32, 32) and (64, 32) in hip.XZ2D_SHAPES and ny % 2 == 0
-                        and os.environ.get("GEOBO_SPECTRAL_FUSED_XZ", "1") != "0")
+        self.pair_xz = (nx, nz) == (32, 32) and (64, 32) in hip.XZ2D_SHAPES and ny % 2 == 0 and self.opts["fused_xz"]
         # 32 x 32 planes, better: FOUR consecutive y-planes as one 64 x 64 plane of the radix-2 kernels with the folded matrices of
         # diag(G32, G32) (geobo_xz2d_fold_quad): no zero blocks in z, folded in both axes, four waves per workgroup
         self.quad_xz = ((nx, nz) == (32, 32) and ny % 4 == 0 and 64 in hip.XZ2D_FOLD_N and self.fold
-                        and os.environ.get("GEOBO_XZ_QUAD", "1") != "0" and os.environ.get("GEOBO_SPECTRAL_FUSED_XZ", "1") != "0")
+                        and self.opts["quad"] and self.opts["fused_xz"])
         if self.quad_xz:
             fe, fo = folded_matrices(32)
             fq = np.zeros((64, 32, 2))
@@ -198,7 +201,8 @@ class SpectralProduct:
             return fn()
         # (one name per kernel symbol: single-block launches run toeplitz_y_kernel<ny, 2>, the others <ny, 1>)
         name = "kernel:toeplitz_y" if len(tabs) >= 2 or ny > 64 else "kernel:toeplitz_y_single"
-        return self.kernel_timer(name, 8.0 * R * C * (ny + (2 if accumulate else 1) * len(tabs) * (y1 - y0)), fn)
+        fl, fv = self.y_stage_flop(1, len(tabs), y1 - y0)
+        return self.kernel_timer(name, 8.0 * R * C * (ny + (2 if accumulate else 1) * len(tabs) * (y1 - y0)), fn, valu=R * fv, flop=R * fl)
 
     def buf(self, name, n):
         b = self._bufs.get(name)
@@ -323,19 +327,32 @@ class SpectralProduct:
             # multiply-adds), forward x step and both inverse steps one cos / sin row per frequency group and residue class (a quarter)
             fwd = 2.0 * ny * (0.5 * nx * pn(Pz) * nz + 0.25 * pn(Px) * pn(Pz) * nx)
             bwd = 0.25 * bwd
-        if self.dense_y:
-            # ny <= 64: the kernel computes every output y and stores the slab; ny = 128: chunks of 16 outputs covering the slab
-            bwd += 2.0 * ny * (ny if ny <= 64 else (slab + 15) // 16 * 16) * Px * Pz
-        else:
+        if not self.dense_y:
             fwd += 2.0 * pn(Py) * Px * Pz * ny
             bwd += 2.0 * pn(slab) * Px * Pz * Py
-        return rows * (fwd + nblocks * bwd)
+        return rows * (fwd + nblocks * bwd + (self.y_stage_flop(1, nblocks, slab)[0] if self.dense_y else 0.0))
+
+    def y_stage_flop(self, terms, nblocks, slab=None, shared=False):
+        """(executed flop, its vector-pipe part) of the y stage per row: `terms` input spectra, `nblocks` output blocks.
+        Direct kernels (toeplitz.hip): ny multiply-adds per output, block and term on the vector pipe (ny <= 64: every output y is
+        computed and the slab stored; ny > 64: chunks of 16 outputs covering the slab); `shared`: the two-term rows of a block pair
+        whose cross blocks coincide cost three products instead of four.
+        In-kernel spectral product (spectral_y.hip): ny^2 / 2 multiply-adds per transform and mode on the matrix pipe -- one analysis
+        per term, one synthesis per block -- plus the orbit butterflies on the vector pipe: 16 additions per orbit and analysis,
+        4 mul + 8 fma + 8 add per orbit and block (one term) or 8 add + 8 mul + 16 fma + 32 add per orbit for a block pair of two-term
+        rows (ny / 4 orbits per mode)."""
+        ny, C = self.ny, self.Px * self.Pz
+        if self.y_mfma:
+            valu = C * ny * (4.0 * terms + (7.0 * nblocks if terms == 1 else 10.0 * nblocks))
+            return C * 1.0 * ny * ny * (terms + nblocks) + valu, valu
+        outs = ny if (ny <= 64 or slab is None) else (slab + 15) // 16 * 16
+        nprod = terms * nblocks * (0.75 if shared and terms == 2 and nblocks == 2 else 1.0)
+        f = 2.0 * ny * outs * C * nprod
+        return f, f
 
     def flops_valu(self, rows, nblocks, slab=None):
-        """The part of flops() executed on the fp64 VALU (the Toeplitz y stage); everything else is MFMA."""
-        ny = self.ny
-        outs = ny if (ny <= 64 or slab is None) else (slab + 15) // 16 * 16
-        return rows * nblocks * 2.0 * ny * outs * self.Px * self.Pz if self.dense_y else 0.0
+        """The part of flops() executed on the fp64 VALU (the y stage's vector-pipe work); everything else is MFMA."""
+        return rows * self.y_stage_flop(1, nblocks, slab)[1] if self.dense_y else 0.0
 
     def eigenvalues(self, table_mirrored):
         """What product() needs of one covariance block, from the (z-mirrored) lattice table of geobo_cov_table:
@@ -430,7 +447,7 @@ class SpectralProduct:
         self.sym_residual = None
         a, b = pair
         if not (self.fused_ss() and self.ny in hip.TOEPLITZ_Y2T_NY and b == a + 1 and a % 2 == 0 and b < len(gens_g)
-                and os.environ.get("GEOBO_Y2S", "1") != "0"):
+                and self.opts["y2s"]):
             return None
         x = gens_g[b]
         # (cross weight 0 -- gp_coeff = [.., .., 0], a legal prior -- makes both cross blocks exactly zero: 0 / 0 must not read as
@@ -506,7 +523,8 @@ class SpectralProduct:
                     if self.kernel_timer is None:
                         fn()
                     else:
-                        self.kernel_timer(kname, 8.0 * Rb * C * (2 * ny + 2 * ny), fn, valu=2.0 * nprod * ny * ny * C * Rb)
+                        self.kernel_timer(kname, 8.0 * Rb * C * (2 * ny + 2 * ny), fn, valu=Rb * self.y_stage_flop(2, 2, shared=nprod == 3)[1],
+                                          flop=Rb * self.y_stage_flop(2, 2, shared=nprod == 3)[0])
                     for i, jj in enumerate(js):
                         hip.xz2d_fold_inv_ss(nx, Rb, ny, sg[i], ny * Cp, Cp, self.F["x"], self.F["z"], ss[jj])
                     continue
@@ -521,12 +539,16 @@ class SpectralProduct:
                     hip.xz2d_fold_inv_ss(nx, Rb, ny, sg[i], ny * Cp, Cp, self.F["x"], self.F["z"], ss[jj],
                                          src2=sm[i] if sm is not None else None, in2_row=ny * Cp, r2_first=0)
 
-    def flops_ss(self, rows_one, rows_two, nblocks):
-        """Executed flop of reduce_ss: rows_one one-term rows, rows_two two-term rows (forward + y stage per term, one second
+    def flops_ss(self, rows_one, rows_two, nblocks, shared=False):
+        """Executed flop of reduce_ss: rows_one one-term rows, rows_two two-term rows (forward transform per term, y stage, one second
         inverse step per row; the first inverse step per term)."""
         nx, ny, nz, Px, Pz = self.nx, self.ny, self.nz, self.Px, self.Pz
         fwd = 1.0 * ny * (nx * nz * Pz + 0.5 * Px * nx * Pz)           # radix 2 along z (half the plain products), radix 4 along x (a quarter)
-        toe = 2.0 * ny * ny * Px * Pz
         inv1, inv2 = 0.5 * ny * Px * Pz * nz, 0.5 * ny * nx * Px * nz  # radix 4 both ways
         terms = rows_one + 2 * rows_two
-        return terms * (fwd + nblocks * (toe + inv1)) + (rows_one + rows_two) * nblocks * inv2
+        y = rows_one * self.y_stage_flop(1, nblocks)[0] + rows_two * self.y_stage_flop(2, nblocks, shared=shared)[0]
+        return terms * (fwd + nblocks * inv1) + (rows_one + rows_two) * nblocks * inv2 + y
+
+    def valu_ss(self, rows_one, rows_two, nblocks, shared=False):
+        """The vector-pipe part of flops_ss (the y stage's share on the fp64 VALU)."""
+        return rows_one * self.y_stage_flop(1, nblocks)[1] + rows_two * self.y_stage_flop(2, nblocks, shared=shared)[1]

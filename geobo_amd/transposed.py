@@ -6,7 +6,6 @@ every family shares: mixin of engine.PosteriorEngine.
   _posterior_zpath              V = (L^-1 A3) K through the covariance kernels, squared and summed on the way out (inversion.py:114-117,238)
   _mean_rows, _drill_rows_ss    the mean as three rows through the covariance product; the rows behind the sensor rows
 """
-import os
 
 import torch
 
@@ -124,7 +123,7 @@ class TransposedPosteriorMixin:
         Zg, Zm = self._workspace2d("Zg", 2 * Msp, N), self._workspace2d("Zm", Msp, N)
         # Z = L^-1[:, operator columns] A: on a lattice survey a (y, x) convolution of every row's sensor image with the operator's
         # stencil table (lattice_gram.apply_transpose: 2e8 flop per row), otherwise two triangular MFMA GEMMs (2.1e9 flop per row)
-        lat = (self._gram is not None and self._gram.edge_supported() and Msp == nx * ny and os.environ.get("GEOBO_Z_LATTICE", "1") != "0"
+        lat = (self._gram is not None and self._gram.edge_supported() and Msp == nx * ny and self.route.opt("z_lattice")
                and all(self._lam.get(f) is not None and self._lam[f][0] is A for f, A in (("grav", A_g), ("magn", A_m))))
         if lat:
             gram = self._gram
@@ -161,8 +160,9 @@ class TransposedPosteriorMixin:
         tg, tm = [swap(g) for g in gens_g], [swap(g) for g in gens_m]
         # blocks (0, 1) and (1, 0) of a symmetric prior coincide: three y-stage products per two-term row instead of four
         y2s = sp.y2s_tables(tg, tm) if tuple(props[:2]) == (0, 1) else None
-        self._timed("posterior_spectral", sp.flops_ss(Msp, Msp, P_c), lambda: sp.reduce_ss(Zg, 2 * Msp, tg, Zm, Msp, tm, ss, y2s=y2s),
-                    valu=(2.5 if y2s is not None and P_c == 2 else 3.0) * Msp * P_c * 2.0 * ny * ny * sp.Px * sp.Pz)
+        shared = y2s is not None and P_c == 2
+        self._timed("posterior_spectral", sp.flops_ss(Msp, Msp, P_c, shared), lambda: sp.reduce_ss(Zg, 2 * Msp, tg, Zm, Msp, tm, ss, y2s=y2s),
+                    valu=sp.valu_ss(Msp, Msp, P_c, shared))
         if zx:
             ssum = torch.stack([t.sum(0).view(ny, nz, nx).transpose(1, 2).reshape(-1) for t in ss])   # planes came out as [iz][ix]
         else:

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GEOBO_VERSION 212 /* 201: flag word of geobo_gemm_nt, (64, 32) instance of geobo_xz2d, workspace layout of geobo_potrf_inv; 202: geobo_ymul, geobo_xz2d_fold_lattice; 203: geobo_sumsq_accum, geobo_lamdot_z, geobo_toeplitz_y2t, geobo_xz2d_fold_quad; 204: geobo_toeplitz_y3_add; 205: workspace layout of geobo_potrf_inv (one T buffer per tree node); 206: geobo_potrf_inv as one persistent tile-DAG launch from m = 1024 (workspace: + counters); 207: geobo_gemm_fold; 208: geobo_gemm_fold_lamdot; 209: geobo_toeplitz_y2s; 210: geobo_xz2d_fold* dense planes take the quarter-period group order of the basis (radix 4); 211: geobo_ymul_fold; 212: geobo_spectral_y, geobo_spectral_y2s, geobo_spectral_y_basis */
+#define GEOBO_VERSION 212 /* 201: flag word of geobo_gemm_nt, (64, 32) instance of geobo_xz2d, workspace layout of geobo_potrf_inv; 202: geobo_ymul, geobo_xz2d_fold_lattice; 203: geobo_sumsq_accum, geobo_lamdot_z, geobo_toeplitz_y2t, geobo_xz2d_fold_quad; 204: geobo_toeplitz_y3_add; 205: workspace layout of geobo_potrf_inv (one T buffer per tree node); 206: geobo_potrf_inv as one persistent tile-DAG launch from m = 1024 (workspace: + counters); 207: geobo_gemm_fold; 208: geobo_gemm_fold_lamdot; 209: geobo_toeplitz_y2s; 210: geobo_xz2d_fold* dense planes take the quarter-period group order of the basis (radix 4); 211: geobo_ymul_fold; 212: geobo_spectral_y, geobo_spectral_y2s, geobo_spectral_y_basis, geobo_rowgemv */
 
 #define GEOBO_PAD_M 256 /* row padding of M-like dimensions (observation rows)            */
 #define GEOBO_PAD_N 128 /* padding of voxel-like dimensions (columns / contraction index) */
@@ -434,6 +434,11 @@ int geobo_potrf_ctx_create(void** ctx);
 int geobo_potrf_ctx_destroy(void* ctx);
 int geobo_potrf_inv(int64_t m, double* A, int64_t ld, double* Linv, int64_t ldi, int* info, void* ws,
                     size_t ws_bytes, void* ctx, void* stream);
+
+/* Row dot products  out[r] = sum_(c < n) X[r, c] * v[c]  of a row-major matrix (n even, ld even, X and v 16-byte aligned): a forward
+ * operator applied to a model, data = A rho (simcube.py:147-150 -- the synthetic surveys of bench.py and of the tests; np.dot there).
+ * One workgroup per row, fixed reduction tree: deterministic.  HBM read bound. */
+int geobo_rowgemv(int64_t m, int64_t n, const double* X, int64_t ld, const double* v, double* out, void* stream);
 
 /* Sum of squares over the rows of a batch of V = (L^-1 A3) K (the transposed order of inversion.py:114-117; diag of K - V^T V,
  * inversion.py:238) for grids without the fused inverse-transform reduction (geobo_xz2d_fold_inv_ss, n = 64):

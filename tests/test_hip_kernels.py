@@ -590,6 +590,19 @@ def test_toeplitz_y2s_matches_torch(hip, ny, C, R):
         hip.toeplitz_y2s(80, C, R, flat(src_g), flat(src_m), flat(d0), flat(t01), flat(d1), [flat(o) for o in outs])
 
 
+@pytest.mark.parametrize("m,n,ld", [(1, 2, 2), (300, 4096, 4224), (4096, 262144, 262144), (37, 1000, 1002)])
+def test_rowgemv_matches_torch(hip, m, n, ld):
+    # out[r] = X[r, :n] . v (geobo_rowgemv: data = A rho of the synthetic surveys); padded leading dimension, NaN behind the valid columns
+    X = torch.full((m, ld), float("nan"), dtype=torch.float64, device="cuda")
+    X[:, :n] = _rand((m, n), 71)
+    v = _rand((n,), 72)
+    out = hip.rowgemv(X[:, :n], v)
+    torch.cuda.synchronize()
+    ref = (X[:, :n].cpu().numpy() * v.cpu().numpy()[None, :]).sum(axis=1)
+    assert np.abs(out.cpu().numpy() - ref).max() <= 1e-13 * np.abs(X[:, :n].cpu().numpy()).sum(axis=1).max()
+    assert torch.equal(hip.rowgemv(X[:, :n], v), out)
+
+
 @pytest.mark.parametrize("ny,C,R,nprop,y0,y1", [(64, 64, 5, 2, 0, 64), (64, 16384, 7, 2, 0, 64), (64, 256, 3, 1, 0, 64), (64, 128, 4, 2, 8, 40),
                                                  (48, 64, 5, 2, 0, 48), (48, 128, 3, 1, 5, 48), (32, 1024, 9, 2, 0, 32), (32, 64, 2, 1, 0, 17),
                                                  (64, 48, 6, 2, 0, 64), (64, 16, 1, 2, 0, 64), (64, 1040, 4, 2, 0, 64)])
@@ -902,10 +915,10 @@ def test_lattice_transposed_application_matches_the_gemm(hip, ny, nrows, monkeyp
             print("  fused (zx layout): %.2e" % err2)
             assert err2 <= 1e-12
             # the product W = Lambda * lhat formed inside the inverse kernel (default) against W written and read back: same arithmetic
-            monkeypatch.setenv("GEOBO_Z_MUL", "0")
+            gram.sp.opts["z_mul"] = False               # (the option GEOBO_Z_MUL=0 resolves to: plan.SWITCHES)
             out3 = torch.full((nrows, N + 16), float("nan"), dtype=torch.float64, device="cuda")[:, :N]
             gram.apply_transpose_zx(Lv, nrows, gram.transpose_tables3(lam), out3)
-            monkeypatch.delenv("GEOBO_Z_MUL")
+            gram.sp.opts["z_mul"] = True
             pl2 = slice(pl, N - pl)                     # (the boundary slabs of out2 were overwritten above)
             dev = (out3[:, pl2] - out2[:, pl2]).abs().max().item() / out2[:, pl2].abs().max().item()
             assert dev <= 1e-14                        # (the k-steps of the first contraction are summed in two chains there, four here)

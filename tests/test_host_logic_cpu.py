@@ -190,7 +190,10 @@ def test_route_table():
     assert dict(plan_route(32, 32, 32).kernels)["xz"] == "quad" and dict(plan_route(32, 32, 32, env={"GEOBO_XZ_QUAD": "0"}).kernels)["xz"] == "pair"
     # configs 3 / 4 (64^3 fp64): one rank on the fused kernels with A K materialised, from two ranks sharded by sensor rows
     r = plan_route(64, 64, 64, operators="auto")
-    assert r.family == "single" and r.single and not r.rows and r.note == "" and dict(r.kernels) == dict(xz="fold", y="toeplitz", gram="fused", ss="fused")
+    assert r.family == "single" and r.single and not r.rows and r.note == "" and dict(r.kernels) == dict(xz="fold", y="mfma", gram="fused", ss="fused")
+    assert dict(plan_route(64, 64, 64, env={"GEOBO_Y_MFMA": "0"}).kernels)["y"] == "toeplitz" and not plan_route(64, 64, 64, env={"GEOBO_Y_MFMA": "0"}).opt("y_mfma")
+    assert dict(plan_route(64, 48, 64).kernels)["y"] == "mfma" and dict(plan_route(32, 32, 32).kernels)["y"] == "mfma"
+    assert plan_route(64, 64, 64).opts()["z_mul"] and not plan_route(64, 64, 64, env={"GEOBO_Z_MUL": "0"}).opts()["z_mul"]
     for w in (2, 4, 8):
         r = plan_route(64, 64, 64, world=w, rank=w - 1)
         assert r.family == "rows" and r.rows and not r.single and r.exchange and r.exchange_without_rows == (w >= 4)
@@ -261,7 +264,7 @@ def test_planner_and_kernel_wrappers_share_one_instance_table():
     re-exported by hip.py / LatticeGram; this pins that."""
     from geobo_amd import hip, plan
     from geobo_amd.lattice_gram import LatticeGram
-    assert hip.XZ2D_SHAPES is plan.XZ2D_SHAPES and hip.XZ2D_FOLD_N is plan.XZ2D_FOLD_N and hip.TOEPLITZ_NY is plan.TOEPLITZ_NY
+    assert hip.XZ2D_SHAPES is plan.XZ2D_SHAPES and hip.XZ2D_FOLD_N is plan.XZ2D_FOLD_N and hip.TOEPLITZ_NY is plan.TOEPLITZ_NY and hip.SPECTRAL_Y_NY is plan.SPECTRAL_Y_NY
     assert (hip.PAD_M, hip.PAD_N) == (plan.PAD_M, plan.PAD_N) == (256, 128)
     for dims in ((64, 64, 64), (64, 48, 64), (64, 32, 64), (32, 32, 32), (48, 64, 64), (128, 128, 128), (20, 16, 16)):
         assert LatticeGram.fast(*dims) == plan.lattice_gram_fast(*dims)

@@ -796,10 +796,13 @@ def test_full_size_64cube_properties():
     rm = (A_m @ pad(inv.mu_rec[N:2 * N]))[:eng.Ms].cpu().numpy() - inv.Fs3[eng.Ms:2 * eng.Ms]
     # with sigma = 0.1 on unit-variance data the residual of a well-posed GP fit is small compared with the data
     assert np.sqrt(np.mean(rg ** 2)) < 0.1 and np.sqrt(np.mean(rm ** 2)) < 0.1
-    cb, (c0, b, smp) = bench.cpu_baseline(inv, [float(x) for x in inv.gp_length], target_seconds=3.0)
-    assert np.abs(smp[0][0] - inv.mu_rec[c0:c0 + b]).max() <= 1e-10 * np.abs(inv.mu_rec[:N]).max()
-    assert np.abs(smp[0][1] - var[c0:c0 + b]).max() <= 1e-10
-    assert np.abs(smp[1][0] - inv.mu_rec[N + c0:N + c0 + b]).max() <= 1e-10 * np.abs(inv.mu_rec[N:2 * N]).max()
+    cb, (cols, smp) = bench.cpu_baseline(inv, [float(x) for x in inv.gp_length], target_seconds=3.0)
+    iy_s = cols // (n * n)
+    assert iy_s.min() == 0 and iy_s.max() == n - 1 and np.isin(inv._sel[:5], cols).all()      # spread: padded slabs, drilled voxels
+    assert np.abs(smp[0][0] - inv.mu_rec[cols]).max() <= 1e-10 * np.abs(inv.mu_rec[:N]).max()
+    assert np.abs(smp[0][1] - var[cols]).max() <= 1e-10
+    assert np.abs(smp[1][0] - inv.mu_rec[N + cols]).max() <= 1e-10 * np.abs(inv.mu_rec[N:2 * N]).max()
+    assert np.abs(smp[1][1] - var[N + cols]).max() <= 1e-10
     assert all(c.shape == (n, n, n) for c in cubes)
 
     # ---- independent spot checks: nothing below borrows A, A K, AkA or L from the device -------------------------------------

@@ -26,6 +26,9 @@ DRIVERS = {"posterior": ("run_posterior_once.py", "gemm_f64_kernel<4, 2, 2, 1", 
            "toeplitz": ("run_spectral_kernels_once.py toeplitz", "toeplitz_y_kernel", "pmc_toeplitz_y.json"),
            "toeplitz2t": ("run_spectral_kernels_once.py toeplitz2t", "toeplitz_y2_kernel", "pmc_toeplitz_y2t.json"),
            "toeplitz2s": ("run_spectral_kernels_once.py toeplitz2s", "toeplitz_y2s_kernel", "pmc_toeplitz_y2s.json"),
+           "spectral_y": ("run_spectral_kernels_once.py spectral_y", "spectral_y_kernel<64, 1, 2", "pmc_spectral_y.json"),
+           "spectral_y1": ("run_spectral_kernels_once.py spectral_y1", "spectral_y_kernel<64, 1, 1", "pmc_spectral_y1.json"),
+           "spectral_y2s": ("run_spectral_kernels_once.py spectral_y2s", "spectral_y_kernel<64, 2, 2", "pmc_spectral_y2s.json"),
            "xcorr": ("run_spectral_kernels_once.py xcorr", "xcorr_kernel", "pmc_xcorr.json"),
            "fold_fwd": ("run_spectral_kernels_once.py fold_fwd", "xz_fold_fwd_kernel", "pmc_xz2d_fold_fwd.json"),
            "fold_bwd": ("run_spectral_kernels_once.py fold_bwd", "xz_fold_inv_kernel", "pmc_xz2d_fold_bwd.json"),

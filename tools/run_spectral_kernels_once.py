@@ -47,6 +47,20 @@ if which in ("all", "toeplitz2s"):
     outs = [torch.empty(R * n * C, dtype=torch.float64, device=dev) for _ in range(2)]
     timed("toeplitz_y2s", R * C * 2.0 * n * n * 3, R * n * C * 8.0 * 4, lambda: hip.toeplitz_y2s(n, C, R, src_g, src_m, t3[0], t3[1], t3[2], outs))
     del src_g, src_m, t3, outs
+if which in ("all", "spectral_y", "spectral_y1", "spectral_y2s"):
+    # the y stage through its own spectrum on the matrix pipe (geobo_spectral_y*): executed flop = ny^2 / 2 multiply-adds per transform
+    # and mode on MFMA + the orbit butterflies (adds count 1, multiplies 1, fused multiply-adds 2)
+    C = P * P
+    src_g, src_m = rnd(R * n * C), rnd(R * n * C)
+    t3 = [rnd(n * C) for _ in range(3)]
+    outs = [torch.empty(R * n * C, dtype=torch.float64, device=dev) for _ in range(2)]
+    if which in ("all", "spectral_y"):
+        timed("spectral_y", R * C * (3.0 * n * n + 18.0 * n), R * n * C * 8.0 * 3, lambda: hip.spectral_y(n, C, R, src_g, t3[:2], outs))
+    if which in ("all", "spectral_y1"):
+        timed("spectral_y1", R * C * (2.0 * n * n + 11.0 * n), R * n * C * 8.0 * 2, lambda: hip.spectral_y(n, C, R, src_g, t3[:1], outs[:1]))
+    if which in ("all", "spectral_y2s"):
+        timed("spectral_y2s", R * C * (4.0 * n * n + 28.0 * n), R * n * C * 8.0 * 4, lambda: hip.spectral_y2s(n, C, R, src_g, src_m, t3[0], t3[1], t3[2], outs))
+    del src_g, src_m, t3, outs
 if which in ("all", "xcorr"):
     src = rnd(R, P * n * n)
     lam = rnd(P * n * P)
