@@ -328,6 +328,258 @@ int launch(const SYArgs& g, hipStream_t st) {
   return (g.y0 == 0 && g.y1 == NY) ? launch_full<NY, NIN, NOUT, true>(g, st) : launch_full<NY, NIN, NOUT, false>(g, st);
 }
 
+// ---- long y axes (ny = 80 .. 128; 128 = BASELINE config 5): FOUR waves share one tile of 16 modes ------------------------------------------
+// At ny = 128 a lane of the kernel above would hold 64 spectral values per term, 32 eigenvalues per table (three to six tables) and 64
+// values per block on the way back: over the register file.  Here the work on a tile is split between the four waves of a workgroup,
+// and the split changes twice on the way through the spectrum:
+//   analysis    wave rho reads and contracts the inputs of ITS residue class y' = 4 j + rho (a quarter of the tile: nothing is read
+//               twice) against every orbit tile: NT x ny/16 MFMAs -> the class sums C_rho, S_rho of all orbits;
+//   exchange 1  the class sums of orbit tile T go to wave T (LDS, 32 KiB, one barrier);
+//   butterfly   wave T owns the orbits omega = 8 T .. 8 T + 7 (two per lane) and THEIR eigenvalues: 2 x 4 per table and lane -- a quarter;
+//   exchange 2  the scaled class sums Y[rho] of every output block go back to wave rho (32 KiB per block, one barrier for all blocks);
+//   synthesis   wave rho owns the outputs y = 4 j + rho: (ny/64 tiles of j) x (4 NT k-steps), final -- no partial sums to add -- and stores
+//               them (optionally adding into the output: the second term of a two-term row, geobo_toeplitz_y3_add's form).
+// ny = 80 / 96 have three orbit tiles: wave 3 sits out the butterflies.  A wave's fragments (analysis and synthesis of its class) stay in
+// registers; those of the eigenvalue transform are read from the blob in the prologue.
+struct SY3Args {
+  const double* in[2];      // [R][NY][S] per term (NIN = 2: V_j = T(tab[0][j]) in[0] + T(tab[1][j]) in[1], the two-term rows)
+  const double* tab[2][3];
+  double* out[3];
+  const double* basis;
+  int64_t C, S, R;
+  int y0, y1;
+};
+
+template <int NY, int NIN, int NOUT, bool ACC>
+__global__ void __launch_bounds__(256, 1) spectral_y_split_kernel(SY3Args g) {
+  using S = Shape<NY>;
+  constexpr int NT = S::NT, MJ = S::MJ, KS = S::KS;
+  static_assert(NT <= 4 && NOUT >= 1 && NOUT <= 3 && NIN >= 1 && NIN <= 2 && !(ACC && NIN == 2), "shape");
+  // LDS holds the two exchange areas only: ex1[dest T][src rho][reg][lane] (class sums), ex2[block][dest rho][src T][reg][lane] (scaled
+  // class sums).  The fragments a wave needs -- analysis of ITS class, synthesis of ITS class: 2 x ny/4 doubles per lane -- stay in
+  // registers for the whole launch (in LDS they cost 128 KiB at ny = 128 and a read next to every MFMA; with the exchange areas apart
+  // from each other and from the fragments a row needs TWO barriers instead of 2 + 2 per block).
+  extern __shared__ __attribute__((aligned(16))) double exch[];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 15, gq = lane >> 4;
+  lds_double* const ex1 = (lds_double*)exch + lane;
+  lds_double* const ex2 = ex1 + NIN * 4 * 4 * 4 * 64;                     // ex1: [term][dest T][src rho][reg]
+  const int64_t Sd = g.S, m0 = (int64_t)blockIdx.x * 16;
+  const int S8 = (int)(Sd * 8);
+  const unsigned voff = (unsigned)((4 * gq) * S8 + c * 8);
+  const bool orb = w < NT;                                                // this wave owns an orbit tile
+
+  double ffrag[KS * NT], ifrag[NT * 4 * MJ];
+  {
+    const double* bf = g.basis + lane;
+#pragma unroll
+    for (int i = 0; i < KS * NT; ++i) ffrag[i] = bf[(size_t)(w * KS * NT + i) * 64];                       // fwd(rho = w, s, T)
+#pragma unroll
+    for (int i = 0; i < NT * 4 * MJ; ++i) ifrag[i] = bf[(size_t)(S::NF_FWD + w * NT * 4 * MJ + i) * 64];   // inv(rho = w, T, r, mj)
+  }
+  d4 lam[NIN][NOUT][2];
+  if (orb) {
+    const int T8 = (int)(g.C * 8);
+    const unsigned tvoff = (unsigned)(gq * T8 + c * 8);
+    const double* ef = g.basis + ((size_t)S::eig(2 * w, 0)) * 64 + lane;    // eigenvalue fragments of tau = 2 w, 2 w + 1
+#pragma unroll
+    for (int u = 0; u < NIN; ++u)
+#pragma unroll
+      for (int t = 0; t < NOUT; ++t) {
+        const rsrc_t tr = make_rsrc(g.tab[u][t] + m0, NY * T8);
+        lam[u][t][0] = d4{0., 0., 0., 0.};
+        lam[u][t][1] = d4{0., 0., 0., 0.};
+#pragma unroll 4
+        for (int s = 0; s < S::KE; ++s) {
+          const double tv = ld_lane(tr, tvoff, 4 * s * T8);
+          lam[u][t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ef[(size_t)s * 64], tv, lam[u][t][0], 0, 0, 0);
+          lam[u][t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ef[(size_t)(S::KE + s) * 64], tv, lam[u][t][1], 0, 0, 0);
+        }
+      }
+  }
+
+  int64_t r = blockIdx.y;
+  if (r >= g.R) return;
+  const int64_t rstep = gridDim.y, rowlen = (int64_t)NY * Sd;
+  const int64_t ostep = (int64_t)(g.y1 - g.y0) * Sd;
+  const int in_bytes = NY * S8;
+
+  auto load_row = [&](double (&x)[NIN][KS], int64_t row) {     // this wave's residue class: planes y' = 16 s + 4 g + w
+#pragma unroll
+    for (int u = 0; u < NIN; ++u) {
+      const rsrc_t rs = make_rsrc(g.in[u] + row * rowlen + m0, in_bytes);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) x[u][s] = ld_stream(rs, voff, (16 * s + w) * S8);
+    }
+  };
+
+  auto body = [&](double (&x)[NIN][KS], double (&xn)[NIN][KS], int64_t row) {
+    if (row + rstep < g.R) load_row(xn, row + rstep);
+    // accumulating form: the outputs this wave will add into are requested HERE, a whole row of arithmetic ahead of their use (requested
+    // next to the synthesis they cost a memory latency per block: 5.6 ms against 3.5 for three blocks at ny = 128)
+    double prev[ACC ? NOUT : 1][MJ][4];
+    if constexpr (ACC) {
+#pragma unroll
+      for (int jb = 0; jb < NOUT; ++jb) {
+        const rsrc_t dst = make_rsrc(g.out[jb] + row * ostep + m0 - (int64_t)g.y0 * Sd, g.y1 * S8);
+#pragma unroll
+        for (int mj = 0; mj < MJ; ++mj)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int yb = 64 * mj + 16 * rr + w, y = yb + 4 * gq;
+            prev[jb][mj][rr] = (16 * mj + 4 * rr < S::NJ && y >= g.y0 && y < g.y1) ? ld_lane(dst, voff, yb * S8) : 0.0;
+          }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NIN; ++u) {
+      d4 acc[NT];
+#pragma unroll
+      for (int T = 0; T < NT; ++T) acc[T] = d4{0., 0., 0., 0.};
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int T = 0; T < NT; ++T) acc[T] = __builtin_amdgcn_mfma_f64_16x16x4f64(ffrag[s * NT + T], x[u][s], acc[T], 0, 0, 0);
+#pragma unroll
+      for (int T = 0; T < NT; ++T)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ex1[(((u * 4 + T) * 4 + w) * 4 + q) * 64] = acc[T][q];
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);                                    // lgkmcnt(0): this wave's exchange writes have landed
+    __builtin_amdgcn_s_barrier();                                          // (1) every class's sums of this row are in ex1
+    if (orb) {
+      double a[NIN][2][4], b[NIN][2][4];
+#pragma unroll
+      for (int u = 0; u < NIN; ++u) {
+        double cs[4][4];
+#pragma unroll
+        for (int rho = 0; rho < 4; ++rho)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) cs[rho][q] = ex1[(((u * 4 + w) * 4 + rho) * 4 + q) * 64];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const double Cc[4] = {cs[0][h], cs[1][h], cs[2][h], cs[3][h]};
+          const double Ss[4] = {cs[0][2 + h], cs[1][2 + h], cs[2][2 + h], cs[3][2 + h]};
+          bfly_fwd(Cc, Ss, a[u][h], b[u][h]);
+        }
+      }
+#pragma unroll
+      for (int jb = 0; jb < NOUT; ++jb) {
+        double Y[4][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          double sa, da, sb, db, tb0, tb1, tb2, tb3;
+          if constexpr (NIN == 1) {
+            const d4 l = lam[0][jb][h];
+            const double t0 = l[0] * a[0][h][0], t1 = l[2] * a[0][h][2], u0 = l[0] * b[0][h][0], u1 = l[2] * b[0][h][2];
+            sa = __builtin_fma(l[1], a[0][h][1], t0); da = __builtin_fma(-l[1], a[0][h][1], t0);
+            sb = __builtin_fma(l[3], a[0][h][3], t1); db = __builtin_fma(-l[3], a[0][h][3], t1);
+            tb1 = __builtin_fma(l[1], b[0][h][1], u0); tb0 = __builtin_fma(-l[1], b[0][h][1], u0);
+            tb3 = __builtin_fma(l[3], b[0][h][3], u1); tb2 = __builtin_fma(-l[3], b[0][h][3], u1);
+          } else {
+            // the two terms meet in the spectrum: Y^ = lambda_g x^_g + lambda_m x^_m per member of the orbit
+            const d4 lg = lam[0][jb][h], lm = lam[1][jb][h];
+            double ya[4], yb[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+              ya[f] = __builtin_fma(lm[f], a[1][h][f], lg[f] * a[0][h][f]);
+              yb[f] = __builtin_fma(lm[f], b[1][h][f], lg[f] * b[0][h][f]);
+            }
+            sa = ya[0] + ya[1]; da = ya[0] - ya[1]; sb = ya[2] + ya[3]; db = ya[2] - ya[3];
+            tb0 = yb[0] - yb[1]; tb1 = yb[0] + yb[1]; tb2 = yb[2] - yb[3]; tb3 = yb[2] + yb[3];
+          }
+          Y[0][h] = sa + sb; Y[2][h] = sa - sb; Y[1][h] = da + tb3; Y[3][h] = da - tb3;
+          Y[0][2 + h] = tb0 + tb2; Y[2][2 + h] = tb0 - tb2; Y[1][2 + h] = tb1 - db; Y[3][2 + h] = tb1 + db;
+        }
+#pragma unroll
+        for (int rho = 0; rho < 4; ++rho)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) ex2[(((jb * 4 + rho) * 4 + w) * 4 + rr) * 64] = Y[rho][rr];
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();                                          // (A) every orbit tile's scaled class sums, all blocks, are in ex2
+    // (no further barrier: ex1 is rewritten only by waves that are past (A) -- every read of it lies in front of (A) -- and ex2 only
+    // behind the next row's (1), which a wave reaches after its own reads of ex2 below)
+#pragma unroll
+    for (int jb = 0; jb < NOUT; ++jb) {
+      // slab [y0, y1): the descriptor's base sits y0 planes in front of the row (see the kernel above)
+      const rsrc_t dst = make_rsrc(g.out[jb] + row * ostep + m0 - (int64_t)g.y0 * Sd, g.y1 * S8);
+      double yin[NT][4];
+#pragma unroll
+      for (int T = 0; T < NT; ++T)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) yin[T][rr] = ex2[(((jb * 4 + w) * 4 + T) * 4 + rr) * 64];
+      d4 o[MJ];
+#pragma unroll
+      for (int mj = 0; mj < MJ; ++mj) o[mj] = d4{0., 0., 0., 0.};
+#pragma unroll
+      for (int T = 0; T < NT; ++T)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+          for (int mj = 0; mj < MJ; ++mj)
+            o[mj] = __builtin_amdgcn_mfma_f64_16x16x4f64(ifrag[(T * 4 + rr) * MJ + mj], yin[T][rr], o[mj], 0, 0, 0);
+#pragma unroll
+      for (int mj = 0; mj < MJ; ++mj)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          if (16 * mj + 4 * rr >= S::NJ) continue;
+          const int yb = 64 * mj + 16 * rr + w;                            // y = 4 (16 mj + g + 4 rr) + rho, rho = w
+          const int y = yb + 4 * gq;
+          if (y >= g.y0 && y < g.y1) {
+            double v = o[mj][rr];
+            if constexpr (ACC) v += prev[jb][mj][rr];
+            st_lane(dst, voff, yb * S8, v);
+          }
+        }
+    }
+  };
+
+  double xa[NIN][KS], xb[NIN][KS];
+  load_row(xa, r);
+  while (true) {
+    body(xa, xb, r);
+    r += rstep;
+    if (r >= g.R) break;
+    body(xb, xa, r);
+    r += rstep;
+    if (r >= g.R) break;
+  }
+}
+
+template <int NY, int NIN, int NOUT, bool ACC>
+int launch_split(const SY3Args& g, hipStream_t st) {
+  using S = Shape<NY>;
+  constexpr size_t lds = (size_t)((NIN + NOUT) * 4 * 4 * 4 * 64) * sizeof(double);
+  static_assert(lds <= 163840, "LDS");
+  auto kern = spectral_y_split_kernel<NY, NIN, NOUT, ACC>;
+  static std::atomic<uint64_t> attr_done{0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return GEOBO_E_LAUNCH;
+  if (!((attr_done.load(std::memory_order_acquire) >> dev) & 1)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return GEOBO_E_LAUNCH;
+    attr_done.fetch_or((uint64_t)1 << dev, std::memory_order_release);
+  }
+  const int64_t nbx = g.C / 16;
+  int64_t gy = 1;                                   // one workgroup per CU: a workgroup keeps its 16 modes for R / gy rows
+  while (nbx * gy < 512 && gy < g.R) ++gy;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nbx, (unsigned)gy), dim3(256), lds, st, g);
+  return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
+}
+
+template <int NY>
+int launch_split_by(const SY3Args& g, int nprop, bool acc, hipStream_t st) {
+  if (acc) return nprop == 1 ? launch_split<NY, 1, 1, true>(g, st) : nprop == 2 ? launch_split<NY, 1, 2, true>(g, st) : launch_split<NY, 1, 3, true>(g, st);
+  return nprop == 1 ? launch_split<NY, 1, 1, false>(g, st) : nprop == 2 ? launch_split<NY, 1, 2, false>(g, st) : launch_split<NY, 1, 3, false>(g, st);
+}
+
+template <int NY>
+int launch_split2_by(const SY3Args& g, int nprop, hipStream_t st) {
+  return nprop == 1 ? launch_split<NY, 2, 1, false>(g, st) : nprop == 2 ? launch_split<NY, 2, 2, false>(g, st) : launch_split<NY, 2, 3, false>(g, st);
+}
+
 template <int NY>
 int fill_basis(double* basis, hipStream_t st) {
   hipLaunchKernelGGL(basis_kernel<NY>, dim3(Shape<NY>::NF), dim3(64), 0, st, basis);
@@ -341,6 +593,10 @@ extern "C" int64_t geobo_spectral_y_basis_doubles(int ny) {
     case 64: return (int64_t)Shape<64>::NF * 64;
     case 48: return (int64_t)Shape<48>::NF * 64;
     case 32: return (int64_t)Shape<32>::NF * 64;
+    case 80: return (int64_t)Shape<80>::NF * 64;
+    case 96: return (int64_t)Shape<96>::NF * 64;
+    case 112: return (int64_t)Shape<112>::NF * 64;
+    case 128: return (int64_t)Shape<128>::NF * 64;
     default: return 0;
   }
 }
@@ -351,6 +607,10 @@ extern "C" int geobo_spectral_y_basis(int ny, double* basis, void* stream) {
     case 64: return fill_basis<64>(basis, (hipStream_t)stream);
     case 48: return fill_basis<48>(basis, (hipStream_t)stream);
     case 32: return fill_basis<32>(basis, (hipStream_t)stream);
+    case 80: return fill_basis<80>(basis, (hipStream_t)stream);
+    case 96: return fill_basis<96>(basis, (hipStream_t)stream);
+    case 112: return fill_basis<112>(basis, (hipStream_t)stream);
+    case 128: return fill_basis<128>(basis, (hipStream_t)stream);
     default: return GEOBO_E_UNSUPPORTED;
   }
 }
@@ -386,5 +646,55 @@ extern "C" int geobo_spectral_y2s(int ny, int64_t C, int64_t plane, int64_t R, c
     case 48: return launch<48, 2, 2>(g, st);
     case 32: return launch<32, 2, 2>(g, st);
     default: return GEOBO_E_UNSUPPORTED;
+  }
+}
+
+extern "C" int geobo_spectral_y3(int ny, int64_t C, int64_t plane, int64_t R, int nprop, const double* in, const double* const* tabs,
+                                 double* const* outs, int y0, int y1, int accumulate, const double* basis, void* stream) {
+  if (!in || !tabs || !outs || !basis || nprop < 1 || nprop > 3) return GEOBO_E_ARG;
+  for (int j = 0; j < nprop; ++j)
+    if (!tabs[j] || !outs[j]) return GEOBO_E_ARG;
+  if (R <= 0 || y0 < 0 || y1 > ny || y1 <= y0 || plane < C) return GEOBO_E_ARG;
+  if (C <= 0 || C % 16 || (int64_t)ny * plane * 8 >= (1ll << 31)) return GEOBO_E_ALIGN;
+  if (ny <= 64) {
+    if (accumulate) return GEOBO_E_UNSUPPORTED;        // (ny <= 64 has the two-term form geobo_spectral_y2s instead)
+    for (int j = 0; j < nprop; j += 2) {
+      const int n = nprop - j >= 2 ? 2 : 1;
+      const int rc = geobo_spectral_y(ny, C, plane, R, n, in, tabs[j], n == 2 ? tabs[j + 1] : nullptr, outs[j], n == 2 ? outs[j + 1] : nullptr, y0, y1,
+                                      basis, stream);
+      if (rc) return rc;
+    }
+    return GEOBO_OK;
+  }
+  SY3Args g;
+  g.in[0] = g.in[1] = in; g.basis = basis; g.C = C; g.S = plane; g.R = R; g.y0 = y0; g.y1 = y1;
+  for (int j = 0; j < 3; ++j) { g.tab[0][j] = g.tab[1][j] = tabs[j < nprop ? j : 0]; g.out[j] = outs[j < nprop ? j : 0]; }
+  hipStream_t st = (hipStream_t)stream;
+  switch (ny) {
+    case 80: return launch_split_by<80>(g, nprop, accumulate != 0, st);
+    case 96: return launch_split_by<96>(g, nprop, accumulate != 0, st);
+    case 112: return launch_split_by<112>(g, nprop, accumulate != 0, st);
+    case 128: return launch_split_by<128>(g, nprop, accumulate != 0, st);
+    default: return GEOBO_E_UNSUPPORTED;
+  }
+}
+
+extern "C" int geobo_spectral_y3t(int ny, int64_t C, int64_t plane, int64_t R, int nprop, const double* in_g, const double* in_m,
+                                  const double* const* tabs_g, const double* const* tabs_m, double* const* outs, const double* basis, void* stream) {
+  if (!in_g || !in_m || !tabs_g || !tabs_m || !outs || !basis || nprop < 1 || nprop > 3) return GEOBO_E_ARG;
+  for (int j = 0; j < nprop; ++j)
+    if (!tabs_g[j] || !tabs_m[j] || !outs[j]) return GEOBO_E_ARG;
+  if (R <= 0 || plane < C) return GEOBO_E_ARG;
+  if (C <= 0 || C % 16 || (int64_t)ny * plane * 8 >= (1ll << 31)) return GEOBO_E_ALIGN;
+  SY3Args g;
+  g.in[0] = in_g; g.in[1] = in_m; g.basis = basis; g.C = C; g.S = plane; g.R = R; g.y0 = 0; g.y1 = ny;
+  for (int j = 0; j < 3; ++j) { g.tab[0][j] = tabs_g[j < nprop ? j : 0]; g.tab[1][j] = tabs_m[j < nprop ? j : 0]; g.out[j] = outs[j < nprop ? j : 0]; }
+  hipStream_t st = (hipStream_t)stream;
+  switch (ny) {
+    case 80: return launch_split2_by<80>(g, nprop, st);
+    case 96: return launch_split2_by<96>(g, nprop, st);
+    case 112: return launch_split2_by<112>(g, nprop, st);
+    case 128: return launch_split2_by<128>(g, nprop, st);
+    default: return GEOBO_E_UNSUPPORTED;   // (ny <= 64: geobo_spectral_y2s)
   }
 }

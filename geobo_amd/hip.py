@@ -612,15 +612,34 @@ def spectral_y_basis(ny, device=None):
     return b
 
 
-def spectral_y(ny, C, R, src, tabs, outs, y0=0, y1=None, plane=None):
-    """The sums of toeplitz_y (one or two property blocks) through the y axis's own spectrum on the matrix pipe (geobo_spectral_y)."""
+def spectral_y(ny, C, R, src, tabs, outs, y0=0, y1=None, plane=None, accumulate=False):
+    """The sums of toeplitz_y (one to three property blocks; accumulate: outs[j] += ..., ny > 64) through the y axis's own spectrum on the
+    matrix pipe (geobo_spectral_y3: ny <= 64 one wave per 16 modes, two blocks per sweep; ny > 64 four waves per 16 modes)."""
     lib = require_gpu()
     y1 = ny if y1 is None else y1
     n = len(tabs)
-    assert 1 <= n <= 2 and len(outs) == n
-    _lib.check(lib.geobo_spectral_y(int(ny), int(C), int(C if plane is None else plane), int(R), n, _p(_chk(src, "src")),
-                                    _p(_chk(tabs[0], "tab")), _p(_chk(tabs[-1], "tab")), _p(_chk(outs[0], "out")), _p(_chk(outs[-1], "out")),
-                                    int(y0), int(y1), _p(spectral_y_basis(ny, src.device)), _stream()), "geobo_spectral_y")
+    assert 1 <= n <= 3 and len(outs) == n
+    import ctypes
+    tp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in (_chk(t, "tab") for t in tabs)])
+    op = (ctypes.c_void_p * n)(*[o.data_ptr() for o in (_chk(o, "out") for o in outs)])
+    _lib.check(lib.geobo_spectral_y3(int(ny), int(C), int(C if plane is None else plane), int(R), n, _p(_chk(src, "src")), tp, op, int(y0), int(y1),
+                                     1 if accumulate else 0, _p(spectral_y_basis(ny, src.device)), _stream()), "geobo_spectral_y3")
+
+
+SPECTRAL_Y3T_NY = (80, 96, 112, 128)      # y extents of the two-term long-axis form (geobo_spectral_y3t)
+
+
+def spectral_y3t(ny, C, R, src_g, src_m, tabs_g, tabs_m, outs, plane=None):
+    """outs[j] = T(tabs_g[j]) src_g + T(tabs_m[j]) src_m for up to three property blocks, the terms meeting in the y spectrum
+    (geobo_spectral_y3t, ny in SPECTRAL_Y3T_NY)."""
+    lib = require_gpu()
+    n = len(outs)
+    assert 1 <= n <= 3 and len(tabs_g) == n and len(tabs_m) == n
+    import ctypes
+    arr = lambda ts, what: (ctypes.c_void_p * n)(*[t.data_ptr() for t in (_chk(t, what) for t in ts)])
+    _lib.check(lib.geobo_spectral_y3t(int(ny), int(C), int(C if plane is None else plane), int(R), n, _p(_chk(src_g, "src_g")), _p(_chk(src_m, "src_m")),
+                                      arr(tabs_g, "tab"), arr(tabs_m, "tab"), arr(outs, "out"), _p(spectral_y_basis(ny, src_g.device)), _stream()),
+               "geobo_spectral_y3t")
 
 
 def spectral_y2s(ny, C, R, src_g, src_m, tab_d0, tab_x, tab_d1, outs, plane=None):

@@ -23,7 +23,7 @@ PAD_M, PAD_N = 256, 128
 XZ2D_SHAPES = ((48, 64), (64, 64), (64, 32))      # fused (x, z) transform instances (hip.XZ2D_SHAPES)
 XZ2D_FOLD_N = (64,)                               # radix-2 instances (hip.XZ2D_FOLD_N)
 TOEPLITZ_NY = (16, 32, 48, 64, 80, 96, 112, 128)               # Toeplitz y-stage instances (hip.TOEPLITZ_NY)
-SPECTRAL_Y_NY = (32, 48, 64)                      # in-kernel spectral y stage on the matrix pipe (hip.SPECTRAL_Y_NY)
+SPECTRAL_Y_NY = (32, 48, 64, 80, 96, 112, 128)    # in-kernel spectral y stage on the matrix pipe (hip.SPECTRAL_Y_NY); > 64: geobo_spectral_y3 only
 ROWS_MIN_VOXELS = 1 << 18                         # batched-GEMM forms of the row algorithm pay from 64^3 voxels ...
 ROWS_MIN_PLANE = 96 * 96                          # ... and (x, z) planes that fill the 128 x 128 GEMM tiles
 ROWS_MIN_VOXELS_MID, ROWS_MIN_PLANE_MID = 3 << 17, 64 * 64   # ... or from 393 216 voxels with planes of 4096 modes: 80^3 3345 / 4733 ms (52 / 183 GB),

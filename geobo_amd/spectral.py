@@ -191,10 +191,11 @@ class SpectralProduct:
     def _ystage(self, ny, C, R, src, tabs, outs, y0, y1, plane, accumulate=False):
         """geobo_toeplitz_y launch, bracketed for the bench's per-kernel roofline when a timer is set: algorithmic bytes = the rows'
         (x, z)-spectrum read once + one output slab per property block (read as well when the launch accumulates)."""
-        if self.y_mfma and not accumulate:
-            def fn():
-                for j in range(0, len(tabs), 2):        # two property blocks per read of the spectrum
-                    hip.spectral_y(ny, C, R, src, tabs[j:j + 2], outs[j:j + 2], y0, y1, plane=plane)
+        # (the long-axis matrix-pipe kernel computes every output of a row whatever the slab; the windowed direct kernel only the chunks of
+        # 16 that cover it: narrow slabs -- the y-slab shards of the column form -- stay with the direct kernel: 0.55 against 1.33 ms for 16
+        # of 128 planes)
+        if self.y_mfma and (ny > 64 or not accumulate) and (ny <= 64 or 2 * (y1 - y0) >= ny):
+            fn = lambda: hip.spectral_y(ny, C, R, src, tabs, outs, y0, y1, plane=plane, accumulate=accumulate)
         else:
             fn = lambda: hip.toeplitz_y(ny, C, R, src, tabs, outs, y0, y1, plane=plane, accumulate=accumulate)
         if self.kernel_timer is None:
@@ -342,7 +343,7 @@ class SpectralProduct:
         4 mul + 8 fma + 8 add per orbit and block (one term) or 8 add + 8 mul + 16 fma + 32 add per orbit for a block pair of two-term
         rows (ny / 4 orbits per mode)."""
         ny, C = self.ny, self.Px * self.Pz
-        if self.y_mfma:
+        if self.y_mfma and (ny <= 64 or slab is None or 2 * slab >= ny):
             valu = C * ny * (4.0 * terms + (7.0 * nblocks if terms == 1 else 10.0 * nblocks))
             return C * 1.0 * ny * ny * (terms + nblocks) + valu, valu
         outs = ny if (ny <= 64 or slab is None) else (slab + 15) // 16 * 16
@@ -487,8 +488,18 @@ class SpectralProduct:
                     for j in range(0, P_c, 3):
                         js = list(range(j, min(j + 3, P_c)))
                         u2 = [self.buf(("S", "S1", "S2")[i], Rb * ny * Cq) for i in range(len(js))]
-                        self._ystage(ny, C, Rb, t2g, [gens_g[jj] for jj in js], u2, 0, ny, Cq)
-                        self._ystage(ny, C, Rb, t2m, [gens_m[jj] for jj in js], u2, 0, ny, Cq, accumulate=True)
+                        if self.y_mfma and ny in hip.SPECTRAL_Y3T_NY:
+                            # both terms in ONE pass, meeting in the y spectrum (geobo_spectral_y3t): 2 + len(js) transforms instead of
+                            # 2 (1 + len(js)), no read-modify-write of the outputs
+                            fn = lambda: hip.spectral_y3t(ny, C, Rb, t2g, t2m, [gens_g[jj] for jj in js], [gens_m[jj] for jj in js], u2, plane=Cq)
+                            if self.kernel_timer is None:
+                                fn()
+                            else:
+                                fl, fv = self.y_stage_flop(2, len(js))
+                                self.kernel_timer("kernel:toeplitz_y", 8.0 * Rb * C * ny * (2 + len(js)), fn, valu=Rb * fv, flop=Rb * fl)
+                        else:
+                            self._ystage(ny, C, Rb, t2g, [gens_g[jj] for jj in js], u2, 0, ny, Cq)
+                            self._ystage(ny, C, Rb, t2m, [gens_m[jj] for jj in js], u2, 0, ny, Cq, accumulate=True)
                         for i, jj in enumerate(js):
                             self.backward_xz(u2[i], Rb, 0, ny, [(0, ny, vg[jj], vg[jj].stride(0))])
                     for jj in range(P_c):

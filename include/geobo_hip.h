@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GEOBO_VERSION 212 /* 201: flag word of geobo_gemm_nt, (64, 32) instance of geobo_xz2d, workspace layout of geobo_potrf_inv; 202: geobo_ymul, geobo_xz2d_fold_lattice; 203: geobo_sumsq_accum, geobo_lamdot_z, geobo_toeplitz_y2t, geobo_xz2d_fold_quad; 204: geobo_toeplitz_y3_add; 205: workspace layout of geobo_potrf_inv (one T buffer per tree node); 206: geobo_potrf_inv as one persistent tile-DAG launch from m = 1024 (workspace: + counters); 207: geobo_gemm_fold; 208: geobo_gemm_fold_lamdot; 209: geobo_toeplitz_y2s; 210: geobo_xz2d_fold* dense planes take the quarter-period group order of the basis (radix 4); 211: geobo_ymul_fold; 212: geobo_spectral_y, geobo_spectral_y2s, geobo_spectral_y_basis, geobo_rowgemv */
+#define GEOBO_VERSION 212 /* 201: flag word of geobo_gemm_nt, (64, 32) instance of geobo_xz2d, workspace layout of geobo_potrf_inv; 202: geobo_ymul, geobo_xz2d_fold_lattice; 203: geobo_sumsq_accum, geobo_lamdot_z, geobo_toeplitz_y2t, geobo_xz2d_fold_quad; 204: geobo_toeplitz_y3_add; 205: workspace layout of geobo_potrf_inv (one T buffer per tree node); 206: geobo_potrf_inv as one persistent tile-DAG launch from m = 1024 (workspace: + counters); 207: geobo_gemm_fold; 208: geobo_gemm_fold_lamdot; 209: geobo_toeplitz_y2s; 210: geobo_xz2d_fold* dense planes take the quarter-period group order of the basis (radix 4); 211: geobo_ymul_fold; 212: geobo_spectral_y, geobo_spectral_y2s, geobo_spectral_y_basis, geobo_spectral_y3, geobo_spectral_y3t, geobo_rowgemv */
 
 #define GEOBO_PAD_M 256 /* row padding of M-like dimensions (observation rows)            */
 #define GEOBO_PAD_N 128 /* padding of voxel-like dimensions (columns / contraction index) */
@@ -402,7 +402,7 @@ int geobo_toeplitz_y3_add(int ny, int64_t C, int64_t plane, int64_t R, int nprop
  * 2 ny^2), two-term rows with the shared cross block 2 ny^2 (direct, three products: 3 ny^2).  Results agree with the direct kernels
  * to rounding (a few 1e-16 of sum |t| |x|), not bit for bit.
  * basis: geobo_spectral_y_basis_doubles(ny) doubles filled ONCE per ny by geobo_spectral_y_basis (transform fragments in lane order:
- * the library keeps no state of its own).  ny in {32, 48, 64} (GEOBO_E_UNSUPPORTED otherwise; 0 doubles), C % 16 == 0, plane >= C,
+ * the library keeps no state of its own).  ny in {32, 48, 64} here, {80, 96, 112, 128} through geobo_spectral_y3 (GEOBO_E_UNSUPPORTED otherwise; 0 doubles), C % 16 == 0, plane >= C,
  * ny*plane*8 < 2^31.  Replaces the same reference lines as geobo_toeplitz_y: kernels.py:158-195, inversion.py:96,114-117. */
 int64_t geobo_spectral_y_basis_doubles(int ny);
 int geobo_spectral_y_basis(int ny, double* basis, void* stream);
@@ -410,6 +410,23 @@ int geobo_spectral_y(int ny, int64_t C, int64_t plane, int64_t R, int nprop, con
                      double* out0, double* out1, int y0, int y1, const double* basis, void* stream);
 int geobo_spectral_y2s(int ny, int64_t C, int64_t plane, int64_t R, const double* in_g, const double* in_m, const double* tab_d0,
                        const double* tab_x, const double* tab_d1, double* out0, double* out1, const double* basis, void* stream);
+
+/* The same in-kernel spectral product for up to THREE property blocks per sweep (tabs / outs: HOST arrays of nprop device pointers) and
+ * for the long y axes ny in {80, 96, 112, 128} (128: BASELINE config 5), the drop-in for geobo_toeplitz_y3 / geobo_toeplitz_y3_add
+ * (accumulate != 0: outs[j] += the sums -- the second term of a two-term row).  There a lane can no longer hold a tile's spectrum and its
+ * eigenvalues: FOUR waves share one tile of 16 modes -- each analyses one tile of eight orbits with its own eigenvalues, the scaled
+ * class sums change hands through 32 KiB of LDS (two barriers per block), each wave synthesises one residue class of the outputs.
+ * Per mode (n_in + n_out) ny^2 / 2 multiply-adds on MFMA: 2 ny^2 for one term and three blocks (direct: 3 ny^2).
+ * ny <= 64 is forwarded to geobo_spectral_y two blocks at a time (accumulate: GEOBO_E_UNSUPPORTED there).  Same basis blob. */
+int geobo_spectral_y3(int ny, int64_t C, int64_t plane, int64_t R, int nprop, const double* in, const double* const* tabs,
+                      double* const* outs, int y0, int y1, int accumulate, const double* basis, void* stream);
+
+/* Two-term rows on the long y axes in ONE pass (the drop-in for geobo_toeplitz_y3 followed by geobo_toeplitz_y3_add):
+ *     outs[j] = T(tabs_g[j]) in_g + T(tabs_m[j]) in_m,   j < nprop <= 3,  full height
+ * -- the terms meet in the y spectrum (lambda_gj x^_g + lambda_mj x^_m): two analyses + nprop syntheses instead of 2 (1 + nprop)
+ * transforms, and no read-modify-write of the outputs.  ny in {80, 96, 112, 128}; ny <= 64: geobo_spectral_y2s. */
+int geobo_spectral_y3t(int ny, int64_t C, int64_t plane, int64_t R, int nprop, const double* in_g, const double* in_m,
+                       const double* const* tabs_g, const double* const* tabs_m, double* const* outs, const double* basis, void* stream);
 
 /* In-place lower Cholesky of the (m x m, ld) matrix A, m % 256 == 0 (padding rows/cols = identity);
  * scipy.linalg.cholesky(AkA, lower=True), inversion.py:100.  Also writes Linv = L^-1 (m x m, ldi; lower,

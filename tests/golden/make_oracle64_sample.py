@@ -56,7 +56,17 @@ if __name__ == "__main__":
     workers = os.cpu_count() or 1
     t0 = time.time()
     say = lambda *a: print("[%5.0f s]" % (time.time() - t0), *a, flush=True)  # noqa: E731
-    A = (operator("grav", workers), operator("magn", workers))
+    cache = os.environ.get("GEOBO_ORACLE_CACHE")         # optional directory: the two operators (17 GB) survive a restart of this script
+    A = []
+    for func in ("grav", "magn"):
+        f = os.path.join(cache, "oracle64_A_%s.npy" % func) if cache else None
+        if f and os.path.exists(f):
+            A.append(np.load(f))
+        else:
+            A.append(operator(func, workers))
+            if f:
+                np.save(f, A[-1])
+    A = tuple(A)
     say("operators", A[0].shape)
     sv = O.synthetic_survey(G, MD, A=A)
     d0 = sv["drilldata0"]
@@ -76,9 +86,20 @@ if __name__ == "__main__":
     AkA = np.zeros((M, M))
     S = {j: np.empty((M, q.size)) for j in (0, 1)}           # the sampled columns of A K, property blocks 0 and 1
     B = 128
+    ck = os.path.join(cache, "oracle64_sample_state.npz") if cache else None
+    done = 0                                             # sensor rows (of both operators, in order) already contracted
+    if ck and os.path.exists(ck):
+        st = np.load(ck)
+        if np.array_equal(st["q"], q):
+            AkA, S[0], S[1], done = st["AkA"], st["S0"], st["S1"], int(st["done"])
+            say("resumed at sensor row %d" % done)
     for s, As, r_off in ((0, A[0], 0), (1, A[1], mg)):
         for r0 in range(0, As.shape[0], B):
             r1 = min(As.shape[0], r0 + B)
+            if r_off + r1 <= done:
+                continue
+            if ck and r0 % 1024 == 0 and r_off + r0 > done:
+                np.savez(ck, AkA=AkA, S0=S[0], S1=S[1], done=r_off + r0, q=q)
             w = O.ak_rows_fft(G, As[r0:r1], name, lengths, W, s, (0, 1), workers=workers)
             AkA[r_off + r0:r_off + r1, :mg] = w[0] @ A[0].T
             AkA[r_off + r0:r_off + r1, mg:mg + mm] = w[1] @ A[1].T

@@ -636,7 +636,55 @@ def test_spectral_y_matches_torch(hip, ny, C, R, nprop, y0, y1):
     for j in range(nprop):
         assert torch.equal(outp[j][:, :, :C], outs[j]) and bool((outp[j][:, :, C:] == 7.0).all())
     with pytest.raises(RuntimeError):
-        hip.spectral_y(80, C, R, src.reshape(-1), [t.reshape(-1) for t in tabs], [o.reshape(-1) for o in outs], 0, 80)
+        hip.spectral_y(144, C, R, src.reshape(-1), [t.reshape(-1) for t in tabs], [o.reshape(-1) for o in outs], 0, 144)
+
+
+@pytest.mark.parametrize("ny,C,R,nprop,y0,y1", [(128, 64, 3, 3, 0, 128), (128, 128, 2, 1, 0, 128), (128, 1024, 5, 2, 0, 128), (96, 64, 4, 2, 0, 96),
+                                                 (112, 64, 2, 2, 16, 100), (80, 64, 3, 3, 0, 80), (128, 48, 4, 3, 32, 48), (96, 16, 7, 3, 0, 96)])
+def test_spectral_y_long_axes_match_torch(hip, ny, C, R, nprop, y0, y1):
+    # ny = 80 .. 128 (geobo_spectral_y3): four waves per 16-mode tile -- one orbit tile each in the analysis, one residue class each in the
+    # synthesis, the scaled class sums exchanged through LDS; against torch and the windowed direct kernel, the accumulating form bit for
+    # bit as "first term, then add the second", NaN-poisoned outputs, padded plane stride, slabs, several rows per workgroup
+    S = C + 48
+    mk = lambda fill: [torch.full((R, y1 - y0, S), fill, dtype=torch.float64, device="cuda") for _ in range(nprop)]
+    src, src2 = (torch.full((R, ny, S), float("nan"), dtype=torch.float64, device="cuda") for _ in range(2))
+    src[:, :, :C], src2[:, :, :C] = _rand((R, ny, C), 11), _rand((R, ny, C), 21)
+    tabs, tabs2 = [_rand((ny, C), 12 + j) for j in range(nprop)], [_rand((ny, C), 32 + j) for j in range(nprop)]
+    flat = lambda ts: [t.reshape(-1) for t in ts]
+    outs = mk(7.0)
+    hip.spectral_y(ny, C, R, src.reshape(-1), flat(tabs), flat(outs), y0, y1, plane=S)
+    torch.cuda.synchronize()
+    idx = (torch.arange(ny)[:, None] - torch.arange(ny)[None, :]).abs().cuda()
+    ref = [torch.einsum("ypc,rpc->ryc", tabs[j][idx], src[:, :, :C])[:, y0:y1] for j in range(nprop)]
+    for j in range(nprop):
+        assert normwise(outs[j][:, :, :C].cpu().numpy(), ref[j].cpu().numpy()) < 3e-14
+        assert bool((outs[j][:, :, C:] == 7.0).all())
+    if C % 64 == 0:
+        direct = mk(7.0)
+        hip.toeplitz_y(ny, C, R, src.reshape(-1), flat(tabs), flat(direct), y0, y1, plane=S)
+        for j in range(nprop):
+            assert normwise(outs[j][:, :, :C].cpu().numpy(), direct[j][:, :, :C].cpu().numpy()) < 3e-14
+    again = mk(float("nan"))
+    hip.spectral_y(ny, C, R, src.reshape(-1), flat(tabs), flat(again), y0, y1, plane=S)
+    for j in range(nprop):
+        assert torch.equal(again[j][:, :, :C], outs[j][:, :, :C])
+    # accumulate: the second term adds into the first term's spectrum
+    second = mk(0.0)
+    hip.spectral_y(ny, C, R, src2.reshape(-1), flat(tabs2), flat(second), y0, y1, plane=S)
+    hip.spectral_y(ny, C, R, src2.reshape(-1), flat(tabs2), flat(again), y0, y1, plane=S, accumulate=True)
+    torch.cuda.synchronize()
+    for j in range(nprop):
+        assert torch.equal(again[j][:, :, :C], outs[j][:, :, :C] + second[j][:, :, :C])
+    with pytest.raises(RuntimeError):
+        hip.spectral_y(64, C, R, src.reshape(-1), flat(tabs[:1]), flat(outs[:1]), 0, 64, plane=S, accumulate=True)
+    # both terms in one pass, meeting in the spectrum (geobo_spectral_y3t; full height)
+    if y0 == 0 and y1 == ny:
+        both = mk(float("nan"))
+        hip.spectral_y3t(ny, C, R, src.reshape(-1), src2.reshape(-1), flat(tabs), flat(tabs2), flat(both), plane=S)
+        torch.cuda.synchronize()
+        for j in range(nprop):
+            want = ref[j] + torch.einsum("ypc,rpc->ryc", tabs2[j][idx], src2[:, :, :C])
+            assert normwise(both[j][:, :, :C].cpu().numpy(), want.cpu().numpy()) < 3e-14
 
 
 @pytest.mark.parametrize("ny,C,R", [(64, 256, 5), (64, 16384, 11), (48, 128, 9), (32, 1024, 30), (64, 128, 1), (64, 528, 8)])

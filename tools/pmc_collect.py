@@ -29,6 +29,8 @@ DRIVERS = {"posterior": ("run_posterior_once.py", "gemm_f64_kernel<4, 2, 2, 1", 
            "spectral_y": ("run_spectral_kernels_once.py spectral_y", "spectral_y_kernel<64, 1, 2", "pmc_spectral_y.json"),
            "spectral_y1": ("run_spectral_kernels_once.py spectral_y1", "spectral_y_kernel<64, 1, 1", "pmc_spectral_y1.json"),
            "spectral_y2s": ("run_spectral_kernels_once.py spectral_y2s", "spectral_y_kernel<64, 2, 2", "pmc_spectral_y2s.json"),
+           "spectral_y128": ("run_spectral_kernels_once.py spectral_y128", "spectral_y_split_kernel<128, 1, 3", "pmc_spectral_y128.json"),
+           "spectral_y128_1": ("run_spectral_kernels_once.py spectral_y128_1", "spectral_y_split_kernel<128, 1, 1", "pmc_spectral_y128_1.json"),
            "xcorr": ("run_spectral_kernels_once.py xcorr", "xcorr_kernel", "pmc_xcorr.json"),
            "fold_fwd": ("run_spectral_kernels_once.py fold_fwd", "xz_fold_fwd_kernel", "pmc_xz2d_fold_fwd.json"),
            "fold_bwd": ("run_spectral_kernels_once.py fold_bwd", "xz_fold_inv_kernel", "pmc_xz2d_fold_bwd.json"),

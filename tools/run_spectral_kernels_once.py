@@ -61,6 +61,19 @@ if which in ("all", "spectral_y", "spectral_y1", "spectral_y2s"):
     if which in ("all", "spectral_y2s"):
         timed("spectral_y2s", R * C * (4.0 * n * n + 28.0 * n), R * n * C * 8.0 * 4, lambda: hip.spectral_y2s(n, C, R, src_g, src_m, t3[0], t3[1], t3[2], outs))
     del src_g, src_m, t3, outs
+if which in ("spectral_y128", "spectral_y128_1", "spectral_y3t128"):
+    # the long-axis form (four waves per 16-mode tile) at the 128^3 batch shape: 32 rows of 128 planes x 65536 modes
+    ny_, Rb, C = 128, 32, 4 * 128 * 128
+    src_g, src_m = rnd(Rb * ny_ * C), rnd(Rb * ny_ * C)
+    t6 = [rnd(ny_ * C) for _ in range(6)]
+    outs = [torch.empty(Rb * ny_ * C, dtype=torch.float64, device=dev) for _ in range(3)]
+    if which == "spectral_y128":
+        timed("spectral_y128", Rb * C * (4.0 * ny_ * ny_ + 25.0 * ny_), Rb * ny_ * C * 8.0 * 4, lambda: hip.spectral_y(ny_, C, Rb, src_g, t6[:3], outs))
+    elif which == "spectral_y128_1":
+        timed("spectral_y128_1", Rb * C * (2.0 * ny_ * ny_ + 11.0 * ny_), Rb * ny_ * C * 8.0 * 2, lambda: hip.spectral_y(ny_, C, Rb, src_g, t6[:1], outs[:1]))
+    else:
+        timed("spectral_y3t128", Rb * C * (5.0 * ny_ * ny_ + 38.0 * ny_), Rb * ny_ * C * 8.0 * 5, lambda: hip.spectral_y3t(ny_, C, Rb, src_g, src_m, t6[:3], t6[3:], outs))
+    del src_g, src_m, t6, outs
 if which in ("all", "xcorr"):
     src = rnd(R, P * n * n)
     lam = rnd(P * n * P)
