@@ -510,6 +510,9 @@ __global__ void __launch_bounds__(256, 1) spectral_y_split_kernel(SY3Args g) {
       for (int T = 0; T < NT; ++T)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) yin[T][rr] = ex2[(((jb * 4 + w) * 4 + T) * 4 + rr) * 64];
+      // (all sixteen reads in flight, ONE wait, then the MFMAs back to back: interleaved read -> wait -> MFMA pairs leave an LDS latency
+      // per pair uncovered on a SIMD that runs a single wave)
+      __builtin_amdgcn_sched_barrier(0);
       d4 o[MJ];
 #pragma unroll
       for (int mj = 0; mj < MJ; ++mj) o[mj] = d4{0., 0., 0., 0.};

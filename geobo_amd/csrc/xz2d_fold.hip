@@ -28,6 +28,15 @@
 #include <type_traits>
 #include "geobo_hip.h"
 
+// Cache policy of the spectrum streams (A/B, round 6): the forward transform's 8 MB / row of output and the inverse transform's input are
+// touched once per launch.  XZF_NT_ST: non-temporal stores of the forward output; XZF_NT_LD: aux = nt on the inverse's LDS-DMA loads.
+#ifndef XZF_NT_ST
+#define XZF_NT_ST 0
+#endif
+#ifndef XZF_NT_LD
+#define XZF_NT_LD 0
+#endif
+
 namespace {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -289,7 +298,10 @@ __global__ void __launch_bounds__(256, 2) xz_fold_fwd_kernel(FoldArgs g) {
           z0[v] = o2[1][v][r] + o2[3][v][r]; z1[v] = o2[1][v][r] - o2[3][v][r];
         }
         char* const rowp = op4 + (size_t)(32 * r) * out_rowB;
-        auto put = [&](int k, v2d val) { *reinterpret_cast<v2d*>(rowp + (size_t)k * out_rowB) = val; };
+        auto put = [&](int k, v2d val) {
+          if constexpr (XZF_NT_ST) __builtin_nontemporal_store(val, reinterpret_cast<v2d*>(rowp + (size_t)k * out_rowB));
+          else *reinterpret_cast<v2d*>(rowp + (size_t)k * out_rowB) = val;
+        };
         put(0, u0 + v0);
         put(1, u0 - v0);
         if constexpr (r == 0) {
@@ -318,8 +330,13 @@ __global__ void __launch_bounds__(256, 2) xz_fold_fwd_kernel(FoldArgs g) {
         const v2d plus = (v2d){e2[m][0][r] + o2[m][0][r], e2[m][1][r] + o2[m][1][r]};
         const v2d minus = (v2d){e2[m][0][r] - o2[m][0][r], e2[m][1][r] - o2[m][1][r]};
         char* const rowp = op + (size_t)(2 * (16 * m + 4 * r)) * out_rowB + (m >= MT / 2 ? out_botB : 0);
-        *reinterpret_cast<v2d*>(rowp) = plus;
-        *reinterpret_cast<v2d*>(rowp + out_rowB) = minus;
+        if constexpr (XZF_NT_ST) {
+          __builtin_nontemporal_store(plus, reinterpret_cast<v2d*>(rowp));
+          __builtin_nontemporal_store(minus, reinterpret_cast<v2d*>(rowp + out_rowB));
+        } else {
+          *reinterpret_cast<v2d*>(rowp) = plus;
+          *reinterpret_cast<v2d*>(rowp + out_rowB) = minus;
+        }
       }
     warm = true;
     cur = nxt;
@@ -525,7 +542,7 @@ __global__ void __launch_bounds__(256, 2) xz_fold_inv_kernel(FoldArgs g) {
       const int mrow = R4 ? 32 * (c >> 1) + 8 * (row & 3) + 4 * (c & 1) + (row >> 2) : 16 * c + rowperm(row);
       const char* src = reinterpret_cast<const char*>(plane) + (int64_t)mrow * in_rowB + (c >= RT / 2 ? in_botB : 0) +
                         ((sl & 31) << 4) + (sl >> 5) * in_halfB;
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(ring + slot * K::CHB + row * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(ring + slot * K::CHB + row * 1024), 16, 0, XZF_NT_LD ? 2 : 0);
     }
   };
   // MUL: the two factors of plane p; fetch = this thread's 16-byte pieces of chunk c of both (row w + 4 j of the chunk, slot lane),

@@ -641,6 +641,38 @@ def test_cube64x48_against_whole_cube_oracle(family, monkeypatch):
         assert normwise(torch.diagonal(L)[:M].cpu().numpy(), f["L_diag"]) <= 1e-10
 
 
+@pytest.mark.parametrize("dims", [(64, 48, 64), (64, 32, 64)])
+def test_zero_cross_weight_between_density_and_susceptibility(dims, monkeypatch):
+    """Round-5 advisory: with gp_coeff[2] = 0 (no density-susceptibility correlation: a legal prior, the reference's own gravity-only
+    case) the cross generators K_01 = K_10 are exactly zero, and the symmetry residual of the three-product y stage was 0 / 0 = NaN,
+    which the engine read as "this prior is not symmetric" after the whole step had run.  The step must run, the three-product form
+    must be in use, and the cubes must agree with the four-product path; with the drill block decoupled from density as well."""
+    import bench
+    nx, ny, nz = dims
+    for coeff in ([0.3, 0.2, 0.0], [0.0, 0.2, 0.0]):      # (gp_coeff[1] also scales the synthetic susceptibility: keep it non-zero)
+        s = settings_for(nx, ny, nz, kernelfunc="matern32", gp_coeff=coeff)
+        inv = _inv(s, props=(0, 1))
+        grav, mag, loc, drill0 = bench.synthetic_inputs(inv, 20)
+        del inv
+        outs = []
+        for y2s in ("1", "0"):
+            monkeypatch.setenv("GEOBO_Y2S", y2s)
+            inv = _inv(s, props=(0, 1))
+            inv.gp_length = np.array([200.0, 202.0, 204.0])
+            inv.engine.kernel_events = []
+            outs.append(inv.cubing(grav, mag, drill0[drill0 != 0], loc, drill0))
+            names = {e[0] for e in inv.engine.kernel_events}
+            inv.engine.kernel_events = None
+            assert ("kernel:toeplitz_y2s" in names) == (y2s == "1"), names
+            del inv
+            gc.collect()
+            torch.cuda.empty_cache()
+        monkeypatch.delenv("GEOBO_Y2S")
+        for i in (0, 1, 3, 4):
+            assert np.isfinite(outs[0][i]).all()
+            assert np.abs(outs[0][i] - outs[1][i]).max() <= 1e-11 * np.abs(outs[1][i]).max()
+
+
 def test_three_product_y_stage_against_the_four_product_one_and_its_symmetry_check(monkeypatch):
     """The two-term rows of the transposed posterior take K_10 = K_01 for granted (three y-stage products per mode instead of four,
     geobo_toeplitz_y2s): (i) the cubes agree with the four-product path (GEOBO_Y2S=0) far inside the parity tolerance, (ii) the route
@@ -841,6 +873,50 @@ def test_full_size_64cube_properties():
     assert np.array_equal(inv_auto.mu_rec[:2 * N], res_mu[:2 * N]) and np.array_equal(inv_auto.cov_rec.diagonal()[:2 * N], res_var[:2 * N])
     assert inv_auto.logl == inv.logl
     _independent_checks_64(inv_auto, s, G, Ag_o, Am_o, sens, lengths, W, "auto")
+
+
+def test_headline_64cube_against_the_independent_oracle_sample():
+    """BASELINE config 3 itself (64^3, Matern-3/2, 50 drill rows, two property blocks) BY VALUE at 3078 voxels spread over the cube -- every
+    131st voxel, all drilled voxels, 256 voxels of each 1e6-padded slab iy = 0 / ny-1, the x and z faces, the eight corners -- against
+    golden values in which nothing comes from the device (tests/golden/make_oracle64_sample.py: the oracle's operators, FFT rows of
+    A K, scipy Cholesky, V on the sampled columns).  Round-5 review, item 5c: the full-size value check was a contiguous block at the
+    cube's centre computed with the device's own A and L."""
+    from geobo_amd.config_loader import Settings
+    from geobo_amd.inversion import Inversion
+    f = load_golden("oracle64_sample_matern32.npz")
+    nx, ny, nz = (int(v) for v in f["dims"])
+    n = nx
+    s = Settings(dict(xmax=100.0 * n, ymax=100.0 * n, zLcube=100.0 * n, xNcube=n, yNcube=n, zNcube=n, kernelfunc="matern32"))
+    d0 = np.zeros(nx * ny * nz)
+    d0[f["sel"]] = f["drillvalues"]
+    d0 = d0.reshape(ny, nx, nz)
+    N = nx * ny * nz
+    q = f["voxels"]
+    iy = q // (nx * nz)
+    assert (iy == 0).sum() >= 256 and (iy == ny - 1).sum() >= 256 and np.isin(f["sel"], q).all() and 0 in q and N - 1 in q
+    for kw, what in ((dict(), "auto"), (dict(operators="resident"), "resident")):
+        inv = Inversion(settings=s, props=(0, 1), **kw)
+        inv.gp_length = f["gp_length_in"].copy()
+        cubes = inv.cubing(f["gravfield"], f["magfield"], d0[d0 != 0], f["sensor_locations"], d0)
+        var = inv.cov_rec.diagonal()
+        for j in (0, 1):
+            e_mu = normwise(inv.mu_rec[j * N + q], f["mu"][j])
+            e_var = float(np.abs(var[j * N + q] - f["var"][j]).max())
+            print("64^3 [%s] block %d vs the independent oracle sample: mean %.2e (normwise), variance %.2e (abs)" % (what, j, e_mu, e_var))
+            assert e_mu <= 1e-8 and e_var <= 1e-8
+            assert elementwise_rel(inv.mu_rec[j * N + q], f["mu"][j]) <= 1e-7
+            # the cubes carry the data scaling of inversion.py:240-245
+            assert normwise(cubes[j].reshape(-1)[q], f["mu"][j] * f["data_std"][j]) <= 1e-8
+            assert normwise(cubes[3 + j].reshape(-1)[q], f["var"][j] * f["data_std"][j] ** 2) <= 1e-8
+        assert abs(inv.logl - float(f["logl"])) <= 1e-8 * abs(float(f["logl"]))
+        assert np.array_equal(inv.gp_length, f["gp_length_out"])
+        L = inv.engine.last["L"]
+        M = f["L_diag"].size
+        rows = np.r_[0:inv.engine.Ms, inv.engine.Ms_pad:inv.engine.Ms_pad + inv.engine.Ms, 2 * inv.engine.Ms_pad:2 * inv.engine.Ms_pad + f["sel"].size]
+        assert rows.size == M and normwise(torch.diagonal(L).cpu().numpy()[rows], f["L_diag"]) <= 1e-10
+        del inv
+        gc.collect()
+        torch.cuda.empty_cache()
 
 
 def _independent_checks_64(inv, s, G, Ag_o, Am_o, sens, lengths, W, what):
