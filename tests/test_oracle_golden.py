@@ -209,3 +209,22 @@ def test_synthetic_survey_matches_golden_inputs():
     assert np.array_equal(sv["drilldata0"], f["drilldata0"])
     assert np.array_equal(sv["rho"], f["rho"])
     assert normwise(sv["gravfield"], f["gravfield"]) < 1e-6   # float32-rounded data
+
+
+def test_headline_sample_fixture_is_well_formed():
+    """tests/golden/oracle64_sample_matern32.npz (make_oracle64_sample.py: the 64^3 headline BY VALUE at a spread sample, oracle only):
+    shape of the sample, admissible variances, symmetry of the kept AkA rows, the create_cov length mutation."""
+    f = load_golden("oracle64_sample_matern32.npz")
+    nx, ny, nz = (int(v) for v in f["dims"])
+    N, q = nx * ny * nz, f["voxels"]
+    assert (nx, ny, nz) == (64, 64, 64) and q.size >= 3000 and np.array_equal(q, np.unique(q)) and q[0] == 0 and q[-1] == N - 1
+    iy, ix, iz = np.unravel_index(q, (ny, nx, nz))
+    for a, n in ((iy, ny), (ix, nx), (iz, nz)):
+        assert (a == 0).sum() >= 128 and (a == n - 1).sum() >= 128
+    assert np.isin(f["sel"], q).all() and f["sel"].size == 50
+    assert f["mu"].shape == (2, q.size) and np.isfinite(f["mu"]).all() and (f["var"] > 0).all() and (f["var"] <= 1.0).all()
+    assert np.array_equal(f["gp_length_out"], O.mutate_lengths(f["gp_length_in"].copy()))
+    rows, vals = f["AkA_rows"], f["AkA_values"]
+    sub = vals[:, rows]
+    assert np.abs(sub - sub.T).max() <= 1e-12 * np.abs(sub).max()            # AkA is symmetric (the rows were formed independently)
+    assert (f["L_diag"] > 0).all() and f["L_diag"].size == 2 * nx * ny + 50
