@@ -516,10 +516,15 @@ __device__ __forceinline__ void dag_publish(int* flag, int value) {
   if (threadIdx.x == 0) st_flag(flag, value);
 }
 // broadcast of a value found by thread 0 (which has also issued the agent-scope acquire): all threads return it
+// (round-5 advisory: EVERY wave issues its own agent-scope acquire behind the broadcast barrier -- one buffer_inv per wave -- instead of
+// relying on thread 0's invalidate covering the whole CU, which holds on gfx942 / gfx950 (the vector L1 is per CU) but is outside the
+// HIP memory model.  The producer side stays what MI355X_MICROARCH.md's form R1 prescribes: write-through tile stores, per-wave
+// vmcnt(0), barrier, one relaxed flag store -- an agent-scope RELEASE there would add an L2 write-back to every hand-off of the chain.)
 __device__ __forceinline__ int dag_bcast(int* sh, int v) {
   if (threadIdx.x == 0) sh[0] = v;
   __syncthreads();
   const int r = sh[0];
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   __syncthreads();
   return r;
 }

@@ -57,6 +57,11 @@ class CholeskyError(RuntimeError):
         self.info = info
 
 
+class FactorisationTimeout(RuntimeError):
+    """The persistent tile-DAG factorisation gave up on a hand-off (info = -7: a spin ran into its 4 s wall-clock bound -- a device
+    shared with other processes can do that); the result is undefined.  Inversion retries the step once on the stream schedule."""
+
+
 def create_cov_lengths(gplength):
     """kernels.py:174-180 -- create_cov edits the caller's length array IN PLACE: [l,l,l] -> [l,1.02l,l]."""
     p = np.asarray(gplength)
@@ -884,6 +889,8 @@ class PosteriorEngine(RowFormMixin, TransposedPosteriorMixin, ColumnExchangeMixi
                 self._spectral.sym_residual = None      # read (queued above) exactly once, whatever this step raises
             torch.cuda.current_stream(self.device).synchronize()
             info_h = int(h_info[0])
+            if info_h == -7:
+                raise FactorisationTimeout("geobo_potrf_inv: the tile DAG timed out on a hand-off (info = -7)")
             if info_h != 0:
                 raise CholeskyError(info_h)
             if h_res is not None:

@@ -24,7 +24,7 @@ import numpy as np
 from . import config_loader, geometry
 from . import kernels as kernel
 from . import sensormodel as sm
-from .engine import CholeskyError, PosteriorEngine, create_cov_lengths
+from .engine import CholeskyError, FactorisationTimeout, PosteriorEngine, create_cov_lengths
 
 
 class DiagonalCovariance:
@@ -122,10 +122,27 @@ class Inversion:
         A_g, A_m = self._operators()
         lengths = create_cov_lengths(gp_length)  # in-place edit of the caller's array, like create_cov
         ng, nm = self.gravfield.size, self.magfield.size
-        return self.engine.posterior(A_g, A_m, self._sel, self.Fs3[:ng], self.Fs3[ng:ng + nm], self.Fs3[ng + nm:],
-                                     [float(v) for v in lengths], self.coeffm if coeffm is None else coeffm,
-                                     self.settings.kernelfunc, self.gp_sigma, gp_amp=gp_amp, props=self.props,
-                                     calclogl=calclogl, want_mean_var=want_mean_var)
+        step = lambda: self.engine.posterior(A_g, A_m, self._sel, self.Fs3[:ng], self.Fs3[ng:ng + nm], self.Fs3[ng + nm:],
+                                             [float(v) for v in lengths], self.coeffm if coeffm is None else coeffm,
+                                             self.settings.kernelfunc, self.gp_sigma, gp_amp=gp_amp, props=self.props,
+                                             calclogl=calclogl, want_mean_var=want_mean_var)
+        try:
+            return step()
+        except FactorisationTimeout:
+            # (round-5 advisory) the tile DAG's bounded spins can trip on a device shared with other processes: once more, on the
+            # stream schedule of rounds 2-4 (no inter-workgroup hand-offs), instead of returning an undefined factor
+            import os
+            import warnings
+            warnings.warn("geobo_potrf_inv: tile-DAG hand-off timed out (info = -7); repeating the step on the stream schedule", RuntimeWarning)
+            before = os.environ.get("GEOBO_POTRF")
+            os.environ["GEOBO_POTRF"] = "streams"
+            try:
+                return step()
+            finally:
+                if before is None:
+                    os.environ.pop("GEOBO_POTRF", None)
+                else:
+                    os.environ["GEOBO_POTRF"] = before
 
     # ---- inversion.py:77-122 ----------------------------------------------------------------------------------------
     def predict3(self, calclogl=False, full_cov=False):

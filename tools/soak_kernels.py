@@ -176,6 +176,40 @@ def soak(seed=0, seconds=None, iters=60, verbose=True):
             e = (ow[j] - ref).abs().max().item() / ref.abs().max().item()
             if not e < 1e-13:
                 bad += 1; print("toeplitz windowed ny=%d R=%d C=%d blocks=%d slab [%d, %d) err %.3e" % (nyw, Rw, Cw, npw, ya, yb, e), flush=True)
+        # ---- round 6: the y stage on the matrix pipe.  ny <= 64: a wave per 16 modes, register-prefetched rows (no LDS hand-off between
+        #      waves); ny > 64: four waves per tile with TWO LDS exchanges per row ordered by two barriers -- a missing barrier or an
+        #      exchange area rewritten too early shows up as a sporadic mismatch against the direct kernels / torch, NaN-poisoned outputs
+        for nys in (int(rng.choice([32, 48, 64])), nyw):
+            Cs, Rs, nps = 16 * int(rng.integers(1, 24)), int(rng.integers(1, 12)), int(rng.integers(1, 4))
+            ss1, ss2 = rnd(Rs, nys, Cs), rnd(Rs, nys, Cs)
+            ts1, ts2 = [rnd(nys, Cs) for _ in range(nps)], [rnd(nys, Cs) for _ in range(nps)]
+            ids = (torch.arange(nys)[:, None] - torch.arange(nys)[None, :]).abs().cuda()
+            r1 = [torch.einsum("ypc,rpc->ryc", ts1[j][ids], ss1) for j in range(nps)]
+            os_ = [torch.full((Rs, nys, Cs), float("nan"), dtype=torch.float64, device="cuda") for _ in range(nps)]
+            hip.spectral_y(nys, Cs, Rs, ss1.reshape(-1), flat(ts1), flat(os_))
+            for j in range(nps):
+                e = (os_[j] - r1[j]).abs().max().item() / r1[j].abs().max().item()
+                if not e < 1e-13:
+                    bad += 1; print("spectral_y ny=%d R=%d C=%d blocks=%d err %.3e" % (nys, Rs, Cs, nps, e), flush=True)
+            r2 = [r1[j] + torch.einsum("ypc,rpc->ryc", ts2[j][ids], ss2) for j in range(nps)]
+            if nys > 64:
+                ot = [torch.full((Rs, nys, Cs), float("nan"), dtype=torch.float64, device="cuda") for _ in range(nps)]
+                hip.spectral_y3t(nys, Cs, Rs, ss1.reshape(-1), ss2.reshape(-1), flat(ts1), flat(ts2), flat(ot))
+                hip.spectral_y(nys, Cs, Rs, ss2.reshape(-1), flat(ts2), flat(os_), accumulate=True)
+                for j in range(nps):
+                    e = max((ot[j] - r2[j]).abs().max().item(), (os_[j] - r2[j]).abs().max().item()) / r2[j].abs().max().item()
+                    if not e < 1e-13:
+                        bad += 1; print("spectral_y3t / accumulate ny=%d R=%d C=%d blocks=%d err %.3e" % (nys, Rs, Cs, nps, e), flush=True)
+            else:
+                t00, t01, t11 = rnd(nys, Cs), rnd(nys, Cs), rnd(nys, Cs)
+                o2 = [torch.full((Rs, nys, Cs), float("nan"), dtype=torch.float64, device="cuda") for _ in range(2)]
+                hip.spectral_y2s(nys, Cs, Rs, ss1.reshape(-1), ss2.reshape(-1), (t00 - t01).reshape(-1), t01.reshape(-1), (t11 - t01).reshape(-1), flat(o2))
+                want = [torch.einsum("ypc,rpc->ryc", t00[ids], ss1) + torch.einsum("ypc,rpc->ryc", t01[ids], ss2),
+                        torch.einsum("ypc,rpc->ryc", t01[ids], ss1) + torch.einsum("ypc,rpc->ryc", t11[ids], ss2)]
+                for j in range(2):
+                    e = (o2[j] - want[j]).abs().max().item() / want[j].abs().max().item()
+                    if not e < 1e-13:
+                        bad += 1; print("spectral_y2s ny=%d R=%d C=%d err %.3e" % (nys, Rs, Cs, e), flush=True)
         # ---- round 5: the persistent tile-DAG factorisation (geobo_potrf_inv from m = 1024): inter-workgroup hand-offs through
         #      agent-scope counters.  Random block counts, the result buffers poisoned with NaN (a tile or a zero that is read before
         #      its producer's write-through stores have landed shows up as NaN), every other iteration under uneven load: a long
