@@ -583,6 +583,149 @@ int launch_split2_by(const SY3Args& g, int nprop, hipStream_t st) {
   return nprop == 1 ? launch_split<NY, 2, 1, false>(g, st) : nprop == 2 ? launch_split<NY, 2, 2, false>(g, st) : launch_split<NY, 2, 3, false>(g, st);
 }
 
+// ---- axis passes of the (x, z) transforms for extents without a fused two-axis kernel (round 6) --------------------------------------------
+// The batched axis passes of spectral.py along a STRIDED axis (the x step of the covariance product's transforms: planes of Pz contiguous
+// modes, n or 2n of them per (row, y) item) are the analysis / synthesis halves of the kernel above on their own:
+//     analysis   out[item][p][c] = sum_i G[p][i] in[item][i][c]      (n planes -> P = 2n spectral planes)
+//     synthesis  out[item][i][c] = sum_p G[p][i] in[item][p][c]      (P -> n)
+// with G = spectral.forward_matrix(n) on the HALF-INTEGER basis (spectral.half_modes: spectral positions 8 w .. 8 w + 7 = the orbit of
+// kappa = w + 1/2, rows sqrt(2) cos / sin): radix 4, n^2 / 2 multiply-adds per item and mode, inputs straight from global memory into the
+// B operand layout, no LDS staging of the data.  Four waves per tile of 16 modes as above (wave = residue class on the spatial side,
+// wave = orbit tile on the spectral side, ONE exchange through LDS, double buffered: one barrier per item); the geobo_gemm_fold passes
+// they replace stage both operands through LDS and run at 2.7-3.9 TB/s on both roofs at once (n = 96, 128).
+struct AxisArgs {
+  const double* in;
+  double* out;
+  const double* basis;
+  int64_t C, Si, So, item_in, item_out, R;     // modes per plane, plane strides, item strides (doubles), items
+};
+
+template <int N, bool INV>
+__global__ void __launch_bounds__(256, 2) spectral_axis_kernel(AxisArgs g) {
+  using S = Shape<N>;
+  constexpr int NT = S::NT, MJ = S::MJ, KS = S::KS;
+  static_assert(NT <= 4, "shape");
+  __shared__ __attribute__((aligned(16))) double exch[2 * 4 * 4 * 4 * 64];      // [parity][dest][src][reg][lane]
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 15, gq = lane >> 4;
+  lds_double* const ex = (lds_double*)exch + lane;
+  const int64_t m0 = (int64_t)blockIdx.x * 16;
+  const int Si8 = (int)(g.Si * 8), So8 = (int)(g.So * 8);
+  const bool orb = w < NT;
+  // spatial side: plane 16 s + 4 g + rho (rho = w); spectral side: plane 8 (8 T + 4 h + g) + m (T = w)
+  const unsigned vsp = (unsigned)((4 * gq) * (INV ? So8 : Si8) + c * 8);
+  const unsigned vsk = (unsigned)((8 * gq) * (INV ? Si8 : So8) + c * 8);
+  constexpr double R2 = 1.4142135623730951;
+  double frag[INV ? NT * 4 * MJ : KS * NT];
+  {
+    const double* bf = g.basis + lane;
+#pragma unroll
+    for (int i = 0; i < (INV ? NT * 4 * MJ : KS * NT); ++i)
+      frag[i] = R2 * bf[(size_t)((INV ? S::NF_FWD + w * NT * 4 * MJ : w * KS * NT) + i) * 64];
+  }
+  const int in_bytes = (INV ? 2 * N : N) * Si8, out_bytes = (INV ? N : 2 * N) * So8;
+  int par = 0;
+  for (int64_t r = blockIdx.y; r < g.R; r += gridDim.y, par ^= 1) {
+    const rsrc_t src = make_rsrc(g.in + r * g.item_in + m0, in_bytes);
+    const rsrc_t dst = make_rsrc(g.out + r * g.item_out + m0, out_bytes);
+    lds_double* const eb = ex + par * (4 * 4 * 4 * 64);
+    if constexpr (!INV) {
+      double x[KS];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) x[s] = ld_stream(src, vsp, (16 * s + w) * Si8);
+      d4 acc[NT];
+#pragma unroll
+      for (int T = 0; T < NT; ++T) acc[T] = d4{0., 0., 0., 0.};
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int T = 0; T < NT; ++T) acc[T] = __builtin_amdgcn_mfma_f64_16x16x4f64(frag[s * NT + T], x[s], acc[T], 0, 0, 0);
+#pragma unroll
+      for (int T = 0; T < NT; ++T)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) eb[((T * 4 + w) * 4 + q) * 64] = acc[T][q];
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_s_barrier();
+      if (orb) {
+        double cs[4][4];
+#pragma unroll
+        for (int rho = 0; rho < 4; ++rho)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) cs[rho][q] = eb[((w * 4 + rho) * 4 + q) * 64];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (8 * w + 4 * h >= S::NW) continue;                // (orbit tiles of an extent that is not a multiple of 32: wave uniform)
+          const double Cc[4] = {cs[0][h], cs[1][h], cs[2][h], cs[3][h]};
+          const double Ss[4] = {cs[0][2 + h], cs[1][2 + h], cs[2][2 + h], cs[3][2 + h]};
+          double a[4], b[4];
+          bfly_fwd(Cc, Ss, a, b);
+          const double v[8] = {a[0], a[1], b[0], -b[1], a[2], a[3], b[2], -b[3]};
+#pragma unroll
+          for (int m = 0; m < 8; ++m) st_lane(dst, vsk, (8 * (8 * w + 4 * h) + m) * So8, v[m]);
+        }
+      }
+    } else {
+      if (orb) {
+        double Y[4][4];
+#pragma unroll
+        for (int rho = 0; rho < 4; ++rho)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) Y[rho][q] = 0.0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (8 * w + 4 * h >= S::NW) continue;
+          double v[8];
+#pragma unroll
+          for (int m = 0; m < 8; ++m) v[m] = ld_stream(src, vsk, (8 * (8 * w + 4 * h) + m) * Si8);
+          const double a0 = v[0], a1 = v[1], b0 = v[2], b1 = -v[3], a2 = v[4], a3 = v[5], b2 = v[6], b3 = -v[7];
+          const double sa = a0 + a1, da = a0 - a1, sb = a2 + a3, db = a2 - a3;
+          const double t0 = b0 - b1, t1 = b0 + b1, t2 = b2 - b3, t3 = b2 + b3;
+          Y[0][h] = sa + sb; Y[2][h] = sa - sb; Y[1][h] = da + t3; Y[3][h] = da - t3;
+          Y[0][2 + h] = t0 + t2; Y[2][2 + h] = t0 - t2; Y[1][2 + h] = t1 - db; Y[3][2 + h] = t1 + db;
+        }
+#pragma unroll
+        for (int rho = 0; rho < 4; ++rho)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) eb[((rho * 4 + w) * 4 + q) * 64] = Y[rho][q];
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_s_barrier();
+      double yin[NT][4];
+#pragma unroll
+      for (int T = 0; T < NT; ++T)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) yin[T][q] = eb[((w * 4 + T) * 4 + q) * 64];
+      d4 o[MJ];
+#pragma unroll
+      for (int mj = 0; mj < MJ; ++mj) o[mj] = d4{0., 0., 0., 0.};
+#pragma unroll
+      for (int T = 0; T < NT; ++T)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int mj = 0; mj < MJ; ++mj) o[mj] = __builtin_amdgcn_mfma_f64_16x16x4f64(frag[(T * 4 + q) * MJ + mj], yin[T][q], o[mj], 0, 0, 0);
+#pragma unroll
+      for (int mj = 0; mj < MJ; ++mj)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (16 * mj + 4 * q >= S::NJ) continue;
+          st_lane(dst, vsp, (64 * mj + 16 * q + w) * So8, o[mj][q]);
+        }
+    }
+  }
+}
+
+template <int N>
+int launch_axis(const AxisArgs& g, bool inverse, hipStream_t st) {
+  const int64_t nbx = g.C / 16;
+  int64_t gy = 1;                                   // two workgroups per CU (64 KiB of LDS, < 128 registers): ~2048 workgroups in flight
+  while (nbx * gy < 2048 && gy < g.R) ++gy;
+  if (gy > 65535) gy = 65535;
+  if (inverse) hipLaunchKernelGGL((spectral_axis_kernel<N, true>), dim3((unsigned)nbx, (unsigned)gy), dim3(256), 0, st, g);
+  else hipLaunchKernelGGL((spectral_axis_kernel<N, false>), dim3((unsigned)nbx, (unsigned)gy), dim3(256), 0, st, g);
+  return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
+}
+
 template <int NY>
 int fill_basis(double* basis, hipStream_t st) {
   hipLaunchKernelGGL(basis_kernel<NY>, dim3(Shape<NY>::NF), dim3(64), 0, st, basis);
@@ -699,5 +842,22 @@ extern "C" int geobo_spectral_y3t(int ny, int64_t C, int64_t plane, int64_t R, i
     case 112: return launch_split2_by<112>(g, nprop, st);
     case 128: return launch_split2_by<128>(g, nprop, st);
     default: return GEOBO_E_UNSUPPORTED;   // (ny <= 64: geobo_spectral_y2s)
+  }
+}
+
+extern "C" int geobo_spectral_axis(int inverse, int n, int64_t C, int64_t plane_in, int64_t plane_out, int64_t item_in, int64_t item_out, int64_t items,
+                                   const double* in, double* out, const double* basis, void* stream) {
+  if (!in || !out || !basis || items <= 0) return GEOBO_E_ARG;
+  if (C <= 0 || C % 16 || plane_in < C || plane_out < C) return GEOBO_E_ALIGN;
+  if ((int64_t)2 * n * (plane_in > plane_out ? plane_in : plane_out) * 8 >= (1ll << 31)) return GEOBO_E_ALIGN;
+  AxisArgs g;
+  g.in = in; g.out = out; g.basis = basis; g.C = C; g.Si = plane_in; g.So = plane_out; g.item_in = item_in; g.item_out = item_out; g.R = items;
+  hipStream_t st = (hipStream_t)stream;
+  switch (n) {
+    case 80: return launch_axis<80>(g, inverse != 0, st);
+    case 96: return launch_axis<96>(g, inverse != 0, st);
+    case 112: return launch_axis<112>(g, inverse != 0, st);
+    case 128: return launch_axis<128>(g, inverse != 0, st);
+    default: return GEOBO_E_UNSUPPORTED;
   }
 }

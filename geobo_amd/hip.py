@@ -16,7 +16,7 @@ F64 = torch.float64
 KERNEL_IDS = {"d2": 0, "exp": 1, "exp_x": 2, "matern32": 3, "matern32_x": 4, "sparse": 5, "sparse_x": 6}
 FUNC_IDS = {"grav": 0, "magn": 1}
 # kernel-instance tables and padding units: ONE definition (plan.py, which decides routes from them on the CPU); re-exported here
-from .plan import PAD_M, PAD_N, SPECTRAL_Y_NY, TOEPLITZ_NY, XZ2D_FOLD_N, XZ2D_SHAPES  # noqa: E402,F401
+from .plan import PAD_M, PAD_N, SPECTRAL_AXIS_N, SPECTRAL_Y_NY, TOEPLITZ_NY, XZ2D_FOLD_N, XZ2D_SHAPES  # noqa: E402,F401
 
 
 def kernel_id(name, cross):
@@ -640,6 +640,19 @@ def spectral_y3t(ny, C, R, src_g, src_m, tabs_g, tabs_m, outs, plane=None):
     _lib.check(lib.geobo_spectral_y3t(int(ny), int(C), int(C if plane is None else plane), int(R), n, _p(_chk(src_g, "src_g")), _p(_chk(src_m, "src_m")),
                                       arr(tabs_g, "tab"), arr(tabs_m, "tab"), arr(outs, "out"), _p(spectral_y_basis(ny, src_g.device)), _stream()),
                "geobo_spectral_y3t")
+
+
+# SPECTRAL_AXIS_N (plan.py): extents of the radix-4 axis passes (geobo_spectral_axis); half-integer basis only
+
+
+def spectral_axis(inverse, n, C, plane_in, plane_out, item_in, item_out, items, src, dst):
+    """One axis pass along a strided axis against the half-integer basis G of size n (geobo_spectral_axis): analysis n -> 2n planes or
+    synthesis 2n -> n planes of C contiguous modes per item."""
+    lib = require_gpu()
+    _lib.check(lib.geobo_spectral_axis(1 if inverse else 0, int(n), int(C), int(plane_in), int(plane_out), int(item_in), int(item_out), int(items),
+                                       _p(_chk(src, "src")), _p(_chk(dst, "dst")), _p(spectral_y_basis(n, src.device)), _stream()),
+               "geobo_spectral_axis")
+    return dst
 
 
 def spectral_y2s(ny, C, R, src_g, src_m, tab_d0, tab_x, tab_d1, outs, plane=None):

@@ -23,6 +23,7 @@ PAD_M, PAD_N = 256, 128
 XZ2D_SHAPES = ((48, 64), (64, 64), (64, 32))      # fused (x, z) transform instances (hip.XZ2D_SHAPES)
 XZ2D_FOLD_N = (64,)                               # radix-2 instances (hip.XZ2D_FOLD_N)
 TOEPLITZ_NY = (16, 32, 48, 64, 80, 96, 112, 128)               # Toeplitz y-stage instances (hip.TOEPLITZ_NY)
+SPECTRAL_AXIS_N = (80, 96, 112, 128)              # radix-4 axis passes (hip.SPECTRAL_AXIS_N); extents on the half-integer basis only
 SPECTRAL_Y_NY = (32, 48, 64, 80, 96, 112, 128)    # in-kernel spectral y stage on the matrix pipe (hip.SPECTRAL_Y_NY); > 64: geobo_spectral_y3 only
 ROWS_MIN_VOXELS = 1 << 18                         # batched-GEMM forms of the row algorithm pay from 64^3 voxels ...
 ROWS_MIN_PLANE = 96 * 96                          # ... and (x, z) planes that fill the 128 x 128 GEMM tiles
@@ -46,6 +47,7 @@ SWITCHES = {"fused_xz": "GEOBO_SPECTRAL_FUSED_XZ",   # fused (x, z) transform ke
             "quad": "GEOBO_XZ_QUAD",                 # 32 x 32 planes four at a time through the n = 64 radix-2 kernels (else stacked pairs)
             "dense_y": "GEOBO_SPECTRAL_DENSE_Y",     # y axis applied per mode inside one kernel (else carried through the spectrum by passes)
             "y_mfma": "GEOBO_Y_MFMA",                # ... as an in-kernel spectral product on the matrix pipe (else the direct vector-pipe kernels)
+            "axis_mfma": "GEOBO_AXIS_MFMA",          # x passes of the unfused (x, z) transforms as radix-4 axis kernels (else radix-2 GEMM passes)
             "y2s": "GEOBO_Y2S",                      # two-term rows with the shared cross block K_01 = K_10 (else four products)
             "z_fused": "GEOBO_Z_FUSED",              # rows of L^-1 A: one fused inverse transform per (row, z) plane (else two GEMM passes)
             "z_mul": "GEOBO_Z_MUL",                  # ... its input product formed inside the kernel (else written and read back)
@@ -170,7 +172,8 @@ def plan_route(nx, ny, nz, world=1, rank=0, assembly="f64", operators="resident"
     if family == "rows" and not streamed and rows_r * N_pad * 8 > (40 << 30):
         ops = "streamed"
         notes.append("operator rows of a rank (%.0f GB) are generated per batch instead of being resident" % (rows_r * N_pad * 8 / 1e9))
-    kernels = (("xz", "fold" if (fused_xz and fold) else "fused" if fused_xz else "quad" if quad_xz else "pair" if pair_xz else "gemm"),
+    kernels = (("xz", "fold" if (fused_xz and fold) else "fused" if fused_xz else "quad" if quad_xz else "pair" if pair_xz else
+                "gemm+axis4" if (nx in SPECTRAL_AXIS_N and sw["axis_mfma"]) else "gemm"),
                ("y", ("mfma" if y_mfma else "toeplitz") if dense_y else "spectrum"),
                ("gram", ("fused" if gram_fast else "gemm") if (family in ("rows", "single") and gram_ok) else "per-step"),
                ("ss", ("fused" if fused_ss else "stored") if family in ("rows", "single") else "reduction"))

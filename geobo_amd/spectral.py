@@ -53,6 +53,33 @@ def base_modes(n):
     return modes
 
 
+INTEGER_BASIS_N = (32, 64)      # extents whose fused kernels (xz2d_fold.hip: n = 64, and the four-plane form of 32 x 32 planes) build the
+                                # integer-frequency basis of base_modes() internally; every other extent takes the half-integer basis below
+
+
+def half_integer(n):
+    """True where the axis runs on the HALF-INTEGER (skew-circulant) basis (round 6): a symmetric Toeplitz block of size n is also the
+    leading block of the skew-circulant of size P = 2n (first column k_0 .. k_{n-1}, *, -k_{n-1} .. -k_1), diagonalised by cos / sin of
+    the frequencies kappa = 1/2 .. n - 1/2 with eigenvalues sum_d w_d k(d) cos(2 pi kappa d / P).  No frequency is its own mirror or
+    quarter-period image, so all n frequencies fall into n/4 orbits {kappa, n - kappa, n/2 + kappa, n/2 - kappa} of ONE shape -- what
+    the radix-4 axis kernels of spectral_y.hip want.  Every consumer of G / G^T / E treats the spectral index as opaque (the eigen-data
+    go through the same matrices), and the pair structure row 2b+1 = (-1)^i row 2b of the radix-2 passes holds for every pair."""
+    return n not in INTEGER_BASIS_N
+
+
+def half_modes(n):
+    """Base rows of the half-integer basis as (kind, 2 kappa): orbit omega = 0 .. n/4 - 1 (kappa = omega + 1/2) holds the base rows
+    4 omega + (0: cos kappa, 1: sin kappa, 2: cos(n/2 + kappa), 3: sin(n/2 + kappa)); their mirrors (-1)^i g_b are the eigenvectors of
+    n - kappa and n/2 - kappa: spectral positions 8 omega .. 8 omega + 7 = cos k, cos(n - k), sin k, -sin(n - k), cos(n/2 + k),
+    cos(n/2 - k), sin(n/2 + k), -sin(n/2 - k)."""
+    assert n % 4 == 0
+    modes = []
+    for om in range(n // 4):
+        k2 = 2 * om + 1
+        modes += [("cos", k2), ("sin", k2), ("cos", n + k2), ("sin", n + k2)]
+    return modes
+
+
 def _base_row(kind, om, n):
     P = 2 * n
     z = np.arange(n)
@@ -64,12 +91,24 @@ def _base_row(kind, om, n):
     return np.array([1.0, 1.0, -1.0, -1.0])[z % 4]                # cos(pi z / 2) + sin(pi z / 2), exactly
 
 
+def _half_row(kind, k2, n):
+    """sqrt(2) cos / sin(2 pi kappa z / P), kappa = k2 / 2, with the phase reduced in integers (index over 2P)."""
+    P = 2 * n
+    ang = 2.0 * np.pi * ((k2 * np.arange(n)) % (2 * P)) / (2 * P)
+    return math.sqrt(2.0) * (np.cos(ang) if kind == "cos" else np.sin(ang))
+
+
 def forward_matrix(n):
-    """G (P x n): real eigenvector basis of symmetric circulants of size P = 2n, restricted to the first n inputs, in the
-    pair-interleaved order of base_modes (row 2b = base row b, row 2b+1 = (-1)^z times it)."""
+    """G (P x n): real eigenvector basis of symmetric circulants (integer basis) / skew-circulants (half-integer basis) of size P = 2n,
+    restricted to the first n inputs, pair-interleaved: row 2b = base row b (base_modes / half_modes), row 2b+1 = (-1)^z times it."""
     assert n % 4 == 0
     G = np.empty((2 * n, n))
     alt = 1.0 - 2.0 * (np.arange(n) % 2)
+    if half_integer(n):
+        for b, (kind, k2) in enumerate(half_modes(n)):
+            G[2 * b] = _half_row(kind, k2, n)
+            G[2 * b + 1] = alt * G[2 * b]
+        return G
     for b, (kind, om) in enumerate(base_modes(n)):
         G[2 * b] = _base_row(kind, om, n)
         G[2 * b + 1] = alt * G[2 * b]
@@ -78,9 +117,16 @@ def forward_matrix(n):
 
 def eigen_matrix(n):
     """E (P x n): Lambda' = E k for a half table k(d), d = 0..n-1, laid out on the same row index as G: row 2b carries the
-    eigenvalue of frequency omega_b, row 2b+1 that of n - omega_b."""
+    eigenvalue of the frequency of base row b, row 2b+1 that of its mirror n - frequency."""
     P = 2 * n
     d = np.arange(n)
+    if half_integer(n):
+        f2 = np.empty(P, dtype=np.int64)                          # twice the frequency
+        for b, (kind, k2) in enumerate(half_modes(n)):
+            f2[2 * b], f2[2 * b + 1] = k2, 2 * n - k2
+        E = np.cos(2.0 * np.pi * ((f2[:, None] * d[None, :]) % (2 * P)) / (2 * P))
+        E[:, 1:] *= 2.0
+        return E
     om = np.empty(P, dtype=np.int64)
     for b, (kind, w) in enumerate(base_modes(n)):
         om[2 * b], om[2 * b + 1] = w, n - w
@@ -148,6 +194,8 @@ class SpectralProduct:
         # ... and, where instantiated, through the y axis's own spectrum INSIDE the kernel, on the matrix pipe (round 6: geobo_spectral_y,
         # same arguments, same sums to rounding; GEOBO_Y_MFMA=0 keeps the direct vector-pipe kernels: the A/B of profiles/r06_*)
         self.y_mfma = self.dense_y and ny in hip.SPECTRAL_Y_NY and self.opts["y_mfma"]
+        # x passes of the unfused (x, z) transforms: radix-4 axis kernels on the half-integer basis (geobo_spectral_axis) where instantiated
+        self.x_mfma = nx in hip.SPECTRAL_AXIS_N and half_integer(nx) and self.opts.get("axis_mfma", True)
         # x and z: one fused kernel per direction (geobo_xz2d) where it is instantiated, else two batched GEMM passes
         self.fused_xz = (nx, nz) in hip.XZ2D_SHAPES and self.opts["fused_xz"]
         # 32 x 32 planes: two consecutive y-planes stacked along x go through the (64, 32) instance with diag(Mx, Mx) -- the z step
@@ -255,7 +303,10 @@ class SpectralProduct:
         t1 = self.buf("T1", rows * Pz)
         hip.axis_pass(fold, False, False, hip.pad_n(ny * nx), hip.pad_n(Pz), nz, src, nz, lds, M["z"], nz, 0, t1, Pz, ny * nx * Pz, ny * nx, Pz, R)
         t2 = self.buf(out_name, R * ny * Px * Pz)
-        hip.axis_pass(fold, True, False, hip.pad_n(Px), hip.pad_n(Pz), nx, M["x"], nx, 0, t1, Pz, nx * Pz, t2, Pz, Px * Pz, Px, Pz, R * ny)
+        if self.x_mfma and M is self.G and Pz % 16 == 0:
+            hip.spectral_axis(False, nx, Pz, Pz, Pz, nx * Pz, Px * Pz, R * ny, t1, t2)
+        else:
+            hip.axis_pass(fold, True, False, hip.pad_n(Px), hip.pad_n(Pz), nx, M["x"], nx, 0, t1, Pz, nx * Pz, t2, Pz, Px * Pz, Px, Pz, R * ny)
         return t2
 
     def forward(self, src, R, M, out_name="T3", src_row_stride=None):
@@ -302,8 +353,11 @@ class SpectralProduct:
                          self._paired(self.GT["x"], nx, Px), self.GT["z"], out, ldo, 2 * nx * nz)
             return
         u1 = self.buf("U1", R * Ly * nx * Pz)
-        hip.axis_pass(self.fold, True, True, hip.pad_n(nx), hip.pad_n(Pz), Px, self.GT["x"], Px, 0, u2, Pz, Px * Pz, u1, Pz, nx * Pz, nx, Pz,
-                      R * Ly)
+        if self.x_mfma and Pz % 16 == 0:
+            hip.spectral_axis(True, nx, Pz, Pz, Pz, Px * Pz, nx * Pz, R * Ly, u2, u1)
+        else:
+            hip.axis_pass(self.fold, True, True, hip.pad_n(nx), hip.pad_n(Pz), Px, self.GT["x"], Px, 0, u2, Pz, Px * Pz, u1, Pz, nx * Pz, nx, Pz,
+                          R * Ly)
         for ya, yb, out, ldo in targets:
             slab = yb - ya
             hip.axis_pass(self.fold, False, True, hip.pad_n(slab * nx), hip.pad_n(nz), Pz, u1[(ya - ylo) * nx * Pz:], Pz, Ly * nx * Pz,

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define GEOBO_VERSION 212 /* 201: flag word of geobo_gemm_nt, (64, 32) instance of geobo_xz2d, workspace layout of geobo_potrf_inv; 202: geobo_ymul, geobo_xz2d_fold_lattice; 203: geobo_sumsq_accum, geobo_lamdot_z, geobo_toeplitz_y2t, geobo_xz2d_fold_quad; 204: geobo_toeplitz_y3_add; 205: workspace layout of geobo_potrf_inv (one T buffer per tree node); 206: geobo_potrf_inv as one persistent tile-DAG launch from m = 1024 (workspace: + counters); 207: geobo_gemm_fold; 208: geobo_gemm_fold_lamdot; 209: geobo_toeplitz_y2s; 210: geobo_xz2d_fold* dense planes take the quarter-period group order of the basis (radix 4); 211: geobo_ymul_fold; 212: geobo_spectral_y, geobo_spectral_y2s, geobo_spectral_y_basis, geobo_spectral_y3, geobo_spectral_y3t, geobo_rowgemv */
+#define GEOBO_VERSION 212 /* 201: flag word of geobo_gemm_nt, (64, 32) instance of geobo_xz2d, workspace layout of geobo_potrf_inv; 202: geobo_ymul, geobo_xz2d_fold_lattice; 203: geobo_sumsq_accum, geobo_lamdot_z, geobo_toeplitz_y2t, geobo_xz2d_fold_quad; 204: geobo_toeplitz_y3_add; 205: workspace layout of geobo_potrf_inv (one T buffer per tree node); 206: geobo_potrf_inv as one persistent tile-DAG launch from m = 1024 (workspace: + counters); 207: geobo_gemm_fold; 208: geobo_gemm_fold_lamdot; 209: geobo_toeplitz_y2s; 210: geobo_xz2d_fold* dense planes take the quarter-period group order of the basis (radix 4); 211: geobo_ymul_fold; 212: geobo_spectral_y, geobo_spectral_y2s, geobo_spectral_y_basis, geobo_spectral_y3, geobo_spectral_y3t, geobo_spectral_axis, geobo_rowgemv */
 
 #define GEOBO_PAD_M 256 /* row padding of M-like dimensions (observation rows)            */
 #define GEOBO_PAD_N 128 /* padding of voxel-like dimensions (columns / contraction index) */
@@ -427,6 +427,19 @@ int geobo_spectral_y3(int ny, int64_t C, int64_t plane, int64_t R, int nprop, co
  * transforms, and no read-modify-write of the outputs.  ny in {80, 96, 112, 128}; ny <= 64: geobo_spectral_y2s. */
 int geobo_spectral_y3t(int ny, int64_t C, int64_t plane, int64_t R, int nprop, const double* in_g, const double* in_m,
                        const double* const* tabs_g, const double* const* tabs_m, double* const* outs, const double* basis, void* stream);
+
+/* Axis passes of the (x, z) transforms along a STRIDED axis for extents without a fused two-axis kernel (round 6; the x step of the
+ * covariance product's transforms, kernels.py:158-195 / inversion.py:96,114 through the spectral route):
+ *     inverse == 0 (analysis):   out[item][p][c] = sum_i G[p][i] in[item][i][c],   p < 2n, i < n
+ *     inverse != 0 (synthesis):  out[item][i][c] = sum_p G[p][i] in[item][p][c]
+ * with G the real eigenvector basis of size n on HALF-INTEGER frequencies in orbit order (geobo_amd/spectral.py forward_matrix /
+ * half_modes: spectral positions 8 w .. 8 w + 7 = sqrt(2) x {cos k, cos(n - k), sin k, -sin(n - k), cos(n/2 + k), cos(n/2 - k),
+ * sin(n/2 + k), -sin(n/2 - k)}, k = w + 1/2) -- the drop-in for geobo_gemm_fold / geobo_gemm_batched with that matrix on the X side,
+ * radix 4 on MFMA (n^2 / 2 multiply-adds per item and mode), data straight from global memory into the operand layout.
+ * c < C contiguous modes (C % 16 == 0); planes plane_in / plane_out doubles apart, items item_in / item_out doubles apart.
+ * basis: the blob of geobo_spectral_y_basis(n).  n in {80, 96, 112, 128}; GEOBO_E_UNSUPPORTED otherwise. */
+int geobo_spectral_axis(int inverse, int n, int64_t C, int64_t plane_in, int64_t plane_out, int64_t item_in, int64_t item_out, int64_t items,
+                        const double* in, double* out, const double* basis, void* stream);
 
 /* In-place lower Cholesky of the (m x m, ld) matrix A, m % 256 == 0 (padding rows/cols = identity);
  * scipy.linalg.cholesky(AkA, lower=True), inversion.py:100.  Also writes Linv = L^-1 (m x m, ldi; lower,

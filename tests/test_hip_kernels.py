@@ -687,6 +687,34 @@ def test_spectral_y_long_axes_match_torch(hip, ny, C, R, nprop, y0, y1):
             assert normwise(both[j][:, :, :C].cpu().numpy(), want.cpu().numpy()) < 3e-14
 
 
+@pytest.mark.parametrize("n,C,items", [(128, 256, 37), (96, 192, 50), (80, 160, 7), (112, 64, 3), (128, 16, 700), (96, 48, 1)])
+def test_spectral_axis_matches_the_basis_matrix(hip, n, C, items):
+    # radix-4 axis passes (geobo_spectral_axis) against the plain products with spectral.forward_matrix(n) on the half-integer basis:
+    # analysis G X and synthesis G^T S per item, padded plane / item strides whose padding is neither read into a result nor written
+    from geobo_amd.spectral import forward_matrix, half_integer
+    assert half_integer(n)
+    G = hip.to_dev(forward_matrix(n))
+    P, S = 2 * n, C + 16
+    x = torch.full((items, n + 1, S), float("nan"), dtype=torch.float64, device="cuda")
+    x[:, :n, :C] = _rand((items, n, C), 81)
+    out = torch.full((items, P + 2, S), 7.0, dtype=torch.float64, device="cuda")
+    hip.spectral_axis(False, n, C, S, S, (n + 1) * S, (P + 2) * S, items, x.reshape(-1), out.reshape(-1))
+    torch.cuda.synchronize()
+    ref = torch.einsum("pi,ric->rpc", G, x[:, :n, :C])
+    assert normwise(out[:, :P, :C].cpu().numpy(), ref.cpu().numpy()) < 1e-13
+    assert bool((out[:, P:, :] == 7.0).all()) and bool((out[:, :, C:] == 7.0).all())
+    s = torch.full((items, P + 1, S), float("nan"), dtype=torch.float64, device="cuda")
+    s[:, :P, :C] = _rand((items, P, C), 82)
+    back = torch.full((items, n + 3, S), 7.0, dtype=torch.float64, device="cuda")
+    hip.spectral_axis(True, n, C, S, S, (P + 1) * S, (n + 3) * S, items, s.reshape(-1), back.reshape(-1))
+    torch.cuda.synchronize()
+    ref = torch.einsum("pi,rpc->ric", G, s[:, :P, :C])
+    assert normwise(back[:, :n, :C].cpu().numpy(), ref.cpu().numpy()) < 1e-13
+    assert bool((back[:, n:, :] == 7.0).all()) and bool((back[:, :, C:] == 7.0).all())
+    with pytest.raises(RuntimeError):
+        hip.spectral_axis(False, 64, C, S, S, (n + 1) * S, (P + 2) * S, items, x.reshape(-1), out.reshape(-1))
+
+
 @pytest.mark.parametrize("ny,C,R", [(64, 256, 5), (64, 16384, 11), (48, 128, 9), (32, 1024, 30), (64, 128, 1), (64, 528, 8)])
 def test_spectral_y2s_matches_torch(hip, ny, C, R):
     # two-term rows with a shared cross block, the terms meeting in the y spectrum (geobo_spectral_y2s): against torch, against the

@@ -219,7 +219,7 @@ def test_route_table():
     # share cannot be resident
     for w in (1, 2, 4, 8):
         r = plan_route(128, 128, 128, world=w, assembly="f32", operators="auto")
-        assert r.family == "rows" and dict(r.kernels) == dict(xz="gemm", y="mfma", gram="gemm", ss="stored")
+        assert r.family == "rows" and dict(r.kernels) == dict(xz="gemm+axis4", y="mfma", gram="gemm", ss="stored")
         assert (r.operators == "streamed") == (w < 8)
     assert plan_route(128, 128, 128, world=8, assembly="f32", operators="streamed").operators == "streamed"
     assert fam(96, 96, 96) == "rows" and dict(plan_route(96, 96, 96).kernels)["y"] == "mfma"

@@ -6,10 +6,10 @@ pair-interleaved (row 2b = base row, row 2b+1 = (-1)^i times it): what the folde
 import numpy as np
 import pytest
 
-from geobo_amd.spectral import base_modes, eigen_matrix, folded_matrices, forward_matrix
+from geobo_amd.spectral import base_modes, eigen_matrix, folded_matrices, forward_matrix, half_integer, half_modes
 
 
-@pytest.mark.parametrize("n", [16, 32, 48, 64, 128])
+@pytest.mark.parametrize("n", [16, 32, 48, 64, 80, 96, 112, 128, 144])
 def test_basis_diagonalises_symmetric_toeplitz(n):
     k = np.exp(-0.3 * np.arange(n)) * (1 + 0.1 * np.arange(n))
     G, Em = forward_matrix(n), eigen_matrix(n)
@@ -19,7 +19,39 @@ def test_basis_diagonalises_symmetric_toeplitz(n):
     assert np.abs(G.T @ G / (2 * n) - np.eye(n)).max() < 1e-13          # columns orthogonal, norm^2 = P
 
 
-@pytest.mark.parametrize("n", [16, 64])
+@pytest.mark.parametrize("n", [16, 48, 96, 128])
+def test_half_integer_basis_layout(n):
+    """Round 6: every extent without a fused kernel of its own runs on the half-integer (skew-circulant) basis: n/4 orbits of one shape,
+    spectral positions 8 w .. 8 w + 7 = cos k, cos(n - k), sin k, -sin(n - k), cos(n/2 + k), cos(n/2 - k), sin(n/2 + k), -sin(n/2 - k),
+    k = w + 1/2; the pair structure of the radix-2 passes holds for every pair; the orbit is the radix-4 structure of the axis kernels."""
+    assert half_integer(n) and not half_integer(64) and not half_integer(32)
+    G, Em = forward_matrix(n), eigen_matrix(n)
+    alt = 1.0 - 2.0 * (np.arange(n) % 2)
+    assert np.array_equal(G[1::2], G[0::2] * alt)
+    z, d, P, r2 = np.arange(n), np.arange(n), 2 * n, np.sqrt(2.0)
+    for w in range(n // 4):
+        k = w + 0.5
+        want = [np.cos(2 * np.pi * k * z / P), np.cos(2 * np.pi * (n - k) * z / P), np.sin(2 * np.pi * k * z / P), -np.sin(2 * np.pi * (n - k) * z / P),
+                np.cos(2 * np.pi * (n / 2 + k) * z / P), np.cos(2 * np.pi * (n / 2 - k) * z / P), np.sin(2 * np.pi * (n / 2 + k) * z / P),
+                -np.sin(2 * np.pi * (n / 2 - k) * z / P)]
+        for m, f in enumerate((k, n - k, k, n - k, n / 2 + k, n / 2 - k, n / 2 + k, n / 2 - k)):
+            assert np.abs(G[8 * w + m] - r2 * want[m]).max() < 1e-11
+            assert np.abs(Em[8 * w + m] - np.cos(2 * np.pi * f * d / P) * np.where(d == 0, 1.0, 2.0)).max() < 1e-11
+    assert len(half_modes(n)) == n
+    # radix 4: on a residue class the rows of a whole orbit are +-(cos | sin) of k -- class sums C, S -> the eight positions
+    x = np.random.default_rng(7).standard_normal(n)
+    ref = G @ x
+    for w in range(n // 4):
+        C, S = np.empty(4), np.empty(4)
+        for rho in range(4):
+            i = 4 * np.arange(n // 4) + rho
+            C[rho], S[rho] = G[8 * w, i] @ x[i], G[8 * w + 2, i] @ x[i]
+        got = [C.sum(), C[0] - C[1] + C[2] - C[3], S.sum(), S[0] - S[1] + S[2] - S[3],
+               C[0] - S[1] - C[2] + S[3], C[0] + S[1] - C[2] - S[3], S[0] + C[1] - S[2] - C[3], S[0] - C[1] - S[2] + C[3]]
+        assert np.abs(np.array(got) - ref[8 * w:8 * w + 8]).max() < 1e-12
+
+
+@pytest.mark.parametrize("n", [32, 64])
 def test_pair_interleaved_layout(n):
     G, Em = forward_matrix(n), eigen_matrix(n)
     alt = 1.0 - 2.0 * (np.arange(n) % 2)
@@ -38,7 +70,7 @@ def test_pair_interleaved_layout(n):
     assert np.array_equal(Em[2], Em[3])                                 # (the middle pair sits at positions 2, 3)
 
 
-@pytest.mark.parametrize("n", [16, 64])
+@pytest.mark.parametrize("n", [32, 64])
 def test_radix4_synthesis_identity(n):
     """What the synthesis along z of xz_fold_inv_kernel computes (radix 4): the outputs i = 4j + rho of residue class rho need, per
     frequency omega < n/4, ONE cosine and ONE sine row of the basis -- the eight spectral values of the group enter through two
@@ -70,7 +102,7 @@ def test_radix4_synthesis_identity(n):
         assert np.abs(got - ref).max() < 1e-12
 
 
-@pytest.mark.parametrize("n", [16, 64])
+@pytest.mark.parametrize("n", [32, 64])
 def test_radix4_analysis_identity(n):
     """What the analysis along x of xz_fold_fwd_kernel / xcorr_fold4_kernel computes (radix 4): per residue class rho of the input
     index and frequency w < n/4 ONE cosine-row sum C_rho and ONE sine-row sum S_rho (w = 0: the constant-row and the alternating-row
