@@ -73,7 +73,7 @@ SIGNATURES = {
     "geobo_spectral_y2s": (_int, [_int, _i64, _i64, _i64, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     "geobo_spectral_y3": (_int, [_int, _i64, _i64, _i64, _int, _dp, C.POINTER(_dp), C.POINTER(_dp), _int, _int, _int, _dp, _dp]),
     "geobo_spectral_y3t": (_int, [_int, _i64, _i64, _i64, _int, _dp, _dp, C.POINTER(_dp), C.POINTER(_dp), C.POINTER(_dp), _dp, _dp]),
-    "geobo_spectral_axis": (_int, [_int, _int, _i64, _i64, _i64, _i64, _i64, _i64, _dp, _dp, _dp, _dp]),
+    "geobo_spectral_axis": (_int, [_int, _int, _i64, _i64, _i64, _i64, _i64, _i64, _dp, _dp, _dp, _int, _dp]),
     "geobo_potrf_ws_bytes": (_sz, [_i64]),
     "geobo_potrf_ctx_create": (_int, [C.POINTER(C.c_void_p)]),
     "geobo_potrf_ctx_destroy": (_int, [_dp]),

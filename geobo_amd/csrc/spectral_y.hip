@@ -598,6 +598,7 @@ struct AxisArgs {
   double* out;
   const double* basis;
   int64_t C, Si, So, item_in, item_out, R;     // modes per plane, plane strides, item strides (doubles), items
+  int mask_ends;                               // analysis: input planes 0 and n - 1 count as zero (the lattice Gram's boundary slabs)
 };
 
 template <int N, bool INV>
@@ -633,6 +634,10 @@ __global__ void __launch_bounds__(256, 2) spectral_axis_kernel(AxisArgs g) {
       double x[KS];
 #pragma unroll
       for (int s = 0; s < KS; ++s) x[s] = ld_stream(src, vsp, (16 * s + w) * Si8);
+      if (g.mask_ends) {                                     // plane 16 s + 4 g + rho: 0 = (s 0, g 0, rho 0), n - 1 = (s KS - 1, g 3, rho 3)
+        if (w == 0 && gq == 0) x[0] = 0.0;
+        if (w == 3 && gq == 3) x[KS - 1] = 0.0;
+      }
       d4 acc[NT];
 #pragma unroll
       for (int T = 0; T < NT; ++T) acc[T] = d4{0., 0., 0., 0.};
@@ -846,12 +851,13 @@ extern "C" int geobo_spectral_y3t(int ny, int64_t C, int64_t plane, int64_t R, i
 }
 
 extern "C" int geobo_spectral_axis(int inverse, int n, int64_t C, int64_t plane_in, int64_t plane_out, int64_t item_in, int64_t item_out, int64_t items,
-                                   const double* in, double* out, const double* basis, void* stream) {
+                                   const double* in, double* out, const double* basis, int mask_ends, void* stream) {
   if (!in || !out || !basis || items <= 0) return GEOBO_E_ARG;
   if (C <= 0 || C % 16 || plane_in < C || plane_out < C) return GEOBO_E_ALIGN;
   if ((int64_t)2 * n * (plane_in > plane_out ? plane_in : plane_out) * 8 >= (1ll << 31)) return GEOBO_E_ALIGN;
   AxisArgs g;
   g.in = in; g.out = out; g.basis = basis; g.C = C; g.Si = plane_in; g.So = plane_out; g.item_in = item_in; g.item_out = item_out; g.R = items;
+  g.mask_ends = (mask_ends && !inverse) ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   switch (n) {
     case 80: return launch_axis<80>(g, inverse != 0, st);

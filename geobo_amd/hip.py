@@ -645,12 +645,12 @@ def spectral_y3t(ny, C, R, src_g, src_m, tabs_g, tabs_m, outs, plane=None):
 # SPECTRAL_AXIS_N (plan.py): extents of the radix-4 axis passes (geobo_spectral_axis); half-integer basis only
 
 
-def spectral_axis(inverse, n, C, plane_in, plane_out, item_in, item_out, items, src, dst):
+def spectral_axis(inverse, n, C, plane_in, plane_out, item_in, item_out, items, src, dst, mask_ends=False):
     """One axis pass along a strided axis against the half-integer basis G of size n (geobo_spectral_axis): analysis n -> 2n planes or
-    synthesis 2n -> n planes of C contiguous modes per item."""
+    synthesis 2n -> n planes of C contiguous modes per item.  mask_ends (analysis): input planes 0 and n - 1 count as zero."""
     lib = require_gpu()
     _lib.check(lib.geobo_spectral_axis(1 if inverse else 0, int(n), int(C), int(plane_in), int(plane_out), int(item_in), int(item_out), int(items),
-                                       _p(_chk(src, "src")), _p(_chk(dst, "dst")), _p(spectral_y_basis(n, src.device)), _stream()),
+                                       _p(_chk(src, "src")), _p(_chk(dst, "dst")), _p(spectral_y_basis(n, src.device)), 1 if mask_ends else 0, _stream()),
                "geobo_spectral_axis")
     return dst
 

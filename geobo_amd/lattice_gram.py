@@ -189,7 +189,11 @@ class LatticeGram:
             W = sp.buf("LG_W", R * Px * nz * Py)
             hip.lattice_wbuild(Rb, Py, Px, nz, lamW, lh, W)
             U = sp.buf("LG_U", R * nx * nz * Py)
-            hip.axis_pass(sp.fold, True, True, hip.pad_n(nx), nz * Py, Px, sp.GT["x"], Px, 0, W, nz * Py, Px * nz * Py, U, nz * Py, nx * nz * Py, nx, nz * Py, Rb)
+            if sp.x_mfma and (nz * Py) % 16 == 0 and 2 * nx * nz * Py * 8 < (1 << 31):
+                # x synthesis as a radix-4 axis pass (geobo_spectral_axis): nz Py contiguous modes per plane, Px -> nx planes per row
+                hip.spectral_axis(True, nx, nz * Py, nz * Py, nz * Py, Px * nz * Py, nx * nz * Py, Rb, W, U)
+            else:
+                hip.axis_pass(sp.fold, True, True, hip.pad_n(nx), nz * Py, Px, sp.GT["x"], Px, 0, W, nz * Py, Px * nz * Py, U, nz * Py, nx * nz * Py, nx, nz * Py, Rb)
             hip.axis_pass(sp.fold and 2, False, 2, hip.pad_n(ny), nx * nz, Py, self._GyT0, Py, 0, U, Py, nx * nz * Py, out[r0:], nx * nz, out.stride(0), ny, nx * nz, Rb)
 
     def transpose_tables3(self, lam):
@@ -335,6 +339,9 @@ class LatticeGram:
                 # G_y in registers, rows streamed once; radix 2 where the slab starts on an even y (Gy0 keeps the pair structure: its
                 # zeroed columns are zero in both rows of a pair)
                 hip.ymul(Py, Ly, plane, R, gy, X[r0:], X.stride(0), y1b, Py * plane, fold=sp.fold and y0 % 2 == 0)
+            elif sp.axis_mfma(ny) and y0 == 0 and Ly == ny and plane % 16 == 0 and 2 * ny * plane * 8 < (1 << 31) and X.stride(0) >= ny * plane:
+                # the whole y axis: radix-4 axis pass, the two boundary slabs masked inside the kernel (what Gy0's zeroed columns do)
+                hip.spectral_axis(False, ny, plane, plane, plane, X.stride(0), Py * plane, R, X[r0:], y1b, mask_ends=True)
             else:
                 # (radix-2 when the slab starts on an even y: the parity of the local input index is the basis row pair's)
                 hip.axis_pass(sp.fold and y0 % 2 == 0, True, False, hip.pad_n(Py), hip.pad_n(plane), Ly, gy, ny, 0, X[r0:], plane, X.stride(0),

@@ -195,7 +195,7 @@ class SpectralProduct:
         # same arguments, same sums to rounding; GEOBO_Y_MFMA=0 keeps the direct vector-pipe kernels: the A/B of profiles/r06_*)
         self.y_mfma = self.dense_y and ny in hip.SPECTRAL_Y_NY and self.opts["y_mfma"]
         # x passes of the unfused (x, z) transforms: radix-4 axis kernels on the half-integer basis (geobo_spectral_axis) where instantiated
-        self.x_mfma = nx in hip.SPECTRAL_AXIS_N and half_integer(nx) and self.opts.get("axis_mfma", True)
+        self.x_mfma = self.axis_mfma(nx)
         # x and z: one fused kernel per direction (geobo_xz2d) where it is instantiated, else two batched GEMM passes
         self.fused_xz = (nx, nz) in hip.XZ2D_SHAPES and self.opts["fused_xz"]
         # 32 x 32 planes: two consecutive y-planes stacked along x go through the (64, 32) instance with diag(Mx, Mx) -- the z step
@@ -235,6 +235,10 @@ class SpectralProduct:
         self.R = max(g, rows_per_batch // g * g)
         self._bufs = {}
         self.kernel_timer = None     # callable(name, algorithmic_bytes, fn) -> fn(): the engine's HIP-event bracket for single kernels
+
+    def axis_mfma(self, n):
+        """True where a pass along a strided axis of extent n runs as a radix-4 axis kernel (geobo_spectral_axis)."""
+        return n in hip.SPECTRAL_AXIS_N and half_integer(n) and self.opts.get("axis_mfma", True)
 
     def _ystage(self, ny, C, R, src, tabs, outs, y0, y1, plane, accumulate=False):
         """geobo_toeplitz_y launch, bracketed for the bench's per-kernel roofline when a timer is set: algorithmic bytes = the rows'

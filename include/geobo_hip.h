@@ -437,9 +437,11 @@ int geobo_spectral_y3t(int ny, int64_t C, int64_t plane, int64_t R, int nprop, c
  * sin(n/2 + k), -sin(n/2 - k)}, k = w + 1/2) -- the drop-in for geobo_gemm_fold / geobo_gemm_batched with that matrix on the X side,
  * radix 4 on MFMA (n^2 / 2 multiply-adds per item and mode), data straight from global memory into the operand layout.
  * c < C contiguous modes (C % 16 == 0); planes plane_in / plane_out doubles apart, items item_in / item_out doubles apart.
+ * mask_ends != 0 (analysis only): the input planes 0 and n - 1 count as zero -- the y step of the lattice Gram, whose boundary slabs
+ * (the +-1e6 m padding of A_sens) do not enter the stencil correlation.
  * basis: the blob of geobo_spectral_y_basis(n).  n in {80, 96, 112, 128}; GEOBO_E_UNSUPPORTED otherwise. */
 int geobo_spectral_axis(int inverse, int n, int64_t C, int64_t plane_in, int64_t plane_out, int64_t item_in, int64_t item_out, int64_t items,
-                        const double* in, double* out, const double* basis, void* stream);
+                        const double* in, double* out, const double* basis, int mask_ends, void* stream);
 
 /* In-place lower Cholesky of the (m x m, ld) matrix A, m % 256 == 0 (padding rows/cols = identity);
  * scipy.linalg.cholesky(AkA, lower=True), inversion.py:100.  Also writes Linv = L^-1 (m x m, ldi; lower,

@@ -713,6 +713,11 @@ def test_spectral_axis_matches_the_basis_matrix(hip, n, C, items):
     assert bool((back[:, n:, :] == 7.0).all()) and bool((back[:, :, C:] == 7.0).all())
     with pytest.raises(RuntimeError):
         hip.spectral_axis(False, 64, C, S, S, (n + 1) * S, (P + 2) * S, items, x.reshape(-1), out.reshape(-1))
+    # boundary planes masked inside the kernel (the lattice Gram's y step)
+    hip.spectral_axis(False, n, C, S, S, (n + 1) * S, (P + 2) * S, items, x.reshape(-1), out.reshape(-1), mask_ends=True)
+    torch.cuda.synchronize()
+    ref = torch.einsum("pi,ric->rpc", G[:, 1:n - 1], x[:, 1:n - 1, :C])
+    assert normwise(out[:, :P, :C].cpu().numpy(), ref.cpu().numpy()) < 1e-13
 
 
 @pytest.mark.parametrize("ny,C,R", [(64, 256, 5), (64, 16384, 11), (48, 128, 9), (32, 1024, 30), (64, 128, 1), (64, 528, 8)])
