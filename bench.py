@@ -28,6 +28,8 @@ Prints ONE JSON line on rank 0 (see the driver contract); extra objects:
                 geobo_posterior_reduce, --method dense: geobo_ak_fused_grid -- fp64 MFMA, algorithmic flop against 78.6 TFLOP/s.)
   roofline_assembly  the HBM-bound regime of SURVEY 8(d): one materialised covariance block (geobo_k_block), bytes written per
                 launch / HIP-event duration against 8 TB/s (outside the timed steps)
+  roofline_factorisation  the blocked Cholesky + triangular inverse on fp64 MFMA tiles (geobo_potrf_inv, one persistent launch per step):
+                executed flop / HIP-event duration inside the timed steps against 78.6 TFLOP/s
   cpu_baseline  the NumPy/OpenBLAS oracle (kind "port") timed on this box's host cores on a bounded column sample of
                 the same workload, plus the whole matrix-free oracle step at 16^3 and 32^3 (64^3 extrapolated from 32^3, labelled)
 """
@@ -99,6 +101,25 @@ PMC_VALU_FILES = {"toeplitz_y": "r05_pmc_toeplitz_y_valu.json", "toeplitz_y2t": 
                   "toeplitz_y2s": "r05_pmc_toeplitz_y2s_valu.json", "spectral_y": "r06_pmc_spectral_y_valu.json",
                   "spectral_y2s": "r06_pmc_spectral_y2s_valu.json"}
 GPU_DENSE_ROUTE = "profiles/r06_bench64_dense.json"   # builder-run bench line of `--method dense` (same algorithm as the CPU sample)
+
+
+def factorisation_roofline(stage, steps):
+    """north_star's second evidence item: the blocked Cholesky + L^-1 of AkA (inversion.py:100,105) on fp64 MFMA tiles, ONE persistent
+    tile-DAG launch per step (csrc/potrf.hip), timed with HIP events inside the timed steps; flop = M_pad^3 / 3 (factor) + M_pad^3 / 3
+    (inverse of the triangular factor), the arithmetic the kernel executes on its padded tiles; MFMA issue from the committed counter pass."""
+    sec, fl = stage["seconds"] / steps, stage["flop"] / steps
+    r = {"bound": "mfma", "kernel": "geobo_potrf_inv (potrf_dag_kernel: one launch = L, L^-1, log-determinant)", "achieved": fl / sec / 1e12,
+         "peak": 78.6, "unit": "TFLOP/s", "frac": fl / sec / 78.6e12, "flop_per_launch": fl, "mean_launch_s": sec, "traffic": None,
+         "bound_note": "dependency-chain bound: for 40 of the 66 tile columns at M_pad = 8448 the trailing update is shorter than the chain "
+                       "diagonal tile -> panel -> next diagonal tile (profiles/r05_potrf_dag_trace_8448.txt)"}
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_potrf_dag.json")))
+        r["issue_counters"] = {"mfma_busy_frac_of_simd_cycles": d["derived"]["mfma_busy_frac_of_simd_cycles"],
+                               "source": "profiles/r05_pmc_potrf_dag.json (rocprofv3 --pmc passes of ONE launch at M_pad = 8448; not collected in this run)"}
+        r["traffic"] = d["derived"]["hbm_bytes_per_launch_corrected"]
+    except Exception:
+        pass
+    return r
 
 
 def pmc_traffic(kernel, executed_flop_per_launch):
@@ -632,6 +653,8 @@ def main():
                 "logl_rel": float(abs(inv.logl - float(golden["logl"])) / abs(float(golden["logl"]))), "tolerance": "1e-8 (north_star)"}
         if world == 1 and a.assembly == "f64":
             out["roofline_assembly"] = assembly_roofline(inv, [float(v) for v in inv.gp_length])
+        if "potrf_inv" in stages and stages["potrf_inv"]["flop"] > 0:
+            out["roofline_factorisation"] = factorisation_roofline(stages["potrf_inv"], a.steps)
         if not a.no_cpu and world == 1:   # CPU baseline: rank 0 at N = 1 only
             lengths = inv.gp_length
             cb, (cols, smp) = cpu_baseline(inv, [float(v) for v in lengths])

@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--rank", type=int, default=0)
     ap.add_argument("--drill", type=int, default=50)
     ap.add_argument("--no-oracle", action="store_true")
+    ap.add_argument("--repeat", type=int, default=1, help="passes of the rank's step; the last one is reported, the first as `cold`")
     ap.add_argument("--sequential", action="store_true", help="every rank's posterior share as well: the complete cubes of the 8-rank job "
                     "on this one GPU (0 < var <= 1, data residuals, checksums)")
     a = ap.parse_args()
@@ -110,66 +111,78 @@ def main():
             print("%-34s %8.2f s   (max alloc %.1f GB)" % (key, stamps[key], torch.cuda.max_memory_allocated() / 1e9), file=sys.stderr, flush=True)
         return r
 
-    A_g, A_m = stage("operators (plans, Q, slabs)", lambda: (eng.operator("grav", loc, B=s.magneticField * 0.), eng.operator("magn", loc, B=s.magneticField)))
-    eng._spectral_product()
-    assert eng._rows_ok(A_g, A_m)
-    eng._rowpath = True
-    z = lambda v: (v - v.mean()) / v.std()
-    vd = lambda v: hip.to_dev(np.asarray(v).reshape(-1, 1))
-    grav = apply_rows(eng, A_g, vd(rho))[:, 0].cpu().numpy().astype(np.float32).astype(np.float64)
-    mag = apply_rows(eng, A_m, vd(chi))[:, 0].cpu().numpy().astype(np.float32).astype(np.float64)
-    y_g, y_m, y_d = z(grav), z(mag), (z(rho.reshape(-1)[sel]) if sel.size else np.zeros(0))
-    M_pad = hip.pad_m(2 * Msp + sel.size)
-    # ---- AkA: this rank's row blocks (timed), then the other ranks' (what the all-gather delivers) -------------------------------
-    blocks, drill = [None] * G, None
-    order = [a.rank] + [r for r in range(G) if r != a.rank]
-    for r in order:
-        eng.rank = r
-        key = "A K -> AkA row blocks (this rank)" if r == a.rank else "AkA row blocks of the %d peers" % (G - 1)
-        lo, dr = stage(key, lambda: eng._rows_aka_local(props, sel_t, lengths, W, name, 1.0), quiet=r != a.rank)
-        blocks[r] = lo.clone() if G > 1 else lo
-        drill = dr
-    eng.rank = a.rank
-    AkA = eng._workspace("AkA", (M_pad, M_pad))
-    AkA.zero_()
-    eng._rows_aka_place(AkA, blocks, drill, sel_t)
-    eng._finish_AkA(AkA, M_pad, sel_t, lengths, name, 1.0, s.gp_err)
-    del blocks
-    AkA_low = None
-    if not a.no_oracle:
-        AkA_low = {}          # entries the oracle will look at, read before the factorisation overwrites the matrix
-    sens = [n + 3, (n // 2) * n + n // 3, n * n - 2]
-    if AkA_low is not None:
-        for s_ in (0, 1):
-            for r in sens:
-                row = s_ * Msp + r
-                for t_ in (0, 1):
-                    for r2 in sens:
-                        col = t_ * Msp + r2
-                        if col <= row:
-                            AkA_low[(row, col)] = float(AkA[row, col].item())
-    ctx = hip.PotrfContext()
-    Linv, info = stage("Cholesky + L^-1", lambda: hip.potrf_inv(AkA, eng._workspace("Linv", (M_pad, M_pad)),
-                                                                eng._workspace("potrf_ws", (hip.potrf_ws_doubles(M_pad),)), ctx=ctx))
-    assert int(info.item()) == 0, "AkA not positive definite"
-    u, stats = hip.trmv_stats(Linv, eng._pad_y(y_g, y_m, y_d, M_pad), AkA)
-    st = stats.cpu().numpy()
-    logl = -0.5 * (st[0] + st[1] + N * np.log(2 * np.pi))
-    # ---- posterior: this rank's share (timed); --sequential: every rank's ----------------------------------------------------------
-    mu_t, var_t = stage("posterior (this rank's rows)", lambda: eng._posterior_rows(Linv, u, sel_t, lengths, W, name, 1.0, props, M_pad))
-    mu = mu_t.cpu().numpy().reshape(3, N)
-    part = (1.0 - var_t).cpu().numpy().reshape(3, N)          # the rank's partial sums of squares (the all-reduce is the identity here)
-    total_ss = part.copy()
-    if a.sequential:
-        for r in range(G):
-            if r != a.rank:
-                eng.rank = r
-                _, v_r = stage("posterior shares of the %d peers" % (G - 1), lambda: eng._posterior_rows(Linv, u, sel_t, lengths, W, name, 1.0, props, M_pad),
-                               quiet=True)
-                total_ss += (1.0 - v_r).cpu().numpy().reshape(3, N)
+    peers, cold = None, None
+    for rep in range(a.repeat):
+        # (--repeat 2: the first pass pays what a process pays once -- code objects of every kernel, the allocator's first 100 GB, the
+        # plans -- and is reported as `cold`; the step a fit loop repeats is the last pass)
+        if rep:
+            cold = dict(stamps)
+            stamps.clear()
+            del ev[:]
+        A_g, A_m = stage("operators (plans, Q, slabs)", lambda: (eng.operator("grav", loc, B=s.magneticField * 0.), eng.operator("magn", loc, B=s.magneticField)))
+        eng._spectral_product()
+        assert eng._rows_ok(A_g, A_m)
+        eng._rowpath = True
+        z = lambda v: (v - v.mean()) / v.std()
+        vd = lambda v: hip.to_dev(np.asarray(v).reshape(-1, 1))
+        grav = apply_rows(eng, A_g, vd(rho))[:, 0].cpu().numpy().astype(np.float32).astype(np.float64)
+        mag = apply_rows(eng, A_m, vd(chi))[:, 0].cpu().numpy().astype(np.float32).astype(np.float64)
+        y_g, y_m, y_d = z(grav), z(mag), (z(rho.reshape(-1)[sel]) if sel.size else np.zeros(0))
+        M_pad = hip.pad_m(2 * Msp + sel.size)
+        # ---- AkA: this rank's row blocks (timed), then the other ranks' (what the all-gather delivers) -------------------------------
+        blocks, drill = [None] * G, None
+        order = [a.rank] + [r for r in range(G) if r != a.rank]
+        for r in order:
+            if r != a.rank and peers is not None:
+                blocks[r] = peers[r]                         # (a repeat: what the all-gather delivers is the first pass's)
+                continue
+            eng.rank = r
+            key = "A K -> AkA row blocks (this rank)" if r == a.rank else "AkA row blocks of the %d peers" % (G - 1)
+            lo, dr = stage(key, lambda: eng._rows_aka_local(props, sel_t, lengths, W, name, 1.0), quiet=r != a.rank)
+            blocks[r] = lo.clone() if G > 1 else lo
+            drill = dr
         eng.rank = a.rank
-    rank_step = sum(stamps[k] for k in ("operators (plans, Q, slabs)", "A K -> AkA row blocks (this rank)", "Cholesky + L^-1",
-                                         "posterior (this rank's rows)"))
+        AkA = eng._workspace("AkA", (M_pad, M_pad))
+        AkA.zero_()
+        eng._rows_aka_place(AkA, blocks, drill, sel_t)
+        eng._finish_AkA(AkA, M_pad, sel_t, lengths, name, 1.0, s.gp_err)
+        peers = blocks
+        del blocks
+        AkA_low = None
+        if not a.no_oracle:
+            AkA_low = {}          # entries the oracle will look at, read before the factorisation overwrites the matrix
+        sens = [n + 3, (n // 2) * n + n // 3, n * n - 2]
+        if AkA_low is not None:
+            for s_ in (0, 1):
+                for r in sens:
+                    row = s_ * Msp + r
+                    for t_ in (0, 1):
+                        for r2 in sens:
+                            col = t_ * Msp + r2
+                            if col <= row:
+                                AkA_low[(row, col)] = float(AkA[row, col].item())
+        ctx = hip.PotrfContext()
+        Linv, info = stage("Cholesky + L^-1", lambda: hip.potrf_inv(AkA, eng._workspace("Linv", (M_pad, M_pad)),
+                                                                    eng._workspace("potrf_ws", (hip.potrf_ws_doubles(M_pad),)), ctx=ctx))
+        assert int(info.item()) == 0, "AkA not positive definite"
+        u, stats = hip.trmv_stats(Linv, eng._pad_y(y_g, y_m, y_d, M_pad), AkA)
+        st = stats.cpu().numpy()
+        logl = -0.5 * (st[0] + st[1] + N * np.log(2 * np.pi))
+        # ---- posterior: this rank's share (timed); --sequential: every rank's ----------------------------------------------------------
+        mu_t, var_t = stage("posterior (this rank's rows)", lambda: eng._posterior_rows(Linv, u, sel_t, lengths, W, name, 1.0, props, M_pad))
+        mu = mu_t.cpu().numpy().reshape(3, N)
+        part = (1.0 - var_t).cpu().numpy().reshape(3, N)          # the rank's partial sums of squares (the all-reduce is the identity here)
+        total_ss = part.copy()
+        if a.sequential and rep == a.repeat - 1:
+            for r in range(G):
+                if r != a.rank:
+                    eng.rank = r
+                    _, v_r = stage("posterior shares of the %d peers" % (G - 1), lambda: eng._posterior_rows(Linv, u, sel_t, lengths, W, name, 1.0, props, M_pad),
+                                   quiet=True)
+                    total_ss += (1.0 - v_r).cpu().numpy().reshape(3, N)
+            eng.rank = a.rank
+        rank_step = sum(stamps[k] for k in ("operators (plans, Q, slabs)", "A K -> AkA row blocks (this rank)", "Cholesky + L^-1",
+                                             "posterior (this rank's rows)"))
     checks = {}
     if not a.no_oracle:
         from scipy.linalg import solve_triangular
@@ -259,7 +272,7 @@ def main():
     out = dict(what="BASELINE config 5: rank %d of %d in the row form, %d^3 voxels x 3 properties, fp32 covariance tables, streamed operators"
                     % (a.rank, G, n),
                route=eng.route.describe(), N_voxels=N, M_rows=2 * Ms + sel.size, M_pad=M_pad, covariance_tables="fp32-rounded",
-               wall_seconds=stamps, rank_step_seconds=rank_step, logl=float(logl),
+               wall_seconds=stamps, rank_step_seconds=rank_step, wall_seconds_cold_pass=cold, logl=float(logl),
                kernel_stage_seconds={k: round(v["seconds"], 3) for k, v in stages.items()},
                kernel_stage_tflops_executed={k: round(v["flop"] / v["seconds"] / 1e12, 2) for k, v in stages.items() if v["flop"] > 0 and v["seconds"] > 0},
                memory_map_GB=dict(sorted(ws_gb.items(), key=lambda kv: -kv[1])[:24]), max_memory_allocated_GB=torch.cuda.max_memory_allocated() / 1e9,

@@ -14,6 +14,7 @@ cp gpurun_out/pmc_xz2d_fold_inv_mul_valu.json gpurun_out/${R}_pmc_xz2d_fold_inv_
 python tools/pmc_collect.py kblock_grid > /dev/null 2>&1; cp gpurun_out/pmc_k_block_grid_f64.json gpurun_out/${R}_pmc_k_block_grid_f64.json
 for k in fold_fwd fold_bwd fold_inv_ss fold_inv_mul xcorr_fold ymul toeplitz toeplitz2s spectral_y spectral_y1 spectral_y2s spectral_y128 spectral_y3t128; do python tools/run_spectral_kernels_once.py $k 2>&1 | grep -v amdgpu.ids | tail -1; done > gpurun_out/${R}_spectral_kernels_once.txt
 (python tools/time_toeplitz.py; python tools/time_toeplitz.py 96; python tools/time_toeplitz.py 128) 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_time_y_stage.txt
+(python tools/time_axis_passes.py 96 16; python tools/time_axis_passes.py 128 16) 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_time_axis_passes.txt
 # the driver's command, then the same under rocprofv3 (kernel stats), then the A/B with the direct y stage on the same box
 python bench.py --steps 20 --warmup 5 2> gpurun_out/${R}_bench64.err | grep '^{' > gpurun_out/${R}_bench64_spectral.json
 (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_b && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu 2>/dev/null | grep '^{' > $ROOT/gpurun_out/${R}_bench64_spectral_under_rocprof.json; cp $(find /tmp/prof_b -name "*kernel_stats.csv" | head -1) $ROOT/gpurun_out/${R}_bench64_spectral_kernel_stats.csv)

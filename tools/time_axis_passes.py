@@ -1,4 +1,4 @@
-"""Warm timing of the radix-2 batched axis passes (geobo_gemm_fold) of a grid without fused (x, z) kernels: the four passes of one
+"""Warm timing of the batched axis passes (radix-2 GEMM passes geobo_gemm_fold; round 6: + the radix-4 axis kernels geobo_spectral_axis) of a grid without fused (x, z) kernels: the four passes of one
 covariance product (z and x analysis, x and z synthesis) on R rows of an n^3 grid, HIP events around 10 repetitions of each.
     python tools/time_axis_passes.py [n = 128] [R = 16]"""
 import os, sys
@@ -29,6 +29,12 @@ passes = {
     "z synthesis (INV_Z)": (lambda: hip.axis_pass(fold, False, True, hip.pad_n(ny * nx), hip.pad_n(nz), Pz, u1, Pz, ny * nx * Pz, sp.GT["z"], Pz, 0, out, nz, N, ny * nx, nz, R),
                             R * ny * nx * nz * Pz * 1.0, 8.0 * R * (ny * nx * Pz + N)),
 }
+if sp.x_mfma:
+    # round 6: the x passes as radix-4 axis kernels on the half-integer basis (geobo_spectral_axis: n^2 / 2 multiply-adds per item and mode)
+    passes["x analysis  (axis kernel)"] = (lambda: hip.spectral_axis(False, nx, Pz, Pz, Pz, nx * Pz, Px * Pz, R * ny, t1, t2),
+                                           R * ny * Px * Pz * nx * 0.5, 8.0 * R * ny * (nx * Pz + Px * Pz))
+    passes["x synthesis (axis kernel)"] = (lambda: hip.spectral_axis(True, nx, Pz, Pz, Pz, Px * Pz, nx * Pz, R * ny, t2, u1),
+                                           R * ny * nx * Pz * Px * 0.5, 8.0 * R * ny * (Px * Pz + nx * Pz))
 for name, (f, flop, by) in passes.items():
     for _ in range(3): f()
     torch.cuda.synchronize()
