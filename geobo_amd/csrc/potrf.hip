@@ -133,13 +133,14 @@ __global__ void __launch_bounds__(256) potf2_inv_kernel(double* __restrict__ A, 
 //   * the trailing matrix and the running inverse live in REGISTERS as 16 x 16 fp64 MFMA accumulator tiles (D layout), owned by
 //     COLUMN: wave w of the four holds the tiles (i, c), i >= c, of columns c = w and c = w + 4 of both A and Y (12 - 2 w tiles each);
 //   * step s: the owner of column s puts its tiles (i, s), i >= s, into LDS (one of two panel buffers);  barrier;
-//     EVERY wave factorises the 16 x 16 pivot tile redundantly, lane r (mod 16) holding row r, partners' values through v_readlane
-//     (no LDS, no barrier: the four 16-lane groups of a wave carry identical copies), and inverts it by forward substitution with
-//     lane c holding column c;  the panel tiles L_is = A_is X_ss^T (i > s; 4 MFMAs each, spread over the waves) go back to the same
+//     EVERY wave factorises and inverts the 16 x 16 pivot tile redundantly, without LDS memory or barriers (round 6: row layout, the
+//     four 16-lane groups of the wave sharing the columns, partners' values through v_readlane and the LDS crossbar -- see step (2) of
+//     potf2b_body);  the panel tiles L_is = A_is X_ss^T (i > s; 4 MFMAs each, spread over the waves) go back to the same
 //     LDS rows and to memory;  barrier;  every wave updates its own tiles:  A_ic -= L_is L_cs^T (c > s)  and -- forward substitution
 //     of the inverse fused in, as in the column kernel --  X_sc = X_ss Y_sc (c < s; its own register tile is the B operand),
 //     Y_ic -= L_is X_sc (i > s, c <= s; B operand = the X_sc tile the same wave has just finished: column ownership keeps it local).
-// Same arithmetic as the column kernel up to summation order; IEEE sqrt and division kept in the pivot.
+// Same recurrences as the column kernel up to summation order; the pivot's sqrt(d) and 1 / sqrt(d) come from one v_rsq_f64 seed (an
+// ulp or two from the IEEE pair of the column kernel).
 constexpr int PS = 17;   // LDS row stride of a 16-wide panel in doubles (conflict-free b64 fragment reads)
 
 template <int I, int E, class F>
@@ -161,6 +162,28 @@ __device__ __forceinline__ void stg(double* p, double v) {
   else *p = v;
 }
 
+// 1 / sqrt(d) and sqrt(d) from one v_rsq_f64 seed y (good to ~ 2^-26): ONE third-order step, y (1 + e / 2 + 3 e^2 / 8) with
+// e = 1 - d y^2 -- four dependent operations where the coupled Newton form needs ten and the IEEE sqrt + division about thirty (the
+// reciprocal is what the column step's chain waits for); sqrt(d) = d y' with one residual correction, off that chain.  Both within an ulp
+// or two of the IEEE pair.  d <= 0 or NaN gives NaN (the caller raises info).
+__device__ __forceinline__ void rsqrt_pair(double d, double& rt, double& rinv) {
+  const double y = __builtin_amdgcn_rsq(d);
+  const double t = d * y;
+  const double e = __builtin_fma(-t, y, 1.0);
+  const double p = __builtin_fma(0.375, e, 0.5), q = y * e;
+  const double ri = __builtin_fma(q, p, y);
+  double g = d * ri;
+  g = __builtin_fma(__builtin_fma(-g, g, d), 0.5 * ri, g);
+  rt = g;
+  rinv = ri;
+}
+
+// v of the lane whose byte index (4 x lane) is given: the LDS crossbar, no memory access
+__device__ __forceinline__ double bperm(double v, int byte_lane) {
+  const int lo = __builtin_amdgcn_ds_bpermute(byte_lane, __double2loint(v)), hi = __builtin_amdgcn_ds_bpermute(byte_lane, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double rdlane(double v, int lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
   return __hiloint2double(hi, lo);
@@ -176,8 +199,7 @@ template <int W> struct Own {
 
 template <int W, bool PUB>
 __device__ __forceinline__ void potf2b_body(double* __restrict__ A, int64_t ld, double* __restrict__ Linv, int64_t ldi, int kb_global,
-                                            int* __restrict__ info, double (&pan)[2][NB][PS], double (&xss)[4][16][PS],
-                                            double (&bc)[4][2][16]) {
+                                            int* __restrict__ info, double (&pan)[2][NB][PS], double (&xss)[4][16][PS]) {
   using O = Own<W>;
   constexpr int NT = O::NT;
   const int lane = threadIdx.x & 63, lr = lane & 15, q4 = lane >> 4;
@@ -204,51 +226,89 @@ __device__ __forceinline__ void potf2b_body(double* __restrict__ A, int64_t ld, 
       });
     }
     __syncthreads();
-    // (2) pivot tile, redundantly in every wave, in the accumulator (D) layout: lane (q4, lr) holds rows q4 + 4 r of column lr of the
-    //     tile and of its running inverse.  Column step j: column j of the tile and row j of the inverse go through this wave's own
-    //     2 x 16 doubles of LDS (wave-local: program order, no barrier), then one rank-1 update of both.  Entries above the diagonal of
-    //     the tile carry don't-care values (never read back; the store masks them).
-    double t[4], xt[4];
+    // (2) pivot tile, redundantly in every wave.
+    // ROW layout (round 6), the four 16-lane groups of the wave sharing the columns -- lane (g, i) = 16 g + i holds the entries
+    // T_i[4 k + g], k < 4, of row i of the tile and the same entries of the running inverse: 2 x 4 registers, every lane does a quarter of
+    // a row's updates (the accumulator-layout pivot of round 4 went through two LDS round trips and ~ 100 instructions per column step, the
+    // same count as a row-per-lane form in which the four groups repeat each other: 250 ns per column, 128 columns per diagonal block,
+    // on the chain of the whole factorisation).  Column step j: the pivot out of lane (j % 4, j) by v_readlane; 1 / sqrt(d) from
+    // v_rsq_f64 (one third-order step: no IEEE sqrt, no division); the scaled column j, which lives in group j % 4,
+    // reaches every lane that needs an entry of it -- its own row's l_ij, and l_cj for the columns c it holds -- by ds_bpermute (the LDS
+    // crossbar: no memory, no barrier); rows of the inverse are kept UNSCALED (Y_j, with X_j = Y_j / l_jj applied once at the end), so a
+    // step's inverse update is one fused multiply-add per held column against Y_j[c] fetched from lane (g, j).
+    const int g4 = q4, byte_i = 4 * lr, byte_g = 64 * q4;
+    double T[4], Yr[4], rinv_mine = 1.0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      t[r] = pan[buf][16 * s + q4 + 4 * r][lr];
-      xt[r] = (q4 + 4 * r == lr) ? 1.0 : 0.0;
+    for (int k = 0; k < 4; ++k) {
+      T[k] = pan[buf][16 * s + lr][4 * k + g4];
+      Yr[k] = (4 * k + g4 == lr) ? 1.0 : 0.0;
     }
+    // Software-pipelined: the step's crossbar fetches are issued first, and while they are in flight the pivot of the NEXT column is
+    // formed beside them instead of being fetched back through the updates -- d_{j+1} = t - l^2 with t, the entry (j+1, j+1) as the
+    // previous step left it (read ahead by v_readlane), and l = l_{j+1,j} read out of the scaled column the same way: the same fused
+    // multiply-add the owning lane applies to its own copy (identical bits) -- and its reciprocal square root is taken.  What remains on
+    // the loop-carried chain is scale -> crossbar -> one multiply-add.  A non-positive / NaN pivot is recorded without a branch and raised
+    // after the tile.
+    double d = rdlane(T[0], 0);
+    int badj = (d > 0.0) ? -1 : 0;
+    double rt, rinv;
+    rsqrt_pair(d, rt, rinv);
+    double tn = rdlane(T[0], 17);                              // entry (1, 1)
     sfor<0, 16>([&](auto jj) {
-      constexpr int j = decltype(jj)::value, jr = j / 4, jq = j % 4;
-      if (lr == j) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bc[W][0][q4 + 4 * r] = t[r];
+      constexpr int j = decltype(jj)::value, gj = j % 4, kj = j / 4;
+      const double lsrc = (lr > j) ? T[kj] * rinv : 0.0;       // column j below the diagonal, scaled (meaningful in group gj; 0 in the rows <= j)
+      const double li = bperm(lsrc, 64 * gj + byte_i);         // l_ij of this lane's row
+      double lc[4], yj[4];
+      sfor<kj, 4>([&](auto kk) {                               // l_cj of the held column c = 4 k + g (0 for c <= j: the update is a no-op there)
+        constexpr int k = decltype(kk)::value;
+        lc[k] = bperm(lsrc, 64 * gj + 16 * k + 4 * g4);
+      });
+      sfor<0, kj + 1>([&](auto kk) {                           // Y_jc of the held columns (c > j: zero)
+        constexpr int k = decltype(kk)::value;
+        yj[k] = bperm(Yr[k], byte_g + 4 * j);
+      });
+      double rt_n = rt, rinv_n = rinv;
+      if constexpr (j < 15) {
+        const double ln = rdlane(lsrc, 16 * gj + j + 1);
+        d = __builtin_fma(-ln, ln, tn);
+        badj = (badj < 0 && !(d > 0.0)) ? j + 1 : badj;
+        rsqrt_pair(d, rt_n, rinv_n);
       }
-      if (q4 == jq) bc[W][1][lr] = xt[jr];
-      __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0)
-      const double d = bc[W][0][j];
-      double ci[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) ci[r] = bc[W][0][q4 + 4 * r];
-      const double cc = bc[W][0][lr], xr = bc[W][1][lr];
-      if (!(d > 0.0) && !bad_seen) {   // non-positive or NaN pivot: LAPACK dpotrf's info (1-based)
-        bad_seen = true;
-        if (threadIdx.x == 0 && *info == 0) *info = kb_global + 16 * s + j + 1;
-      }
-      const double rt = sqrt(d), rinv = 1.0 / rt;
-      const double lc = (lr > j) ? cc * rinv : 0.0;            // l_cj for this lane's column (columns <= j are finished)
-      const double xj = xr * rinv;                             // row j of the inverse, final (zero right of the diagonal)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = q4 + 4 * r;
-        const double li = ci[r] * rinv;
-        t[r] = __builtin_fma(-li, lc, t[r]);                   // rows <= j, columns > j: above the diagonal (don't care)
-        if (lr == j) t[r] = row > j ? li : (row == j ? rt : t[r]);
-        xt[r] = row > j ? __builtin_fma(-li, xj, xt[r]) : (row == j ? xj : xt[r]);
-      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (g4 == gj) T[kj] = (lr == j) ? rt : lsrc;             // column j is final (rows < j: above the diagonal, zero)
+      sfor<kj, 4>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        T[k] = __builtin_fma(-li, lc[k], T[k]);
+      });
+      const double li2 = li * rinv;
+      sfor<0, kj + 1>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        Yr[k] = __builtin_fma(-li2, yj[k], Yr[k]);             // Y_ic -= l_ij / l_jj Y_jc  (rows <= j: l = 0)
+      });
+      rinv_mine = (lr == j) ? rinv : rinv_mine;
+      if constexpr (j < 14) tn = rdlane(T[(j + 2) / 4], 16 * ((j + 2) % 4) + j + 2);
+      rt = rt_n;
+      rinv = rinv_n;
     });
-#pragma unroll
-    for (int r = 0; r < 4; ++r) xss[W][q4 + 4 * r][lr] = xt[r];      // row-major X_ss, this wave's own copy
+    if (badj >= 0 && !bad_seen) {      // non-positive or NaN pivot: LAPACK dpotrf's info (1-based), the first one wins
+      bad_seen = true;
+      if (threadIdx.x == 0 && *info == 0) *info = kb_global + 16 * s + badj + 1;
+    }
+    // back to the accumulator (D) layout through this wave's own 16 x 16 LDS tile (wave-local: program order, no barrier)
+    double xt[4];
     if constexpr (s % 4 == W) {                                // L_ss to memory (upper part zero) by the column's owner
 #pragma unroll
-      for (int r = 0; r < 4; ++r) stg<PUB>(A + (int64_t)(16 * s + q4 + 4 * r) * ld + 16 * s + lr, (lr <= q4 + 4 * r) ? t[r] : 0.0);
+      for (int k = 0; k < 4; ++k) xss[W][lr][4 * k + g4] = T[k];
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        stg<PUB>(A + (int64_t)(16 * s + q4 + 4 * r) * ld + 16 * s + lr, (lr <= q4 + 4 * r) ? xss[W][q4 + 4 * r][lr] : 0.0);
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xss[W][lr][4 * k + g4] = Yr[k] * rinv_mine;     // row-major X_ss, this wave's own copy
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xt[r] = xss[W][q4 + 4 * r][lr];
     __builtin_amdgcn_s_waitcnt(0xc07f);                        // lgkmcnt(0): this wave's xss copy is written (wave-local: no barrier)
     // MFMA fragments of X_ss: A[i = lr][k = 4 t + q4] (also B[k][j] = X_ss^T: the same addresses)
     double xf[4];
@@ -325,13 +385,12 @@ __global__ void __launch_bounds__(256) potf2b_inv_kernel(double* __restrict__ A,
                                                          int kb_global, int* __restrict__ info) {
   __shared__ double pan[2][NB][PS];
   __shared__ double xss[4][16][PS];
-  __shared__ double bc[4][2][16];
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   switch (w) {     // four specialisations: the tile lists differ per wave, every register index is static; all hit the same barriers
-    case 0: potf2b_body<0, false>(A, ld, Linv, ldi, kb_global, info, pan, xss, bc); break;
-    case 1: potf2b_body<1, false>(A, ld, Linv, ldi, kb_global, info, pan, xss, bc); break;
-    case 2: potf2b_body<2, false>(A, ld, Linv, ldi, kb_global, info, pan, xss, bc); break;
-    default: potf2b_body<3, false>(A, ld, Linv, ldi, kb_global, info, pan, xss, bc); break;
+    case 0: potf2b_body<0, false>(A, ld, Linv, ldi, kb_global, info, pan, xss); break;
+    case 1: potf2b_body<1, false>(A, ld, Linv, ldi, kb_global, info, pan, xss); break;
+    case 2: potf2b_body<2, false>(A, ld, Linv, ldi, kb_global, info, pan, xss); break;
+    default: potf2b_body<3, false>(A, ld, Linv, ldi, kb_global, info, pan, xss); break;
   }
 }
 
@@ -534,12 +593,11 @@ __device__ __forceinline__ int dag_bcast(int* sh, int v) {
 __device__ __noinline__ void potf2b_dag(double* T, int64_t ld, double* D, int64_t ldi, int kb_global, int* info, double* smem) {
   double (&pan)[2][NB][PS] = *reinterpret_cast<double (*)[2][NB][PS]>(smem);
   double (&xss)[4][16][PS] = *reinterpret_cast<double (*)[4][16][PS]>(smem + 2 * NB * PS);
-  double (&bc)[4][2][16] = *reinterpret_cast<double (*)[4][2][16]>(smem + 2 * NB * PS + 4 * 16 * PS);
   switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {
-    case 0: potf2b_body<0, true>(T, ld, D, ldi, kb_global, info, pan, xss, bc); break;
-    case 1: potf2b_body<1, true>(T, ld, D, ldi, kb_global, info, pan, xss, bc); break;
-    case 2: potf2b_body<2, true>(T, ld, D, ldi, kb_global, info, pan, xss, bc); break;
-    default: potf2b_body<3, true>(T, ld, D, ldi, kb_global, info, pan, xss, bc); break;
+    case 0: potf2b_body<0, true>(T, ld, D, ldi, kb_global, info, pan, xss); break;
+    case 1: potf2b_body<1, true>(T, ld, D, ldi, kb_global, info, pan, xss); break;
+    case 2: potf2b_body<2, true>(T, ld, D, ldi, kb_global, info, pan, xss); break;
+    default: potf2b_body<3, true>(T, ld, D, ldi, kb_global, info, pan, xss); break;
   }
 }
 
