@@ -111,11 +111,12 @@ def factorisation_roofline(stage, steps):
     r = {"bound": "mfma", "kernel": "geobo_potrf_inv (potrf_dag_kernel: one launch = L, L^-1, log-determinant)", "achieved": fl / sec / 1e12,
          "peak": 78.6, "unit": "TFLOP/s", "frac": fl / sec / 78.6e12, "flop_per_launch": fl, "mean_launch_s": sec, "traffic": None,
          "bound_note": "dependency-chain bound: for 40 of the 66 tile columns at M_pad = 8448 the trailing update is shorter than the chain "
-                       "diagonal tile -> panel -> next diagonal tile (profiles/r05_potrf_dag_trace_8448.txt)"}
+                       "diagonal tile -> panel -> next diagonal tile (profiles/r06_potrf_dag_trace_8448.txt)"}
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_potrf_dag.json")))
+        pf = [f for f in ("r06_pmc_potrf_dag.json", "r05_pmc_potrf_dag.json") if os.path.exists(os.path.join(ROOT, "profiles", f))][0]
+        d = json.load(open(os.path.join(ROOT, "profiles", pf)))
         r["issue_counters"] = {"mfma_busy_frac_of_simd_cycles": d["derived"]["mfma_busy_frac_of_simd_cycles"],
-                               "source": "profiles/r05_pmc_potrf_dag.json (rocprofv3 --pmc passes of ONE launch at M_pad = 8448; not collected in this run)"}
+                               "source": "profiles/%s (rocprofv3 --pmc passes of ONE launch at M_pad = 8448; not collected in this run)" % pf}
         r["traffic"] = d["derived"]["hbm_bytes_per_launch_corrected"]
     except Exception:
         pass

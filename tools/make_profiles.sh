@@ -12,6 +12,8 @@ for f in pmc_spectral_y pmc_spectral_y2s pmc_spectral_y128 pmc_toeplitz_y pmc_to
 for k in fold_inv_mul fold_inv_ss; do python tools/pmc_collect.py $k valu > /dev/null 2>&1; done
 cp gpurun_out/pmc_xz2d_fold_inv_mul_valu.json gpurun_out/${R}_pmc_xz2d_fold_inv_mul_valu.json; cp gpurun_out/pmc_xz2d_fold_inv_ss_valu.json gpurun_out/${R}_pmc_xz2d_fold_inv_ss_valu.json
 python tools/pmc_collect.py kblock_grid > /dev/null 2>&1; cp gpurun_out/pmc_k_block_grid_f64.json gpurun_out/${R}_pmc_k_block_grid_f64.json
+for k in potrf_dag axis128_fwd axis128_inv; do python tools/pmc_collect.py $k > /dev/null 2>&1; done
+cp gpurun_out/pmc_potrf_dag.json gpurun_out/${R}_pmc_potrf_dag.json; cp gpurun_out/pmc_spectral_axis128_fwd.json gpurun_out/${R}_pmc_spectral_axis128_fwd.json; cp gpurun_out/pmc_spectral_axis128_inv.json gpurun_out/${R}_pmc_spectral_axis128_inv.json
 for k in fold_fwd fold_bwd fold_inv_ss fold_inv_mul xcorr_fold ymul toeplitz toeplitz2s spectral_y spectral_y1 spectral_y2s spectral_y128 spectral_y3t128; do python tools/run_spectral_kernels_once.py $k 2>&1 | grep -v amdgpu.ids | tail -1; done > gpurun_out/${R}_spectral_kernels_once.txt
 (python tools/time_toeplitz.py; python tools/time_toeplitz.py 96; python tools/time_toeplitz.py 128) 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_time_y_stage.txt
 (python tools/time_axis_passes.py 96 16; python tools/time_axis_passes.py 128 16) 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_time_axis_passes.txt

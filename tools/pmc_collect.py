@@ -31,6 +31,8 @@ DRIVERS = {"posterior": ("run_posterior_once.py", "gemm_f64_kernel<4, 2, 2, 1", 
            "spectral_y2s": ("run_spectral_kernels_once.py spectral_y2s", "spectral_y_kernel<64, 2, 2", "pmc_spectral_y2s.json"),
            "spectral_y128": ("run_spectral_kernels_once.py spectral_y128", "spectral_y_split_kernel<128, 1, 3", "pmc_spectral_y128.json"),
            "spectral_y128_1": ("run_spectral_kernels_once.py spectral_y128_1", "spectral_y_split_kernel<128, 1, 1", "pmc_spectral_y128_1.json"),
+           "axis128_fwd": ("run_spectral_kernels_once.py axis128_fwd", "spectral_axis_kernel<128, false", "pmc_spectral_axis128_fwd.json"),
+           "axis128_inv": ("run_spectral_kernels_once.py axis128_inv", "spectral_axis_kernel<128, true", "pmc_spectral_axis128_inv.json"),
            "xcorr": ("run_spectral_kernels_once.py xcorr", "xcorr_kernel", "pmc_xcorr.json"),
            "fold_fwd": ("run_spectral_kernels_once.py fold_fwd", "xz_fold_fwd_kernel", "pmc_xz2d_fold_fwd.json"),
            "fold_bwd": ("run_spectral_kernels_once.py fold_bwd", "xz_fold_inv_kernel", "pmc_xz2d_fold_bwd.json"),

@@ -74,6 +74,16 @@ if which in ("spectral_y128", "spectral_y128_1", "spectral_y3t128"):
     else:
         timed("spectral_y3t128", Rb * C * (5.0 * ny_ * ny_ + 38.0 * ny_), Rb * ny_ * C * 8.0 * 5, lambda: hip.spectral_y3t(ny_, C, Rb, src_g, src_m, t6[:3], t6[3:], outs))
     del src_g, src_m, t6, outs
+if which in ("axis128_fwd", "axis128_inv"):
+    # radix-4 axis passes (geobo_spectral_axis) at the x-pass shape of a 128^3 batch: 16 rows x 128 y-planes = 2048 items of
+    # 128 <-> 256 planes x 256 contiguous modes
+    n_, Pz_, items = 128, 256, 16 * 128
+    lo, hi = rnd(items * n_ * Pz_), rnd(items * 2 * n_ * Pz_)
+    if which == "axis128_fwd":
+        timed("axis128_fwd", items * Pz_ * 2.0 * n_ * n_, items * Pz_ * 8.0 * 3 * n_, lambda: hip.spectral_axis(False, n_, Pz_, Pz_, Pz_, n_ * Pz_, 2 * n_ * Pz_, items, lo, hi))
+    else:
+        timed("axis128_inv", items * Pz_ * 2.0 * n_ * n_, items * Pz_ * 8.0 * 3 * n_, lambda: hip.spectral_axis(True, n_, Pz_, Pz_, Pz_, 2 * n_ * Pz_, n_ * Pz_, items, hi, lo))
+    del lo, hi
 if which in ("all", "xcorr"):
     src = rnd(R, P * n * n)
     lam = rnd(P * n * P)
