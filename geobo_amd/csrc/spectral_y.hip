@@ -551,24 +551,277 @@ __global__ void __launch_bounds__(256, 1) spectral_y_split_kernel(SY3Args g) {
   }
 }
 
+// Pipelined long-axis kernel (round 6, second half; one-term forms).  Ablations of the four-wave kernel above at ny = 128, three blocks
+// (profiles/r06_spectral_y_ab.txt): without its loads and stores 3.26 of 3.57 ms remain; without its MFMAs 2.14 ms (then HBM-bound,
+// 4.0 TB/s); its MFMAs alone are 1.86 ms of matrix-pipe time.  So a row costs the pipe 8192 cycles of MFMA and about 6000 more in which
+// nothing is issued: the three phases of a row (analysis | orbit butterflies + eigenvalues | synthesis) are separated by workgroup
+// barriers and the middle one is pure latency -- LDS round trips and a short vector chain on NT of the waves.  Splitting every role over
+// two waves per SIMD changed nothing (2.86 / 3.62 ms: both waves of a SIMD sit in the same phase).  Here the phases of DIFFERENT steps
+// overlap instead: waves 0..3 (one per SIMD) only do matrix work, waves 4..7 only the orbit tiles; a step is one (row, block) pair,
+//     step t:  matrix waves  -- synthesis of pair t - 1 (ex2[(t-1) & 1]), stores;  behind a row's last block: analysis of the next row
+//                               into ex1[(k+1) & 1]
+//              orbit waves   -- pair t: (first block of a row: class sums from ex1[k & 1] -> spectrum, kept in registers) eigenvalues,
+//                               inverse butterfly -> ex2[t & 1]
+//              ONE barrier
+// with both exchange areas double buffered: 4 x 32 KiB for any number of blocks.  Same arithmetic and summation order per output as the
+// four-wave kernel: bit-identical results.
+template <int NY, int NIN, int NOUT, bool ACC>
+__global__ void __launch_bounds__(512, 1) spectral_y_pipe_kernel(SY3Args g) {
+  using S = Shape<NY>;
+  constexpr int NT = S::NT, MJ = S::MJ, KS = S::KS, EX = 4 * 4 * 4 * 64;
+  static_assert(NT <= 4 && NOUT >= 1 && NOUT <= 3 && NIN >= 1 && NIN <= 2 && !(ACC && NIN == 2), "shape");
+  // ex1 needs its second buffer only where a row is ONE step (one block): with two or three blocks the next row's analysis runs in the
+  // row's LAST step and the orbit waves read ex1 in its FIRST
+  constexpr int E1B = NOUT == 1 ? 2 : 1;
+  extern __shared__ __attribute__((aligned(16))) double exch[];
+  const int lane = threadIdx.x & 63, w8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int w = w8 & 3;                                                   // matrix waves: residue class rho; orbit waves: orbit tile T
+  const bool mat = w8 < 4, orb = !mat && w < NT;
+  const int c = lane & 15, gq = lane >> 4;
+  lds_double* const ex1 = (lds_double*)exch + lane;                       // [parity][term][dest T][src rho][reg]
+  lds_double* const ex2 = ex1 + E1B * NIN * EX;                           // [parity][dest rho][src T][reg]
+  const int64_t Sd = g.S, m0 = (int64_t)blockIdx.x * 16;
+  const int S8 = (int)(Sd * 8);
+  const unsigned voff = (unsigned)((4 * gq) * S8 + c * 8);
+  const int64_t r0 = blockIdx.y, rstep = gridDim.y, rowlen = (int64_t)NY * Sd;
+  if (r0 >= g.R) return;
+  const int K = (int)((g.R - r0 + rstep - 1) / rstep);                    // rows of this workgroup
+  const int nsteps = K * NOUT;
+  const int64_t ostep = (int64_t)(g.y1 - g.y0) * Sd;
+  const int in_bytes = NY * S8;
+
+  if (mat) {
+    double ffrag[KS * NT], ifrag[NT * 4 * MJ];
+    {
+      const double* bf = g.basis + lane;
+#pragma unroll
+      for (int i = 0; i < KS * NT; ++i) ffrag[i] = bf[(size_t)(w * KS * NT + i) * 64];
+#pragma unroll
+      for (int i = 0; i < NT * 4 * MJ; ++i) ifrag[i] = bf[(size_t)(S::NF_FWD + w * NT * 4 * MJ + i) * 64];
+    }
+    auto load_row = [&](double (&x)[NIN][KS], int k) {
+#pragma unroll
+      for (int u = 0; u < NIN; ++u) {
+        const rsrc_t rs = make_rsrc(g.in[u] + (r0 + k * rstep) * rowlen + m0, in_bytes);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) x[u][s] = ld_stream(rs, voff, (16 * s + w) * S8);
+      }
+    };
+    auto analysis = [&](const double (&x)[NIN][KS], int k) {
+      const int par = E1B == 2 ? (k & 1) : 0;
+#pragma unroll
+      for (int u = 0; u < NIN; ++u) {
+        d4 acc[NT];
+#pragma unroll
+        for (int T = 0; T < NT; ++T) acc[T] = d4{0., 0., 0., 0.};
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+          for (int T = 0; T < NT; ++T) acc[T] = __builtin_amdgcn_mfma_f64_16x16x4f64(ffrag[s * NT + T], x[u][s], acc[T], 0, 0, 0);
+#pragma unroll
+        for (int T = 0; T < NT; ++T)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) ex1[(par * NIN + u) * EX + ((T * 4 + w) * 4 + q) * 64] = acc[T][q];
+      }
+    };
+    auto load_prev = [&](double (&pv)[MJ][4], int k, auto JB) {            // accumulating form: the outputs pair (k, JB) will be added into
+      constexpr int jb = decltype(JB)::value;
+      const rsrc_t dst = make_rsrc(g.out[jb] + (r0 + k * rstep) * ostep + m0 - (int64_t)g.y0 * Sd, g.y1 * S8);
+#pragma unroll
+      for (int mj = 0; mj < MJ; ++mj)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int yb = 64 * mj + 16 * rr + w, y = yb + 4 * gq;
+          pv[mj][rr] = (16 * mj + 4 * rr < S::NJ && y >= g.y0 && y < g.y1) ? ld_lane(dst, voff, yb * S8) : 0.0;
+        }
+    };
+    double x[NIN][KS], prev[ACC ? MJ : 1][4], pnext[ACC ? MJ : 1][4];
+    load_row(x, 0);
+    analysis(x, 0);
+    if (K > 1) load_row(x, 1);
+    if constexpr (ACC) load_prev(prev, 0, std::integral_constant<int, 0>{});
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+    auto synthesis = [&](int kk, auto JB, int par) {                       // pair (row kk, block JB) out of ex2[par]
+      constexpr int jb = decltype(JB)::value;
+      const rsrc_t dst = make_rsrc(g.out[jb] + (r0 + kk * rstep) * ostep + m0 - (int64_t)g.y0 * Sd, g.y1 * S8);
+      lds_double* const e2 = ex2 + par * EX;
+      double yin[NT][4];
+#pragma unroll
+      for (int T = 0; T < NT; ++T)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) yin[T][rr] = e2[((w * 4 + T) * 4 + rr) * 64];
+      __builtin_amdgcn_sched_barrier(0);
+      d4 o[MJ];
+#pragma unroll
+      for (int mj = 0; mj < MJ; ++mj) o[mj] = d4{0., 0., 0., 0.};
+#pragma unroll
+      for (int T = 0; T < NT; ++T)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+          for (int mj = 0; mj < MJ; ++mj)
+            o[mj] = __builtin_amdgcn_mfma_f64_16x16x4f64(ifrag[(T * 4 + rr) * MJ + mj], yin[T][rr], o[mj], 0, 0, 0);
+#pragma unroll
+      for (int mj = 0; mj < MJ; ++mj)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          if (16 * mj + 4 * rr >= S::NJ) continue;
+          const int yb = 64 * mj + 16 * rr + w, y = yb + 4 * gq;
+          if (y >= g.y0 && y < g.y1) {
+            double v = o[mj][rr];
+            if constexpr (ACC) v += prev[mj][rr];
+            st_lane(dst, voff, yb * S8, v);
+          }
+        }
+    };
+    auto step_end = [&]() {
+      if constexpr (ACC) {
+#pragma unroll
+        for (int mj = 0; mj < MJ; ++mj)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) prev[mj][rr] = pnext[mj][rr];
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_s_barrier();
+    };
+    using std::integral_constant;
+    for (int kk = 0; kk < K; ++kk) {
+      // step (kk, 0): the previous row's last pair
+      if constexpr (ACC) { if (kk > 0) load_prev(pnext, kk, integral_constant<int, 0>{}); }
+      if (kk > 0) synthesis(kk - 1, integral_constant<int, NOUT - 1>{}, (kk * NOUT - 1) & 1);
+      if constexpr (NOUT == 1) {
+        if (kk + 1 < K) { analysis(x, kk + 1); if (kk + 2 < K) load_row(x, kk + 2); }
+      }
+      if (kk > 0 || !ACC) step_end(); else { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_s_barrier(); }
+      if constexpr (NOUT >= 2) {                                           // step (kk, 1): pair (kk, 0)
+        if constexpr (ACC) load_prev(pnext, kk, integral_constant<int, 1>{});
+        synthesis(kk, integral_constant<int, 0>{}, (kk * NOUT) & 1);
+        if constexpr (NOUT == 2) {
+          if (kk + 1 < K) { analysis(x, kk + 1); if (kk + 2 < K) load_row(x, kk + 2); }
+        }
+        step_end();
+      }
+      if constexpr (NOUT >= 3) {                                           // step (kk, 2): pair (kk, 1)
+        if constexpr (ACC) load_prev(pnext, kk, integral_constant<int, 2>{});
+        synthesis(kk, integral_constant<int, 1>{}, (kk * NOUT + 1) & 1);
+        if (kk + 1 < K) { analysis(x, kk + 1); if (kk + 2 < K) load_row(x, kk + 2); }
+        step_end();
+      }
+    }
+    synthesis(K - 1, integral_constant<int, NOUT - 1>{}, (K * NOUT - 1) & 1);   // drain
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();
+  } else {
+    d4 lam[NIN][NOUT][2];
+    if (orb) {
+      const int T8 = (int)(g.C * 8);
+      const unsigned tvoff = (unsigned)(gq * T8 + c * 8);
+      const double* ef = g.basis + ((size_t)S::eig(2 * w, 0)) * 64 + lane;
+#pragma unroll
+      for (int u = 0; u < NIN; ++u)
+#pragma unroll
+        for (int t = 0; t < NOUT; ++t) {
+          const rsrc_t tr = make_rsrc(g.tab[u][t] + m0, NY * T8);
+          lam[u][t][0] = d4{0., 0., 0., 0.};
+          lam[u][t][1] = d4{0., 0., 0., 0.};
+#pragma unroll 4
+          for (int s = 0; s < S::KE; ++s) {
+            const double tv = ld_lane(tr, tvoff, 4 * s * T8);
+            lam[u][t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ef[(size_t)s * 64], tv, lam[u][t][0], 0, 0, 0);
+            lam[u][t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ef[(size_t)(S::KE + s) * 64], tv, lam[u][t][1], 0, 0, 0);
+          }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();                                          // row 0's class sums are in ex1[0]
+    double a[NIN][2][4], b[NIN][2][4];
+    for (int kk = 0; kk < K; ++kk) {
+#pragma unroll
+      for (int jb = 0; jb < NOUT; ++jb) {
+        if (orb) {
+          if (jb == 0) {
+#pragma unroll
+            for (int u = 0; u < NIN; ++u) {
+              lds_double* const e1 = ex1 + ((E1B == 2 ? (kk & 1) : 0) * NIN + u) * EX;
+              double cs[4][4];
+#pragma unroll
+              for (int rho = 0; rho < 4; ++rho)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cs[rho][q] = e1[((w * 4 + rho) * 4 + q) * 64];
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                const double Cc[4] = {cs[0][h], cs[1][h], cs[2][h], cs[3][h]};
+                const double Ss[4] = {cs[0][2 + h], cs[1][2 + h], cs[2][2 + h], cs[3][2 + h]};
+                bfly_fwd(Cc, Ss, a[u][h], b[u][h]);
+              }
+            }
+          }
+          double Y[4][4];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            double sa, da, sb, db, tb0, tb1, tb2, tb3;
+            if constexpr (NIN == 1) {
+              const d4 l = lam[0][jb][h];
+              const double t0 = l[0] * a[0][h][0], t1 = l[2] * a[0][h][2], u0 = l[0] * b[0][h][0], u1 = l[2] * b[0][h][2];
+              sa = __builtin_fma(l[1], a[0][h][1], t0); da = __builtin_fma(-l[1], a[0][h][1], t0);
+              sb = __builtin_fma(l[3], a[0][h][3], t1); db = __builtin_fma(-l[3], a[0][h][3], t1);
+              tb1 = __builtin_fma(l[1], b[0][h][1], u0); tb0 = __builtin_fma(-l[1], b[0][h][1], u0);
+              tb3 = __builtin_fma(l[3], b[0][h][3], u1); tb2 = __builtin_fma(-l[3], b[0][h][3], u1);
+            } else {
+              // the two terms meet in the spectrum: Y^ = lambda_g x^_g + lambda_m x^_m per member of the orbit
+              const d4 lg = lam[0][jb][h], lm = lam[1][jb][h];
+              double ya[4], yb[4];
+#pragma unroll
+              for (int f = 0; f < 4; ++f) {
+                ya[f] = __builtin_fma(lm[f], a[1][h][f], lg[f] * a[0][h][f]);
+                yb[f] = __builtin_fma(lm[f], b[1][h][f], lg[f] * b[0][h][f]);
+              }
+              sa = ya[0] + ya[1]; da = ya[0] - ya[1]; sb = ya[2] + ya[3]; db = ya[2] - ya[3];
+              tb0 = yb[0] - yb[1]; tb1 = yb[0] + yb[1]; tb2 = yb[2] - yb[3]; tb3 = yb[2] + yb[3];
+            }
+            Y[0][h] = sa + sb; Y[2][h] = sa - sb; Y[1][h] = da + tb3; Y[3][h] = da - tb3;
+            Y[0][2 + h] = tb0 + tb2; Y[2][2 + h] = tb0 - tb2; Y[1][2 + h] = tb1 - db; Y[3][2 + h] = tb1 + db;
+          }
+          lds_double* const e2 = ex2 + ((kk * NOUT + jb) & 1) * EX;
+#pragma unroll
+          for (int rho = 0; rho < 4; ++rho)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) e2[((rho * 4 + w) * 4 + rr) * 64] = Y[rho][rr];
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_s_barrier();                                          // (the matrix waves' drain step)
+  }
+}
+
+#ifndef SY_PIPE
+#define SY_PIPE 1        // 0: the four-wave kernel for the one-term forms as well: the A/B
+#endif
 template <int NY, int NIN, int NOUT, bool ACC>
 int launch_split(const SY3Args& g, hipStream_t st) {
   using S = Shape<NY>;
-  constexpr size_t lds = (size_t)((NIN + NOUT) * 4 * 4 * 4 * 64) * sizeof(double);
+  constexpr bool PIPE = SY_PIPE && !(NIN == 2 && NOUT == 1);   // the pipelined kernel (eight waves) wherever its exchange areas fit
+  constexpr size_t lds = (size_t)((PIPE ? (NOUT == 1 ? 2 : 1) * NIN + 2 : NIN + NOUT) * 4 * 4 * 4 * 64) * sizeof(double);
   static_assert(lds <= 163840, "LDS");
-  auto kern = spectral_y_split_kernel<NY, NIN, NOUT, ACC>;
+  const void* kern;
+  if constexpr (PIPE) kern = reinterpret_cast<const void*>(spectral_y_pipe_kernel<NY, NIN, NOUT, ACC>);
+  else kern = reinterpret_cast<const void*>(spectral_y_split_kernel<NY, NIN, NOUT, ACC>);
   static std::atomic<uint64_t> attr_done{0};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return GEOBO_E_LAUNCH;
   if (!((attr_done.load(std::memory_order_acquire) >> dev) & 1)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return GEOBO_E_LAUNCH;
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return GEOBO_E_LAUNCH;
     attr_done.fetch_or((uint64_t)1 << dev, std::memory_order_release);
   }
   const int64_t nbx = g.C / 16;
   int64_t gy = 1;                                   // one workgroup per CU: a workgroup keeps its 16 modes for R / gy rows
   while (nbx * gy < 512 && gy < g.R) ++gy;
-  hipLaunchKernelGGL(kern, dim3((unsigned)nbx, (unsigned)gy), dim3(256), lds, st, g);
+  if constexpr (PIPE) hipLaunchKernelGGL((spectral_y_pipe_kernel<NY, NIN, NOUT, ACC>), dim3((unsigned)nbx, (unsigned)gy), dim3(512), lds, st, g);
+  else hipLaunchKernelGGL((spectral_y_split_kernel<NY, NIN, NOUT, ACC>), dim3((unsigned)nbx, (unsigned)gy), dim3(256), lds, st, g);
   return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
 }
 

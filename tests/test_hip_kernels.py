@@ -229,6 +229,27 @@ def test_potrf_inv_matches_torch(hip, m, fork):
     assert abs(st[1] - float(torch.log(torch.diag(Lref) ** 2).sum())) < 1e-9
 
 
+@pytest.mark.parametrize("m,cond", [(1024, 1e2), (2048, 1e10), (4096, 1e12)])
+def test_potrf_backward_error_is_lapack_s(hip, m, cond):
+    """The diagonal block's pivots take 1 / sqrt(d) from a v_rsq_f64 seed and one third-order step (round 6; no IEEE sqrt, no division):
+    the factor's backward error |L L^T - A| / |A| must stay what LAPACK's is on ill-conditioned matrices too, and L^-1 L = I to the
+    matrix's condition."""
+    torch.manual_seed(m)
+    Q, _ = torch.linalg.qr(torch.randn(m, m, dtype=torch.float64, device="cuda"))
+    ev = torch.logspace(0, -float(np.log10(cond)), m, dtype=torch.float64, device="cuda")
+    S = (Q * ev) @ Q.t()
+    S = 0.5 * (S + S.t())
+    Lref = torch.linalg.cholesky(S)
+    L = S.clone()
+    Linv, info = hip.potrf_inv(L, Linv=torch.full((m, m), float("nan"), dtype=torch.float64, device="cuda"))
+    assert int(info.item()) == 0
+    Ld = torch.tril(L)
+    back, back_ref = ((Ld @ Ld.t() - S).norm() / S.norm()).item(), ((Lref @ Lref.t() - S).norm() / S.norm()).item()
+    assert back < 2.0 * back_ref + 1e-16, (back, back_ref)
+    eye = torch.eye(m, dtype=torch.float64, device="cuda")
+    assert ((Linv @ Ld - eye).norm() / m ** 0.5).item() < 1e-15 * cond + 1e-13
+
+
 def test_concurrent_factorisations_on_two_streams(hip):
     """Two host threads, two caller streams, one fork context each: the library holds no process-global streams / events /
     caches, so the factorisations may overlap freely and must each match torch (run several rounds to let them interleave)."""
