@@ -177,7 +177,7 @@ def soak(seed=0, seconds=None, iters=60, verbose=True):
             if not e < 1e-13:
                 bad += 1; print("toeplitz windowed ny=%d R=%d C=%d blocks=%d slab [%d, %d) err %.3e" % (nyw, Rw, Cw, npw, ya, yb, e), flush=True)
         # ---- round 6: the y stage on the matrix pipe.  ny <= 64: a wave per 16 modes, register-prefetched rows (no LDS hand-off between
-        #      waves); ny > 64: four waves per tile with TWO LDS exchanges per row ordered by two barriers -- a missing barrier or an
+        #      waves); ny > 64: eight waves per tile in two roles (matrix waves / orbit waves), double-buffered LDS exchanges ordered by ONE barrier per (row, block) step -- a missing barrier or an
         #      exchange area rewritten too early shows up as a sporadic mismatch against the direct kernels / torch, NaN-poisoned outputs
         for nys in (int(rng.choice([32, 48, 64])), nyw):
             Cs, Rs, nps = 16 * int(rng.integers(1, 24)), int(rng.integers(1, 12)), int(rng.integers(1, 4))
