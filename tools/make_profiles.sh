@@ -14,7 +14,7 @@ cp gpurun_out/pmc_xz2d_fold_inv_mul_valu.json gpurun_out/${R}_pmc_xz2d_fold_inv_
 python tools/pmc_collect.py kblock_grid > /dev/null 2>&1; cp gpurun_out/pmc_k_block_grid_f64.json gpurun_out/${R}_pmc_k_block_grid_f64.json
 for k in potrf_dag axis128_fwd axis128_inv; do python tools/pmc_collect.py $k > /dev/null 2>&1; done
 cp gpurun_out/pmc_potrf_dag.json gpurun_out/${R}_pmc_potrf_dag.json; cp gpurun_out/pmc_spectral_axis128_fwd.json gpurun_out/${R}_pmc_spectral_axis128_fwd.json; cp gpurun_out/pmc_spectral_axis128_inv.json gpurun_out/${R}_pmc_spectral_axis128_inv.json
-for k in fold_fwd fold_bwd fold_inv_ss fold_inv_mul xcorr_fold ymul toeplitz toeplitz2s spectral_y spectral_y1 spectral_y2s spectral_y128 spectral_y3t128; do python tools/run_spectral_kernels_once.py $k 2>&1 | grep -v amdgpu.ids | tail -1; done > gpurun_out/${R}_spectral_kernels_once.txt
+for k in fold_fwd fold_bwd fold_inv_ss fold_inv_mul xcorr_fold ymul toeplitz toeplitz2s spectral_y spectral_y1 spectral_y2s spectral_y128 spectral_y3t128 axis128_fwd axis128_inv; do python tools/run_spectral_kernels_once.py $k 2>&1 | grep -v amdgpu.ids | tail -1; done > gpurun_out/${R}_spectral_kernels_once.txt
 (python tools/time_toeplitz.py; python tools/time_toeplitz.py 96; python tools/time_toeplitz.py 128) 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_time_y_stage.txt
 (python tools/time_axis_passes.py 96 16; python tools/time_axis_passes.py 128 16) 2>&1 | grep -v amdgpu.ids > gpurun_out/${R}_time_axis_passes.txt
 # the driver's command, then the same under rocprofv3 (kernel stats), then the A/B with the direct y stage on the same box
@@ -28,6 +28,8 @@ python bench.py --gpus 1 --backend nccl --check --steps 5 --warmup 2 --no-cpu 2>
 python bench.py --size 32 --kernel exp --drill 0 --steps 20 --warmup 3 --no-cpu 2>/dev/null | grep '^{' > gpurun_out/${R}_bench32_config2.json
 (cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_c && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c -- python $ROOT/tests/dryrun_config5.py --size 128 --world 8 --rank 0 --no-oracle > $ROOT/gpurun_out/${R}_config5_rank0_under_rocprof.json 2>/dev/null; cp $(find /tmp/prof_c -name "*kernel_stats.csv" | head -1) $ROOT/gpurun_out/${R}_config5_rank0_kernel_stats.csv)
 python tools/emulate_rank.py --of 2,4,8 > gpurun_out/${R}_emulated_ranks.json 2>/dev/null
-python tests/dryrun_config5.py --size 128 --world 8 --rank 0 > gpurun_out/${R}_config5_rank0_of_8_rowform.json 2> gpurun_out/${R}_config5_rank0.err
+python tests/dryrun_config5.py --size 128 --world 8 --rank 0 --repeat 2 > gpurun_out/${R}_config5_rank0_of_8_rowform.json 2> gpurun_out/${R}_config5_rank0.err
 python bench.py --size 96 --steps 2 --warmup 1 --no-cpu 2>/dev/null | grep '^{' > gpurun_out/${R}_bench96_one_gpu.json
 python bench.py --size 128 --props 3 --assembly f32 --steps 1 --warmup 1 --no-cpu 2>/dev/null | grep '^{' > gpurun_out/${R}_bench128x3_f32_one_gpu.json
+GEOBO_HIP_LIB= python tools/run_potrf_once.py 2048 noctx 2>&1 | tail -1 > gpurun_out/${R}_potrf_times.txt; python tools/run_potrf_once.py 8448 noctx 2>&1 | tail -1 >> gpurun_out/${R}_potrf_times.txt
+python tools/soak_kernels.py 41 180 > gpurun_out/${R}_soak_final_kernels.txt 2>&1

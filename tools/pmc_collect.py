@@ -29,8 +29,8 @@ DRIVERS = {"posterior": ("run_posterior_once.py", "gemm_f64_kernel<4, 2, 2, 1", 
            "spectral_y": ("run_spectral_kernels_once.py spectral_y", "spectral_y_kernel<64, 1, 2", "pmc_spectral_y.json"),
            "spectral_y1": ("run_spectral_kernels_once.py spectral_y1", "spectral_y_kernel<64, 1, 1", "pmc_spectral_y1.json"),
            "spectral_y2s": ("run_spectral_kernels_once.py spectral_y2s", "spectral_y_kernel<64, 2, 2", "pmc_spectral_y2s.json"),
-           "spectral_y128": ("run_spectral_kernels_once.py spectral_y128", "spectral_y_split_kernel<128, 1, 3", "pmc_spectral_y128.json"),
-           "spectral_y128_1": ("run_spectral_kernels_once.py spectral_y128_1", "spectral_y_split_kernel<128, 1, 1", "pmc_spectral_y128_1.json"),
+           "spectral_y128": ("run_spectral_kernels_once.py spectral_y128", "spectral_y_pipe_kernel<128, 1, 3", "pmc_spectral_y128.json"),
+           "spectral_y128_1": ("run_spectral_kernels_once.py spectral_y128_1", "spectral_y_pipe_kernel<128, 1, 1", "pmc_spectral_y128_1.json"),
            "axis128_fwd": ("run_spectral_kernels_once.py axis128_fwd", "spectral_axis_kernel<128, false", "pmc_spectral_axis128_fwd.json"),
            "axis128_inv": ("run_spectral_kernels_once.py axis128_inv", "spectral_axis_kernel<128, true", "pmc_spectral_axis128_inv.json"),
            "xcorr": ("run_spectral_kernels_once.py xcorr", "xcorr_kernel", "pmc_xcorr.json"),
