@@ -409,12 +409,12 @@ __global__ void __launch_bounds__(256) potf2b_inv_kernel(double* __restrict__ A,
 // (MI355X_MICROARCH.md "inter-workgroup visibility", form R1).  Task order: column step s = the tiles (s..nb-1, s) of L, diagonal first,
 // then row s - XD of X (its inputs were final XD steps ago: filler work under the latency chain diag -> sub-diagonal tile -> next diag).
 // Summation order is fixed by the tile, not by timing: bit-reproducible.  Every spin is bounded (abort flag + wall-clock limit).
-constexpr int DBK = 16, DXS = 16, DNST = 3;
+constexpr int DBK = 16, DXS = 16, DNST = 4;   // (the task loop's segments rotate three stages; the walker's use four)
 constexpr int DXBUF = NB * DXS;                  // X chunk [128 rows][16 k], 128-byte rows, XOR-swizzled 16-byte slots
 constexpr int DYS_NN = NB + 4;                   // row stride of a [16 k][128 cols] chunk (the X_kc operand of the inverse tiles)
 constexpr int DYBUF = DBK * DYS_NN;              // >= NB * DXS: also holds a [128 cols][16 k] chunk
 constexpr int DSTAGE = DXBUF + DYBUF;
-constexpr int DAG_LDS_DOUBLES = DNST * DSTAGE;   // 99 840 bytes: one workgroup per CU
+constexpr int DAG_LDS_DOUBLES = DNST * DSTAGE;   // 133 120 bytes: one workgroup per CU
 constexpr size_t DAG_LDS_BYTES = (size_t)DAG_LDS_DOUBLES * sizeof(double) + 64;
 constexpr int DAG_CTL = 16;                      // control words in front of the counters: [0] task head, [1] abort
 constexpr int DAG_XDELAY = 6;
@@ -432,7 +432,7 @@ constexpr int DAG_XDELAY = 6;
 
 struct DagArgs {
   double* A; int64_t ld; double* Linv; int64_t ldi; int* info;
-  int* ctl;          // [0] head, [1] abort, [DAG_CTL .. +nb) rows of L final up to (count), then nb x nb flags of X
+  int* ctl;          // [0] head, [1] abort, [DAG_CTL .. +nb) rows of L final up to (count), then nb x nb flags of X, then 2 nb flags of the parked tiles
   int nb, xdelay;
 };
 
@@ -562,6 +562,148 @@ __device__ __forceinline__ void dag_load_neg(v4d (&acc)[4][4], const double* T, 
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[m][n][r] = -tw[(int64_t)(m * 16 + 4 * r) * ld + n * 16];
 }
+// ---- the chain in ONE workgroup (round 6, second half) -----------------------------------------------------------------------------
+// Task log of the round-5 DAG: a column's chain is diag (44 us) -> hand-off -> L_{j+1,j} = S D_j^T (22) -> hand-off -> last update of
+// the next diagonal tile (22); halving the MFMAs of the two tile products changed the launch by 1.3 %: the links wait for a tile another
+// XCD has just published, chunk by chunk (NOTES.md section 14).  Now workgroup 0 WALKS the chain and never hands off: it factorises
+// S_jj, forms L_{j+1,j} with D_j still in its own L2, publishes it, applies it to the next diagonal tile itself, factorises again.  What
+// it needs from others are two PARKED partial sums per column -- S_{j+1,j} (all k < j) and S_{j+1,j+1} (all k < j) -- which the former
+// sub-diagonal and diagonal tasks now park and flag instead of waiting for D_j; their inputs are final one column earlier, so the tiles
+// are old by the time the walker reads them.  Everything else (the tiles (i >= j + 2, j), the rows of X) is unchanged.  (The same
+// four-stage counted-wait ring in the task loop's segments was measured and is NOT used there: 8448 8.64 -> 9.09 ms -- their chunks are
+// not latency-bound, and the hand-scheduled fragment prefetch of dag_segment is worth more than the depth.)  No new wait
+// cycle: the walker at column j waits for helpers whose inputs are tiles of columns < j, published by ordinary tasks that wait for D_k,
+// k < j, which the walker has already published.  Needs a second resident workgroup (grids of one keep the round-5 roles).
+// With the latency gone the two products are bound by their MFMAs (13.7 us each on one CU), and both are half empty:
+//   * L_{j+1,j} = S D_j^T: D_j is lower triangular -- the 16-deep chunk kc only reaches the 16-column tiles ct >= kc; the column tiles
+//     are dealt {0, 1, 6, 7} | {2, 3, 4, 5} to the two wave columns (18 of 32 chunk-tiles each instead of 10 | 26);
+//   * the diagonal tile is only read below its diagonal (potf2b_body loads col <= row): its 36 lower 16 x 16 tiles are dealt
+//     10 | 8 | 8 | 10 to the waves for the walker's update.
+// A map names the tiles of a wave's accumulators: acc[m][n] = tile (rb + m, ct[n]), bit 4 m + n of `act` set where it exists.  Staging
+// and barriers are those of dag_segment (every wave stages, every wave meets): only MFMAs are skipped.
+#ifndef DAG_WALKER
+#define DAG_WALKER 1     // 0: the round-5 roles (every link of the chain a task of its own): the A/B
+#endif
+// The walker pays where the launch is chain-bound: M = 1024 0.81 -> 0.77 ms, 2048 1.72 -> 1.54, 4224 3.55 -> 3.40.  From ~ 40 block
+// columns the middle of the factorisation is work-bound, the parked sums arrive late (the walker waited 21 us per column for the diagonal
+// tile's at M = 8448) and a workgroup that does not take tiles is missed: 8448 8.58 -> 8.64 ms, 16 640 48.1 -> 48.9.  Larger matrices
+// keep the round-5 roles.
+#ifndef DAG_WALK_NB
+#define DAG_WALK_NB 40
+#endif
+struct DagMap { int rb, ct[4]; unsigned act; };
+__device__ __forceinline__ DagMap dag_map_tri(int wave) {      // L = S D^T
+  const int wm = wave >> 1, wn = wave & 1;
+  return wn ? DagMap{4 * wm, {2, 3, 4, 5}, 0xFFFFu} : DagMap{4 * wm, {0, 1, 6, 7}, 0xFFFFu};
+}
+__device__ __forceinline__ DagMap dag_map_lower(int wave) {    // the lower tiles of a diagonal tile (m >= n: 0xF731; m < 2: 0x00FF)
+  switch (wave) {
+    case 0: return DagMap{0, {0, 1, 2, 3}, 0xF731u};
+    case 1: return DagMap{4, {0, 1, 2, 3}, 0x00FFu};
+    case 2: return DagMap{6, {0, 1, 2, 3}, 0x00FFu};
+    default: return DagMap{4, {4, 5, 6, 7}, 0xF731u};
+  }
+}
+// NT segment on a map; TRI: Y is lower triangular
+template <bool TRI>
+__device__ __forceinline__ void dag_segment_map(v4d (&acc)[4][4], const double* Xp, int64_t ldx, const double* Yp, int64_t ldy, int klen,
+                                                double* smem, const DagMap& mp) {
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4, srow = tid >> 3;
+  const char* const Xb = reinterpret_cast<const char*>(Xp);
+  const char* const Yb = reinterpret_cast<const char*>(Yp);
+  int64_t xsrc[4], ysrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = i * 32 + srow;
+    xsrc[i] = ((int64_t)row * ldx + 2 * ((tid & 7) ^ dswz(row))) * 8;
+    ysrc[i] = ((int64_t)row * ldy + 2 * ((tid & 7) ^ dswz(row))) * 8;
+  }
+  auto stage = [&](int k0, int st) {
+    double* const xs = smem + st * DSTAGE;
+    double* const ys = xs + DXBUF;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(Xb + xsrc[i] + (int64_t)k0 * 8), (lds_ptr_t)(xs + (i * 32 + wave * 8) * DXS), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(Yb + ysrc[i] + (int64_t)k0 * 8), (lds_ptr_t)(ys + (i * 32 + wave * 8) * DXS), 16, 0, 0);
+  };
+  const int xoff0 = 2 * ((2 * lg + 0) ^ dswz(lr)), xoff1 = 2 * ((2 * lg + 1) ^ dswz(lr));
+  const double* const xfrag = smem + (mp.rb * 16 + lr) * DXS;
+  const double* const yfrag = smem + DXBUF + lr * DXS;
+  auto read_half = [&](int st, int h, v2d (&av)[4], v2d (&bv)[4]) {
+    const double* xb = xfrag + st * DSTAGE + (h ? xoff1 : xoff0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) av[m] = *reinterpret_cast<const v2d*>(xb + m * 16 * DXS);
+    const double* yb = yfrag + st * DSTAGE + (h ? xoff1 : xoff0);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) bv[n] = *reinterpret_cast<const v2d*>(yb + mp.ct[n] * 16 * DXS);
+  };
+  // FOUR stages, three chunks in flight, counted waits (the walker's segments read tiles that an acquire has just pushed out of this
+  // XCD's caches: ~ 2.5 us per access; with the task loop's ring -- every chunk barrier a full drain, __syncthreads -- each of the
+  // eight chunks of a 128-deep product waited that long: 20-27 us per product, measured per phase).  klen = 8 chunks exactly.
+  static_assert(DNST >= 4, "stages");
+  stage(0, 0);
+  stage(DBK, 1);
+  stage(2 * DBK, 2);
+  sfor<0, NB / DBK>([&](auto cc) {
+    constexpr int c = decltype(cc)::value, NCH = NB / DBK;
+    constexpr int after = (NCH - 1 - c) < 2 ? (NCH - 1 - c) : 2;        // stages issued behind chunk c that may stay in flight
+    // chunk c has landed (this wave's part; the barrier covers the others'), and every wave is past its reads of chunk c - 1
+    if constexpr (after == 2) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if constexpr (after == 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if constexpr (c + 3 < NCH) stage((c + 3) * DBK, (c + 3) % 4);        // into the slot chunk c - 1 has just left
+    v2d a0[4], b0[4], a1[4], b1[4];
+    read_half(c % 4, 0, a0, b0);
+    read_half(c % 4, 1, a1, b1);
+    unsigned on = mp.act;
+    if constexpr (TRI) {
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+        if (c > mp.ct[n]) on &= ~(0x1111u << n);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+          if (on & (1u << (4 * m + n)))
+            acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(t < 2 ? a0[m][t & 1] : a1[m][t & 1], t < 2 ? b0[n][t & 1] : b1[n][t & 1],
+                                                             acc[m][n], 0, 0, 0);
+    }
+  });
+  __syncthreads();                                                      // (the ring is free for whoever stages next)
+}
+template <bool PUB>
+__device__ __forceinline__ void dag_store_map(const v4d (&acc)[4][4], double* T, int64_t ld, double sgn, const DagMap& mp) {
+  const int lane = threadIdx.x & 63;
+  double* const tw = T + (int64_t)(mp.rb * 16 + (lane >> 4)) * ld + (lane & 15);
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+      if (mp.act & (1u << (4 * m + n))) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stg<PUB>(tw + (int64_t)(m * 16 + 4 * r) * ld + mp.ct[n] * 16, sgn * acc[m][n][r]);
+      }
+}
+__device__ __forceinline__ void dag_load_neg_map(v4d (&acc)[4][4], const double* T, int64_t ld, const DagMap& mp) {
+  const int lane = threadIdx.x & 63;
+  const double* const tw = T + (int64_t)(mp.rb * 16 + (lane >> 4)) * ld + (lane & 15);
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        acc[m][n][r] = (mp.act & (1u << (4 * m + n))) ? -tw[(int64_t)(m * 16 + 4 * r) * ld + mp.ct[n] * 16] : 0.0;
+}
 __device__ __forceinline__ void dag_zero(v4d (&acc)[4][4]) {
 #pragma unroll
   for (int m = 0; m < 4; ++m)
@@ -601,6 +743,66 @@ __device__ __noinline__ void potf2b_dag(double* T, int64_t ld, double* D, int64_
   }
 }
 
+// the chain walker as a function of its own (inlined into the task loop it raised the kernel's spills from 38 to 101 registers)
+__device__ __noinline__ bool dag_walk(const DagArgs& a, double* smem) {
+  int* const sh = reinterpret_cast<int*>(smem + DAG_LDS_DOUBLES);
+  int* const ready = a.ctl + DAG_CTL;
+  const int nb = a.nb, tid = threadIdx.x;
+  int* const pd = ready + nb + (int64_t)nb * nb;
+  int* const pl = pd + nb;
+  v4d acc[4][4];
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const DagMap mlow = dag_map_lower(wv), mtri = dag_map_tri(wv);
+  auto wait_flag = [&](const int* f) {
+    int ok = 1;
+    if (tid == 0) {
+      Spin sp;
+      while (ld_flag(f) < 1)
+        if (sp.fail(a.ctl, a.info)) { ok = 0; break; }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    return dag_bcast(sh, ok);
+  };
+#ifdef DAG_WALK_STATS
+  long long ws_t[6] = {0, 0, 0, 0, 0, 0};
+#define WS_MARK(i) do { const long long n_ = (long long)wall_clock64(); ws_t[i] += n_ - ws_last; ws_last = n_; } while (0)
+  long long ws_last = (long long)wall_clock64();
+#else
+#define WS_MARK(i) do { } while (0)
+#endif
+  for (int s = 0; s < nb; ++s) {
+    double* const Tss = a.A + (int64_t)s * NB * a.ld + (int64_t)s * NB;
+    double* const Ds = a.Linv + (int64_t)s * NB * a.ldi + (int64_t)s * NB;
+    // S_ss is complete and visible here (s = 0: the input; else stored below behind vmcnt(0), a fence and a barrier)
+    potf2b_dag(Tss, a.ld, Ds, a.ldi, s * NB, a.info, smem);
+    dag_publish(ready + s, s + 1);
+    WS_MARK(0);
+    if (s + 1 == nb) break;
+    double* const Tl = a.A + (int64_t)(s + 1) * NB * a.ld + (int64_t)s * NB;          // tile (s + 1, s)
+    double* const Tn = a.A + (int64_t)(s + 1) * NB * a.ld + (int64_t)(s + 1) * NB;    // tile (s + 1, s + 1)
+    if (!wait_flag(pl + s + 1)) return false;
+    WS_MARK(1);
+    dag_zero(acc);
+    dag_segment_map<true>(acc, Tl, a.ld, Ds, a.ldi, NB, smem, mtri);                   // L_{s+1,s} = S D_s^T
+    dag_store_map<true>(acc, Tl, a.ld, 1.0, mtri);
+    dag_publish(ready + s + 1, s + 1);
+    WS_MARK(2);
+    if (!wait_flag(pd + s + 1)) return false;
+    WS_MARK(3);
+    dag_load_neg_map(acc, Tn, a.ld, mlow);
+    dag_segment_map<false>(acc, Tl, a.ld, Tl, a.ld, NB, smem, mlow);                   // ... + L_{s+1,s} L_{s+1,s}^T, lower tiles
+    dag_store_map<false>(acc, Tn, a.ld, -1.0, mlow);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    WS_MARK(4);
+  }
+#ifdef DAG_WALK_STATS
+  if (tid == 0) for (int q = 0; q < 5; ++q) a.ctl[2 + q] = (int)ws_t[q];
+#endif
+  return true;
+}
+
 __global__ void __launch_bounds__(256) potrf_dag_kernel(const DagArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   int* const sh = reinterpret_cast<int*>(smem + DAG_LDS_DOUBLES);
@@ -608,6 +810,12 @@ __global__ void __launch_bounds__(256) potrf_dag_kernel(const DagArgs a) {
   int* const xflag = ready + a.nb;
   const int nb = a.nb, XD = a.xdelay, total = nb * nb;
   const int tid = threadIdx.x;
+  int* const pd = xflag + (int64_t)nb * nb;      // pd[j] = 1: S_jj with every column k < j - 1 applied is parked in the tile's place
+  int* const pl = pd + nb;                        // pl[i] = 1: S_{i,i-1} with every column k < i - 1 applied is parked
+  const bool walk = DAG_WALKER && gridDim.x >= 2 && nb <= DAG_WALK_NB;
+  if (walk && blockIdx.x == 0) {
+    if (!dag_walk(a, smem)) return;
+  }
   int cur_s = 0, cur_base = 0;     // claimed indices grow: decode incrementally
   auto step_tasks = [&](int s) { return (s < nb ? nb - s : 0) + ((s >= XD && s - XD < nb) ? s - XD : 0); };
   for (;;) {
@@ -617,7 +825,7 @@ __global__ void __launch_bounds__(256) potrf_dag_kernel(const DagArgs a) {
     t = dag_bcast(sh, t);
     if (t >= total) return;
 #ifdef GEOBO_DAG_TRACE
-    long long* const trace = reinterpret_cast<long long*>((reinterpret_cast<uintptr_t>(xflag + (int64_t)nb * nb) + 7) & ~(uintptr_t)7) + (int64_t)t * 8;
+    long long* const trace = reinterpret_cast<long long*>((reinterpret_cast<uintptr_t>(xflag + (int64_t)nb * nb + 2 * nb) + 7) & ~(uintptr_t)7) + (int64_t)t * 8;
     long long t_poll = 0, t_p0 = 0;
     int n_seg = 0;
     DAG_T(1, ((long long)blockIdx.x << 8) | (__builtin_amdgcn_s_getreg(6164) & 7));   // hwreg(HW_REG_XCC_ID = 20, 0, 4)
@@ -633,11 +841,15 @@ __global__ void __launch_bounds__(256) potrf_dag_kernel(const DagArgs a) {
       dag_load_neg(acc, Tij, a.ld);
       int have = 0;
       bool fin = false;
+      // with the walker: the diagonal task stops one column early (the walker applies column j - 1 itself), and it and the task of the
+      // tile under the diagonal PARK their sums instead of finishing the tile
+      const bool park = walk && i <= j + 1;
+      const int lim = (walk && i == j) ? (j > 0 ? j - 1 : 0) : j;
       for (;;) {
         const double *Xp, *Yp;
         int64_t ldy;
         int klen;
-        if (have < j) {
+        if (have < lim) {
           int f = 0;
           if (tid == 0) {
             Spin sp;
@@ -647,7 +859,7 @@ __global__ void __launch_bounds__(256) potrf_dag_kernel(const DagArgs a) {
             for (;;) {
               const int ri = ld_flag(ready + i), rj = (i == j) ? ri : ld_flag(ready + j);
               f = ri < rj ? ri : rj;
-              if (f > j) f = j;
+              if (f > lim) f = lim;
               if (f > have) break;
               if (sp.fail(a.ctl, a.info)) { f = -1; break; }
             }
@@ -664,7 +876,7 @@ __global__ void __launch_bounds__(256) potrf_dag_kernel(const DagArgs a) {
           klen = (f - have) * NB;
           have = f;
         } else {
-          if (i == j) { DAG_T(1, (DAG_NOW() << 16) | ((long long)blockIdx.x << 8)); break; }
+          if (i == j || park) { DAG_T(1, (DAG_NOW() << 16) | ((long long)blockIdx.x << 8)); break; }
           DAG_T(3, DAG_NOW());
           // S is complete: park it in the tile's own place, then L_ij = S D_j^T as one more contraction (X = S from memory)
           dag_store<false>(acc, Tij, a.ld, -1.0);
@@ -692,7 +904,18 @@ __global__ void __launch_bounds__(256) potrf_dag_kernel(const DagArgs a) {
 #endif
         if (fin) break;
       }
-      if (i == j) {
+      if (park) {
+        if (i == j) {
+          if (j > 0) {                                         // (S_00 is the input itself: the walker starts on it at once)
+            dag_store<true>(acc, Tij, a.ld, -1.0);
+            dag_publish(pd + j, 1);
+          }
+        } else {
+          dag_store<true>(acc, Tij, a.ld, -1.0);
+          dag_publish(pl + i, 1);
+        }
+        DAG_T(3, DAG_NOW()); DAG_T(4, DAG_NOW()); DAG_T(5, DAG_NOW()); DAG_T(6, t_poll); DAG_T(7, n_seg);
+      } else if (i == j) {
         dag_store<false>(acc, Tij, a.ld, -1.0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -880,9 +1103,9 @@ struct PotrfCtx { int dev; hipStream_t s[3]; hipEvent_t ev[NEV]; };
 
 size_t dag_ctl_bytes(int64_t nb) {
 #ifdef GEOBO_DAG_TRACE
-  return (size_t)(DAG_CTL + nb + nb * nb + 2) * sizeof(int) + (size_t)nb * nb * 8 * sizeof(long long);
+  return (size_t)(DAG_CTL + 3 * nb + nb * nb + 2) * sizeof(int) + (size_t)nb * nb * 8 * sizeof(long long);
 #else
-  return (size_t)(DAG_CTL + nb + nb * nb) * sizeof(int);
+  return (size_t)(DAG_CTL + 3 * nb + nb * nb) * sizeof(int);
 #endif
 }
 

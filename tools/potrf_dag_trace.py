@@ -39,7 +39,7 @@ def tree(n):
 
 
 raw = ws.cpu().numpy().view(np.uint8)
-off = tree(nb) * 128 * 128 * 8 + 4 * (16 + nb + nb * nb)
+off = tree(nb) * 128 * 128 * 8 + 4 * (16 + 3 * nb + nb * nb)
 base = ws.data_ptr() + off
 pad = (-base) % 8
 tr = raw[off + pad: off + pad + nb * nb * 64].view(np.int64).reshape(nb * nb, 8)

@@ -214,7 +214,7 @@ def soak(seed=0, seconds=None, iters=60, verbose=True):
         #      agent-scope counters.  Random block counts, the result buffers poisoned with NaN (a tile or a zero that is read before
         #      its producer's write-through stores have landed shows up as NaN), every other iteration under uneven load: a long
         #      GEMM on a second stream takes CUs away while the tasks are drawn ------------------------------------------------------
-        nbd = int(rng.integers(8, 25))
+        nbd = int(rng.integers(8, 25)) if it % 8 else int(rng.integers(41, 45))     # (round 6: <= 40 block columns run the chain walker)
         md = 128 * nbd
         Bd = rnd(md, 256)
         Sd = Bd @ Bd.t() / 256 + 0.3 * torch.eye(md, dtype=torch.float64, device="cuda")
