@@ -803,6 +803,8 @@ __device__ __noinline__ bool dag_walk(const DagArgs& a, double* smem) {
   return true;
 }
 
+// WALK: the chain walker's roles (chosen at launch: <= DAG_WALK_NB block columns and a second workgroup); false = exactly the round-5 kernel
+template <bool WALK>
 __global__ void __launch_bounds__(256) potrf_dag_kernel(const DagArgs a) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   int* const sh = reinterpret_cast<int*>(smem + DAG_LDS_DOUBLES);
@@ -812,7 +814,7 @@ __global__ void __launch_bounds__(256) potrf_dag_kernel(const DagArgs a) {
   const int tid = threadIdx.x;
   int* const pd = xflag + (int64_t)nb * nb;      // pd[j] = 1: S_jj with every column k < j - 1 applied is parked in the tile's place
   int* const pl = pd + nb;                        // pl[i] = 1: S_{i,i-1} with every column k < i - 1 applied is parked
-  const bool walk = DAG_WALKER && gridDim.x >= 2 && nb <= DAG_WALK_NB;
+  constexpr bool walk = WALK;
   if (walk && blockIdx.x == 0) {
     if (!dag_walk(a, smem)) return;
   }
@@ -1115,7 +1117,9 @@ int potrf_inv_dag(int64_t m, double* A, int64_t ld, double* Linv, int64_t ldi, i
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return GEOBO_E_LAUNCH;
   if (!((attr_done.load(std::memory_order_acquire) >> dev) & 1)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_dag_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_dag_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)DAG_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_dag_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)DAG_LDS_BYTES) != hipSuccess)
       return GEOBO_E_LAUNCH;
     attr_done.fetch_or((uint64_t)1 << dev, std::memory_order_release);
@@ -1128,7 +1132,8 @@ int potrf_inv_dag(int64_t m, double* A, int64_t ld, double* Linv, int64_t ldi, i
   a.xdelay = DAG_XDELAY;
   if (const char* e = getenv("GEOBO_POTRF_XDELAY")) { const int v = atoi(e); if (v >= 0 && v <= 64) a.xdelay = v; }
   int grid = cus < nb * nb ? cus : nb * nb;
-  hipLaunchKernelGGL(potrf_dag_kernel, dim3(grid), dim3(256), DAG_LDS_BYTES, st, a);
+  if (DAG_WALKER && grid >= 2 && nb <= DAG_WALK_NB) hipLaunchKernelGGL(potrf_dag_kernel<true>, dim3(grid), dim3(256), DAG_LDS_BYTES, st, a);
+  else hipLaunchKernelGGL(potrf_dag_kernel<false>, dim3(grid), dim3(256), DAG_LDS_BYTES, st, a);
   return hipGetLastError() == hipSuccess ? GEOBO_OK : GEOBO_E_LAUNCH;
 }
 
