@@ -451,7 +451,9 @@ int geobo_spectral_axis(int inverse, int n, int64_t C, int64_t plane_in, int64_t
  * From m = 1024 the call is ONE persistent launch (round 5, potrf.hip "tile DAG"): one 256-thread workgroup per CU draws the 128 x 128
  * tiles of L (left-looking: a tile is accumulated in registers over its whole contraction) and of L^-1 (forward substitution by block
  * rows) in dependency order from a global counter and synchronises through agent-scope counters in ws; every spin is bounded -- info
- * = -7 reports a scheduler time-out (never seen; the result is then undefined).  ctx is not used by that form.  Below m = 1024, or
+ * = -7 reports a scheduler time-out (never seen; the result is then undefined).  ctx is not used by that form.  Up to 40 block columns
+ * (m <= 5120, round 6) ONE workgroup walks the latency chain -- diagonal tile, tile under it, update of the next diagonal tile -- with
+ * the other workgroups parking the partial sums it needs; larger matrices keep every link a task of its own.  Below m = 1024, or
  * with GEOBO_POTRF=streams in the environment, the stream schedule of rounds 2-4 runs:
  * ctx: fork context or NULL.  With a context (three internal streams, ordered after / before `stream` by events) the
  * trailing update of every step runs one step behind on the first stream (look-ahead), and the L^-1 tree -- dozens of small

@@ -55,10 +55,11 @@ def test_host_side_helpers(lib):
             mid += 1
         return (n - mid) * mid + tree_blocks(mid) + tree_blocks(n - mid)
     assert tree_blocks(8) == 16 + 2 * 4 + 4 * 1 and tree_blocks(66) == 2145
-    # ... followed by the counters of the persistent tile-DAG kernel: 16 control words, nb row counters, nb x nb tile flags
+    # ... followed by the counters of the persistent tile-DAG kernel: 16 control words, nb row counters, nb x nb tile flags, 2 nb flags of
+    # the partial sums parked for the chain walker (round 6)
     for m in (256, 1024, 2048, 8448, 33024):
         nb = m // 128
-        assert lib.geobo_potrf_ws_bytes(m) == tree_blocks(nb) * 128 * 128 * 8 + 4 * (16 + nb + nb * nb)
+        assert lib.geobo_potrf_ws_bytes(m) == tree_blocks(nb) * 128 * 128 * 8 + 4 * (16 + 3 * nb + nb * nb)
 
 
 def test_argument_validation_without_gpu(lib):
