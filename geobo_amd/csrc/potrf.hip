@@ -2,7 +2,9 @@
 // solve_triangular, inversion.py:100,105,114), plus u = L^-1 y and the log-likelihood statistics
 // (inversion.py:105-110).
 //
-// Right-looking, block size 128:
+// From m = 1024: ONE persistent launch, the tile DAG further down (round 5; round 6: the diagonal block's pivot tile in a row layout
+// without LDS memory, and up to 40 block columns one workgroup walking the latency chain).  Below, and with GEOBO_POTRF=streams, the
+// stream schedule of rounds 2-4 -- right-looking, block size 128:
 //   potf2_inv_kernel  one workgroup factors the 128x128 diagonal block in registers (2-D cyclic over 256 threads),
 //                     carrying the inverse along by forward substitution, and writes L_kk and L_kk^-1 (the latter
 //                     straight into the diagonal block of Linv);
